@@ -1,0 +1,339 @@
+// head_api.hip -- C-ABI entry points of the head training / inference path (include/acez.h, group T).
+// Host-side orchestration only: every entry point enqueues kernels of head_kernels.hip on the caller's stream.
+#include "head_kernels.hip"
+#include "acez_common.h"
+#include <vector>
+#include <new>
+
+using namespace acez;
+
+struct acez_trainer {
+  acez_train_config cfg;
+  acez_param_buffers pb;
+  acez_train_buffer buf;
+  bool have_buf = false;
+  int device = 0;
+  int L = 0, nb = 0, no = 4;
+  int64_t n_wide = 0, n_params = 0, fc3_off = 0;
+  int64_t fc3_stride = 0;
+  int nslabs = 1;
+  int max_batch = 0;
+  int last_n = 0;
+  // device allocations
+  uint16_t *Wb = nullptr, *WbT = nullptr, *W3b = nullptr;
+  std::vector<uint16_t*> out;   // post-relu output of each wide layer
+  std::vector<uint16_t*> R;     // residual stream, R[0] = gathered features
+  std::vector<uint16_t*> dZ;    // gradient wrt each wide layer's pre-activation
+  uint16_t* dR[2] = {nullptr, nullptr};
+  float* slabs = nullptr;
+  float* fc3_partials = nullptr;
+  float* stat_partials = nullptr;
+  float* xyz = nullptr;
+  float *log_loss = nullptr, *log_inl = nullptr;
+  int log_cap = 0;
+  TrainState* st = nullptr;
+  SchedConfig sc;
+  std::vector<void*> allocs;
+};
+
+static int dmalloc(acez_trainer* tr, void** p, size_t bytes) {
+  ACEZ_HIP_CHECK(hipMalloc(p, bytes));
+  tr->allocs.push_back(*p);
+  return ACEZ_OK;
+}
+
+extern "C" int64_t acez_head_num_params(const acez_head_desc* head) {
+  if (!head) return -1;
+  const int64_t L = 3 + 3 * (int64_t)head->num_head_blocks + 2;
+  const int64_t no = head->use_homogeneous ? 4 : 3;
+  return L * (512 * 512 + 512) + no * 513;
+}
+
+extern "C" void acez_trainer_destroy(acez_trainer* tr) {
+  if (!tr) return;
+  for (void* p : tr->allocs) (void)hipFree(p);
+  delete tr;
+}
+
+extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* cfg, const acez_param_buffers* params,
+                                   int device) {
+  ACEZ_REQUIRE(out && cfg && params, "null pointer");
+  ACEZ_REQUIRE(cfg->head.num_head_blocks >= 0 && 3 + 3 * cfg->head.num_head_blocks + 2 <= MAX_LAYERS, "num_head_blocks out of range");
+  ACEZ_REQUIRE(cfg->max_batch > 0 && cfg->global_batch > 0, "batch sizes must be positive");
+  ACEZ_REQUIRE(params->d_params && params->d_adam_m && params->d_adam_v && params->d_grad, "null parameter buffer");
+  ACEZ_REQUIRE(params->n_params == acez_head_num_params(&cfg->head), "n_params does not match the head description");
+  ACEZ_REQUIRE(cfg->schedule >= 0 && cfg->schedule <= 2, "unknown schedule");
+  ACEZ_REQUIRE(cfg->loss_type >= 0 && cfg->loss_type <= 4, "unknown loss type");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device visible: the head kernels need a gfx950 GPU (there is no CPU fallback)");
+    return ACEZ_ERR_NODEVICE;
+  }
+  if (device >= 0) ACEZ_HIP_CHECK(hipSetDevice(device));
+  acez_trainer* tr = new (std::nothrow) acez_trainer();
+  ACEZ_REQUIRE(tr, "out of host memory");
+  ACEZ_HIP_CHECK(hipGetDevice(&tr->device));
+  tr->cfg = *cfg;
+  tr->pb = *params;
+  tr->nb = cfg->head.num_head_blocks;
+  tr->L = 3 + 3 * tr->nb + 2;
+  tr->no = cfg->head.use_homogeneous ? 4 : 3;
+  tr->n_wide = (int64_t)tr->L * (512 * 512 + 512);
+  tr->fc3_off = tr->n_wide;
+  tr->n_params = params->n_params;
+  tr->fc3_stride = ((int64_t)tr->no * 513 + 3) & ~3LL;
+  tr->max_batch = cfg->max_batch;
+  tr->nslabs = 256 / (16 * tr->L);
+  if (tr->nslabs < 1) tr->nslabs = 1;
+
+  int rc = ACEZ_OK;
+  const size_t act_bytes = (size_t)tr->max_batch * 512 * sizeof(uint16_t);
+  auto A = [&](void** p, size_t bytes) { if (rc == ACEZ_OK) rc = dmalloc(tr, p, bytes); };
+  A((void**)&tr->Wb, (size_t)tr->L * 262144 * 2);
+  A((void**)&tr->WbT, (size_t)tr->L * 262144 * 2);
+  A((void**)&tr->W3b, (size_t)tr->no * 512 * 2);
+  tr->out.resize(tr->L, nullptr);
+  tr->dZ.resize(tr->L, nullptr);
+  tr->R.resize(tr->nb + 2, nullptr);
+  for (int l = 0; l < tr->L; ++l) { A((void**)&tr->out[l], act_bytes); A((void**)&tr->dZ[l], act_bytes); }
+  for (int b = 0; b < tr->nb + 2; ++b) A((void**)&tr->R[b], act_bytes);
+  A((void**)&tr->dR[0], act_bytes);
+  A((void**)&tr->dR[1], act_bytes);
+  A((void**)&tr->slabs, (size_t)tr->nslabs * tr->n_wide * sizeof(float));
+  const int max_blocks = (tr->max_batch + 31) / 32;
+  A((void**)&tr->fc3_partials, (size_t)max_blocks * tr->fc3_stride * sizeof(float));
+  A((void**)&tr->stat_partials, (size_t)max_blocks * 4 * sizeof(float));
+  A((void**)&tr->xyz, (size_t)tr->max_batch * 3 * sizeof(float));
+  tr->log_cap = cfg->iterations + 8;
+  A((void**)&tr->log_loss, (size_t)tr->log_cap * sizeof(float));
+  A((void**)&tr->log_inl, (size_t)tr->log_cap * sizeof(float));
+  A((void**)&tr->st, sizeof(TrainState));
+  if (rc != ACEZ_OK) { acez_trainer_destroy(tr); return rc; }
+
+  SchedConfig& sc = tr->sc;
+  sc.schedule = cfg->schedule; sc.iterations = cfg->iterations; sc.warmup_iterations = cfg->warmup_iterations;
+  sc.cooldown_iterations = cfg->cooldown_iterations; sc.loss_type = cfg->loss_type;
+  sc.circle_schedule = cfg->circle_schedule; sc.refine_calibration = cfg->refine_calibration;
+  sc.soft_clamp = cfg->soft_clamp; sc.soft_clamp_min = cfg->soft_clamp_min;
+  sc.lr_min = cfg->lr_min; sc.lr_max = cfg->lr_max; sc.warmup_lr = cfg->warmup_lr;
+  sc.cooldown_trigger_percent = cfg->cooldown_trigger_percent;
+  sc.beta1 = cfg->beta1; sc.beta2 = cfg->beta2; sc.eps = cfg->eps; sc.weight_decay = cfg->weight_decay;
+  sc.calib_lr = cfg->calib_lr;
+  hipLaunchKernelGGL(sched_init_kernel, dim3(1), dim3(64), 0, 0, tr->st, sc);
+  ACEZ_HIP_CHECK(hipGetLastError());
+  ACEZ_HIP_CHECK(hipMemset(tr->log_loss, 0, (size_t)tr->log_cap * sizeof(float)));
+  ACEZ_HIP_CHECK(hipMemset(tr->log_inl, 0, (size_t)tr->log_cap * sizeof(float)));
+  ACEZ_HIP_CHECK(hipDeviceSynchronize());
+  *out = tr;
+  return ACEZ_OK;
+}
+
+extern "C" int acez_trainer_set_buffer(acez_trainer* tr, const acez_train_buffer* buf) {
+  ACEZ_REQUIRE(tr && buf, "null pointer");
+  ACEZ_REQUIRE(buf->d_features && buf->d_target_px && buf->d_view_idx && buf->n_patches > 0, "empty patch buffer");
+  ACEZ_REQUIRE(buf->d_view_aug_inv && buf->d_view_K && buf->d_view_Kinv && buf->d_view_image && buf->n_views > 0, "empty view table");
+  ACEZ_REQUIRE(buf->d_image_pose_inv && buf->n_images > 0, "empty pose table");
+  tr->buf = *buf;
+  tr->have_buf = true;
+  return ACEZ_OK;
+}
+
+static void fill_adam_args(acez_trainer* tr, AdamArgs& a) {
+  a.params = tr->pb.d_params; a.m = tr->pb.d_adam_m; a.v = tr->pb.d_adam_v; a.grad = tr->pb.d_grad;
+  a.Wb = tr->Wb; a.WbT = tr->WbT; a.W3b = tr->W3b;
+  for (int l = 0; l < tr->L; ++l) { a.w_off[l] = (int64_t)l * 262656; a.b_off[l] = a.w_off[l] + 262144; }
+  a.fc3_off = tr->fc3_off; a.n_fc3 = (int64_t)tr->no * 513; a.n_params = tr->n_params;
+  a.n_layers = tr->L; a.no = tr->no; a.st = tr->st;
+}
+
+extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
+  ACEZ_REQUIRE(tr, "null trainer");
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  AdamArgs a;
+  fill_adam_args(tr, a);
+  const int nblk = tr->L * 64 + (tr->no * 512 + 255) / 256;
+  hipLaunchKernelGGL(recast_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+  ACEZ_HIP_CHECK(hipGetLastError());
+  return ACEZ_OK;
+}
+
+// forward chain on n rows whose input features are in `in0`; returns the fc2 output buffer
+static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, const TrainState* st, hipStream_t s) {
+  const float* P = tr->pb.d_params;
+  const dim3 grid(4, (n + 127) / 128), blk(256);
+  auto gemm = [&](int l, const uint16_t* in, uint16_t* out_main, const uint16_t* res, uint16_t* out_aux) {
+    RowGemmArgs g{};
+    g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144;
+    g.add = nullptr; g.mask = nullptr; g.res = res; g.out_main = out_main; g.out_aux = out_aux;
+    g.M = n; g.N = 512; g.K = 512; g.relu = 1; g.aux_mode = res ? AUX_RESIDUAL : AUX_NONE; g.st = st;
+    hipLaunchKernelGGL(rowgemm_kernel, grid, blk, 0, s, g);
+  };
+  const uint16_t* r = in0;
+  for (int b = 0; b <= tr->nb; ++b) {
+    gemm(3 * b, r, tr->out[3 * b], nullptr, nullptr);
+    gemm(3 * b + 1, tr->out[3 * b], tr->out[3 * b + 1], nullptr, nullptr);
+    gemm(3 * b + 2, tr->out[3 * b + 1], tr->out[3 * b + 2], r, tr->R[b + 1]);
+    r = tr->R[b + 1];
+  }
+  const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
+  gemm(f1, r, tr->out[f1], nullptr, nullptr);
+  gemm(f2, tr->out[f1], tr->out[f2], nullptr, nullptr);
+  return tr->out[f2];
+}
+
+static void fill_loss_head(acez_trainer* tr, LossArgs& a) {
+  a.W3 = tr->W3b; a.b3 = tr->pb.d_params + tr->fc3_off + (int64_t)tr->no * 512;
+  a.no = tr->no; a.use_homogeneous = tr->cfg.head.use_homogeneous;
+  for (int i = 0; i < 3; ++i) a.mean[i] = tr->cfg.head.mean[i];
+  a.max_inv_scale = tr->cfg.head.max_inv_scale; a.min_inv_scale = tr->cfg.head.min_inv_scale; a.h_beta = tr->cfg.head.h_beta;
+}
+
+extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, int n, void* stream) {
+  ACEZ_REQUIRE(tr && d_indices, "null pointer");
+  ACEZ_REQUIRE(tr->have_buf, "acez_trainer_set_buffer has not been called");
+  ACEZ_REQUIRE(n > 0 && n <= tr->max_batch, "n must be in [1, max_batch]");
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  hipStream_t s = (hipStream_t)stream;
+  const TrainState* st = tr->st;
+  tr->last_n = n;
+
+  hipLaunchKernelGGL(sched_pre_kernel, dim3(1), dim3(64), 0, s, tr->st, tr->sc);
+  hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024), dim3(256), 0, s,
+                     (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n, st);
+  uint16_t* act = launch_forward(tr, tr->R[0], n, st, s);
+
+  const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
+  const int nblk = (n + 31) / 32;
+  {
+    LossArgs a{};
+    fill_loss_head(tr, a);
+    a.act = act; a.n = n;
+    a.idx = d_indices; a.target_px = tr->buf.d_target_px; a.view_idx = tr->buf.d_view_idx;
+    a.view_aug_inv = tr->buf.d_view_aug_inv; a.view_K = tr->buf.d_view_K; a.view_Kinv = tr->buf.d_view_Kinv;
+    a.view_image = tr->buf.d_view_image; a.image_pose_inv = tr->buf.d_image_pose_inv;
+    a.loss_type = tr->cfg.loss_type; a.refine_calibration = tr->cfg.refine_calibration;
+    a.hard_clamp = tr->cfg.hard_clamp; a.depth_min = tr->cfg.depth_min; a.depth_max = tr->cfg.depth_max;
+    a.depth_target = tr->cfg.depth_target; a.inlier_px = tr->cfg.inlier_px_threshold;
+    a.inv_batch = 1.0f / (float)tr->cfg.global_batch; a.focal_init = tr->cfg.focal_init;
+    a.st = st; a.out_xyz = tr->xyz; a.dZ = tr->dZ[f2];
+    a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
+    hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, s, a);
+  }
+
+  // input-gradient chain
+  const dim3 grid(4, (n + 127) / 128), blk(256);
+  auto dgrad = [&](int l, const uint16_t* add, const uint16_t* mask, uint16_t* out_main, uint16_t* out_aux) {
+    RowGemmArgs g{};
+    g.In = tr->dZ[l]; g.W = tr->WbT + (size_t)l * 262144; g.bias = nullptr; g.add = add; g.mask = mask; g.res = nullptr;
+    g.out_main = out_main; g.out_aux = out_aux; g.M = n; g.N = 512; g.K = 512; g.relu = 0;
+    g.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE; g.st = st;
+    hipLaunchKernelGGL(rowgemm_kernel, grid, blk, 0, s, g);
+  };
+  dgrad(f2, nullptr, tr->out[f1], tr->dZ[f1], nullptr);
+  int cur = 0;
+  dgrad(f1, nullptr, tr->out[3 * tr->nb + 2], tr->dZ[3 * tr->nb + 2], tr->dR[cur]);
+  for (int b = tr->nb; b >= 0; --b) {
+    dgrad(3 * b + 2, nullptr, tr->out[3 * b + 1], tr->dZ[3 * b + 1], nullptr);
+    dgrad(3 * b + 1, nullptr, tr->out[3 * b], tr->dZ[3 * b], nullptr);
+    if (b > 0) {
+      dgrad(3 * b, tr->dR[cur], tr->out[3 * (b - 1) + 2], tr->dZ[3 * (b - 1) + 2], tr->dR[cur ^ 1]);
+      cur ^= 1;
+    }
+  }
+
+  // weight gradients of all wide layers in one launch
+  {
+    WgradArgs a{};
+    for (int l = 0; l < tr->L; ++l) {
+      a.dZ[l] = tr->dZ[l];
+      a.w_off[l] = (int64_t)l * 262656; a.b_off[l] = a.w_off[l] + 262144;
+    }
+    for (int b = 0; b <= tr->nb; ++b) {
+      a.In[3 * b] = tr->R[b]; a.In[3 * b + 1] = tr->out[3 * b]; a.In[3 * b + 2] = tr->out[3 * b + 1];
+    }
+    a.In[f1] = tr->R[tr->nb + 1]; a.In[f2] = tr->out[f1];
+    a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.st = st;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(16 * tr->nslabs, tr->L), dim3(256), 0, s, a);
+  }
+  {
+    GradReduceArgs a{};
+    a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.nslabs = tr->nslabs; a.fc3_partials = tr->fc3_partials;
+    a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials; a.n_loss_blocks = nblk; a.grad = tr->pb.d_grad;
+    a.n_wide = tr->n_wide; a.n_params = tr->n_params; a.st = st;
+    const int64_t tot = tr->n_params + 4;
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a);
+  }
+  ACEZ_HIP_CHECK(hipGetLastError());
+  return ACEZ_OK;
+}
+
+extern "C" int acez_train_update(acez_trainer* tr, void* stream) {
+  ACEZ_REQUIRE(tr, "null trainer");
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  hipStream_t s = (hipStream_t)stream;
+  AdamArgs a;
+  fill_adam_args(tr, a);
+  const int nsmall = (int)(((int64_t)tr->L * 512 + (int64_t)tr->no * 513 + 255) / 256);
+  hipLaunchKernelGGL(adamw_kernel, dim3(tr->L * 64 + nsmall), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, tr->st, tr->sc, (const float*)(tr->pb.d_grad + tr->n_params),
+                     1.0f / (float)tr->cfg.global_batch, tr->log_loss, tr->log_inl, tr->log_cap);
+  ACEZ_HIP_CHECK(hipGetLastError());
+  return ACEZ_OK;
+}
+
+extern "C" int acez_train_step(acez_trainer* tr, const int64_t* d_indices, int n, void* stream) {
+  int rc = acez_train_backward(tr, d_indices, n, stream);
+  if (rc != ACEZ_OK) return rc;
+  return acez_train_update(tr, stream);
+}
+
+extern "C" int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out, void* stream) {
+  ACEZ_REQUIRE(tr && h_out, "null pointer");
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  TrainState hs;
+  ACEZ_HIP_CHECK(hipMemcpyAsync(&hs, tr->st, sizeof(TrainState), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  h_out->iteration = hs.iteration; h_out->max_iterations = hs.max_iterations; h_out->in_cooldown = hs.in_cooldown;
+  h_out->nan_flag = hs.nan_flag; h_out->lr = hs.lr; h_out->last_loss = hs.last_loss;
+  h_out->last_batch_inliers = hs.last_inliers; h_out->focal_scale = 1.0 + hs.calib_g;
+  return hs.nan_flag ? ACEZ_ERR_NAN : ACEZ_OK;
+}
+
+extern "C" int acez_trainer_get_log(acez_trainer* tr, int first, int count, float* h_loss, float* h_inliers, void* stream) {
+  ACEZ_REQUIRE(tr, "null trainer");
+  ACEZ_REQUIRE(first >= 0 && count >= 0 && first + count <= tr->log_cap, "log range out of bounds");
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (h_loss) ACEZ_HIP_CHECK(hipMemcpyAsync(h_loss, tr->log_loss + first, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (h_inliers) ACEZ_HIP_CHECK(hipMemcpyAsync(h_inliers, tr->log_inl + first, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, s));
+  ACEZ_HIP_CHECK(hipStreamSynchronize(s));
+  return ACEZ_OK;
+}
+
+extern "C" int acez_trainer_last_scene_coords(acez_trainer* tr, float* h_xyz, int n, void* stream) {
+  ACEZ_REQUIRE(tr && h_xyz, "null pointer");
+  ACEZ_REQUIRE(n > 0 && n <= tr->max_batch, "n out of range");
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  ACEZ_HIP_CHECK(hipMemcpyAsync(h_xyz, tr->xyz, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return ACEZ_OK;
+}
+
+extern "C" int acez_head_forward(acez_trainer* tr, const void* d_features, int n, float* d_out_xyz, void* stream) {
+  ACEZ_REQUIRE(tr && d_features && d_out_xyz, "null pointer");
+  ACEZ_REQUIRE(n > 0, "n must be positive");
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  hipStream_t s = (hipStream_t)stream;
+  const uint16_t* f = (const uint16_t*)d_features;
+  for (int done = 0; done < n; done += tr->max_batch) {
+    const int cnt = (n - done < tr->max_batch) ? n - done : tr->max_batch;
+    uint16_t* act = launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
+    LossArgs a{};
+    fill_loss_head(tr, a);
+    a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr; a.out_xyz = d_out_xyz + (size_t)done * 3;
+    hipLaunchKernelGGL(loss_kernel, dim3((cnt + 31) / 32), dim3(256), 0, s, a);
+  }
+  ACEZ_HIP_CHECK(hipGetLastError());
+  return ACEZ_OK;
+}

@@ -1,0 +1,121 @@
+// head_kernels.h -- argument structs shared by the head kernels and their host-side launcher.
+#pragma once
+#include <stdint.h>
+
+namespace acez {
+
+constexpr int MAX_LAYERS = 20;
+
+enum { AUX_NONE = 0, AUX_RESIDUAL = 1, AUX_UNMASKED = 2 };
+enum { LOSS_TANH = 0, LOSS_DYNTANH = 1, LOSS_L1 = 2, LOSS_L1_SQRT = 3, LOSS_L1_LOGL1 = 4 };
+enum { SCHED_CONSTANT = 0, SCHED_1CYCLEPOLY = 1, SCHED_CIRCLE = 2 };
+
+struct AdamScalars {
+  float decay, one_minus_beta1, beta2, one_minus_beta2, bc2_sqrt, eps, step_size;
+};
+
+// Device-resident schedule / optimiser state: the training loop never synchronises the host.
+struct TrainState {
+  int active;          // this step runs (iteration < max_iterations and no NaN)
+  int iteration;       // TrainerACE.iteration
+  int max_iterations;  // ScheduleACE.max_iterations
+  int in_cooldown;
+  int warmup_epoch;    // last_epoch of the warm-up LinearLR / of OneCycleLR
+  int cooldown_epoch;  // last_epoch of the cool-down LinearLR
+  int nan_flag;
+  int opt_steps;       // AdamW state['step']
+  int crit_count;
+  int calib_steps;
+  float loss_weight;   // soft clamp of this iteration
+  float last_loss, last_inliers;
+  float crit_buf[100];  // cooldown_criterium_buffer
+  double lr;            // param_group['lr']
+  double calib_g, calib_m, calib_v;
+  AdamScalars adam;
+};
+
+struct SchedConfig {
+  int schedule, iterations, warmup_iterations, cooldown_iterations;
+  int loss_type, circle_schedule, refine_calibration;
+  float soft_clamp, soft_clamp_min;
+  double lr_min, lr_max, warmup_lr, cooldown_trigger_percent;
+  double beta1, beta2, eps, weight_decay, calib_lr;
+};
+
+struct RowGemmArgs {
+  const uint16_t* In;    // [M][K] bf16
+  const uint16_t* W;     // [N][K] bf16
+  const float* bias;     // [N] or null
+  const uint16_t* add;   // [M][N] or null: added before the activation
+  const uint16_t* mask;  // [M][N] or null: out_main is zeroed where mask <= 0
+  const uint16_t* res;   // [M][N] residual input for AUX_RESIDUAL
+  uint16_t* out_main;
+  uint16_t* out_aux;
+  int M, N, K, relu, aux_mode;
+  const TrainState* st;
+};
+
+struct WgradArgs {
+  const uint16_t* dZ[MAX_LAYERS];
+  const uint16_t* In[MAX_LAYERS];
+  int64_t w_off[MAX_LAYERS], b_off[MAX_LAYERS];
+  float* slabs;
+  int64_t slab_stride;
+  int M, nslabs;
+  const TrainState* st;
+};
+
+struct LossArgs {
+  const uint16_t* act;  // [n][512] output of fc2
+  const uint16_t* W3;   // [no][512] bf16
+  const float* b3;      // [no] fp32
+  int n, no, use_homogeneous;
+  float mean[3], max_inv_scale, min_inv_scale, h_beta;
+  // training only (idx == null -> inference)
+  const int64_t* idx;
+  const float* target_px;
+  const int32_t* view_idx;
+  const float* view_aug_inv;
+  const float* view_K;
+  const float* view_Kinv;
+  const int32_t* view_image;
+  const float* image_pose_inv;
+  int loss_type, refine_calibration;
+  float hard_clamp, depth_min, depth_max, depth_target, inlier_px, inv_batch, focal_init;
+  const TrainState* st;
+  // outputs
+  float* out_xyz;        // [n][3] or null
+  uint16_t* dZ;          // [n][512] gradient wrt the fc2 pre-activation
+  float* fc3_partials;   // [blocks][fc3_stride]
+  int64_t fc3_stride;
+  float* stat_partials;  // [blocks][4]
+};
+
+struct GradReduceArgs {
+  const float* slabs;
+  int64_t slab_stride;
+  int nslabs;
+  const float* fc3_partials;
+  int64_t fc3_stride;
+  const float* stat_partials;
+  int n_loss_blocks;
+  float* grad;
+  int64_t n_wide, n_params;
+  const TrainState* st;
+};
+
+struct AdamArgs {
+  float* params;
+  float* m;
+  float* v;
+  const float* grad;
+  uint16_t* Wb;
+  uint16_t* WbT;
+  uint16_t* W3b;
+  int64_t w_off[MAX_LAYERS], b_off[MAX_LAYERS];
+  int64_t fc3_off, n_fc3, n_params;
+  int n_layers, no;
+  const TrainState* st;
+};
+
+}  // namespace acez

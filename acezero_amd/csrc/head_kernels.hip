@@ -1,0 +1,859 @@
+// head_kernels.hip -- gfx950 kernels of the ACE scene-coordinate head (training + inference).
+//
+// What is computed (reference file:line):
+//   gather                ace_trainer.py:485-494   training_buffer['features'][random_batch_indices]
+//   rowgemm (fwd)         ace_network.py:122-136   relu(conv1x1(x)) chains, residual adds at :126,:133
+//   loss kernel           ace_network.py:137-147   fc3 + softplus de-homogenisation + mean
+//                         ace_trainer.py:521-613   projection, masks, ReproLoss (ace_loss.py:39-91), loss/B
+//                         + the analytic gradient of all of it wrt the fc3 outputs
+//   rowgemm (dgrad)       autograd of the 1x1 convs wrt their inputs (+ relu masks, residual fan-in)
+//   wgrad                 autograd of the 1x1 convs wrt weight and bias, all layers in one launch
+//   grad_reduce / adamw   ace_schedule.py:106-126 (AdamW step), torch.optim.AdamW semantics
+//   sched                 ace_schedule.py:72-101,115-126 (cool-down trigger, LinearLR / OneCycleLR)
+//
+// Data layout: activations are row-major [rows][512] bf16 (a row = one patch = 1 KiB); weights are kept as
+// fp32 masters plus two bf16 compute copies, W [out][in] and W^T [in][out], so that the forward GEMM and the
+// input-gradient GEMM both see a reduction-contiguous second operand. MFMA: v_mfma_f32_32x32x16_bf16, fp32
+// accumulate, computed as D[i = output channel][j = row] so that each lane ends up holding 4 consecutive
+// channels of one row (an 8-byte row-major store).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "head_kernels.h"
+
+namespace acez {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even fp32 -> bf16 (same as torch .to(bfloat16)); NaN stays NaN.
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  uint2 r;
+  r.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  r.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+  return r;
+}
+__device__ __forceinline__ void unpack4(uint2 v, float* o) {
+  o[0] = __uint_as_float(v.x << 16);
+  o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16);
+  o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gather: out[r][:] = features[idx[r]][:]   (one wave copies one 1 KiB row per instruction)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
+                                                     uint16_t* __restrict__ out, int n, const TrainState* st) {
+  if (st && !st->active) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < n; r += nwaves) {
+    const int64_t src = idx[r];
+    const uint4 v = *reinterpret_cast<const uint4*>(feat + src * 512 + lane * 8);
+    *reinterpret_cast<uint4*>(out + (size_t)r * 512 + lane * 8) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rowgemm: Out[m][n] = epi( sum_k In[m][k] * W[n][k] ),  128 x 128 tile, BK = 64, 4 waves of 64 x 64.
+// LDS tiles are [row][64] bf16 with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7, which makes
+// the ds_read_b128 fragment reads of 32 consecutive rows conflict-free.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+__global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
+  if (a.st && !a.st->active) return;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[2][2][128 * 64];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wn = w >> 1, wm = w & 1;
+  const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+  const int M = a.M, N = a.N, K = a.K;
+  const int KT = K >> 6;
+
+  uint4 rW[4], rI[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int q = t + 256 * p, row = q >> 3, c = q & 7;
+      rW[p] = *reinterpret_cast<const uint4*>(a.W + (size_t)(n0 + row) * K + kt * 64 + c * 8);
+      const int m = m0 + row;
+      rI[p] = (m < M) ? *reinterpret_cast<const uint4*>(a.In + (size_t)m * K + kt * 64 + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int q = t + 256 * p, row = q >> 3, c = q & 7;
+      const int off = swz(row, c);
+      *reinterpret_cast<uint4*>(&smem[buf][0][off]) = rW[p];
+      *reinterpret_cast<uint4*>(&smem[buf][1][off]) = rI[p];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) gload(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 fa[2], fb[2];
+      const int c = 2 * kk + (l >> 5);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rowa = wn * 64 + i * 32 + (l & 31);
+        fa[i] = *reinterpret_cast<const bf16x8*>(&smem[buf][0][swz(rowa, c)]);
+        const int rowb = wm * 64 + i * 32 + (l & 31);
+        fb[i] = *reinterpret_cast<const bf16x8*>(&smem[buf][1][swz(rowb, c)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds row m (B index j = l & 31) and channels nb .. nb+3 per register group g
+  const int h = l >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wm * 64 + j * 32 + (l & 31);
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nb = n0 + wn * 64 + i * 32 + 8 * g + 4 * h;
+        float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        const size_t o = (size_t)m * N + nb;
+        if (a.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(a.bias + nb);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (a.add) {
+          float ad[4];
+          unpack4(*reinterpret_cast<const uint2*>(a.add + o), ad);
+          v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
+        }
+        if (a.relu) {
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
+        uint2 y = pack4(v[0], v[1], v[2], v[3]);
+        if (a.aux_mode == AUX_RESIDUAL) {
+          // out_aux = bf16( float(bf16(y)) + float(res) )   (ace_network.py:126,133)
+          float yf[4], rf[4];
+          unpack4(y, yf);
+          unpack4(*reinterpret_cast<const uint2*>(a.res + o), rf);
+          *reinterpret_cast<uint2*>(a.out_aux + o) = pack4(yf[0] + rf[0], yf[1] + rf[1], yf[2] + rf[2], yf[3] + rf[3]);
+        } else if (a.aux_mode == AUX_UNMASKED) {
+          *reinterpret_cast<uint2*>(a.out_aux + o) = y;
+        }
+        if (a.mask) {
+          // relu backward: keep the gradient where the forward activation was > 0
+          const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + o);
+          // bf16 > 0  <=>  sign bit clear and magnitude non-zero
+          const uint32_t m0b = mk.x & 0xffffu, m1b = mk.x >> 16, m2b = mk.y & 0xffffu, m3b = mk.y >> 16;
+          uint32_t lo = y.x, hi = y.y;
+          if (!(m0b != 0 && m0b < 0x8000u)) lo &= 0xffff0000u;
+          if (!(m1b != 0 && m1b < 0x8000u)) lo &= 0x0000ffffu;
+          if (!(m2b != 0 && m2b < 0x8000u)) hi &= 0xffff0000u;
+          if (!(m3b != 0 && m3b < 0x8000u)) hi &= 0x0000ffffu;
+          y.x = lo; y.y = hi;
+        }
+        *reinterpret_cast<uint2*>(a.out_main + o) = y;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad: dW_l[n][c] = sum_m dZ_l[m][n] * In_l[m][c],  db_l[n] = sum_m dZ_l[m][n], all wide layers in one
+// launch (grid.y = layer), split-K over rows (slab s = blockIdx.x / 16). Both operands are row-major with
+// the reduction index m as the slow dimension, so the MFMA fragments (8 consecutive m for one column) are
+// read with ds_read_b64_tr_b16 from an untransposed [64 m][128 cols] LDS tile (row pitch 320 B: the four
+// rows a 32-lane group touches fall on disjoint banks).
+// ---------------------------------------------------------------------------------------------------
+constexpr int WG_PITCH = 160;  // uint16 elements per LDS row (128 + 32 pad)
+
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* tile, int k0, int col0, int l) {
+  // returns, for lane l, the 8 values tile[k0 + 8*(l>>5) + e][col0 + (l & 31)], e = 0..7
+  const int q = l >> 4, i16 = l & 15;
+  const int row = k0 + 8 * (q >> 1) + (i16 >> 2);
+  const int col = col0 + 16 * (q & 1) + 4 * (i16 & 3);
+  const uint16_t* p = tile + row * WG_PITCH + col;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * WG_PITCH));
+  s16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  if (a.st && !a.st->active) return;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[2][2][64 * WG_PITCH];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wn = w >> 1, wc = w & 1;
+  const int layer = blockIdx.y;
+  const int tile = blockIdx.x & 15, slab = blockIdx.x >> 4;
+  const int n0 = (tile >> 2) * 128, c0 = (tile & 3) * 128;
+  const uint16_t* __restrict__ Z = a.dZ[layer];
+  const uint16_t* __restrict__ X = a.In[layer];
+  const int M = a.M;
+  // rows of this slab: [mb, me), multiple of 64 per slab except the tail
+  const int rows_per_slab = ((M + a.nslabs * 64 - 1) / (a.nslabs * 64)) * 64;
+  const int mb = slab * rows_per_slab;
+  const int me = min(M, mb + rows_per_slab);
+  const int KT = (me > mb) ? (me - mb + 63) >> 6 : 0;
+
+  uint4 rZ[4], rX[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int q = t + 256 * p, row = q >> 4, c = q & 15;
+      const int m = mb + kt * 64 + row;
+      if (m < me) {
+        rZ[p] = *reinterpret_cast<const uint4*>(Z + (size_t)m * 512 + n0 + c * 8);
+        rX[p] = *reinterpret_cast<const uint4*>(X + (size_t)m * 512 + c0 + c * 8);
+      } else {
+        rZ[p] = make_uint4(0, 0, 0, 0);
+        rX[p] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int q = t + 256 * p, row = q >> 4, c = q & 15;
+      *reinterpret_cast<uint4*>(&smem[buf][0][row * WG_PITCH + c * 8]) = rZ[p];
+      *reinterpret_cast<uint4*>(&smem[buf][1][row * WG_PITCH + c * 8]) = rX[p];
+    }
+  };
+
+  f32x16 acc[2][2], accb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  const bool do_bias = (c0 == 0) && (wc == 0);
+  s16x8 ones_s;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones_s[e] = (short)0x3f80;  // bf16 1.0
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+
+  if (KT > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) gload(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = tr_frag(&smem[buf][0][0], kk * 16, wn * 64 + i * 32, l);
+        fb[i] = tr_frag(&smem[buf][1][0], kk * 16, wc * 64 + i * 32, l);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, accb[i], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < KT) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* __restrict__ G = a.slabs + (size_t)slab * a.slab_stride;
+  const int h = l >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + (l & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        G[a.w_off[layer] + (size_t)n * 512 + c] = acc[i][j][r];
+      }
+    }
+    if (do_bias && (l & 31) == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        G[a.b_off[layer] + n] = accb[i][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// loss kernel (32 rows per workgroup):
+//   A  fc3 forward, one wave per row, fp32 accumulate
+//   B  one thread per row: de-homogenise, project, masks, robust loss and d(loss)/d(fc3 outputs)
+//   C  one thread per channel pair: fc3 weight-gradient partials and the masked input gradient dZ
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
+  if (a.st && !a.st->active) return;
+  __shared__ float s_s[32][4];
+  __shared__ float s_ds[32][4];
+  __shared__ float s_red[32][4];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int m0 = blockIdx.x * 32;
+  const int n = a.n, no = a.no;
+
+  // ---- phase A
+  {
+    float w3[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < no) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a.W3 + (size_t)j * 512 + l * 8);
+        unpack4(make_uint2(v.x, v.y), &w3[j][0]);
+        unpack4(make_uint2(v.z, v.w), &w3[j][4]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w3[j][e] = 0.f;
+      }
+    }
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = w * 8 + rr, m = m0 + r;
+      float x[8];
+      if (m < n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a.act + (size_t)m * 512 + l * 8);
+        unpack4(make_uint2(v.x, v.y), &x[0]);
+        unpack4(make_uint2(v.z, v.w), &x[4]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+      }
+      float p[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sacc = fmaf(x[e], w3[j][e], sacc);
+        p[j] = sacc;
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] += __shfl_xor(p[j], off);
+      }
+      if (l == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_s[r][j] = (j < no) ? p[j] + a.b3[j] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B
+  if (t < 32) {
+    const int r = t, m = m0 + r;
+    float loss = 0.f, inl = 0.f, fgrad = 0.f, ds[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m < n) {
+      const float s0 = s_s[r][0], s1 = s_s[r][1], s2 = s_s[r][2], s3 = s_s[r][3];
+      float X[3], hval = 1.f, bx = 0.f;
+      bool hclamped = false;
+      if (a.use_homogeneous) {
+        bx = a.h_beta * s3;
+        const float sp = (bx > 20.f) ? s3 : log1pf(expf(bx)) / a.h_beta;  // F.softplus(beta), ace_network.py:142
+        const float hraw = sp + a.max_inv_scale;
+        hclamped = hraw > a.min_inv_scale;                                // clamp_(max=min_inv_scale) :143
+        hval = hclamped ? a.min_inv_scale : hraw;
+        X[0] = s0 / hval + a.mean[0];
+        X[1] = s1 / hval + a.mean[1];
+        X[2] = s2 / hval + a.mean[2];
+      } else {
+        X[0] = s0 + a.mean[0];
+        X[1] = s1 + a.mean[1];
+        X[2] = s2 + a.mean[2];
+      }
+      if (a.out_xyz) {
+        a.out_xyz[(size_t)m * 3 + 0] = X[0];
+        a.out_xyz[(size_t)m * 3 + 1] = X[1];
+        a.out_xyz[(size_t)m * 3 + 2] = X[2];
+      }
+      if (a.idx) {  // training: geometry + loss (skipped for pure inference)
+        const int64_t p = a.idx[m];
+        const float tu = a.target_px[p * 2 + 0], tv = a.target_px[p * 2 + 1];
+        const int view = a.view_idx[p];
+        const float* A = a.view_aug_inv + (size_t)view * 12;
+        const float* T = a.image_pose_inv + (size_t)a.view_image[view] * 16;
+        float K[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) K[i] = a.view_K[(size_t)view * 9 + i];
+        float kscale = 0.f;
+        if (a.refine_calibration) {
+          // refine_calibration.py:34-53: K[:2,:2] = (1+g) * f0 * (K00/f0) * I2
+          kscale = K[0] / a.focal_init;
+          const float f = (1.f + (float)a.st->calib_g) * a.focal_init * kscale;
+          K[0] = f; K[1] = 0.f; K[3] = 0.f; K[4] = f;
+        }
+        // P = A(3x4) . T(4x4)    ace_trainer.py:530
+        float P[12];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fmaf(A[i * 4 + k], T[k * 4 + j], acc);
+            P[i * 4 + j] = acc;
+          }
+        float Xc[3], pp[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Xc[i] = fmaf(P[i * 4 + 0], X[0], fmaf(P[i * 4 + 1], X[1], fmaf(P[i * 4 + 2], X[2], P[i * 4 + 3])));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pp[i] = fmaf(K[i * 3 + 0], Xc[0], fmaf(K[i * 3 + 1], Xc[1], K[i * 3 + 2] * Xc[2]));
+        const bool zclamped = pp[2] < a.depth_min;                 // clamp_(min=depth_min) :545
+        const float pz = zclamped ? a.depth_min : pp[2];
+        const float u = pp[0] / pz, v = pp[1] / pz;
+        const float du = u - tu, dv = v - tv;
+        const float e = fabsf(du) + fabsf(dv);                     // L1 norm :552
+        const bool invalid = (Xc[2] < a.depth_min) || (e > a.hard_clamp) || (Xc[2] > a.depth_max);  // :558-565
+        float dXc[3];
+        if (!invalid) {
+          float ge;
+          const float wgt = a.st->loss_weight;
+          if (a.loss_type == LOSS_TANH || a.loss_type == LOSS_DYNTANH) {
+            const float th = tanhf(e / wgt);
+            loss = wgt * th;
+            ge = 1.f - th * th;
+          } else if (a.loss_type == LOSS_L1) {
+            const bool big = e > wgt;
+            loss = big ? 0.f : e;
+            ge = big ? 0.f : 1.f;
+          } else if (a.loss_type == LOSS_L1_SQRT) {
+            const bool big = e > wgt;
+            loss = big ? sqrtf(wgt * e) : e;
+            ge = big ? 0.5f * wgt / sqrtf(wgt * e) : 1.f;
+          } else {
+            const bool big = e > wgt;
+            loss = big ? logf(1.f + wgt * e) : e;
+            ge = big ? wgt / (1.f + wgt * e) : 1.f;
+          }
+          inl = (e < a.inlier_px) ? 1.f : 0.f;                      // :585
+          const float gu = ge * sgn(du), gv = ge * sgn(dv);
+          float dp[3];
+          dp[0] = gu / pz;
+          dp[1] = gv / pz;
+          dp[2] = zclamped ? 0.f : -(gu * pp[0] + gv * pp[1]) / (pz * pz);
+          if (a.refine_calibration) fgrad = (dp[0] * Xc[0] + dp[1] * Xc[1]) * a.focal_init * kscale;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) dXc[j] = K[0 * 3 + j] * dp[0] + K[1 * 3 + j] * dp[1] + K[2 * 3 + j] * dp[2];
+        } else {
+          // proxy target at constant depth, ace_trainer.py:592-600
+          const float* Ki = a.view_Kinv + (size_t)view * 9;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const float tgt = a.depth_target * fmaf(Ki[i * 3 + 0], tu, fmaf(Ki[i * 3 + 1], tv, Ki[i * 3 + 2]));
+            const float d = tgt - Xc[i];
+            loss += fabsf(d);
+            dXc[i] = -sgn(d);
+          }
+        }
+        const float invB = a.inv_batch;
+        float dX[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dX[k] = (P[0 * 4 + k] * dXc[0] + P[1 * 4 + k] * dXc[1] + P[2 * 4 + k] * dXc[2]) * invB;
+        fgrad *= invB;
+        if (a.use_homogeneous) {
+          ds[0] = dX[0] / hval;
+          ds[1] = dX[1] / hval;
+          ds[2] = dX[2] / hval;
+          float dh = -(dX[0] * s0 + dX[1] * s1 + dX[2] * s2) / (hval * hval);
+          if (hclamped) dh = 0.f;
+          if (bx > 20.f) ds[3] = dh;
+          else {
+            const float z = expf(bx);
+            ds[3] = dh * z / (z + 1.f);
+          }
+        } else {
+          ds[0] = dX[0]; ds[1] = dX[1]; ds[2] = dX[2]; ds[3] = 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_ds[r][j] = ds[j];
+    s_red[r][0] = loss; s_red[r][1] = inl; s_red[r][2] = fgrad; s_red[r][3] = 0.f;
+  }
+  __syncthreads();
+  if (!a.idx) return;  // inference: no gradients
+
+  if (t < 3) {  // fixed-order sum over the 32 rows -> one partial per workgroup
+    float acc = 0.f;
+    for (int r = 0; r < 32; ++r) acc += s_red[r][t];
+    a.stat_partials[(size_t)blockIdx.x * 4 + t] = acc;
+  }
+
+  // ---- phase C: thread t owns channels 2t, 2t+1
+  {
+    float w3[4][2], gw[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < no) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(a.W3 + (size_t)j * 512 + 2 * t);
+        w3[j][0] = __uint_as_float(v << 16);
+        w3[j][1] = __uint_as_float(v & 0xffff0000u);
+      } else {
+        w3[j][0] = w3[j][1] = 0.f;
+      }
+      gw[j][0] = gw[j][1] = 0.f;
+    }
+    for (int r = 0; r < 32; ++r) {
+      const int m = m0 + r;
+      if (m >= n) break;
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(a.act + (size_t)m * 512 + 2 * t);
+      const float x0 = __uint_as_float(v << 16), x1 = __uint_as_float(v & 0xffff0000u);
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float dsj = s_ds[r][j];
+        d0 = fmaf(dsj, w3[j][0], d0);
+        d1 = fmaf(dsj, w3[j][1], d1);
+        gw[j][0] = fmaf(dsj, x0, gw[j][0]);
+        gw[j][1] = fmaf(dsj, x1, gw[j][1]);
+      }
+      if (!(x0 > 0.f)) d0 = 0.f;  // relu mask of the fc2 output
+      if (!(x1 > 0.f)) d1 = 0.f;
+      *reinterpret_cast<uint32_t*>(a.dZ + (size_t)m * 512 + 2 * t) = (uint32_t)f2bf(d0) | ((uint32_t)f2bf(d1) << 16);
+    }
+    float* gp = a.fc3_partials + (size_t)blockIdx.x * a.fc3_stride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < no) *reinterpret_cast<float2*>(gp + (size_t)j * 512 + 2 * t) = make_float2(gw[j][0], gw[j][1]);
+    if (t < no) {
+      float acc = 0.f;
+      for (int r = 0; r < 32; ++r) acc += s_ds[r][t];
+      gp[(size_t)no * 512 + t] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// grad_reduce: flat gradient = fixed-order sum of the wgrad slabs (wide layers) and of the per-workgroup
+// partials of the loss kernel (fc3 + statistics). Deterministic: no atomics anywhere in the step.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
+  if (a.st && !a.st->active) return;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < a.n_wide) {
+    float acc = 0.f;
+    for (int s = 0; s < a.nslabs; ++s) acc += a.slabs[(size_t)s * a.slab_stride + i];
+    a.grad[i] = acc;
+  } else if (i < a.n_params) {
+    const int64_t k = i - a.n_wide;
+    float acc = 0.f;
+    for (int b = 0; b < a.n_loss_blocks; ++b) acc += a.fc3_partials[(size_t)b * a.fc3_stride + k];
+    a.grad[i] = acc;
+  } else if (i < a.n_params + 4) {
+    const int k = (int)(i - a.n_params);
+    float acc = 0.f;
+    if (k < 3)
+      for (int b = 0; b < a.n_loss_blocks; ++b) acc += a.stat_partials[(size_t)b * 4 + k];
+    a.grad[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// adamw: torch.optim.AdamW single-tensor semantics on the flat fp32 masters, fused with the bf16 recast of
+// W and W^T. One workgroup per 64 x 64 weight tile (transposed copy staged through LDS); the biases and
+// fc3 are handled by the trailing workgroups.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float adamw_one(float p, float g, float& m, float& v, const AdamScalars& s) {
+  p = p * s.decay;                       // p.mul_(1 - lr * wd)
+  m = m + (g - m) * s.one_minus_beta1;   // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * s.beta2 + s.one_minus_beta2 * g * g;
+  const float denom = sqrtf(v) / s.bc2_sqrt + s.eps;
+  return p - s.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+  const TrainState* st = a.st;
+  if (!st->active) return;
+  const float lossv = a.grad[a.n_params];
+  if (lossv != lossv) return;  // NaN loss: the reference aborts before the optimiser step (ace_trainer.py:615-617)
+  const AdamScalars s = st->adam;
+  __shared__ uint16_t tileT[64][66];
+  const int t = threadIdx.x;
+  const int b = blockIdx.x;
+  const int tiles_per_layer = 64;
+  if (b < a.n_layers * tiles_per_layer) {
+    const int layer = b / tiles_per_layer, tl = b % tiles_per_layer;
+    const int r0 = (tl >> 3) * 64, c0 = (tl & 7) * 64;
+    const int64_t woff = a.w_off[layer];
+    // 64 x 64 tile: thread handles 16 elements, rows (t>>4) + 16*i, 4 consecutive cols
+    const int cc = (t & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (t >> 4) + 16 * i;
+      const int64_t o = woff + (int64_t)(r0 + rr) * 512 + c0 + cc;
+      float4 p = *reinterpret_cast<float4*>(a.params + o);
+      const float4 g = *reinterpret_cast<const float4*>(a.grad + o);
+      float4 m = *reinterpret_cast<float4*>(a.m + o);
+      float4 v = *reinterpret_cast<float4*>(a.v + o);
+      p.x = adamw_one(p.x, g.x, m.x, v.x, s);
+      p.y = adamw_one(p.y, g.y, m.y, v.y, s);
+      p.z = adamw_one(p.z, g.z, m.z, v.z, s);
+      p.w = adamw_one(p.w, g.w, m.w, v.w, s);
+      *reinterpret_cast<float4*>(a.params + o) = p;
+      *reinterpret_cast<float4*>(a.m + o) = m;
+      *reinterpret_cast<float4*>(a.v + o) = v;
+      const uint2 pk = pack4(p.x, p.y, p.z, p.w);
+      *reinterpret_cast<uint2*>(a.Wb + (size_t)layer * 262144 + (size_t)(r0 + rr) * 512 + c0 + cc) = pk;
+      tileT[cc + 0][rr] = (uint16_t)(pk.x & 0xffff);
+      tileT[cc + 1][rr] = (uint16_t)(pk.x >> 16);
+      tileT[cc + 2][rr] = (uint16_t)(pk.y & 0xffff);
+      tileT[cc + 3][rr] = (uint16_t)(pk.y >> 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (t >> 4) + 16 * i;  // row of W^T tile = column of W
+      uint2 pk;
+      pk.x = (uint32_t)tileT[rr][cc + 0] | ((uint32_t)tileT[rr][cc + 1] << 16);
+      pk.y = (uint32_t)tileT[rr][cc + 2] | ((uint32_t)tileT[rr][cc + 3] << 16);
+      *reinterpret_cast<uint2*>(a.WbT + (size_t)layer * 262144 + (size_t)(c0 + rr) * 512 + r0 + cc) = pk;
+    }
+  } else {
+    // small parameters: biases of the wide layers, fc3 weight + bias
+    const int sb = b - a.n_layers * tiles_per_layer;
+    const int64_t k = (int64_t)sb * 256 + t;
+    const int64_t n_bias = (int64_t)a.n_layers * 512;
+    int64_t o = -1;
+    if (k < n_bias) o = a.b_off[k >> 9] + (k & 511);
+    else if (k < n_bias + a.n_fc3) o = a.fc3_off + (k - n_bias);
+    if (o >= 0) {
+      float p = a.params[o], m = a.m[o], v = a.v[o];
+      p = adamw_one(p, a.grad[o], m, v, s);
+      a.params[o] = p; a.m[o] = m; a.v[o] = v;
+      if (k >= n_bias && (k - n_bias) < (int64_t)a.no * 512) a.W3b[k - n_bias] = f2bf(p);
+    }
+  }
+}
+
+// recast only (no optimiser step): used after loading weights
+__global__ __launch_bounds__(256) void recast_kernel(AdamArgs a) {
+  __shared__ uint16_t tileT[64][66];
+  const int t = threadIdx.x, b = blockIdx.x;
+  if (b < a.n_layers * 64) {
+    const int layer = b / 64, tl = b % 64;
+    const int r0 = (tl >> 3) * 64, c0 = (tl & 7) * 64;
+    const int64_t woff = a.w_off[layer];
+    const int cc = (t & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (t >> 4) + 16 * i;
+      const float4 p = *reinterpret_cast<const float4*>(a.params + woff + (int64_t)(r0 + rr) * 512 + c0 + cc);
+      const uint2 pk = pack4(p.x, p.y, p.z, p.w);
+      *reinterpret_cast<uint2*>(a.Wb + (size_t)layer * 262144 + (size_t)(r0 + rr) * 512 + c0 + cc) = pk;
+      tileT[cc + 0][rr] = (uint16_t)(pk.x & 0xffff);
+      tileT[cc + 1][rr] = (uint16_t)(pk.x >> 16);
+      tileT[cc + 2][rr] = (uint16_t)(pk.y & 0xffff);
+      tileT[cc + 3][rr] = (uint16_t)(pk.y >> 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (t >> 4) + 16 * i;
+      uint2 pk;
+      pk.x = (uint32_t)tileT[rr][cc + 0] | ((uint32_t)tileT[rr][cc + 1] << 16);
+      pk.y = (uint32_t)tileT[rr][cc + 2] | ((uint32_t)tileT[rr][cc + 3] << 16);
+      *reinterpret_cast<uint2*>(a.WbT + (size_t)layer * 262144 + (size_t)(c0 + rr) * 512 + r0 + cc) = pk;
+    }
+  } else {
+    const int64_t k = (int64_t)(b - a.n_layers * 64) * 256 + t;
+    if (k < (int64_t)a.no * 512) a.W3b[k] = f2bf(a.params[a.fc3_off + k]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// schedule (one thread): ace_schedule.py:72-101 before the step, :115-126 after it. The learning rate is
+// advanced with the same chainable recurrences torch.optim.lr_scheduler uses, in double.
+// ---------------------------------------------------------------------------------------------------
+__device__ double det_cos_pi(double x);  // cos(pi * x), x in [0, 1]
+
+__device__ double onecycle_lr(const SchedConfig& c, int step_num) {
+  // torch OneCycleLR(max_lr, total_steps, pct_start=0.3, anneal='cos', div_factor=25, final_div_factor=1e4,
+  //                  three_phase=False, cycle_momentum=False)
+  const double initial_lr = c.lr_max / 25.0;
+  const double min_lr = initial_lr / 1e4;
+  const double end1 = 0.3 * (double)c.iterations - 1.0;
+  const double end2 = (double)c.iterations - 1.0;
+  double start, end, pct;
+  if ((double)step_num <= end1 || c.iterations <= 1) {
+    start = initial_lr; end = c.lr_max;
+    pct = (end1 > 0) ? (double)step_num / end1 : 1.0;
+  } else {
+    start = c.lr_max; end = min_lr;
+    pct = ((double)step_num - end1) / (end2 - end1);
+  }
+  const double cos_out = det_cos_pi(pct) + 1.0;
+  return end + (start - end) / 2.0 * cos_out;
+}
+
+__global__ void sched_pre_kernel(TrainState* st, SchedConfig c) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int it = st->iteration;
+  // check_and_set_cooldown(iteration)   ace_schedule.py:72-101
+  if (c.schedule == SCHED_1CYCLEPOLY && !st->in_cooldown && it >= c.warmup_iterations) {
+    const bool by_duration = it >= (st->max_iterations - c.cooldown_iterations);
+    double mn = 1e300;
+    const int cnt = st->crit_count;
+    for (int i = 0; i < cnt; ++i) mn = fmin(mn, (double)st->crit_buf[i]);
+    const bool dynamic = (cnt > 0) && (mn > c.cooldown_trigger_percent);
+    if (by_duration || dynamic) {
+      st->in_cooldown = 1;
+      st->cooldown_epoch = 0;
+      st->max_iterations = it + c.cooldown_iterations;
+    }
+  }
+  st->active = (it < st->max_iterations && !st->nan_flag) ? 1 : 0;   // ace_trainer.py:509-510
+  // loss weight of this iteration (ace_loss.py:55-69)
+  float wgt = c.soft_clamp;
+  if (c.loss_type == LOSS_DYNTANH) {
+    double sw = (double)it / (double)c.iterations;
+    if (c.circle_schedule) sw = 1.0 - sqrt(1.0 - sw * sw);
+    wgt = (float)((1.0 - sw) * (double)c.soft_clamp + (double)c.soft_clamp_min);
+  }
+  st->loss_weight = wgt;
+  // scalars of torch.optim.AdamW for this step (double like the Python side, then cast like the fp32 kernels)
+  {
+    const double lr = st->lr;
+    const int step = st->opt_steps + 1;
+    const double bc1 = 1.0 - pow(c.beta1, (double)step);
+    const double bc2 = 1.0 - pow(c.beta2, (double)step);
+    AdamScalars s;
+    s.decay = (float)(1.0 - lr * c.weight_decay);
+    s.one_minus_beta1 = (float)(1.0 - c.beta1);
+    s.beta2 = (float)c.beta2;
+    s.one_minus_beta2 = (float)(1.0 - c.beta2);
+    s.bc2_sqrt = (float)sqrt(bc2);
+    s.eps = (float)c.eps;
+    s.step_size = (float)(lr / bc1);
+    st->adam = s;
+  }
+}
+
+// initial state: lr as left by the torch scheduler constructors (ace_schedule.py:12-70)
+__global__ void sched_init_kernel(TrainState* st, SchedConfig c) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->active = 0; st->iteration = 0; st->max_iterations = c.iterations; st->in_cooldown = 0;
+  st->warmup_epoch = 0; st->cooldown_epoch = 0; st->nan_flag = 0; st->opt_steps = 0; st->crit_count = 0;
+  st->calib_steps = 0; st->loss_weight = c.soft_clamp; st->last_loss = 0.f; st->last_inliers = 0.f;
+  st->calib_g = 0.0; st->calib_m = 0.0; st->calib_v = 0.0;
+  if (c.schedule == SCHED_CONSTANT) st->lr = c.lr_min;
+  else if (c.schedule == SCHED_1CYCLEPOLY) st->lr = c.lr_max * (c.warmup_lr / c.lr_max);  // LinearLR._initial_step
+  else st->lr = onecycle_lr(c, 0);
+}
+
+__global__ void sched_post_kernel(TrainState* st, SchedConfig c, const float* grad_stats, float inv_global_batch,
+                                  float* log_loss, float* log_inl, int log_cap) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!st->active) return;
+  const float loss = grad_stats[0] * inv_global_batch;
+  const float inl = grad_stats[1] * inv_global_batch;
+  st->last_loss = loss;
+  st->last_inliers = inl;
+  if (loss != loss) st->nan_flag = 1;   // ace_trainer.py:615-617
+  const int it = st->iteration;
+  if (it < log_cap) { log_loss[it] = loss; log_inl[it] = inl; }
+  st->opt_steps += 1;
+  // calibration refiner: its own AdamW on the scalar g (refine_calibration.py:21-26,58-59)
+  if (c.refine_calibration) {
+    const double g = (double)grad_stats[2];
+    const double lr = c.calib_lr;
+    st->calib_steps += 1;
+    double p = st->calib_g;
+    p = p * (1.0 - lr * c.weight_decay);
+    st->calib_m = st->calib_m + (g - st->calib_m) * (1.0 - c.beta1);
+    st->calib_v = st->calib_v * c.beta2 + (1.0 - c.beta2) * g * g;
+    const double bc1 = 1.0 - pow(c.beta1, (double)st->calib_steps);
+    const double bc2 = 1.0 - pow(c.beta2, (double)st->calib_steps);
+    const double denom = sqrt(st->calib_v) / sqrt(bc2) + c.eps;
+    p = p - (lr / bc1) * (st->calib_m / denom);
+    // fp32 parameter in the reference
+    st->calib_g = (double)(float)p;
+    st->calib_m = (double)(float)st->calib_m;
+    st->calib_v = (double)(float)st->calib_v;
+  }
+  // scheduler.step()   ace_schedule.py:115-126
+  if (c.schedule == SCHED_1CYCLEPOLY) {
+    if (st->in_cooldown) {
+      // LinearLR(start=1, end=lr_min/lr_max, total_iters=cooldown_iterations), chainable form
+      const int e = ++st->cooldown_epoch;
+      const double sf = 1.0, ef = c.lr_min / c.lr_max;
+      if (e <= c.cooldown_iterations)
+        st->lr = st->lr * (1.0 + (ef - sf) / ((double)c.cooldown_iterations * sf + (double)(e - 1) * (ef - sf)));
+    } else {
+      const int e = ++st->warmup_epoch;
+      const double sf = c.warmup_lr / c.lr_max, ef = 1.0;
+      if (e <= c.warmup_iterations)
+        st->lr = st->lr * (1.0 + (ef - sf) / ((double)c.warmup_iterations * sf + (double)(e - 1) * (ef - sf)));
+    }
+    // rolling buffer of the last 100 batch_inliers
+    if (st->crit_count < 100) st->crit_buf[st->crit_count++] = inl;
+    else {
+      for (int i = 0; i < 99; ++i) st->crit_buf[i] = st->crit_buf[i + 1];
+      st->crit_buf[99] = inl;
+    }
+  } else if (c.schedule == SCHED_CIRCLE) {
+    const int e = ++st->warmup_epoch;
+    st->lr = onecycle_lr(c, e);
+  }
+  st->iteration = it + 1;   // ace_trainer.py:495
+}
+
+// cos(pi x) for x in [0,1] with basic operations only (Taylor around the nearest multiple of 1/2).
+__device__ double det_cos_pi(double x) {
+  const double PI = 3.14159265358979323846;
+  // reduce: cos(pi x) = -sin(pi (x - 1/2))
+  const double y = (x - 0.5) * PI;  // in [-pi/2, pi/2]
+  const double y2 = y * y;
+  // sin(y), Taylor to y^21 (|y| <= pi/2: remainder < 1e-17)
+  double term = y, sum = y;
+  for (int k = 1; k <= 11; ++k) {
+    term = -term * y2 / (double)((2 * k) * (2 * k + 1));
+    sum += term;
+  }
+  return -sum;
+}
+
+}  // namespace acez

@@ -1,0 +1,238 @@
+/*
+ * acez.h -- C ABI of libacez.so, the MI355X (gfx950) implementation of ACE Zero's hot path.
+ *
+ * Two groups of entry points, one per hot-path row group of SURVEY.md section 8:
+ *
+ *   (R) DSAC* RANSAC-PnP registration     replaces  dsacstar/dsacstar.cpp:66-186 (dsacstar_rgb_forward),
+ *                                                   bound at dsacstar/dsacstar.cpp:898-899 as
+ *                                                   dsacstar.forward_rgb and called from
+ *                                                   register_mapping.py:229-242.
+ *   (T) scene-coordinate head training    replaces  ace_trainer.py:454-497 (run_epoch gathers) and
+ *                                                   ace_trainer.py:499-679 (training_step), i.e.
+ *                                                   ace_network.py:120-149 (Head.forward),
+ *                                                   ace_loss.py:39-91 (ReproLoss.compute),
+ *                                                   ace_schedule.py:72-126 (ScheduleACE).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / pybind types cross this boundary.
+ *   - every "d_" pointer is a DEVICE pointer (HBM), every "h_" pointer a host pointer.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream). All device work is enqueued on it;
+ *     functions documented as asynchronous return before the work completes.
+ *   - return value: ACEZ_OK (0) or a negative error code; nothing throws across the boundary.
+ *     "PnP failed" is NOT an error (dsacstar_util.h:104-117,185-196): the call succeeds with a zero pose.
+ *   - the library owns only its contexts and their workspaces; all in/out buffers are caller-owned.
+ */
+#ifndef ACEZ_H
+#define ACEZ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACEZ_OK 0
+#define ACEZ_ERR_INVALID (-1)   /* bad argument (null pointer, bad shape, unsupported option)          */
+#define ACEZ_ERR_HIP (-2)       /* a HIP runtime call failed; acez_last_error() has the message         */
+#define ACEZ_ERR_NODEVICE (-3)  /* no gfx950 device visible                                              */
+#define ACEZ_ERR_NAN (-4)       /* NaN loss detected (ace_trainer.py:615-617 aborts here)                */
+
+/* Message of the last error on this thread (never NULL). */
+const char* acez_last_error(void);
+/* Library version string, e.g. "acez 0.1 (gfx950)". */
+const char* acez_version(void);
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int acez_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (R) DSAC* registration
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Arguments of dsacstar.forward_rgb (dsacstar.cpp:66-78) that are shared by all frames of a batch. */
+typedef struct acez_ransac_params {
+  int32_t hypotheses;        /* ransacHypotheses    (register_mapping.py:64, 64; ace_zero.py:140, 32)   */
+  int32_t max_tries;         /* max_hypotheses_tries (register_mapping.py:67 1e6; ace_zero.py:233, 16)  */
+  float inlier_threshold;    /* inlierThreshold, px (register_mapping.py:70, 10)                        */
+  float inlier_alpha;        /* inlierAlpha         (register_mapping.py:73, 100)                       */
+  float max_reproj;          /* maxReproj, px       (register_mapping.py:76, 100)                       */
+  int32_t subsampling;       /* subSampling = network.OUTPUT_SUBSAMPLE = 8 (ace_network.py:159)         */
+  int32_t max_ref_steps;     /* MAX_REF_STEPS = 100 (dsacstar.cpp:47); <=0 selects 100                  */
+  int32_t reserved;
+} acez_ransac_params;
+
+/* Per-frame pinhole intrinsics: focalLength, ppointX, ppointY of dsacstar.cpp:70-72. */
+typedef struct acez_intrinsics {
+  float focal, ppx, ppy;
+} acez_intrinsics;
+
+typedef struct acez_ransac acez_ransac; /* opaque context: stream-ordered workspaces for up to max_frames */
+
+/* Create a registration context able to process batches of up to `max_frames` frames of at most
+ * `max_h` x `max_w` scene coordinates (60x80 for 480x640 input). device < 0 selects the current device. */
+int acez_ransac_create(acez_ransac** out, int max_frames, int max_h, int max_w, int device);
+void acez_ransac_destroy(acez_ransac* ctx);
+
+/* Batched device variant -- scene coordinates never leave HBM.
+ *   d_scene_coords  float32 [n_frames][3][h][w], the layout Regressor.forward produces (ace_network.py:265-270)
+ *   h_intrinsics    n_frames entries (host)
+ *   seed            randomSeed of dsacstar.cpp:77
+ *   h_frame_ids     n_frames entries (host) or NULL (= 0..n-1). The random stream is keyed by
+ *                   (seed, frame_id, hypothesis, try, draw), see DESIGN.md "RNG"; this replaces the
+ *                   call-order dependent ThreadRand (thread_rand.cpp:13-42).
+ *   d_out_poses     float32 [n_frames][4][4] row-major cam->world pose (dsacstar.cpp:177-182)
+ *   d_out_inliers   int32   [n_frames] return value of forward_rgb (dsacstar.cpp:185)
+ *   d_out_masks     uint8   [n_frames][h][w] inlier map that produced the pose, or NULL
+ * Asynchronous on `stream`. */
+int acez_register_rgb_device(acez_ransac* ctx, const float* d_scene_coords, int n_frames, int h, int w,
+                             const acez_ransac_params* params, const acez_intrinsics* h_intrinsics,
+                             uint64_t seed, const uint64_t* h_frame_ids, float* d_out_poses,
+                             int32_t* d_out_inliers, uint8_t* d_out_masks, void* stream);
+
+/* Host-buffer variant with the exact argument meaning of dsacstar.forward_rgb for ONE frame
+ * (what the reference's pybind wrapper would call). Strides are in elements, as an ATen accessor
+ * reads them (dsacstar.cpp:83-84). Synchronous. Returns ACEZ_OK and writes *out_inliers. */
+int acez_register_rgb_host(acez_ransac* ctx, const float* h_scene_coords, int64_t stride_c,
+                           int64_t stride_h, int64_t stride_w, int h, int w,
+                           const acez_ransac_params* params, const acez_intrinsics* intr, uint64_t seed,
+                           uint64_t frame_id, float* h_out_pose16, int32_t* out_inliers,
+                           uint8_t* h_out_mask /* nullable, h*w */);
+
+/* Diagnostics for the parity tests: copies the per-hypothesis results of the LAST device call.
+ *   h_hyp_poses  float64 [n_frames][hypotheses][6]  (rvec, tvec) after sampling
+ *   h_scores     float64 [n_frames][hypotheses]     soft inlier scores
+ *   h_best       int32   [n_frames]                 selected hypothesis
+ *   h_refined    float64 [n_frames][6]              (rvec, tvec) after refinement
+ * Any pointer may be NULL. Synchronous. */
+int acez_ransac_debug_fetch(acez_ransac* ctx, int n_frames, int hypotheses, double* h_hyp_poses,
+                            double* h_scores, int32_t* h_best, double* h_refined);
+
+/* ------------------------------------------------------------------------------------------------
+ * (T) head training / inference
+ * ---------------------------------------------------------------------------------------------- */
+
+#define ACEZ_HEAD_CHANNELS 512 /* ace_network.py:82, hard-coded in the reference too */
+
+/* learning-rate schedules of ace_schedule.py:17-67 */
+#define ACEZ_SCHED_CONSTANT 0
+#define ACEZ_SCHED_1CYCLEPOLY 1
+#define ACEZ_SCHED_CIRCLE 2
+/* loss types of ace_loss.py:39-91 */
+#define ACEZ_LOSS_TANH 0
+#define ACEZ_LOSS_DYNTANH 1
+#define ACEZ_LOSS_L1 2
+#define ACEZ_LOSS_L1_SQRT 3
+#define ACEZ_LOSS_L1_LOGL1 4
+
+typedef struct acez_head_desc {
+  int32_t num_head_blocks;   /* train_ace.py:83, default 1 -> 8 layers of 512x512 + fc3                */
+  int32_t use_homogeneous;   /* train_ace.py:89, default 1 -> fc3 has 4 outputs                         */
+  float mean[3];             /* Head.mean (ace_network.py:118)                                          */
+  float max_inv_scale;       /* 1/homogeneous_max_scale = 0.25 (ace_network.py:112)                     */
+  float min_inv_scale;       /* 1/homogeneous_min_scale = 100  (ace_network.py:114)                     */
+  float h_beta;              /* ln2/(1-max_inv_scale)          (ace_network.py:113)                     */
+} acez_head_desc;
+
+typedef struct acez_train_config {
+  acez_head_desc head;
+  int32_t max_batch;           /* upper bound of rows per step on this rank (train_ace.py:137, 5120)     */
+  int32_t global_batch;        /* loss normaliser B (ace_trainer.py:613); = max_batch on one GPU         */
+  /* loss (ace_trainer.py:158-166, ace_loss.py) */
+  int32_t loss_type;
+  float soft_clamp;            /* repro_loss_soft_clamp 50                                               */
+  float soft_clamp_min;        /* repro_loss_soft_clamp_min 1                                            */
+  int32_t circle_schedule;     /* ace_loss.py:62                                                         */
+  float hard_clamp;            /* repro_loss_hard_clamp 1000                                             */
+  float depth_min, depth_max, depth_target; /* 0.1, 1000, 10 (train_ace.py:166-176)                      */
+  float inlier_px_threshold;   /* learning_rate_cooldown_trigger_px_threshold 10                         */
+  /* optimiser + schedule (ace_schedule.py) */
+  int32_t schedule;
+  int32_t iterations;          /* options.iterations                                                     */
+  double lr_min, lr_max;
+  int32_t warmup_iterations;   /* 1cyclepoly                                                             */
+  double warmup_lr;
+  int32_t cooldown_iterations;
+  double cooldown_trigger_percent; /* 0.7                                                                */
+  double beta1, beta2, eps, weight_decay; /* AdamW defaults 0.9 0.999 1e-8 1e-2                          */
+  /* calibration refinement (refine_calibration.py): 0 = off */
+  int32_t refine_calibration;
+  float focal_init;            /* CalibrationRefiner.focal_length_init                                   */
+  double calib_lr;
+  int32_t reserved;
+} acez_train_config;
+
+/* Caller-owned parameter storage, so the host side can expose the same state_dict keys as
+ * ace_network.Head (ace_trainer.py:690-693) as views of one flat tensor.
+ * Flat order = Head.named_parameters(): for each 512x512 layer {weight[out][in], bias[out]},
+ * then fc3.weight[no][512], fc3.bias[no]  (2 103 300 floats for the default head). */
+typedef struct acez_param_buffers {
+  float* d_params;  /* fp32 master weights                                   */
+  float* d_adam_m;  /* AdamW exp_avg                                         */
+  float* d_adam_v;  /* AdamW exp_avg_sq                                      */
+  float* d_grad;    /* flat fp32 gradient + 4 trailing stats floats {loss_sum, inlier_count, focal_grad, nan_flag};
+                       this is the bucket a data-parallel host all-reduces between
+                       acez_train_backward and acez_train_update */
+  int64_t n_params; /* must equal acez_head_num_params(head)                 */
+} acez_param_buffers;
+
+/* The training buffer of ace_trainer.py:330-340, with the per-image data stored once per view
+ * (image x augmentation pass) instead of once per patch. */
+typedef struct acez_train_buffer {
+  const void* d_features;      /* bf16 [n_patches][512]                                                */
+  const float* d_target_px;    /* f32  [n_patches][2]                                                  */
+  const int32_t* d_view_idx;   /* i32  [n_patches]  -> view                                            */
+  int64_t n_patches;
+  const float* d_view_aug_inv; /* f32 [n_views][3][4]   aug_poses_inv (ace_trainer.py:331)             */
+  const float* d_view_K;       /* f32 [n_views][3][3]   intrinsics                                     */
+  const float* d_view_Kinv;    /* f32 [n_views][3][3]   intrinsics_inv                                 */
+  const int32_t* d_view_image; /* i32 [n_views]  -> image (pose_idx of ace_trainer.py:339)             */
+  int32_t n_views;
+  const float* d_image_pose_inv; /* f32 [n_images][4][4] world->cam poses_inv (ace_trainer.py:332)      */
+  int32_t n_images;
+} acez_train_buffer;
+
+typedef struct acez_train_state {
+  int32_t iteration;        /* TrainerACE.iteration                                                    */
+  int32_t max_iterations;   /* ScheduleACE.max_iterations (rewritten by the cool-down trigger)         */
+  int32_t in_cooldown;
+  int32_t nan_flag;
+  double lr;                /* lr the NEXT optimiser step will use                                     */
+  float last_loss;          /* loss of the last completed step (already / global_batch)                */
+  float last_batch_inliers; /* fraction, ace_trainer.py:586                                            */
+  double focal_scale;       /* 1 + global_f (refine_calibration.py:28-32)                              */
+} acez_train_state;
+
+typedef struct acez_trainer acez_trainer;
+
+int64_t acez_head_num_params(const acez_head_desc* head);
+int acez_trainer_create(acez_trainer** out, const acez_train_config* cfg, const acez_param_buffers* params,
+                        int device);
+void acez_trainer_destroy(acez_trainer* tr);
+int acez_trainer_set_buffer(acez_trainer* tr, const acez_train_buffer* buf);
+/* Re-derive the bf16 compute copies (W and W^T) from the fp32 master weights; call after loading weights. */
+int acez_trainer_sync_weights(acez_trainer* tr, void* stream);
+
+/* One iteration of ace_trainer.py:499-679 on `n` buffer rows selected by d_indices (int64, device),
+ * split in two so that a data-parallel host can all-reduce d_grad in between:
+ *   backward: schedule bookkeeping, gather, head forward, loss, head backward -> d_grad
+ *   update  : AdamW on the fp32 masters, bf16 recast, scheduler step
+ * Both are asynchronous and never synchronise the host. A step issued after the schedule has ended
+ * (iteration >= max_iterations, ace_trainer.py:509-510) is a device-side no-op. */
+int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, int n, void* stream);
+int acez_train_update(acez_trainer* tr, void* stream);
+/* Convenience: backward + update. */
+int acez_train_step(acez_trainer* tr, const int64_t* d_indices, int n, void* stream);
+/* Synchronises `stream` and copies the schedule state. */
+int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out, void* stream);
+/* Per-iteration log kept on the device: loss and batch_inliers of iterations [first, first+count). */
+int acez_trainer_get_log(acez_trainer* tr, int first, int count, float* h_loss, float* h_inliers, void* stream);
+/* Scene coordinates predicted in the last backward call: f32 [n][3] (diagnostics / tests). */
+int acez_trainer_last_scene_coords(acez_trainer* tr, float* h_xyz, int n, void* stream);
+
+/* Head inference (Regressor.get_scene_coordinates, ace_network.py:262-263) on n feature rows:
+ *   d_features bf16 [n][512]  ->  d_out_xyz f32 [n][3].   Asynchronous. */
+int acez_head_forward(acez_trainer* tr, const void* d_features, int n, float* d_out_xyz, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACEZ_H */

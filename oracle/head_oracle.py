@@ -1,0 +1,375 @@
+"""CPU oracle of the ACE head training step -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(acezero_amd/) never does.  It restates, with plain torch-CPU tensor algebra and a hand-written backward pass,
+what the reference computes in
+
+    ace_network.py:120-149   Head.forward
+    ace_trainer.py:499-679   TrainerACE.training_step (geometry, masks, loss / B)
+    ace_loss.py:39-91        ReproLoss.compute
+    ace_schedule.py:12-126   ScheduleACE (AdamW + LR schedules + cool-down trigger)
+    refine_calibration.py:34-59
+
+Two arithmetic modes:
+  * "fp32": no rounding anywhere.  PINNED against the reference itself: tests/golden/head_*.npz were produced by
+    running the reference's own TrainerACE.training_step (tests/golden/make_head_golden.py) and
+    tests/test_head_oracle.py checks this oracle against them.
+  * "bf16": operands of every 512-wide matmul (activations, weights, propagated gradients) are rounded to
+    bfloat16 at the points where the HIP kernels store them; accumulation stays fp32.  This is what the GPU
+    results are compared with (tolerance 1e-3 relative, BASELINE.json north_star).
+"""
+import math
+
+import numpy as np
+import torch
+
+LOSS_TYPES = {"tanh": 0, "dyntanh": 1, "l1": 2, "l1+sqrt": 3, "l1+logl1": 4}
+
+
+def bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def head_layer_names(num_head_blocks):
+    """state_dict prefixes of the 512-wide layers in Head.named_parameters() order (ace_network.py:85-107)."""
+    names = ["res3_conv1", "res3_conv2", "res3_conv3"]
+    for b in range(num_head_blocks):
+        names += [f"{b}c0", f"{b}c1", f"{b}c2"]
+    names += ["fc1", "fc2"]
+    return names
+
+
+def num_params(num_head_blocks, use_homogeneous=True):
+    L = 3 + 3 * num_head_blocks + 2
+    no = 4 if use_homogeneous else 3
+    return L * (512 * 512 + 512) + no * 513
+
+
+class HeadParams:
+    """Flat fp32 parameter vector with (weight, bias) views per layer, same order as the C ABI."""
+
+    def __init__(self, flat, num_head_blocks=1, use_homogeneous=True):
+        self.nb = num_head_blocks
+        self.L = 3 + 3 * num_head_blocks + 2
+        self.no = 4 if use_homogeneous else 3
+        assert flat.numel() == num_params(num_head_blocks, use_homogeneous)
+        self.flat = flat
+        self.W, self.b = [], []
+        o = 0
+        for _ in range(self.L):
+            self.W.append(flat[o:o + 262144].view(512, 512))
+            o += 262144
+            self.b.append(flat[o:o + 512])
+            o += 512
+        self.W3 = flat[o:o + self.no * 512].view(self.no, 512)
+        o += self.no * 512
+        self.b3 = flat[o:o + self.no]
+
+
+def init_params(seed, num_head_blocks=1, use_homogeneous=True, scale=1.0):
+    """Deterministic (numpy PCG64) stand-in for nn.Conv2d's default init: U(-1/sqrt(512), 1/sqrt(512))."""
+    n = num_params(num_head_blocks, use_homogeneous)
+    rng = np.random.default_rng(seed)
+    bound = scale / math.sqrt(512.0)
+    return torch.from_numpy(rng.uniform(-bound, bound, size=n).astype(np.float32))
+
+
+class HeadOracle:
+    def __init__(self, flat_params, mean, num_head_blocks=1, use_homogeneous=True, mode="fp32",
+                 homogeneous_min_scale=0.01, homogeneous_max_scale=4.0):
+        assert mode in ("fp32", "bf16")
+        self.mode = mode
+        self.r = bf16_round if mode == "bf16" else (lambda x: x)
+        self.p = HeadParams(flat_params, num_head_blocks, use_homogeneous)
+        self.nb = num_head_blocks
+        self.homog = use_homogeneous
+        self.mean = torch.as_tensor(mean, dtype=torch.float32).view(3)
+        # buffers of ace_network.py:109-115 (float32 arithmetic like torch.tensor([..]))
+        max_scale = torch.tensor([homogeneous_max_scale])
+        min_scale = torch.tensor([homogeneous_min_scale])
+        self.max_inv_scale = float((1.0 / max_scale).item())
+        self.h_beta = float((math.log(2) / (1.0 - 1.0 / max_scale)).item())
+        self.min_inv_scale = float((1.0 / min_scale).item())
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, feats):
+        """feats [B,512] fp32 (bf16-representable in bf16 mode). Returns fc3 output s [B,no] and the tape."""
+        r, p = self.r, self.p
+        tape = {"out": [None] * p.L, "R": [None] * (self.nb + 2)}
+        R = r(feats)
+        tape["R"][0] = R
+        for b in range(self.nb + 1):
+            l = 3 * b
+            x1 = r(torch.relu(R @ r(p.W[l]).t() + p.b[l]))
+            x2 = r(torch.relu(x1 @ r(p.W[l + 1]).t() + p.b[l + 1]))
+            y3 = r(torch.relu(x2 @ r(p.W[l + 2]).t() + p.b[l + 2]))
+            tape["out"][l], tape["out"][l + 1], tape["out"][l + 2] = x1, x2, y3
+            R = r(y3 + R)  # ace_network.py:126,133
+            tape["R"][b + 1] = R
+        f1i = 3 * (self.nb + 1)
+        f1 = r(torch.relu(R @ r(p.W[f1i]).t() + p.b[f1i]))
+        f2 = r(torch.relu(f1 @ r(p.W[f1i + 1]).t() + p.b[f1i + 1]))
+        tape["out"][f1i], tape["out"][f1i + 1] = f1, f2
+        s = f2 @ r(p.W3).t() + p.b3
+        return s, tape
+
+    def dehomogenise(self, s):
+        """ace_network.py:139-147. Returns X [B,3] and the pieces the backward needs."""
+        if not self.homog:
+            return s[:, :3] + self.mean, None
+        s3 = s[:, 3]
+        bx = self.h_beta * s3
+        sp = torch.where(bx > 20.0, s3, torch.log1p(torch.exp(bx)) / self.h_beta)
+        hraw = sp + self.max_inv_scale
+        clamped = hraw > self.min_inv_scale
+        h = torch.where(clamped, torch.full_like(hraw, self.min_inv_scale), hraw)
+        X = s[:, :3] / h[:, None] + self.mean
+        return X, (h, clamped, bx)
+
+    def scene_coordinates(self, feats):
+        s, _ = self.forward(feats)
+        return self.dehomogenise(s)[0]
+
+    # ------------------------------------------------------------------ loss + gradient wrt s
+    def loss_and_ds(self, s, batch, cfg, iteration, focal_scale=1.0):
+        """batch: dict with target_px [B,2], aug_inv [B,3,4], pose_inv [B,4,4], K [B,3,3], Kinv [B,3,3].
+        Returns dict(loss_sum, inliers, ds [B,no], focal_grad, X)."""
+        B = s.shape[0]
+        invB = 1.0 / float(cfg["global_batch"])
+        X, hh = self.dehomogenise(s)
+        tu, tv = batch["target_px"][:, 0], batch["target_px"][:, 1]
+        P = torch.bmm(batch["aug_inv"], batch["pose_inv"])  # [B,3,4]   ace_trainer.py:530
+        Xh = torch.cat([X, torch.ones(B, 1)], dim=1)
+        Xc = torch.bmm(P, Xh[:, :, None])[:, :, 0]  # :533
+        K = batch["K"].clone()
+        kscale = None
+        if cfg.get("refine_calibration", False):
+            f0 = float(cfg["focal_init"])
+            kscale = K[:, 0, 0] / f0
+            f = (np.float32(focal_scale) * np.float32(f0)) * kscale
+            K[:, 0, 0] = f
+            K[:, 0, 1] = 0.0
+            K[:, 1, 0] = 0.0
+            K[:, 1, 1] = f
+        pp = torch.bmm(K, Xc[:, :, None])[:, :, 0]  # :536-540
+        dmin, dmax = float(cfg["depth_min"]), float(cfg["depth_max"])
+        zcl = pp[:, 2] < dmin
+        pz = torch.where(zcl, torch.full_like(pp[:, 2], dmin), pp[:, 2])  # :545
+        u, v = pp[:, 0] / pz, pp[:, 1] / pz
+        du, dv = u - tu, v - tv
+        e = du.abs() + dv.abs()  # :552
+        invalid = (Xc[:, 2] < dmin) | (e > float(cfg["hard_clamp"])) | (Xc[:, 2] > dmax)  # :558-565
+        valid = ~invalid
+        # loss weight (ace_loss.py:55-69)
+        lt = cfg["loss_type"]
+        w = float(cfg["soft_clamp"])
+        if lt == "dyntanh":
+            sw = iteration / float(cfg["iterations"])
+            if cfg.get("circle_schedule", True):
+                sw = 1 - np.sqrt(1 - sw ** 2)
+            w = float(np.float32((1 - sw) * cfg["soft_clamp"] + cfg["soft_clamp_min"]))
+        if lt in ("tanh", "dyntanh"):
+            th = torch.tanh(e / w)
+            lv = w * th
+            ge = 1 - th * th
+        elif lt == "l1":
+            big = e > w
+            lv = torch.where(big, torch.zeros_like(e), e)
+            ge = torch.where(big, torch.zeros_like(e), torch.ones_like(e))
+        elif lt == "l1+sqrt":
+            big = e > w
+            lv = torch.where(big, torch.sqrt(w * e), e)
+            ge = torch.where(big, 0.5 * w / torch.sqrt(w * e), torch.ones_like(e))
+        else:
+            big = e > w
+            lv = torch.where(big, torch.log(1 + w * e), e)
+            ge = torch.where(big, w / (1 + w * e), torch.ones_like(e))
+        inl = (valid & (e < float(cfg["inlier_px_threshold"]))).float()
+        gu, gv = ge * torch.sign(du), ge * torch.sign(dv)
+        dp = torch.stack([gu / pz, gv / pz, torch.where(zcl, torch.zeros_like(pz), -(gu * pp[:, 0] + gv * pp[:, 1]) / (pz * pz))], dim=1)
+        dXc_valid = torch.bmm(K.transpose(1, 2), dp[:, :, None])[:, :, 0]
+        # invalid branch: proxy target at constant depth (ace_trainer.py:592-600)
+        px_h = torch.stack([tu, tv, torch.ones_like(tu)], dim=1)
+        tgt = float(cfg["depth_target"]) * torch.bmm(batch["Kinv"], px_h[:, :, None])[:, :, 0]
+        d = tgt - Xc
+        li = d.abs().sum(dim=1)
+        dXc_inv = -torch.sign(d)
+        loss_rows = torch.where(valid, lv, li)
+        dXc = torch.where(valid[:, None], dXc_valid, dXc_inv)
+        dX = torch.bmm(P[:, :, :3].transpose(1, 2), dXc[:, :, None])[:, :, 0] * invB
+        focal_grad = 0.0
+        if kscale is not None:
+            fg = torch.where(valid, (dp[:, 0] * Xc[:, 0] + dp[:, 1] * Xc[:, 1]) * float(cfg["focal_init"]) * kscale, torch.zeros_like(e))
+            focal_grad = float((fg * invB).sum())
+        if self.homog:
+            h, clamped, bx = hh
+            ds = torch.zeros(B, 4)
+            ds[:, :3] = dX / h[:, None]
+            dh = -(dX * s[:, :3]).sum(dim=1) / (h * h)
+            dh = torch.where(clamped, torch.zeros_like(dh), dh)
+            z = torch.exp(bx)
+            ds[:, 3] = torch.where(bx > 20.0, dh, dh * z / (z + 1))
+        else:
+            ds = dX.clone()
+        return {"loss_sum": float(loss_rows.sum()), "inliers": float(inl.sum()), "ds": ds, "focal_grad": focal_grad,
+                "X": X, "e": e, "valid": valid}
+
+    # ------------------------------------------------------------------ backward through the MLP
+    def backward(self, tape, ds):
+        """Returns the flat gradient (same layout as the parameters)."""
+        r, p = self.r, self.p
+        g = torch.zeros_like(p.flat)
+        G = HeadParams(g, self.nb, self.homog)
+        f1i = 3 * (self.nb + 1)
+        f2 = tape["out"][f1i + 1]
+        G.W3.copy_(ds.t() @ f2)
+        G.b3.copy_(ds.sum(dim=0))
+        dZ = [None] * p.L
+        dZ[f1i + 1] = r((ds @ r(p.W3)) * (f2 > 0))
+        dZ[f1i] = r(dZ[f1i + 1] @ r(p.W[f1i + 1])) * (tape["out"][f1i] > 0)
+        t = r(dZ[f1i] @ r(p.W[f1i]))
+        dR = t
+        dZ[3 * self.nb + 2] = t * (tape["out"][3 * self.nb + 2] > 0)
+        for b in range(self.nb, -1, -1):
+            l = 3 * b
+            dZ[l + 1] = r(dZ[l + 2] @ r(p.W[l + 2])) * (tape["out"][l + 1] > 0)
+            dZ[l] = r(dZ[l + 1] @ r(p.W[l + 1])) * (tape["out"][l] > 0)
+            if b > 0:
+                t = r(dZ[l] @ r(p.W[l]) + dR)
+                dR = t
+                dZ[l - 1] = t * (tape["out"][l - 1] > 0)
+        ins = [None] * p.L
+        for b in range(self.nb + 1):
+            ins[3 * b] = tape["R"][b]
+            ins[3 * b + 1] = tape["out"][3 * b]
+            ins[3 * b + 2] = tape["out"][3 * b + 1]
+        ins[f1i] = tape["R"][self.nb + 1]
+        ins[f1i + 1] = tape["out"][f1i]
+        for l in range(p.L):
+            G.W[l].copy_(dZ[l].t() @ ins[l])
+            G.b[l].copy_(dZ[l].sum(dim=0))
+        return g
+
+
+class ScheduleOracle:
+    """ace_schedule.py restated with the chainable LR recurrences of torch.optim.lr_scheduler (LinearLR,
+    OneCycleLR) in Python floats, plus single-tensor AdamW (torch.optim.AdamW defaults)."""
+
+    def __init__(self, cfg, n_params):
+        self.c = cfg
+        self.schedule = cfg["schedule"]
+        self.max_iterations = cfg["iterations"]
+        self.in_cooldown = False
+        self.buf = []
+        self.warm_epoch = 0
+        self.cool_epoch = 0
+        self.steps = 0
+        self.m = torch.zeros(n_params)
+        self.v = torch.zeros(n_params)
+        if self.schedule == "constant":
+            self.lr = cfg["lr_min"]
+        elif self.schedule == "1cyclepoly":
+            self.lr = cfg["lr_max"] * (cfg["warmup_lr"] / cfg["lr_max"])
+        else:
+            self.lr = self._onecycle(0)
+        self.beta1, self.beta2, self.eps, self.wd = 0.9, 0.999, 1e-8, 1e-2
+        # calibration refiner state
+        self.calib_g, self.calib_m, self.calib_v, self.calib_steps = 0.0, 0.0, 0.0, 0
+
+    def _onecycle(self, step_num):
+        c = self.c
+        initial_lr = c["lr_max"] / 25.0
+        min_lr = initial_lr / 1e4
+        end1 = float(0.3 * c["iterations"]) - 1
+        end2 = c["iterations"] - 1
+        if step_num <= end1:
+            start, end, pct = initial_lr, c["lr_max"], (step_num / end1 if end1 > 0 else 1.0)
+        else:
+            start, end, pct = c["lr_max"], min_lr, (step_num - end1) / (end2 - end1)
+        return end + (start - end) / 2.0 * (math.cos(math.pi * pct) + 1)
+
+    def check_and_set_cooldown(self, iteration):
+        c = self.c
+        if self.schedule != "1cyclepoly" or self.in_cooldown or iteration < c["warmup_iterations"]:
+            return
+        by_duration = iteration >= (self.max_iterations - c["cooldown_iterations"])
+        dynamic = len(self.buf) > 0 and min(self.buf) > c["cooldown_trigger_percent"]
+        if by_duration or dynamic:
+            self.in_cooldown = True
+            self.cool_epoch = 0
+            self.max_iterations = iteration + c["cooldown_iterations"]
+
+    def adamw(self, p, g):
+        self.steps += 1
+        lr = self.lr
+        p.mul_(1 - lr * self.wd)
+        self.m.lerp_(g, 1 - self.beta1)
+        self.v.mul_(self.beta2).addcmul_(g, g, value=1 - self.beta2)
+        bc1 = 1 - self.beta1 ** self.steps
+        bc2 = 1 - self.beta2 ** self.steps
+        denom = (self.v.sqrt() / math.sqrt(bc2)).add_(self.eps)
+        p.addcdiv_(self.m, denom, value=-(lr / bc1))
+
+    def calib_step(self, g):
+        lr = self.c["calib_lr"]
+        self.calib_steps += 1
+        f32 = lambda x: float(np.float32(x))
+        p = self.calib_g * (1 - lr * self.wd)
+        self.calib_m = self.calib_m + (g - self.calib_m) * (1 - self.beta1)
+        self.calib_v = self.calib_v * self.beta2 + (1 - self.beta2) * g * g
+        bc1 = 1 - self.beta1 ** self.calib_steps
+        bc2 = 1 - self.beta2 ** self.calib_steps
+        denom = math.sqrt(self.calib_v) / math.sqrt(bc2) + self.eps
+        p = p - (lr / bc1) * (self.calib_m / denom)
+        self.calib_g, self.calib_m, self.calib_v = f32(p), f32(self.calib_m), f32(self.calib_v)
+
+    def sched_step(self, batch_inliers):
+        c = self.c
+        if self.schedule == "1cyclepoly":
+            if self.in_cooldown:
+                self.cool_epoch += 1
+                e, sf, ef, T = self.cool_epoch, 1.0, c["lr_min"] / c["lr_max"], c["cooldown_iterations"]
+                if e <= T:
+                    self.lr = self.lr * (1.0 + (ef - sf) / (T * sf + (e - 1) * (ef - sf)))
+            else:
+                self.warm_epoch += 1
+                e, sf, ef, T = self.warm_epoch, c["warmup_lr"] / c["lr_max"], 1.0, c["warmup_iterations"]
+                if e <= T:
+                    self.lr = self.lr * (1.0 + (ef - sf) / (T * sf + (e - 1) * (ef - sf)))
+            self.buf.append(batch_inliers)
+            if len(self.buf) > 100:
+                self.buf = self.buf[1:]
+        elif self.schedule == "circle":
+            self.warm_epoch += 1
+            self.lr = self._onecycle(self.warm_epoch)
+
+
+class TrainerOracle:
+    """training_step of ace_trainer.py:499-679 on explicit per-patch inputs."""
+
+    def __init__(self, flat_params, mean, cfg, mode="fp32"):
+        self.cfg = cfg
+        self.head = HeadOracle(flat_params, mean, cfg.get("num_head_blocks", 1), cfg.get("use_homogeneous", True), mode)
+        self.sched = ScheduleOracle(cfg, flat_params.numel())
+        self.iteration = 0
+        self.log = []
+
+    def step(self, feats, batch):
+        cfg, sch = self.cfg, self.sched
+        sch.check_and_set_cooldown(self.iteration)
+        if self.iteration >= sch.max_iterations:
+            return None
+        s, tape = self.head.forward(feats)
+        out = self.head.loss_and_ds(s, batch, cfg, self.iteration, focal_scale=1.0 + sch.calib_g)
+        grad = self.head.backward(tape, out["ds"])
+        loss = out["loss_sum"] / cfg["global_batch"]
+        inl = out["inliers"] / cfg["global_batch"]
+        lr_used = sch.lr
+        sch.adamw(self.head.p.flat, grad)
+        if cfg.get("refine_calibration", False):
+            sch.calib_step(out["focal_grad"])
+        sch.sched_step(inl)
+        rec = {"iteration": self.iteration, "loss": loss, "inliers": inl, "lr": lr_used, "grad": grad, "X": out["X"]}
+        self.log.append({k: rec[k] for k in ("iteration", "loss", "inliers", "lr")})
+        self.iteration += 1
+        return rec

@@ -1,0 +1,182 @@
+"""Generate tests/golden/head_*.npz by running the REFERENCE's own code on CPU (fp32).
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_head_golden.py
+
+What runs is the unmodified ace_trainer.TrainerACE.training_step (ace_trainer.py:499-679) with the reference's
+ace_network.Head, ace_loss.ReproLoss, ace_schedule.ScheduleACE, refine_calibration.CalibrationRefiner, on a
+TrainerACE instance created with object.__new__ and hand-set attributes (the constructor needs a dataset on
+disk and a CUDA device).  Modules the container lacks and this path never calls (torchvision, skimage, roma,
+pyrender, trimesh, matplotlib.pyplot) are stubbed.  Inputs and initial weights come from seeded numpy
+generators (acezero_amd.synth, oracle.head_oracle.init_params) so the fixtures only hold OUTPUTS.
+"""
+import io
+import os
+import sys
+import time
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+for name in ["torchvision", "torchvision.transforms", "torchvision.transforms.functional", "skimage", "skimage.transform",
+             "skimage.io", "skimage.color", "skimage.draw", "roma", "pyrender", "trimesh", "matplotlib.pyplot",
+             "ace_visualizer", "ace_vis_util"]:
+    sys.modules.setdefault(name, MagicMock())
+sys.path.insert(0, REF)
+torch.Tensor.cuda = lambda self, *a, **k: self  # refine_calibration.py:42 calls .cuda()
+
+import ace_loss  # noqa: E402
+import ace_network  # noqa: E402
+import ace_schedule  # noqa: E402
+import ace_trainer  # noqa: E402
+import refine_calibration  # noqa: E402
+from acezero_amd import synth  # noqa: E402
+from oracle import head_oracle  # noqa: E402
+
+CONFIGS = {
+    # ace_zero's mapping settings (ace_zero.py:105-123): tanh, 1cyclepoly, lr_max 0.003
+    "head_tanh_1cyclepoly": dict(loss_type="tanh", schedule="1cyclepoly", lr_min=0.0001, lr_max=0.0006, warmup_iterations=4,
+                                 warmup_lr=0.0001, cooldown_iterations=5, cooldown_trigger_percent=-1.0, iterations=40,
+                                 refine_calibration=False, steps=16),
+    # train_ace.py defaults: dyntanh + OneCycle "circle", lr_max 0.005
+    "head_dyntanh_circle": dict(loss_type="dyntanh", schedule="circle", lr_min=0.0001, lr_max=0.001, warmup_iterations=1000,
+                                warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
+                                refine_calibration=False, steps=10),
+    # focal-length refinement in the loop (BASELINE config 3)
+    "head_tanh_calib": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
+                            warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
+                            refine_calibration=True, steps=8),
+}
+B = 512
+SEED = 2089
+
+
+def full_cfg(c):
+    d = dict(c)
+    d.update(global_batch=B, soft_clamp=50.0, soft_clamp_min=1.0, circle_schedule=True, hard_clamp=1000.0,
+             depth_min=0.1, depth_max=1000.0, depth_target=10.0, inlier_px_threshold=10.0, num_head_blocks=1,
+             use_homogeneous=True, calib_lr=0.001)
+    return d
+
+
+def run_reference(cfg, prob, flat0, batches):
+    opt = types.SimpleNamespace(
+        use_half=False, depth_min=cfg["depth_min"], depth_max=cfg["depth_max"], depth_target=cfg["depth_target"],
+        repro_loss_hard_clamp=cfg["hard_clamp"], learning_rate_cooldown_trigger_px_threshold=cfg["inlier_px_threshold"],
+        pose_refinement_wait=0, iterations=cfg["iterations"], learning_rate_schedule=cfg["schedule"],
+        learning_rate_min=cfg["lr_min"], learning_rate_max=cfg["lr_max"], learning_rate_warmup_iterations=cfg["warmup_iterations"],
+        learning_rate_warmup_learning_rate=cfg["warmup_lr"], learning_rate_cooldown_iterations=cfg["cooldown_iterations"],
+        learning_rate_cooldown_trigger_percent_threshold=cfg["cooldown_trigger_percent"])
+    head = ace_network.Head(torch.from_numpy(prob["mean"]), 1, True)
+    P = head_oracle.HeadParams(flat0.clone(), 1, True)
+    sd = head.state_dict()
+    for l, name in enumerate(head_oracle.head_layer_names(1)):
+        sd[name + ".weight"] = P.W[l].clone().view(512, 512, 1, 1)
+        sd[name + ".bias"] = P.b[l].clone()
+    sd["fc3.weight"] = P.W3.clone().view(4, 512, 1, 1)
+    sd["fc3.bias"] = P.b3.clone()
+    head.load_state_dict(sd)
+    head.train()
+
+    tr = object.__new__(ace_trainer.TrainerACE)
+    tr.options = opt
+    tr.iteration = 0
+    tr.epoch = 0
+    tr.use_depth = False
+    tr.iterations_output = 10 ** 9
+    tr.ace_visualizer = None
+    tr.training_start = time.time()
+    tr.log_file = io.StringIO()
+    tr.regressor = types.SimpleNamespace(get_scene_coordinates=head)
+    tr.training_scheduler = ace_schedule.ScheduleACE(head, opt)
+    tr.repro_loss = ace_loss.ReproLoss(total_iterations=cfg["iterations"], soft_clamp=cfg["soft_clamp"],
+                                       soft_clamp_min=cfg["soft_clamp_min"], type=cfg["loss_type"], circle_schedule=True)
+
+    class NoRefiner:  # pose_refinement 'none' (refine_poses.py:221-223)
+        def get_current_poses(self, p, idx): return p.clone()
+        def zero_grad(self, set_to_none=False): pass
+        def step(self): pass
+        def get_all_original_poses(self): return torch.zeros(1, 3, 4)
+        def get_all_current_poses(self): return torch.zeros(1, 3, 4)
+    tr.pose_refiner = NoRefiner()
+    if cfg["refine_calibration"]:
+        ds = types.SimpleNamespace(get_focal_length=lambda i: float(prob["focal"]), __len__=lambda: 1)
+        cr = object.__new__(refine_calibration.CalibrationRefiner)
+        cr.focal_length_init = float(prob["focal"])
+        cr.global_f = torch.zeros(1).detach().requires_grad_()
+        cr.optimizer = torch.optim.AdamW([cr.global_f], lr=cfg["calib_lr"])
+        tr.K_optimizer = cr
+    else:
+        tr.K_optimizer = None
+
+    rec = {"loss": [], "inliers": [], "lr": [], "max_iterations": [], "focal_scale": []}
+    sched = tr.training_scheduler
+    orig_backward, orig_step = sched.backward, sched.step
+
+    def backward(loss):
+        rec["loss"].append(float(loss))
+        orig_backward(loss)
+
+    def step(batch_inliers):
+        rec["inliers"].append(float(batch_inliers))
+        rec["lr"].append(float(sched.optimizer.param_groups[0]["lr"]))
+        orig_step(batch_inliers)
+    sched.backward, sched.step = backward, step
+
+    snaps = {}
+    coords0 = None
+    for it, idx in enumerate(batches):
+        pp = synth.expand_per_patch(prob, idx)
+        t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in pp.items()}
+        if it == 0:
+            with torch.no_grad():
+                f = t["features"][None, None, ...].view(-1, 16, 32, 512).permute(0, 3, 1, 2)
+                coords0 = head(f).permute(0, 2, 3, 1).flatten(0, 2).clone().numpy()
+        n_before = len(rec["loss"])
+        ace_trainer.TrainerACE.training_step(tr, t["features"], t["target_px"], t["aug_inv"], t["pose_inv"], t["K"], t["Kinv"],
+                                             torch.zeros(B, 3), t["pose_idx"][:, None])
+        ran = len(rec["loss"]) > n_before
+        rec["max_iterations"].append(int(sched.max_iterations))
+        rec["focal_scale"].append(float(1 + tr.K_optimizer.global_f) if tr.K_optimizer is not None else 1.0)
+        if not ran:
+            break
+        tr.iteration += 1
+        snap = torch.cat([p.detach().flatten() for p in head.parameters()]).numpy().copy()
+        if it == 0:
+            snaps[0] = snap
+        snaps = {0: snaps[0], it: snap}
+    return rec, snaps, coords0
+
+
+def main():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    for name, c in CONFIGS.items():
+        cfg = full_cfg(c)
+        prob = synth.make_training_problem(seed=SEED, n_images=6, views_per_image=2, patches_per_view=128)
+        # the trainer stores features in half precision; keep them bf16-representable so both modes see the same inputs
+        prob["features"] = torch.from_numpy(prob["features"]).to(torch.bfloat16).to(torch.float32).numpy()
+        flat0 = head_oracle.init_params(SEED + 1)
+        rng = np.random.default_rng(SEED + 2)
+        n = prob["features"].shape[0]
+        batches = [rng.permutation(n)[:B] for _ in range(cfg["steps"])]
+        rec, snaps, coords0 = run_reference(cfg, prob, flat0, batches)
+        first = snaps[0]
+        last_it = max(snaps)
+        sel = np.arange(0, first.size, 997)
+        np.savez_compressed(
+            os.path.join(out_dir, name + ".npz"),
+            loss=np.array(rec["loss"], np.float64), inliers=np.array(rec["inliers"], np.float64), lr=np.array(rec["lr"], np.float64),
+            max_iterations=np.array(rec["max_iterations"], np.int64), focal_scale=np.array(rec["focal_scale"], np.float64),
+            coords0=coords0[:64].astype(np.float32), param_sel=sel, params_after_first=first[sel], params_after_last=snaps[last_it][sel],
+            last_it=np.int64(last_it), steps_run=np.int64(len(rec["loss"])))
+        print(name, "steps run", len(rec["loss"]), "loss", rec["loss"][:3], "inl", rec["inliers"][:3], "lr", rec["lr"][:3],
+              "max_it", rec["max_iterations"][-1], "focal", rec["focal_scale"][-1])
+
+
+if __name__ == "__main__":
+    main()

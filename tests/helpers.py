@@ -1,0 +1,49 @@
+"""Shared helpers of the parity tests (inputs identical to tests/golden/make_head_golden.py)."""
+import numpy as np
+import torch
+
+from acezero_amd import synth
+from oracle import head_oracle
+
+B = 512
+SEED = 2089
+
+HEAD_CONFIGS = {
+    "head_tanh_1cyclepoly": dict(loss_type="tanh", schedule="1cyclepoly", lr_min=0.0001, lr_max=0.0006, warmup_iterations=4,
+                                 warmup_lr=0.0001, cooldown_iterations=5, cooldown_trigger_percent=-1.0, iterations=40,
+                                 refine_calibration=False, steps=16),
+    "head_dyntanh_circle": dict(loss_type="dyntanh", schedule="circle", lr_min=0.0001, lr_max=0.001, warmup_iterations=1000,
+                                warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
+                                refine_calibration=False, steps=10),
+    "head_tanh_calib": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
+                            warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
+                            refine_calibration=True, steps=8),
+}
+
+
+def full_cfg(c, prob=None):
+    d = dict(c)
+    d.update(global_batch=B, soft_clamp=50.0, soft_clamp_min=1.0, circle_schedule=True, hard_clamp=1000.0,
+             depth_min=0.1, depth_max=1000.0, depth_target=10.0, inlier_px_threshold=10.0, num_head_blocks=1,
+             use_homogeneous=True, calib_lr=0.001)
+    if prob is not None:
+        d["focal_init"] = float(prob["focal"])
+    return d
+
+
+def golden_problem():
+    prob = synth.make_training_problem(seed=SEED, n_images=6, views_per_image=2, patches_per_view=128)
+    prob["features"] = torch.from_numpy(prob["features"]).to(torch.bfloat16).to(torch.float32).numpy()
+    flat0 = head_oracle.init_params(SEED + 1)
+    return prob, flat0
+
+
+def golden_batches(prob, steps):
+    rng = np.random.default_rng(SEED + 2)
+    n = prob["features"].shape[0]
+    return [rng.permutation(n)[:B] for _ in range(steps)]
+
+
+def torch_batch(prob, idx):
+    pp = synth.expand_per_patch(prob, idx)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in pp.items()}

@@ -1,0 +1,57 @@
+"""CPU: the head oracle (fp32 mode) against the golden vectors produced by the reference's own training_step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import head_oracle
+from tests import helpers
+
+
+@pytest.mark.parametrize("name", list(helpers.HEAD_CONFIGS))
+def test_oracle_fp32_matches_reference_golden(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    prob, flat0 = helpers.golden_problem()
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS[name], prob)
+    batches = helpers.golden_batches(prob, cfg["steps"])
+    tr = head_oracle.TrainerOracle(flat0.clone(), prob["mean"], cfg, mode="fp32")
+    losses, inl, lrs, maxit, focal = [], [], [], [], []
+    snaps = {}
+    for it, idx in enumerate(batches):
+        b = helpers.torch_batch(prob, idx)
+        if it == 0:
+            X0 = tr.head.scene_coordinates(b["features"])[:64].numpy()
+            np.testing.assert_allclose(X0, g["coords0"], rtol=1e-4, atol=1e-4)
+        rec = tr.step(b["features"], b)
+        maxit.append(tr.sched.max_iterations)
+        focal.append(1.0 + tr.sched.calib_g)
+        if rec is None:
+            break
+        losses.append(rec["loss"]); inl.append(rec["inliers"]); lrs.append(rec["lr"])
+        snaps[it] = tr.head.p.flat.clone().numpy()
+    assert len(losses) == int(g["steps_run"])
+    np.testing.assert_allclose(lrs, g["lr"], rtol=1e-12)
+    np.testing.assert_array_equal(maxit, g["max_iterations"])
+    np.testing.assert_allclose(inl, g["inliers"], atol=1.5 / helpers.B)
+    # the first steps pin the arithmetic; later ones only bound the drift (mask/sign flips amplify 1e-7 differences)
+    np.testing.assert_allclose(losses[:5], g["loss"][:5], rtol=2e-5)
+    np.testing.assert_allclose(losses, g["loss"], rtol=3e-2)
+    sel = g["param_sel"]
+    np.testing.assert_allclose(snaps[0][sel], g["params_after_first"], rtol=0, atol=2e-6)
+    # after several AdamW steps sign flips of tiny gradients can move single weights by ~lr; compare robustly
+    d = np.abs(snaps[int(g["last_it"])][sel] - g["params_after_last"])
+    moved = np.abs(snaps[int(g["last_it"])][sel] - flat0.numpy()[sel]).mean()
+    assert np.median(d) < 0.05 * moved and d.max() < 0.02, (np.median(d), moved, d.max())
+    np.testing.assert_allclose(focal, g["focal_scale"], rtol=0, atol=2e-5)
+
+
+def test_bf16_mode_close_to_fp32():
+    prob, flat0 = helpers.golden_problem()
+    idx = helpers.golden_batches(prob, 1)[0]
+    b = helpers.torch_batch(prob, idx)
+    h32 = head_oracle.HeadOracle(flat0.clone(), prob["mean"], mode="fp32")
+    h16 = head_oracle.HeadOracle(flat0.clone(), prob["mean"], mode="bf16")
+    X32, X16 = h32.scene_coordinates(b["features"]), h16.scene_coordinates(b["features"])
+    rel = (X32 - X16).norm() / (X32 - torch.from_numpy(prob["mean"])).norm()
+    assert rel < 0.05
