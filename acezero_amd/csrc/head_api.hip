@@ -34,6 +34,30 @@ struct acez_trainer {
   TrainState* st = nullptr;
   SchedConfig sc;
   std::vector<void*> allocs;
+  // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<std::pair<int, std::pair<int, int>>> ev_used;  // (class, (start idx, stop idx))
+  size_t ev_next = 0;
+};
+
+enum { KC_SCHED = 0, KC_GATHER, KC_GEMM_FWD, KC_LOSS, KC_GEMM_DGRAD, KC_WGRAD, KC_REDUCE, KC_ADAMW, KC_COUNT };
+
+struct ProfScope {
+  acez_trainer* tr; hipStream_t s; int cls; int i0 = -1;
+  ProfScope(acez_trainer* t, hipStream_t st, int c) : tr(t), s(st), cls(c) {
+    if (!tr->profiling) return;
+    if (tr->ev_next + 2 > tr->ev_pool.size()) {
+      for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; tr->ev_pool.push_back(e); }
+    }
+    i0 = (int)tr->ev_next; tr->ev_next += 2;
+    (void)hipEventRecord(tr->ev_pool[i0], s);
+  }
+  ~ProfScope() {
+    if (i0 < 0) return;
+    (void)hipEventRecord(tr->ev_pool[i0 + 1], s);
+    tr->ev_used.push_back({cls, {i0, i0 + 1}});
+  }
 };
 
 static int dmalloc(acez_trainer* tr, void** p, size_t bytes) {
@@ -52,6 +76,7 @@ extern "C" int64_t acez_head_num_params(const acez_head_desc* head) {
 extern "C" void acez_trainer_destroy(acez_trainer* tr) {
   if (!tr) return;
   for (void* p : tr->allocs) (void)hipFree(p);
+  for (hipEvent_t e : tr->ev_pool) (void)hipEventDestroy(e);
   delete tr;
 }
 
@@ -160,6 +185,7 @@ extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
 
 // forward chain on n rows whose input features are in `in0`; returns the fc2 output buffer
 static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, const TrainState* st, hipStream_t s) {
+  auto PS = [&](int c) { return ProfScope(tr, s, c); };
   const float* P = tr->pb.d_params;
   const dim3 grid(4, (n + 127) / 128), blk(256);
   auto gemm = [&](int l, const uint16_t* in, uint16_t* out_main, const uint16_t* res, uint16_t* out_aux) {
@@ -167,6 +193,7 @@ static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, co
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144;
     g.add = nullptr; g.mask = nullptr; g.res = res; g.out_main = out_main; g.out_aux = out_aux;
     g.M = n; g.N = 512; g.K = 512; g.relu = 1; g.aux_mode = res ? AUX_RESIDUAL : AUX_NONE; g.st = st;
+    auto ps = PS(KC_GEMM_FWD);
     hipLaunchKernelGGL(rowgemm_kernel, grid, blk, 0, s, g);
   };
   const uint16_t* r = in0;
@@ -198,9 +225,11 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
   const TrainState* st = tr->st;
   tr->last_n = n;
 
-  hipLaunchKernelGGL(sched_pre_kernel, dim3(1), dim3(64), 0, s, tr->st, tr->sc);
+  { ProfScope ps(tr, s, KC_SCHED); hipLaunchKernelGGL(sched_pre_kernel, dim3(1), dim3(64), 0, s, tr->st, tr->sc); }
+  ProfScope* psg = new ProfScope(tr, s, KC_GATHER);
   hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024), dim3(256), 0, s,
                      (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n, st);
+  delete psg;
   uint16_t* act = launch_forward(tr, tr->R[0], n, st, s);
 
   const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
@@ -218,6 +247,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.inv_batch = 1.0f / (float)tr->cfg.global_batch; a.focal_init = tr->cfg.focal_init;
     a.st = st; a.out_xyz = tr->xyz; a.dZ = tr->dZ[f2];
     a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
+    ProfScope ps(tr, s, KC_LOSS);
     hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, s, a);
   }
 
@@ -228,6 +258,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     g.In = tr->dZ[l]; g.W = tr->WbT + (size_t)l * 262144; g.bias = nullptr; g.add = add; g.mask = mask; g.res = nullptr;
     g.out_main = out_main; g.out_aux = out_aux; g.M = n; g.N = 512; g.K = 512; g.relu = 0;
     g.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE; g.st = st;
+    ProfScope ps(tr, s, KC_GEMM_DGRAD);
     hipLaunchKernelGGL(rowgemm_kernel, grid, blk, 0, s, g);
   };
   dgrad(f2, nullptr, tr->out[f1], tr->dZ[f1], nullptr);
@@ -254,6 +285,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     }
     a.In[f1] = tr->R[tr->nb + 1]; a.In[f2] = tr->out[f1];
     a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.st = st;
+    ProfScope ps(tr, s, KC_WGRAD);
     hipLaunchKernelGGL(wgrad_kernel, dim3(16 * tr->nslabs, tr->L), dim3(256), 0, s, a);
   }
   {
@@ -262,6 +294,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials; a.n_loss_blocks = nblk; a.grad = tr->pb.d_grad;
     a.n_wide = tr->n_wide; a.n_params = tr->n_params; a.st = st;
     const int64_t tot = tr->n_params + 4;
+    ProfScope ps(tr, s, KC_REDUCE);
     hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a);
   }
   ACEZ_HIP_CHECK(hipGetLastError());
@@ -275,7 +308,8 @@ extern "C" int acez_train_update(acez_trainer* tr, void* stream) {
   AdamArgs a;
   fill_adam_args(tr, a);
   const int nsmall = (int)(((int64_t)tr->L * 512 + (int64_t)tr->no * 513 + 255) / 256);
-  hipLaunchKernelGGL(adamw_kernel, dim3(tr->L * 64 + nsmall), dim3(256), 0, s, a);
+  { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3(tr->L * 64 + nsmall), dim3(256), 0, s, a); }
+  ProfScope ps2(tr, s, KC_SCHED);
   hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, tr->st, tr->sc, (const float*)(tr->pb.d_grad + tr->n_params),
                      1.0f / (float)tr->cfg.global_batch, tr->log_loss, tr->log_inl, tr->log_cap);
   ACEZ_HIP_CHECK(hipGetLastError());
@@ -335,5 +369,31 @@ extern "C" int acez_head_forward(acez_trainer* tr, const void* d_features, int n
     hipLaunchKernelGGL(loss_kernel, dim3((cnt + 31) / 32), dim3(256), 0, s, a);
   }
   ACEZ_HIP_CHECK(hipGetLastError());
+  return ACEZ_OK;
+}
+
+// Per-kernel-class timing (diagnostics for bench.py's roofline leg): when enabled every launch of the following
+// train_backward/update calls is bracketed by HIP events on the launch stream. acez_trainer_get_profile
+// synchronises, returns the summed milliseconds and launch counts per class
+// {sched, gather, gemm_fwd, loss, gemm_dgrad, wgrad, grad_reduce, adamw} and clears the record.
+extern "C" int acez_trainer_set_profiling(acez_trainer* tr, int enable) {
+  ACEZ_REQUIRE(tr, "null trainer");
+  tr->profiling = enable != 0;
+  return ACEZ_OK;
+}
+extern "C" int acez_trainer_get_profile(acez_trainer* tr, float* h_ms8, int32_t* h_counts8) {
+  ACEZ_REQUIRE(tr && h_ms8 && h_counts8, "null pointer");
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  ACEZ_HIP_CHECK(hipDeviceSynchronize());
+  for (int i = 0; i < KC_COUNT; ++i) { h_ms8[i] = 0.f; h_counts8[i] = 0; }
+  for (auto& u : tr->ev_used) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, tr->ev_pool[u.second.first], tr->ev_pool[u.second.second]) == hipSuccess) {
+      h_ms8[u.first] += ms;
+      h_counts8[u.first] += 1;
+    }
+  }
+  tr->ev_used.clear();
+  tr->ev_next = 0;
   return ACEZ_OK;
 }

@@ -1,0 +1,207 @@
+"""Host side of the head path: device buffers (torch tensors as plain HBM allocations) + the C-ABI trainer.
+
+Mirrors the reference's seams:
+  HeadTrainer.state_dict()/load_state_dict()  ->  Head.state_dict() keys of ace_network.py (ace_trainer.py:690-693)
+  HeadTrainer.step(indices)                   ->  TrainerACE.training_step (ace_trainer.py:499-679)
+  HeadTrainer.get_scene_coordinates(features) ->  Regressor.get_scene_coordinates (ace_network.py:262-263)
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+LOSS_TYPES = {"tanh": 0, "dyntanh": 1, "l1": 2, "l1+sqrt": 3, "l1+logl1": 4, "l1+log": 4}
+SCHEDULES = {"constant": 0, "1cyclepoly": 1, "circle": 2}
+
+
+def layer_names(num_head_blocks):
+    names = ["res3_conv1", "res3_conv2", "res3_conv3"]
+    for b in range(num_head_blocks):
+        names += [f"{b}c0", f"{b}c1", f"{b}c2"]
+    return names + ["fc1", "fc2"]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HeadTrainer:
+    """One head + its optimiser/schedule state on one GPU, driven through libacez.so."""
+
+    def __init__(self, mean, *, num_head_blocks=1, use_homogeneous=True, max_batch=5120, global_batch=None,
+                 loss_type="dyntanh", soft_clamp=50.0, soft_clamp_min=1.0, circle_schedule=True, hard_clamp=1000.0,
+                 depth_min=0.1, depth_max=1000.0, depth_target=10.0, inlier_px_threshold=10.0, schedule="circle",
+                 iterations=25000, lr_min=0.0005, lr_max=0.005, warmup_iterations=1000, warmup_lr=0.0005,
+                 cooldown_iterations=5000, cooldown_trigger_percent=0.7, refine_calibration=False, focal_init=0.0,
+                 calib_lr=0.001, homogeneous_min_scale=0.01, homogeneous_max_scale=4.0, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HeadTrainer needs a GPU: the head kernels are HIP only (no CPU fallback)")
+        self.lib = N.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.nb, self.homog = int(num_head_blocks), bool(use_homogeneous)
+        self.L = 3 + 3 * self.nb + 2
+        self.no = 4 if self.homog else 3
+        self.mean = torch.as_tensor(mean, dtype=torch.float32).view(3).clone()
+        max_scale = torch.tensor([homogeneous_max_scale])
+        min_scale = torch.tensor([homogeneous_min_scale])
+        self.buffers = {  # ace_network.py:109-118
+            "max_scale": max_scale, "min_scale": min_scale, "max_inv_scale": 1.0 / max_scale,
+            "h_beta": math.log(2) / (1.0 - 1.0 / max_scale), "min_inv_scale": 1.0 / min_scale,
+            "mean": self.mean.view(1, 3, 1, 1).clone(),
+        }
+        hd = N.HeadDesc(self.nb, int(self.homog), (C.c_float * 3)(*[float(x) for x in self.mean]),
+                        float(self.buffers["max_inv_scale"]), float(self.buffers["min_inv_scale"]), float(self.buffers["h_beta"]))
+        self.n_params = int(self.lib.acez_head_num_params(C.byref(hd)))
+        dev = self.device
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros_like(self.params)
+        self.adam_v = torch.zeros_like(self.params)
+        self.grad = torch.zeros(self.n_params + 4, dtype=torch.float32, device=dev)  # + {loss, inliers, dfocal, pad}
+        self.max_batch = int(max_batch)
+        self.global_batch = int(global_batch or max_batch)
+        cfg = N.TrainConfig()
+        cfg.head = hd
+        cfg.max_batch, cfg.global_batch = self.max_batch, self.global_batch
+        cfg.loss_type = LOSS_TYPES[loss_type]
+        cfg.soft_clamp, cfg.soft_clamp_min, cfg.circle_schedule = soft_clamp, soft_clamp_min, int(circle_schedule)
+        cfg.hard_clamp, cfg.depth_min, cfg.depth_max, cfg.depth_target = hard_clamp, depth_min, depth_max, depth_target
+        cfg.inlier_px_threshold = inlier_px_threshold
+        cfg.schedule, cfg.iterations = SCHEDULES[schedule], int(iterations)
+        cfg.lr_min, cfg.lr_max, cfg.warmup_iterations, cfg.warmup_lr = lr_min, lr_max, int(warmup_iterations), warmup_lr
+        cfg.cooldown_iterations, cfg.cooldown_trigger_percent = int(cooldown_iterations), cooldown_trigger_percent
+        cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay = 0.9, 0.999, 1e-8, 1e-2  # torch.optim.AdamW defaults
+        cfg.refine_calibration, cfg.focal_init, cfg.calib_lr = int(refine_calibration), float(focal_init), calib_lr
+        pb = N.ParamBuffers(_ptr(self.params), _ptr(self.adam_m), _ptr(self.adam_v), _ptr(self.grad), self.n_params)
+        h = C.c_void_p()
+        N.check(self.lib.acez_trainer_create(C.byref(h), C.byref(cfg), C.byref(pb), self.device.index))
+        self._h = h
+        self._buf = None
+        self.iterations = int(iterations)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.acez_trainer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- parameters <-> Head.state_dict()
+    def _views(self):
+        out, o = {}, 0
+        for name in layer_names(self.nb):
+            out[name + ".weight"] = self.params[o:o + 262144].view(512, 512, 1, 1)
+            o += 262144
+            out[name + ".bias"] = self.params[o:o + 512]
+            o += 512
+        out["fc3.weight"] = self.params[o:o + self.no * 512].view(self.no, 512, 1, 1)
+        o += self.no * 512
+        out["fc3.bias"] = self.params[o:o + self.no]
+        return out
+
+    def state_dict(self):
+        """Same keys / shapes as ace_network.Head.state_dict() (fp32; the trainer saves .half(), ace_trainer.py:690)."""
+        sd = {k: v.clone() for k, v in self.buffers.items() if self.homog or k == "mean"}
+        sd.update({k: v.detach().clone() for k, v in self._views().items()})
+        return sd
+
+    def load_state_dict(self, sd):
+        views = self._views()
+        for k, v in views.items():
+            v.copy_(sd[k].to(torch.float32).view_as(v))
+        if "mean" in sd and not torch.allclose(sd["mean"].float().view(3).cpu(), self.mean):
+            raise ValueError("mean of the checkpoint differs from the mean this trainer was created with")
+        self.sync_weights()
+
+    def load_flat(self, flat):
+        self.params.copy_(torch.as_tensor(flat, dtype=torch.float32).to(self.device))
+        self.sync_weights()
+
+    def sync_weights(self):
+        N.check(self.lib.acez_trainer_sync_weights(self._h, _stream()))
+
+    # ---------------------------------------------------------------- training buffer
+    def set_buffer(self, features, target_px, view_idx, view_aug_inv, view_K, view_Kinv, view_image, image_pose_inv):
+        """All arguments are arrays/tensors in the de-duplicated layout of acez_train_buffer (include/acez.h)."""
+        dev = self.device
+        t = lambda x, dt: torch.as_tensor(x).to(device=dev, dtype=dt).contiguous()
+        self._buf = {
+            "features": t(features, torch.bfloat16), "target_px": t(target_px, torch.float32), "view_idx": t(view_idx, torch.int32),
+            "view_aug_inv": t(view_aug_inv, torch.float32), "view_K": t(view_K, torch.float32),
+            "view_Kinv": t(view_Kinv, torch.float32), "view_image": t(view_image, torch.int32),
+            "image_pose_inv": t(image_pose_inv, torch.float32),
+        }
+        b = self._buf
+        assert b["features"].shape[1] == 512
+        tb = N.TrainBuffer(_ptr(b["features"]), _ptr(b["target_px"]), _ptr(b["view_idx"]), b["features"].shape[0],
+                           _ptr(b["view_aug_inv"]), _ptr(b["view_K"]), _ptr(b["view_Kinv"]), _ptr(b["view_image"]),
+                           b["view_aug_inv"].shape[0], _ptr(b["image_pose_inv"]), b["image_pose_inv"].shape[0])
+        N.check(self.lib.acez_trainer_set_buffer(self._h, C.byref(tb)))
+
+    @property
+    def buffer_size(self):
+        return 0 if self._buf is None else int(self._buf["features"].shape[0])
+
+    # ---------------------------------------------------------------- the step
+    def backward(self, indices):
+        """indices: int64 CUDA tensor of buffer rows (<= max_batch). Asynchronous."""
+        assert indices.dtype == torch.int64 and indices.is_cuda and indices.is_contiguous()
+        N.check(self.lib.acez_train_backward(self._h, _ptr(indices), int(indices.numel()), _stream()))
+
+    def update(self):
+        N.check(self.lib.acez_train_update(self._h, _stream()))
+
+    def step(self, indices):
+        assert indices.dtype == torch.int64 and indices.is_cuda and indices.is_contiguous()
+        N.check(self.lib.acez_train_step(self._h, _ptr(indices), int(indices.numel()), _stream()))
+
+    def state(self):
+        st = N.TrainState()
+        rc = self.lib.acez_trainer_get_state(self._h, C.byref(st), _stream())
+        if rc not in (0, -4):
+            N.check(rc)
+        return {"iteration": st.iteration, "max_iterations": st.max_iterations, "in_cooldown": bool(st.in_cooldown),
+                "nan": bool(st.nan_flag), "lr": st.lr, "loss": st.last_loss, "batch_inliers": st.last_batch_inliers,
+                "focal_scale": st.focal_scale}
+
+    def log(self, first, count):
+        loss = np.zeros(count, np.float32)
+        inl = np.zeros(count, np.float32)
+        N.check(self.lib.acez_trainer_get_log(self._h, first, count, loss.ctypes.data_as(C.c_void_p),
+                                              inl.ctypes.data_as(C.c_void_p), _stream()))
+        return loss, inl
+
+    def last_scene_coords(self, n):
+        out = np.zeros((n, 3), np.float32)
+        N.check(self.lib.acez_trainer_last_scene_coords(self._h, out.ctypes.data_as(C.c_void_p), n, _stream()))
+        return out
+
+    KERNEL_CLASSES = ("sched", "gather", "gemm_fwd", "loss", "gemm_dgrad", "wgrad", "grad_reduce", "adamw")
+
+    def set_profiling(self, on):
+        N.check(self.lib.acez_trainer_set_profiling(self._h, int(bool(on))))
+
+    def get_profile(self):
+        """{class: (total_ms, launches)} measured with HIP events on the launch stream since profiling was enabled."""
+        ms = np.zeros(8, np.float32)
+        cnt = np.zeros(8, np.int32)
+        N.check(self.lib.acez_trainer_get_profile(self._h, ms.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
+
+    # ---------------------------------------------------------------- inference
+    def get_scene_coordinates(self, features):
+        """features: [n,512] CUDA tensor (any float dtype) -> [n,3] float32 CUDA tensor."""
+        f = features.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        out = torch.empty(f.shape[0], 3, dtype=torch.float32, device=self.device)
+        N.check(self.lib.acez_head_forward(self._h, _ptr(f), int(f.shape[0]), _ptr(out), _stream()))
+        return out

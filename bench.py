@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the ACE Zero hot path on MI355X (contract: see the round prompt / DESIGN.md).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+A "step" is one training iteration of the scene-coordinate head (ace_trainer.py:499-679) on 5120 patches per
+GPU drawn from an 8M-patch synthetic feature buffer resident in HBM (BASELINE config[1]: full ace_zero.py
+mapping on one MI355X, default head).  `value` = patches/s of the whole job.  The same run also times the second
+half of the metric, DSAC* registration (images/s, scene coordinates resident in HBM, ace_zero's 32 hypotheses /
+16 tries), and reports it under "registration".  With N > 1 the feature buffer is sharded across ranks
+(each rank owns buffer_patches/N rows... here: its own 8M/N-row shard), every rank runs 5120 rows per step and the
+flat gradient bucket is summed with one RCCL all-reduce per step (weak scaling: global batch = 5120 N);
+registration frames are sharded across ranks with no collective.
+
+Extra objects on the JSON line: "roofline" for the dominant kernel (rowgemm_kernel, bf16 MFMA), measured live
+with HIP events on the launch stream, and "cpu_baseline": the oracle (a port -- the reference cannot run on the
+GPU box) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 5120                      # train_ace.py:137
+FLOP_PER_PATCH = 12_070_912       # fwd 4 198 400 + wgrad 4 198 400 + dgrad 3 674 112
+GEMM_FLOP_PER_LAUNCH_PER_ROW = 2 * 512 * 512
+MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--buffer-patches", type=int, default=8_000_000)   # train_ace.py:122
+    ap.add_argument("--reg-frames", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_buffer(n_patches, device, seed):
+    """Synthetic training buffer directly in HBM (geometry from acezero_amd.synth, features generated on device)."""
+    from acezero_amd import synth
+    views = 2000
+    prob = synth.make_training_problem(seed=seed, n_images=1000, views_per_image=2, patches_per_view=8)
+    g = torch.Generator(device=device).manual_seed(seed)
+    feats = torch.empty(n_patches, 512, dtype=torch.bfloat16, device=device)
+    chunk = 1 << 20
+    for lo in range(0, n_patches, chunk):
+        hi = min(n_patches, lo + chunk)
+        feats[lo:hi] = torch.randn(hi - lo, 512, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+    view_idx = torch.randint(0, views, (n_patches,), generator=g, device=device, dtype=torch.int32)
+    gx = torch.randint(0, 80, (n_patches,), generator=g, device=device)
+    gy = torch.randint(0, 60, (n_patches,), generator=g, device=device)
+    target_px = torch.stack([8.0 * (gx + 0.5), 8.0 * (gy + 0.5)], dim=1).float()
+    return prob, feats, target_px, view_idx
+
+
+def bench_training(args, rank, world, device):
+    from acezero_amd.head import HeadTrainer
+    from oracle import head_oracle
+    per_rank = args.buffer_patches // world
+    prob, feats, target_px, view_idx = make_buffer(per_rank, device, 2089 + rank)
+    total_iters = args.steps + args.warmup + 64
+    tr = HeadTrainer(prob["mean"], max_batch=BATCH, global_batch=BATCH * world, loss_type="tanh", schedule="1cyclepoly",
+                     iterations=max(total_iters, 25000), lr_min=0.0005, lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005,
+                     cooldown_iterations=5000)                                  # ace_zero.py:105-123 mapping settings
+    tr.load_flat(head_oracle.init_params(1))
+    tr.set_buffer(feats, target_px, view_idx, prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"], prob["view_image"],
+                  prob["image_pose_inv"])
+    g = torch.Generator(device=device).manual_seed(8191 + rank)
+    perm = torch.randperm(per_rank, generator=g, device=device)               # ace_trainer.py:466
+    nb = per_rank // BATCH
+    batches = [perm[i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(nb, total_iters))]
+    dist = torch.distributed if world > 1 else None
+
+    def step(i):
+        idx = batches[i % len(batches)]
+        if dist is None:
+            tr.step(idx)
+        else:
+            tr.backward(idx)
+            dist.all_reduce(tr.grad)          # RCCL sum of the flat gradient bucket (+ loss / inlier statistics)
+            tr.update()
+
+    for i in range(args.warmup):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = tr.state()
+    assert st["iteration"] == args.warmup + args.steps and not st["nan"], st
+
+    # roofline leg: per-kernel-class durations from HIP events on the launch stream (outside the timed region:
+    # the events themselves perturb the step time)
+    prof = None
+    if rank == 0:
+        tr.set_profiling(True)
+        for i in range(20):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        prof = tr.get_profile()
+        tr.set_profiling(False)
+    return dt, st, prof
+
+
+def bench_registration(args, rank, world, device):
+    from acezero_amd import dsacstar, synth
+    n = args.reg_frames // world
+    base = synth.make_registration_frames(seed=1305 + rank, n_frames=64)
+    sc = torch.from_numpy(base["scene_coords"]).to(device)
+    reps = (n + 63) // 64
+    sc = sc.repeat(reps, 1, 1, 1)[:n].contiguous()
+    sc += 0.001 * torch.randn(sc.shape, device=device, generator=torch.Generator(device=device).manual_seed(rank))
+    intr = [(base["focal"], base["ppx"], base["ppy"])] * n
+    prm = dict(hyps=32, thr=10.0, alpha=100.0, max_reproj=100.0, sub=8, max_tries=16)   # ace_zero.py:140-142,233
+    ids = [rank * n + i for i in range(n)]
+    dsacstar.register_batch(sc, intr, prm, 1305, ids)      # warm-up (context + code object load)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    poses, inl, _ = dsacstar.register_batch(sc, intr, prm, 1305, ids, want_masks=True)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = float((inl > 1000).float().mean())
+    return n, dt, ok
+
+
+def cpu_baseline():
+    """Oracle timed on the host cores (kind "port": the reference itself is not on the GPU box)."""
+    from acezero_amd import synth
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import dsac_oracle, head_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    prob = synth.make_training_problem(seed=3, n_images=20, views_per_image=2, patches_per_view=128)
+    cfg = dict(loss_type="tanh", schedule="1cyclepoly", iterations=25000, lr_min=0.0005, lr_max=0.003, warmup_iterations=1000,
+               warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, global_batch=BATCH, soft_clamp=50.0,
+               soft_clamp_min=1.0, hard_clamp=1000.0, depth_min=0.1, depth_max=1000.0, depth_target=10.0, inlier_px_threshold=10.0)
+    orc = head_oracle.TrainerOracle(head_oracle.init_params(1), prob["mean"], cfg, mode="fp32")
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, prob["features"].shape[0], BATCH)
+    pp = synth.expand_per_patch(prob, idx)
+    b = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in pp.items()}
+    orc.step(b["features"], b)
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < 12.0 and steps < 40:
+        orc.step(b["features"], b)
+        steps += 1
+    t_train = (time.perf_counter() - t0) / max(steps, 1)
+    fr = synth.make_registration_frames(seed=5, n_frames=16)
+    dsac_oracle.lib()
+
+    def one(i):
+        return dsac_oracle.forward_rgb(fr["scene_coords"][i % 16], 32, 10.0, fr["focal"], fr["ppx"], fr["ppy"], 100.0, 100.0, 8, 1305, i, 16)["inliers"]
+    nfr = 16 * cores
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(one, range(nfr)))
+    t_reg = time.perf_counter() - t0
+    return {"value": BATCH / t_train, "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of 5120 patches, oracle/head_oracle.py fp32 on torch-CPU with {cores} threads; "
+                      f"registration: {nfr} frames, oracle/dsac_oracle.cpp, {cores} threads",
+            "registration_images_per_s": nfr / t_reg}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=device)
+    assert world == args.gpus or world == 1, (world, args.gpus)
+
+    dt, st, prof = bench_training(args, rank, world, device)
+    nreg, dt_reg, reg_ok = bench_registration(args, rank, world, device)
+    if world > 1:
+        t = torch.tensor([dt, dt_reg], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt, dt_reg = float(t[0]), float(t[1])
+    if rank == 0:
+        patches_per_s = BATCH * world * args.steps / dt
+        gemm_ms, gemm_n = 0.0, 0
+        for k in ("gemm_fwd", "gemm_dgrad"):
+            gemm_ms += prof[k][0]
+            gemm_n += prof[k][1]
+        avg_s = gemm_ms / max(gemm_n, 1) * 1e-3
+        achieved = BATCH * GEMM_FLOP_PER_LAUNCH_PER_ROW / avg_s / 1e12 if avg_s > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_rowgemm_hbm_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("bytes_per_launch")
+        out = {
+            "metric": "ACE patches/sec", "value": patches_per_s, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "7-Scenes-chess-like ace_zero mapping step: 8M-patch bf16 feature buffer in HBM, batch 5120 per GPU, "
+                                   "default head (1 block, 2 103 300 params), tanh loss, 1cyclepoly AdamW, pose_refinement none",
+                       "buffer_patches": args.buffer_patches, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
+                       "parallelism": f"dp{world}"},
+            "whole_step_flop_frac_of_mfma_peak": patches_per_s / world * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS * 1e12),
+            "registration": {"metric": "DSAC* images-registered/sec", "value": nreg * world / dt_reg, "unit": "images/s",
+                             "frames": nreg * world, "hypotheses": 32, "max_tries": 16, "frac_frames_registered": reg_ok,
+                             "note": "RANSAC only, 60x80 scene coordinates resident in HBM"},
+            "roofline": {"bound": "mfma", "kernel": "rowgemm_kernel (5120x512x512 bf16, fwd + dgrad launches)", "achieved": achieved,
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "avg_launch_us": avg_s * 1e6, "launches_timed": gemm_n,
+                         "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()}},
+            "final_loss": st["loss"],
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -228,6 +228,12 @@ int acez_trainer_get_log(acez_trainer* tr, int first, int count, float* h_loss, 
 /* Scene coordinates predicted in the last backward call: f32 [n][3] (diagnostics / tests). */
 int acez_trainer_last_scene_coords(acez_trainer* tr, float* h_xyz, int n, void* stream);
 
+/* Diagnostics for the roofline measurement (bench.py): bracket every kernel launch of the following steps with HIP
+ * events on the launch stream; get_profile synchronises and returns summed milliseconds and launch counts for the
+ * 8 kernel classes {sched, gather, gemm_fwd, loss, gemm_dgrad, wgrad, grad_reduce, adamw}, then clears the record. */
+int acez_trainer_set_profiling(acez_trainer* tr, int enable);
+int acez_trainer_get_profile(acez_trainer* tr, float* h_ms8, int32_t* h_counts8);
+
 /* Head inference (Regressor.get_scene_coordinates, ace_network.py:262-263) on n feature rows:
  *   d_features bf16 [n][512]  ->  d_out_xyz f32 [n][3].   Asynchronous. */
 int acez_head_forward(acez_trainer* tr, const void* d_features, int n, float* d_out_xyz, void* stream);
