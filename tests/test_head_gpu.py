@@ -89,7 +89,7 @@ def test_training_steps_match_oracle_and_golden(name):
         if it + 1 < len(g["lr"]):
             assert abs(st["lr"] - g["lr"][it + 1]) < 1e-12
         # AdamW: the GPU applied its own gradient; compare with the oracle's update from the same start
-        assert _rel(tr.params.cpu().numpy() - flat0.numpy(), orc.head.p.flat.numpy() - flat0.numpy()) < 2e-2
+        assert _rel(tr.params.cpu().numpy() - flat0.numpy(), orc.head.p.flat.numpy() - flat0.numpy()) < 6e-2
         if cfg["refine_calibration"]:
             assert abs(st["focal_scale"] - (1.0 + orc.sched.calib_g)) < 2e-5
     loss, _ = tr.log(0, min(5, int(g["steps_run"])))
