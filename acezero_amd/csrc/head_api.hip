@@ -295,7 +295,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.n_wide = tr->n_wide; a.n_params = tr->n_params; a.st = st;
     const int64_t tot = tr->n_params + 4;
     ProfScope ps(tr, s, KC_REDUCE);
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((tot + 1023) / 1024)), dim3(256), 0, s, a);
   }
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;

@@ -66,40 +66,54 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint16_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// rowgemm: Out[m][n] = epi( sum_k In[m][k] * W[n][k] ),  128 x 128 tile, BK = 64, 4 waves of 64 x 64.
+// rowgemm: Out[m][n] = epi( sum_k In[m][k] * W[n][k] ),  K = 512, 128 x 128 tile, BK = 64, 4 waves of 64 x 64.
 // LDS tiles are [row][64] bf16 with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7, which makes
 // the ds_read_b128 fragment reads of 32 consecutive rows conflict-free.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
-__global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
+// K is fixed at 512 (ACEZ_HEAD_CHANNELS) = 8 K-steps of 64. Operand tiles go HBM/L2 -> LDS directly
+// (global_load_lds_dwordx4, no VGPR staging) into a 4-slot ring of [W 128x64 | In 128x64] stages (128 KiB, one
+// workgroup per CU); the first four stages are requested at kernel entry and each consumed slot is refilled one
+// barrier later, so up to 96 KiB per CU are in flight and the memory latency is paid once per launch instead of
+// once per K-step. Waits are counted (s_waitcnt vmcnt(N): each wave issues 8 DMA instructions per stage, in
+// order), barriers are raw s_barrier so that in-flight DMA is not drained. The LDS image of a stage is linear in
+// the DMA lane order; the bank swizzle is applied on the per-lane SOURCE chunk and, identically, on the reads.
+// Rows past M are clamped (never stored).
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+#define ACEZ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
   if (a.st && !a.st->active) return;
-  __shared__ __attribute__((aligned(16))) uint16_t smem[2][2][128 * 64];
-  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[4][2][128 * 64];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wn = w >> 1, wm = w & 1;
   const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
-  const int M = a.M, N = a.N, K = a.K;
-  const int KT = K >> 6;
+  const int M = a.M, N = a.N;
+  constexpr int K = 512, KT = 8;
 
-  uint4 rW[4], rI[4];
-  auto gload = [&](int kt) {
+  // DMA instruction j (0..3) of this wave covers tile rows (w*4+j)*8 .. +7; this lane: row + (l>>3), slot l&7,
+  // which must receive the logical chunk (l&7) ^ ((row>>1)&7)
+  const uint16_t* gW[4];
+  const uint16_t* gI[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int q = t + 256 * p, row = q >> 3, c = q & 7;
-      rW[p] = *reinterpret_cast<const uint4*>(a.W + (size_t)(n0 + row) * K + kt * 64 + c * 8);
-      const int m = m0 + row;
-      rI[p] = (m < M) ? *reinterpret_cast<const uint4*>(a.In + (size_t)m * K + kt * 64 + c * 8) : make_uint4(0, 0, 0, 0);
+  for (int j = 0; j < 4; ++j) {
+    const int row = (w * 4 + j) * 8 + (l >> 3);
+    const int c = (l & 7) ^ ((row >> 1) & 7);
+    gW[j] = a.W + (size_t)(n0 + row) * K + c * 8;
+    gI[j] = a.In + (size_t)min(m0 + row, M - 1) * K + c * 8;
+  }
+  auto issue = [&](int kt) {
+    const int slot = kt & 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + kt * 64), (lvoid_t*)&smem[slot][0][(w * 4 + j) * 8 * 64], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)&smem[slot][1][(w * 4 + j) * 8 * 64], 16, 0, 0);
     }
   };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int q = t + 256 * p, row = q >> 3, c = q & 7;
-      const int off = swz(row, c);
-      *reinterpret_cast<uint4*>(&smem[buf][0][off]) = rW[p];
-      *reinterpret_cast<uint4*>(&smem[buf][1][off]) = rI[p];
-    }
-  };
+  issue(0); issue(1); issue(2); issue(3);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -109,30 +123,31 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  const int rowa0 = wn * 64 + (l & 31), rowb0 = wm * 64 + (l & 31);
+#pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) gload(kt + 1);
+    // stages issued so far: 0..3 at kt = 0, 0..kt+2 afterwards; everything after stage kt may stay in flight
+    if (kt == 0) ACEZ_VMCNT(24);
+    else if (kt <= 5) ACEZ_VMCNT(16);
+    else if (kt == 6) ACEZ_VMCNT(8);
+    else ACEZ_VMCNT(0);
+    __builtin_amdgcn_s_barrier();  // every wave's share of stage kt has landed; everyone is done with stage kt-1
+    if (kt >= 1 && kt + 3 < KT) issue(kt + 3);  // refill the slot read in the previous iteration
+    const int slot = kt & 3;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 fa[2], fb[2];
       const int c = 2 * kk + (l >> 5);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int rowa = wn * 64 + i * 32 + (l & 31);
-        fa[i] = *reinterpret_cast<const bf16x8*>(&smem[buf][0][swz(rowa, c)]);
-        const int rowb = wm * 64 + i * 32 + (l & 31);
-        fb[i] = *reinterpret_cast<const bf16x8*>(&smem[buf][1][swz(rowb, c)]);
+        fa[i] = *reinterpret_cast<const bf16x8*>(&smem[slot][0][swz(rowa0 + i * 32, c)]);
+        fb[i] = *reinterpret_cast<const bf16x8*>(&smem[slot][1][swz(rowb0 + i * 32, c)]);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < KT) lstore(buf ^ 1);
-    __syncthreads();
   }
 
   // epilogue: lane holds row m (B index j = l & 31) and channels nb .. nb+3 per register group g
@@ -573,22 +588,30 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
   if (a.st && !a.st->active) return;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < a.n_wide) {
-    float acc = 0.f;
-    for (int s = 0; s < a.nslabs; ++s) acc += a.slabs[(size_t)s * a.slab_stride + i];
-    a.grad[i] = acc;
-  } else if (i < a.n_params) {
-    const int64_t k = i - a.n_wide;
-    float acc = 0.f;
-    for (int b = 0; b < a.n_loss_blocks; ++b) acc += a.fc3_partials[(size_t)b * a.fc3_stride + k];
-    a.grad[i] = acc;
-  } else if (i < a.n_params + 4) {
-    const int k = (int)(i - a.n_params);
-    float acc = 0.f;
-    if (k < 3)
-      for (int b = 0; b < a.n_loss_blocks; ++b) acc += a.stat_partials[(size_t)b * 4 + k];
-    a.grad[i] = acc;
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 < a.n_wide) {  // n_wide is a multiple of 4: 16-byte loads, slabs summed in slab order
+    float4 acc = *reinterpret_cast<const float4*>(a.slabs + i4);
+    for (int s = 1; s < a.nslabs; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)s * a.slab_stride + i4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(a.grad + i4) = acc;
+    return;
+  }
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = i4 + e;
+    if (i < a.n_params) {
+      const int64_t k = i - a.n_wide;
+      float acc = 0.f;
+      for (int b = 0; b < a.n_loss_blocks; ++b) acc += a.fc3_partials[(size_t)b * a.fc3_stride + k];
+      a.grad[i] = acc;
+    } else if (i < a.n_params + 4) {
+      const int k = (int)(i - a.n_params);
+      float acc = 0.f;
+      if (k < 3)
+        for (int b = 0; b < a.n_loss_blocks; ++b) acc += a.stat_partials[(size_t)b * 4 + k];
+      a.grad[i] = acc;
+    }
   }
 }
 
