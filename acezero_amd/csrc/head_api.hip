@@ -37,8 +37,10 @@ struct acez_trainer {
   // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
-  std::vector<std::pair<int, std::pair<int, int>>> ev_used;  // (class, (start idx, stop idx))
+  struct EvUse { int cls, i0, i1, launches; };
+  std::vector<EvUse> ev_used;
   size_t ev_next = 0;
+  int prof_launches = 0;  // launches inside the currently open scope
 };
 
 enum { KC_SCHED = 0, KC_GATHER, KC_GEMM_FWD, KC_LOSS, KC_GEMM_DGRAD, KC_WGRAD, KC_REDUCE, KC_ADAMW, KC_COUNT };
@@ -51,13 +53,15 @@ struct ProfScope {
       for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; tr->ev_pool.push_back(e); }
     }
     i0 = (int)tr->ev_next; tr->ev_next += 2;
+    tr->prof_launches = 0;
     (void)hipEventRecord(tr->ev_pool[i0], s);
   }
   ~ProfScope() {
     if (i0 < 0) return;
     (void)hipEventRecord(tr->ev_pool[i0 + 1], s);
-    tr->ev_used.push_back({cls, {i0, i0 + 1}});
+    tr->ev_used.push_back({cls, i0, i0 + 1, tr->prof_launches > 0 ? tr->prof_launches : 1});
   }
+  ProfScope(const ProfScope&) = delete;
 };
 
 static int dmalloc(acez_trainer* tr, void** p, size_t bytes) {
@@ -185,7 +189,7 @@ extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
 
 // forward chain on n rows whose input features are in `in0`; returns the fc2 output buffer
 static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, const TrainState* st, hipStream_t s) {
-  auto PS = [&](int c) { return ProfScope(tr, s, c); };
+  ProfScope chain_scope(tr, s, KC_GEMM_FWD);  // one event pair around the whole chain of dependent GEMM launches
   const float* P = tr->pb.d_params;
   const dim3 grid(4, (n + 127) / 128), blk(256);
   auto gemm = [&](int l, const uint16_t* in, uint16_t* out_main, const uint16_t* res, uint16_t* out_aux) {
@@ -193,8 +197,8 @@ static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, co
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144;
     g.add = nullptr; g.mask = nullptr; g.res = res; g.out_main = out_main; g.out_aux = out_aux;
     g.M = n; g.N = 512; g.K = 512; g.relu = 1; g.aux_mode = res ? AUX_RESIDUAL : AUX_NONE; g.st = st;
-    auto ps = PS(KC_GEMM_FWD);
     hipLaunchKernelGGL(rowgemm_kernel, grid, blk, 0, s, g);
+    ++tr->prof_launches;
   };
   const uint16_t* r = in0;
   for (int b = 0; b <= tr->nb; ++b) {
@@ -258,9 +262,10 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     g.In = tr->dZ[l]; g.W = tr->WbT + (size_t)l * 262144; g.bias = nullptr; g.add = add; g.mask = mask; g.res = nullptr;
     g.out_main = out_main; g.out_aux = out_aux; g.M = n; g.N = 512; g.K = 512; g.relu = 0;
     g.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE; g.st = st;
-    ProfScope ps(tr, s, KC_GEMM_DGRAD);
     hipLaunchKernelGGL(rowgemm_kernel, grid, blk, 0, s, g);
+    ++tr->prof_launches;
   };
+  ProfScope* dchain = new ProfScope(tr, s, KC_GEMM_DGRAD);
   dgrad(f2, nullptr, tr->out[f1], tr->dZ[f1], nullptr);
   int cur = 0;
   dgrad(f1, nullptr, tr->out[3 * tr->nb + 2], tr->dZ[3 * tr->nb + 2], tr->dR[cur]);
@@ -273,6 +278,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     }
   }
 
+  delete dchain;
   // weight gradients of all wide layers in one launch
   {
     WgradArgs a{};
@@ -293,9 +299,10 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.nslabs = tr->nslabs; a.fc3_partials = tr->fc3_partials;
     a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials; a.n_loss_blocks = nblk; a.grad = tr->pb.d_grad;
     a.n_wide = tr->n_wide; a.n_params = tr->n_params; a.st = st;
-    const int64_t tot = tr->n_params + 4;
+    const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
+    const int64_t tail_blocks = ((tr->n_params - tr->n_wide + 4) * 64 + 255) / 256;
     ProfScope ps(tr, s, KC_REDUCE);
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((tot + 1023) / 1024)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, a);
   }
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
@@ -388,9 +395,9 @@ extern "C" int acez_trainer_get_profile(acez_trainer* tr, float* h_ms8, int32_t*
   for (int i = 0; i < KC_COUNT; ++i) { h_ms8[i] = 0.f; h_counts8[i] = 0; }
   for (auto& u : tr->ev_used) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, tr->ev_pool[u.second.first], tr->ev_pool[u.second.second]) == hipSuccess) {
-      h_ms8[u.first] += ms;
-      h_counts8[u.first] += 1;
+    if (hipEventElapsedTime(&ms, tr->ev_pool[u.i0], tr->ev_pool[u.i1]) == hipSuccess) {
+      h_ms8[u.cls] += ms;
+      h_counts8[u.cls] += u.launches;
     }
   }
   tr->ev_used.clear();

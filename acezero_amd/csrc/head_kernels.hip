@@ -588,8 +588,10 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
   if (a.st && !a.st->active) return;
-  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i4 < a.n_wide) {  // n_wide is a multiple of 4: 16-byte loads, slabs summed in slab order
+  const int wide_blocks = (int)((a.n_wide / 4 + 255) / 256);
+  if ((int)blockIdx.x < wide_blocks) {  // n_wide is a multiple of 4: 16-byte loads, slabs summed in slab order
+    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= a.n_wide) return;
     float4 acc = *reinterpret_cast<const float4*>(a.slabs + i4);
     for (int s = 1; s < a.nslabs; ++s) {
       const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)s * a.slab_stride + i4);
@@ -598,21 +600,21 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
     *reinterpret_cast<float4*>(a.grad + i4) = acc;
     return;
   }
-  for (int e = 0; e < 4; ++e) {
-    const int64_t i = i4 + e;
-    if (i < a.n_params) {
-      const int64_t k = i - a.n_wide;
-      float acc = 0.f;
-      for (int b = 0; b < a.n_loss_blocks; ++b) acc += a.fc3_partials[(size_t)b * a.fc3_stride + k];
-      a.grad[i] = acc;
-    } else if (i < a.n_params + 4) {
-      const int k = (int)(i - a.n_params);
-      float acc = 0.f;
-      if (k < 3)
-        for (int b = 0; b < a.n_loss_blocks; ++b) acc += a.stat_partials[(size_t)b * 4 + k];
-      a.grad[i] = acc;
-    }
+  // tail: one wavefront per output (fc3 weights/bias, then the 4 statistics); lane-strided partial sums over the
+  // loss kernel's workgroups followed by the fixed butterfly order -> deterministic
+  const int lane = threadIdx.x & 63;
+  const int64_t k = ((int64_t)(blockIdx.x - wide_blocks) * 256 + threadIdx.x) >> 6;
+  const int64_t n_fc3 = a.n_params - a.n_wide;
+  if (k >= n_fc3 + 4) return;
+  float acc = 0.f;
+  if (k < n_fc3) {
+    for (int b = lane; b < a.n_loss_blocks; b += 64) acc += a.fc3_partials[(size_t)b * a.fc3_stride + k];
+  } else if (k - n_fc3 < 3) {
+    for (int b = lane; b < a.n_loss_blocks; b += 64) acc += a.stat_partials[(size_t)b * 4 + (k - n_fc3)];
   }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) a.grad[a.n_wide + k] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------

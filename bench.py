@@ -229,7 +229,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "rowgemm_kernel (5120x512x512 bf16, fwd + dgrad launches)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": gemm_n,
-                         "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()}},
+                         "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()},
+                         "note": "HIP events on the launch stream around each chain of dependent rowgemm launches (8 fwd, 7 dgrad per step): average start-to-start cadence incl. the ~1-2 us kernel boundary; rocprofv3 kernel durations are in profiles/"},
             "final_loss": st["loss"],
         }
         if not args.no_cpu_baseline:

@@ -3,12 +3,15 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 CMD="python $R/bench.py --steps 100 --warmup 20 --buffer-patches 2000000 --reg-frames 1024 --no-cpu-baseline"
+if [ "$1" = "quick" ]; then QUICK=1; fi
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+if [ -z "$QUICK" ]; then
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
+fi
 cd $OUT && find . -type f | head -40; du -sh .; tail -3 $OUT/trace.log
 python - <<'PY'
 import csv, glob, collections, os
