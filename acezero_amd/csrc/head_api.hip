@@ -29,6 +29,7 @@ struct acez_trainer {
   float* fc3_partials = nullptr;
   float* stat_partials = nullptr;
   float* xyz = nullptr;
+  uint16_t* zeros = nullptr;
   float *log_loss = nullptr, *log_inl = nullptr;
   int log_cap = 0;
   TrainState* st = nullptr;
@@ -134,6 +135,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->fc3_partials, (size_t)max_blocks * tr->fc3_stride * sizeof(float));
   A((void**)&tr->stat_partials, (size_t)max_blocks * 4 * sizeof(float));
   A((void**)&tr->xyz, (size_t)tr->max_batch * 3 * sizeof(float));
+  A((void**)&tr->zeros, 1024);
   tr->log_cap = cfg->iterations + 8;
   A((void**)&tr->log_loss, (size_t)tr->log_cap * sizeof(float));
   A((void**)&tr->log_inl, (size_t)tr->log_cap * sizeof(float));
@@ -151,6 +153,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   sc.calib_lr = cfg->calib_lr;
   hipLaunchKernelGGL(sched_init_kernel, dim3(1), dim3(64), 0, 0, tr->st, sc);
   ACEZ_HIP_CHECK(hipGetLastError());
+  ACEZ_HIP_CHECK(hipMemset(tr->zeros, 0, 1024));
   ACEZ_HIP_CHECK(hipMemset(tr->log_loss, 0, (size_t)tr->log_cap * sizeof(float)));
   ACEZ_HIP_CHECK(hipMemset(tr->log_inl, 0, (size_t)tr->log_cap * sizeof(float)));
   ACEZ_HIP_CHECK(hipDeviceSynchronize());
@@ -196,8 +199,8 @@ static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, co
     RowGemmArgs g{};
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144;
     g.add = nullptr; g.mask = nullptr; g.res = res; g.out_main = out_main; g.out_aux = out_aux;
-    g.M = n; g.N = 512; g.K = 512; g.relu = 1; g.aux_mode = res ? AUX_RESIDUAL : AUX_NONE; g.st = st;
-    hipLaunchKernelGGL(rowgemm_kernel, grid, blk, 0, s, g);
+    g.M = n; g.N = 512; g.K = 512; g.relu = 1; g.aux_mode = res ? AUX_RESIDUAL : AUX_NONE; g.st = st; g.dbg = 0;
+    launch_rowgemm(g, grid, s);
     ++tr->prof_launches;
   };
   const uint16_t* r = in0;
@@ -261,8 +264,8 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     RowGemmArgs g{};
     g.In = tr->dZ[l]; g.W = tr->WbT + (size_t)l * 262144; g.bias = nullptr; g.add = add; g.mask = mask; g.res = nullptr;
     g.out_main = out_main; g.out_aux = out_aux; g.M = n; g.N = 512; g.K = 512; g.relu = 0;
-    g.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE; g.st = st;
-    hipLaunchKernelGGL(rowgemm_kernel, grid, blk, 0, s, g);
+    g.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE; g.st = st; g.dbg = 0;
+    launch_rowgemm(g, grid, s);
     ++tr->prof_launches;
   };
   ProfScope* dchain = new ProfScope(tr, s, KC_GEMM_DGRAD);
@@ -290,7 +293,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
       a.In[3 * b] = tr->R[b]; a.In[3 * b + 1] = tr->out[3 * b]; a.In[3 * b + 2] = tr->out[3 * b + 1];
     }
     a.In[f1] = tr->R[tr->nb + 1]; a.In[f2] = tr->out[f1];
-    a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.st = st;
+    a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.st = st; a.zeros = tr->zeros;
     ProfScope ps(tr, s, KC_WGRAD);
     hipLaunchKernelGGL(wgrad_kernel, dim3(16 * tr->nslabs, tr->L), dim3(256), 0, s, a);
   }

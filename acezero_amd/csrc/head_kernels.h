@@ -53,6 +53,7 @@ struct RowGemmArgs {
   uint16_t* out_aux;
   int M, N, K, relu, aux_mode;
   const TrainState* st;
+  int dbg;  // ablation switches for tools/ablate_rowgemm.hip (0 in production): 1 = no epilogue, 2 = no MFMA, 4 = no loads
 };
 
 struct WgradArgs {
@@ -63,6 +64,7 @@ struct WgradArgs {
   int64_t slab_stride;
   int M, nslabs;
   const TrainState* st;
+  const uint16_t* zeros;  // >= 256 bytes of zeros (source of the DMA for rows past the end of a slab)
 };
 
 struct LossArgs {

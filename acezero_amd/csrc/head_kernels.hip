@@ -36,10 +36,19 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+// two fp32 -> packed bf16x2, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32 on gfx950; the compiler emits
+// it for the __bf16 conversion). Branch-free: the bit-twiddling f2bf above costs an exec-mask branch per value.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  bf16x2_t v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   uint2 r;
-  r.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
-  r.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+  r.x = pack2(a, b);
+  r.y = pack2(c, d);
   return r;
 }
 __device__ __forceinline__ void unpack4(uint2 v, float* o) {
@@ -84,6 +93,7 @@ typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 #define ACEZ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX>
 __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
   if (a.st && !a.st->active) return;
   __shared__ __attribute__((aligned(16))) uint16_t smem[4][2][128 * 64];
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
       __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)&smem[slot][1][(w * 4 + j) * 8 * 64], 16, 0, 0);
     }
   };
-  issue(0); issue(1); issue(2); issue(3);
+  if (!(a.dbg & 4)) { issue(0); issue(1); issue(2); issue(3); }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -132,7 +142,8 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
     else if (kt == 6) ACEZ_VMCNT(8);
     else ACEZ_VMCNT(0);
     __builtin_amdgcn_s_barrier();  // every wave's share of stage kt has landed; everyone is done with stage kt-1
-    if (kt >= 1 && kt + 3 < KT) issue(kt + 3);  // refill the slot read in the previous iteration
+    if (kt >= 1 && kt + 3 < KT && !(a.dbg & 4)) issue(kt + 3);  // refill the slot read in the previous iteration
+    if (a.dbg & 2) continue;
     const int slot = kt & 3;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -150,44 +161,68 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
     }
   }
 
-  // epilogue: lane holds row m (B index j = l & 31) and channels nb .. nb+3 per register group g
+  // ---- epilogue, staged through LDS so that every global access is a full 128-byte row segment.
+  // In the MFMA layout a lane holds row m (B index j = l & 31) and 4 consecutive channels per register group;
+  // storing that directly touches 32 rows x 16 B per instruction and was measured at 8-12 us per launch
+  // (tools/ablate_rowgemm.hip), 2x the rest of the kernel. Each wave owns two [64][72] bf16 regions of the
+  // (now idle) ring: A = `add` in / aux out, B = mask|res in / main out.
+  if (a.dbg & 1) { if (acc[0][0][0] == 1.2345e30f) a.out_main[0] = 1; return; }
+  __syncthreads();  // every wave is done reading the ring
+  constexpr int EP = 72;
+  uint16_t* regA = &smem[0][0][0] + w * (2 * 64 * EP);
+  uint16_t* regB = regA + 64 * EP;
+  const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+  const uint16_t* in2 = HAS_MASK ? a.mask : a.res;
+  constexpr bool HAS_IN2 = HAS_MASK || AUX == AUX_RESIDUAL;
+  if (HAS_ADD || HAS_IN2) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (l >> 3), ch = l & 7, m = mw + row;
+      if (m < M) {
+        const size_t o = (size_t)m * N + nw + ch * 8;
+        if (HAS_ADD) *reinterpret_cast<uint4*>(&regA[row * EP + ch * 8]) = *reinterpret_cast<const uint4*>(a.add + o);
+        if (HAS_IN2) *reinterpret_cast<uint4*>(&regB[row * EP + ch * 8]) = *reinterpret_cast<const uint4*>(in2 + o);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
   const int h = l >> 5;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int m = m0 + wm * 64 + j * 32 + (l & 31);
-    if (m >= M) continue;
+    const int ml = j * 32 + (l & 31);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int nb = n0 + wn * 64 + i * 32 + 8 * g + 4 * h;
+        const int nl = i * 32 + 8 * g + 4 * h;
         float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        const size_t o = (size_t)m * N + nb;
-        if (a.bias) {
-          const float4 b = *reinterpret_cast<const float4*>(a.bias + nb);
+        uint16_t* pa = &regA[ml * EP + nl];
+        uint16_t* pb = &regB[ml * EP + nl];
+        if (BIAS_RELU) {
+          const float4 b = *reinterpret_cast<const float4*>(a.bias + nw + nl);
           v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         }
-        if (a.add) {
+        if (HAS_ADD) {
           float ad[4];
-          unpack4(*reinterpret_cast<const uint2*>(a.add + o), ad);
+          unpack4(*reinterpret_cast<const uint2*>(pa), ad);
           v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
         }
-        if (a.relu) {
+        if (BIAS_RELU) {
           v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
         }
         uint2 y = pack4(v[0], v[1], v[2], v[3]);
-        if (a.aux_mode == AUX_RESIDUAL) {
+        if (AUX == AUX_RESIDUAL) {
           // out_aux = bf16( float(bf16(y)) + float(res) )   (ace_network.py:126,133)
           float yf[4], rf[4];
           unpack4(y, yf);
-          unpack4(*reinterpret_cast<const uint2*>(a.res + o), rf);
-          *reinterpret_cast<uint2*>(a.out_aux + o) = pack4(yf[0] + rf[0], yf[1] + rf[1], yf[2] + rf[2], yf[3] + rf[3]);
-        } else if (a.aux_mode == AUX_UNMASKED) {
-          *reinterpret_cast<uint2*>(a.out_aux + o) = y;
+          unpack4(*reinterpret_cast<const uint2*>(pb), rf);
+          *reinterpret_cast<uint2*>(pa) = pack4(yf[0] + rf[0], yf[1] + rf[1], yf[2] + rf[2], yf[3] + rf[3]);
+        } else if (AUX == AUX_UNMASKED) {
+          *reinterpret_cast<uint2*>(pa) = y;
         }
-        if (a.mask) {
+        if (HAS_MASK) {
           // relu backward: keep the gradient where the forward activation was > 0
-          const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + o);
+          const uint2 mk = *reinterpret_cast<const uint2*>(pb);
           // bf16 > 0  <=>  sign bit clear and magnitude non-zero
           const uint32_t m0b = mk.x & 0xffffu, m1b = mk.x >> 16, m2b = mk.y & 0xffffu, m3b = mk.y >> 16;
           uint32_t lo = y.x, hi = y.y;
@@ -197,10 +232,33 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
           if (!(m3b != 0 && m3b < 0x8000u)) hi &= 0x0000ffffu;
           y.x = lo; y.y = hi;
         }
-        *reinterpret_cast<uint2*>(a.out_main + o) = y;
+        *reinterpret_cast<uint2*>(pb) = y;
       }
     }
   }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (l >> 3), ch = l & 7, m = mw + row;
+    if (m < M) {
+      const size_t o = (size_t)m * N + nw + ch * 8;
+      *reinterpret_cast<uint4*>(a.out_main + o) = *reinterpret_cast<const uint4*>(&regB[row * EP + ch * 8]);
+      if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o) = *reinterpret_cast<const uint4*>(&regA[row * EP + ch * 8]);
+    }
+  }
+}
+
+// host-side dispatch on the epilogue shape (the flags of RowGemmArgs select the instantiation)
+static inline void launch_rowgemm(const RowGemmArgs& g, dim3 grid, hipStream_t s) {
+  const dim3 blk(256);
+  const bool br = g.bias != nullptr;
+  if (br && g.aux_mode == AUX_NONE) hipLaunchKernelGGL((rowgemm_kernel<true, false, false, AUX_NONE>), grid, blk, 0, s, g);
+  else if (br && g.aux_mode == AUX_RESIDUAL) hipLaunchKernelGGL((rowgemm_kernel<true, false, false, AUX_RESIDUAL>), grid, blk, 0, s, g);
+  else if (!br && g.mask && !g.add && g.aux_mode == AUX_NONE) hipLaunchKernelGGL((rowgemm_kernel<false, false, true, AUX_NONE>), grid, blk, 0, s, g);
+  else if (!br && g.mask && !g.add && g.aux_mode == AUX_UNMASKED) hipLaunchKernelGGL((rowgemm_kernel<false, false, true, AUX_UNMASKED>), grid, blk, 0, s, g);
+  else if (!br && g.mask && g.add && g.aux_mode == AUX_UNMASKED) hipLaunchKernelGGL((rowgemm_kernel<false, true, true, AUX_UNMASKED>), grid, blk, 0, s, g);
+  else if (!br && g.mask && g.add && g.aux_mode == AUX_NONE) hipLaunchKernelGGL((rowgemm_kernel<false, true, true, AUX_NONE>), grid, blk, 0, s, g);
+  else abort();  // no other epilogue shape exists in the head
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -210,26 +268,29 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
 // read with ds_read_b64_tr_b16 from an untransposed [64 m][128 cols] LDS tile (row pitch 320 B: the four
 // rows a 32-lane group touches fall on disjoint banks).
 // ---------------------------------------------------------------------------------------------------
-constexpr int WG_PITCH = 160;  // uint16 elements per LDS row (128 + 32 pad)
-
+// LDS stage = [64 m][128 cols] bf16 per operand (256-byte rows, no padding: the image is written by LDS-DMA in
+// lane order). The four rows a 32-lane tr-read group touches would share banks, so the 32-byte segment index of a
+// row is XOR-ed with (row & 3) << 1 -- applied to the per-lane DMA source chunk and, identically, to the reads.
 __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* tile, int k0, int col0, int l) {
   // returns, for lane l, the 8 values tile[k0 + 8*(l>>5) + e][col0 + (l & 31)], e = 0..7
   const int q = l >> 4, i16 = l & 15;
-  const int row = k0 + 8 * (q >> 1) + (i16 >> 2);
-  const int col = col0 + 16 * (q & 1) + 4 * (i16 & 3);
-  const uint16_t* p = tile + row * WG_PITCH + col;
+  const int row = k0 + 8 * (q >> 1) + (i16 >> 2);                // row & 3 == i16 >> 2 (also for row + 4)
+  const int colb = (col0 + 16 * (q & 1) + 4 * (i16 & 3)) * 2;    // logical byte offset inside the 256-byte row
+  const int phys = ((((colb >> 5) ^ ((i16 >> 2) << 1)) << 5) | (colb & 31)) >> 1;  // element offset
+  const uint16_t* p = tile + row * 128 + phys;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * WG_PITCH));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 128));
   s16x8 r;
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
   return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
   if (a.st && !a.st->active) return;
-  __shared__ __attribute__((aligned(16))) uint16_t smem[2][2][64 * WG_PITCH];
-  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[4][2][64 * 128];  // 4-slot ring of [dZ | In] stages, 128 KiB
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wn = w >> 1, wc = w & 1;
   const int layer = blockIdx.y;
   const int tile = blockIdx.x & 15, slab = blockIdx.x >> 4;
@@ -243,27 +304,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const int me = min(M, mb + rows_per_slab);
   const int KT = (me > mb) ? (me - mb + 63) >> 6 : 0;
 
-  uint4 rZ[4], rX[4];
-  auto gload = [&](int kt) {
+  // DMA instruction j (0..3) of this wave covers stage rows (w*4+j)*4 .. +3; this lane: row + (l>>4), physical
+  // 16-byte chunk l&15, which must receive the logical chunk whose 32-byte segment index is XOR-swizzled
+  const int prow = l >> 4, pq = l & 15;
+  int srow[4];
+  int lchunk[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int q = t + 256 * p, row = q >> 4, c = q & 15;
-      const int m = mb + kt * 64 + row;
-      if (m < me) {
-        rZ[p] = *reinterpret_cast<const uint4*>(Z + (size_t)m * 512 + n0 + c * 8);
-        rX[p] = *reinterpret_cast<const uint4*>(X + (size_t)m * 512 + c0 + c * 8);
-      } else {
-        rZ[p] = make_uint4(0, 0, 0, 0);
-        rX[p] = make_uint4(0, 0, 0, 0);
-      }
-    }
-  };
-  auto lstore = [&](int buf) {
+  for (int j = 0; j < 4; ++j) {
+    srow[j] = (w * 4 + j) * 4 + prow;
+    lchunk[j] = ((((pq >> 1) ^ ((srow[j] & 3) << 1)) << 1) | (pq & 1)) * 8;  // element offset of the source chunk
+  }
+  auto issue = [&](int kt) {
+    const int slot = kt & 3;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int q = t + 256 * p, row = q >> 4, c = q & 15;
-      *reinterpret_cast<uint4*>(&smem[buf][0][row * WG_PITCH + c * 8]) = rZ[p];
-      *reinterpret_cast<uint4*>(&smem[buf][1][row * WG_PITCH + c * 8]) = rX[p];
+    for (int j = 0; j < 4; ++j) {
+      const int m = mb + kt * 64 + srow[j];
+      const bool ok = m < me;
+      // rows past the slab end must contribute zeros: they are fetched from a zero page
+      const uint16_t* gz = ok ? Z + (size_t)m * 512 + n0 + lchunk[j] : a.zeros + pq * 8;
+      const uint16_t* gx = ok ? X + (size_t)m * 512 + c0 + lchunk[j] : a.zeros + pq * 8;
+      __builtin_amdgcn_global_load_lds((gvoid_t*)gz, (lvoid_t*)&smem[slot][0][(w * 4 + j) * 4 * 128], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)gx, (lvoid_t*)&smem[slot][1][(w * 4 + j) * 4 * 128], 16, 0, 0);
     }
   };
 
@@ -283,21 +344,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   for (int e = 0; e < 8; ++e) ones_s[e] = (short)0x3f80;  // bf16 1.0
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 
-  if (KT > 0) {
-    gload(0);
-    lstore(0);
-  }
-  __syncthreads();
+  for (int kt = 0; kt < 4 && kt < KT; ++kt) issue(kt);
   for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) gload(kt + 1);
+    // stages issued so far: 0..3 at kt = 0, 0..kt+2 afterwards; each wave has 8 DMA instructions per stage in flight
+    const int later = (kt == 0) ? min(3, KT - 1) : min(2, KT - 1 - kt);
+    if (later >= 3) ACEZ_VMCNT(24);
+    else if (later == 2) ACEZ_VMCNT(16);
+    else if (later == 1) ACEZ_VMCNT(8);
+    else ACEZ_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (kt >= 1 && kt + 3 < KT) issue(kt + 3);
+    const int slot = kt & 3;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        fa[i] = tr_frag(&smem[buf][0][0], kk * 16, wn * 64 + i * 32, l);
-        fb[i] = tr_frag(&smem[buf][1][0], kk * 16, wc * 64 + i * 32, l);
+        fa[i] = tr_frag(&smem[slot][0][0], kk * 16, wn * 64 + i * 32, l);
+        fb[i] = tr_frag(&smem[slot][1][0], kk * 16, wc * 64 + i * 32, l);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -308,8 +372,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, accb[i], 0, 0, 0);
       }
     }
-    if (kt + 1 < KT) lstore(buf ^ 1);
-    __syncthreads();
   }
 
   float* __restrict__ G = a.slabs + (size_t)slab * a.slab_stride;
