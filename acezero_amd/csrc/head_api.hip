@@ -232,7 +232,6 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
   const TrainState* st = tr->st;
   tr->last_n = n;
 
-  { ProfScope ps(tr, s, KC_SCHED); hipLaunchKernelGGL(sched_pre_kernel, dim3(1), dim3(64), 0, s, tr->st, tr->sc); }
   ProfScope* psg = new ProfScope(tr, s, KC_GATHER);
   hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024), dim3(256), 0, s,
                      (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n, st);
@@ -293,9 +292,10 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
       a.In[3 * b] = tr->R[b]; a.In[3 * b + 1] = tr->out[3 * b]; a.In[3 * b + 2] = tr->out[3 * b + 1];
     }
     a.In[f1] = tr->R[tr->nb + 1]; a.In[f2] = tr->out[f1];
-    a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.st = st; a.zeros = tr->zeros;
+    a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.n_layers = tr->L; a.st = st; a.zeros = tr->zeros;
     ProfScope ps(tr, s, KC_WGRAD);
-    hipLaunchKernelGGL(wgrad_kernel, dim3(16 * tr->nslabs, tr->L), dim3(256), 0, s, a);
+    const int groups = tr->L * tr->nslabs;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(128 * ((groups + 7) / 8)), dim3(256), 0, s, a);
   }
   {
     GradReduceArgs a{};

@@ -31,6 +31,7 @@ struct TrainState {
   float crit_buf[100];  // cooldown_criterium_buffer
   double lr;            // param_group['lr']
   double calib_g, calib_m, calib_v;
+  double beta1_pow, beta2_pow;  // beta^opt_steps
   AdamScalars adam;
 };
 
@@ -62,7 +63,7 @@ struct WgradArgs {
   int64_t w_off[MAX_LAYERS], b_off[MAX_LAYERS];
   float* slabs;
   int64_t slab_stride;
-  int M, nslabs;
+  int M, nslabs, n_layers;
   const TrainState* st;
   const uint16_t* zeros;  // >= 256 bytes of zeros (source of the DMA for rows past the end of a slab)
 };

@@ -292,8 +292,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wn = w >> 1, wc = w & 1;
-  const int layer = blockIdx.y;
-  const int tile = blockIdx.x & 15, slab = blockIdx.x >> 4;
+  // XCD-aware decode: the 16 output tiles of one (layer, slab) group re-read the same dZ / In rows (4x each); they
+  // are placed on ONE XCD (workgroup b runs on XCD b % 8) so that the re-reads hit that XCD's L2 instead of the
+  // fabric. Measured before: 335 MB per launch at ~5 TB/s = the whole kernel time. Placement only affects speed.
+  const int b = blockIdx.x;
+  const int xcd = b & 7, jx = b >> 3;
+  const int group = xcd + 8 * (jx >> 4), tile = jx & 15;
+  if (group >= a.n_layers * a.nslabs) return;
+  const int layer = group / a.nslabs, slab = group - layer * a.nslabs;
   const int n0 = (tile >> 2) * 128, c0 = (tile & 3) * 128;
   const uint16_t* __restrict__ Z = a.dZ[layer];
   const uint16_t* __restrict__ X = a.In[layer];
@@ -428,6 +434,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
         for (int e = 0; e < 8; ++e) w3[j][e] = 0.f;
       }
     }
+#pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int r = w * 8 + rr, m = m0 + r;
       float x[8];
@@ -614,9 +621,9 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
       }
       gw[j][0] = gw[j][1] = 0.f;
     }
+#pragma unroll 8
     for (int r = 0; r < 32; ++r) {
-      const int m = m0 + r;
-      if (m >= n) break;
+      const int m = min(m0 + r, n - 1);  // rows past the end carry ds == 0 and are not stored
       const uint32_t v = *reinterpret_cast<const uint32_t*>(a.act + (size_t)m * 512 + 2 * t);
       const float x0 = __uint_as_float(v << 16), x1 = __uint_as_float(v & 0xffff0000u);
       float d0 = 0.f, d1 = 0.f;
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
       }
       if (!(x0 > 0.f)) d0 = 0.f;  // relu mask of the fc2 output
       if (!(x1 > 0.f)) d1 = 0.f;
-      *reinterpret_cast<uint32_t*>(a.dZ + (size_t)m * 512 + 2 * t) = (uint32_t)f2bf(d0) | ((uint32_t)f2bf(d1) << 16);
+      if (m0 + r < n) *reinterpret_cast<uint32_t*>(a.dZ + (size_t)m * 512 + 2 * t) = pack2(d0, d1);
     }
     float* gp = a.fc3_partials + (size_t)blockIdx.x * a.fc3_stride;
 #pragma unroll
@@ -816,8 +823,8 @@ __device__ double onecycle_lr(const SchedConfig& c, int step_num) {
   return end + (start - end) / 2.0 * cos_out;
 }
 
-__global__ void sched_pre_kernel(TrainState* st, SchedConfig c) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void sched_prepare(TrainState* st, const SchedConfig& c) {
+  // everything the kernels of iteration `st->iteration` need: cool-down decision, active flag, loss weight, AdamW scalars
   const int it = st->iteration;
   // check_and_set_cooldown(iteration)   ace_schedule.py:72-101
   if (c.schedule == SCHED_1CYCLEPOLY && !st->in_cooldown && it >= c.warmup_iterations) {
@@ -841,12 +848,13 @@ __global__ void sched_pre_kernel(TrainState* st, SchedConfig c) {
     wgt = (float)((1.0 - sw) * (double)c.soft_clamp + (double)c.soft_clamp_min);
   }
   st->loss_weight = wgt;
-  // scalars of torch.optim.AdamW for this step (double like the Python side, then cast like the fp32 kernels)
+  // scalars of torch.optim.AdamW for this step (double like the Python side, then cast like the fp32 kernels);
+  // beta^step is kept as a running product (one multiply per step, same value as pow to ~1e-16 relative)
   {
     const double lr = st->lr;
-    const int step = st->opt_steps + 1;
-    const double bc1 = 1.0 - pow(c.beta1, (double)step);
-    const double bc2 = 1.0 - pow(c.beta2, (double)step);
+    const double b1p = st->beta1_pow * c.beta1, b2p = st->beta2_pow * c.beta2;  // beta^(opt_steps + 1)
+    const double bc1 = 1.0 - b1p;
+    const double bc2 = 1.0 - b2p;
     AdamScalars s;
     s.decay = (float)(1.0 - lr * c.weight_decay);
     s.one_minus_beta1 = (float)(1.0 - c.beta1);
@@ -865,16 +873,17 @@ __global__ void sched_init_kernel(TrainState* st, SchedConfig c) {
   st->active = 0; st->iteration = 0; st->max_iterations = c.iterations; st->in_cooldown = 0;
   st->warmup_epoch = 0; st->cooldown_epoch = 0; st->nan_flag = 0; st->opt_steps = 0; st->crit_count = 0;
   st->calib_steps = 0; st->loss_weight = c.soft_clamp; st->last_loss = 0.f; st->last_inliers = 0.f;
-  st->calib_g = 0.0; st->calib_m = 0.0; st->calib_v = 0.0;
+  st->calib_g = 0.0; st->calib_m = 0.0; st->calib_v = 0.0; st->beta1_pow = 1.0; st->beta2_pow = 1.0;
   if (c.schedule == SCHED_CONSTANT) st->lr = c.lr_min;
   else if (c.schedule == SCHED_1CYCLEPOLY) st->lr = c.lr_max * (c.warmup_lr / c.lr_max);  // LinearLR._initial_step
   else st->lr = onecycle_lr(c, 0);
+  sched_prepare(st, c);
 }
 
 __global__ void sched_post_kernel(TrainState* st, SchedConfig c, const float* grad_stats, float inv_global_batch,
                                   float* log_loss, float* log_inl, int log_cap) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (!st->active) return;
+  if (!st->active) return;  // the schedule has ended: state is frozen (ace_trainer.py:509-510)
   const float loss = grad_stats[0] * inv_global_batch;
   const float inl = grad_stats[1] * inv_global_batch;
   st->last_loss = loss;
@@ -883,6 +892,8 @@ __global__ void sched_post_kernel(TrainState* st, SchedConfig c, const float* gr
   const int it = st->iteration;
   if (it < log_cap) { log_loss[it] = loss; log_inl[it] = inl; }
   st->opt_steps += 1;
+  st->beta1_pow *= c.beta1;
+  st->beta2_pow *= c.beta2;
   // calibration refiner: its own AdamW on the scalar g (refine_calibration.py:21-26,58-59)
   if (c.refine_calibration) {
     const double g = (double)grad_stats[2];
@@ -926,6 +937,7 @@ __global__ void sched_post_kernel(TrainState* st, SchedConfig c, const float* gr
     st->lr = onecycle_lr(c, e);
   }
   st->iteration = it + 1;   // ace_trainer.py:495
+  sched_prepare(st, c);     // bookkeeping of the NEXT iteration, so that a step needs a single schedule launch
 }
 
 // cos(pi x) for x in [0,1] with basic operations only (Taylor around the nearest multiple of 1/2).
