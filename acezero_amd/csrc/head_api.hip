@@ -28,6 +28,8 @@ struct acez_trainer {
   float* slabs = nullptr;
   float* fc3_partials = nullptr;
   float* stat_partials = nullptr;
+  float* bias_partials = nullptr;
+  int64_t bias_layer_stride = 0;
   float* xyz = nullptr;
   uint16_t* zeros = nullptr;
   float *log_loss = nullptr, *log_inl = nullptr;
@@ -134,6 +136,8 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   const int max_blocks = (tr->max_batch + 31) / 32;
   A((void**)&tr->fc3_partials, (size_t)max_blocks * tr->fc3_stride * sizeof(float));
   A((void**)&tr->stat_partials, (size_t)max_blocks * 4 * sizeof(float));
+  tr->bias_layer_stride = (int64_t)max_blocks * 512;
+  A((void**)&tr->bias_partials, (size_t)tr->L * tr->bias_layer_stride * sizeof(float));
   A((void**)&tr->xyz, (size_t)tr->max_batch * 3 * sizeof(float));
   A((void**)&tr->zeros, 1024);
   tr->log_cap = cfg->iterations + 8;
@@ -199,7 +203,7 @@ static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, co
     RowGemmArgs g{};
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144;
     g.add = nullptr; g.mask = nullptr; g.res = res; g.out_main = out_main; g.out_aux = out_aux;
-    g.M = n; g.N = 512; g.K = 512; g.relu = 1; g.aux_mode = res ? AUX_RESIDUAL : AUX_NONE; g.st = st; g.dbg = 0;
+    g.M = n; g.N = 512; g.K = 512; g.relu = 1; g.aux_mode = res ? AUX_RESIDUAL : AUX_NONE; g.st = st; g.dbg = 0; g.bias_partials = nullptr;
     launch_rowgemm(g, grid, s);
     ++tr->prof_launches;
   };
@@ -253,14 +257,16 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.inv_batch = 1.0f / (float)tr->cfg.global_batch; a.focal_init = tr->cfg.focal_init;
     a.st = st; a.out_xyz = tr->xyz; a.dZ = tr->dZ[f2];
     a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
+    a.bias_partials = tr->bias_partials + (size_t)f2 * tr->bias_layer_stride;
     ProfScope ps(tr, s, KC_LOSS);
     hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, s, a);
   }
 
   // input-gradient chain
   const dim3 grid(4, (n + 127) / 128), blk(256);
-  auto dgrad = [&](int l, const uint16_t* add, const uint16_t* mask, uint16_t* out_main, uint16_t* out_aux) {
+  auto dgrad = [&](int l, int l_out, const uint16_t* add, const uint16_t* mask, uint16_t* out_main, uint16_t* out_aux) {
     RowGemmArgs g{};
+    g.bias_partials = tr->bias_partials + (size_t)l_out * tr->bias_layer_stride;
     g.In = tr->dZ[l]; g.W = tr->WbT + (size_t)l * 262144; g.bias = nullptr; g.add = add; g.mask = mask; g.res = nullptr;
     g.out_main = out_main; g.out_aux = out_aux; g.M = n; g.N = 512; g.K = 512; g.relu = 0;
     g.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE; g.st = st; g.dbg = 0;
@@ -268,14 +274,14 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     ++tr->prof_launches;
   };
   ProfScope* dchain = new ProfScope(tr, s, KC_GEMM_DGRAD);
-  dgrad(f2, nullptr, tr->out[f1], tr->dZ[f1], nullptr);
+  dgrad(f2, f1, nullptr, tr->out[f1], tr->dZ[f1], nullptr);
   int cur = 0;
-  dgrad(f1, nullptr, tr->out[3 * tr->nb + 2], tr->dZ[3 * tr->nb + 2], tr->dR[cur]);
+  dgrad(f1, 3 * tr->nb + 2, nullptr, tr->out[3 * tr->nb + 2], tr->dZ[3 * tr->nb + 2], tr->dR[cur]);
   for (int b = tr->nb; b >= 0; --b) {
-    dgrad(3 * b + 2, nullptr, tr->out[3 * b + 1], tr->dZ[3 * b + 1], nullptr);
-    dgrad(3 * b + 1, nullptr, tr->out[3 * b], tr->dZ[3 * b], nullptr);
+    dgrad(3 * b + 2, 3 * b + 1, nullptr, tr->out[3 * b + 1], tr->dZ[3 * b + 1], nullptr);
+    dgrad(3 * b + 1, 3 * b, nullptr, tr->out[3 * b], tr->dZ[3 * b], nullptr);
     if (b > 0) {
-      dgrad(3 * b, tr->dR[cur], tr->out[3 * (b - 1) + 2], tr->dZ[3 * (b - 1) + 2], tr->dR[cur ^ 1]);
+      dgrad(3 * b, 3 * (b - 1) + 2, tr->dR[cur], tr->out[3 * (b - 1) + 2], tr->dZ[3 * (b - 1) + 2], tr->dR[cur ^ 1]);
       cur ^= 1;
     }
   }
@@ -292,7 +298,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
       a.In[3 * b] = tr->R[b]; a.In[3 * b + 1] = tr->out[3 * b]; a.In[3 * b + 2] = tr->out[3 * b + 1];
     }
     a.In[f1] = tr->R[tr->nb + 1]; a.In[f2] = tr->out[f1];
-    a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.n_layers = tr->L; a.st = st; a.zeros = tr->zeros;
+    a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.n_layers = tr->L; a.st = st; a.zeros = tr->zeros; a.dbg = 0;
     ProfScope ps(tr, s, KC_WGRAD);
     const int groups = tr->L * tr->nslabs;
     hipLaunchKernelGGL(wgrad_kernel, dim3(128 * ((groups + 7) / 8)), dim3(256), 0, s, a);
@@ -302,8 +308,10 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.nslabs = tr->nslabs; a.fc3_partials = tr->fc3_partials;
     a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials; a.n_loss_blocks = nblk; a.grad = tr->pb.d_grad;
     a.n_wide = tr->n_wide; a.n_params = tr->n_params; a.st = st;
+    a.bias_partials = tr->bias_partials; a.bias_layer_stride = tr->bias_layer_stride; a.n_layers = tr->L;
+    for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2) ? nblk : 2 * ((n + 127) / 128);
     const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
-    const int64_t tail_blocks = ((tr->n_params - tr->n_wide + 4) * 64 + 255) / 256;
+    const int64_t tail_blocks = (((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4) * 64 + 255) / 256;
     ProfScope ps(tr, s, KC_REDUCE);
     hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, a);
   }

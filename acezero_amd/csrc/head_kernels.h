@@ -52,6 +52,7 @@ struct RowGemmArgs {
   const uint16_t* res;   // [M][N] residual input for AUX_RESIDUAL
   uint16_t* out_main;
   uint16_t* out_aux;
+  float* bias_partials;  // [row tiles * 2][512] column sums of out_main (masked launches) or null
   int M, N, K, relu, aux_mode;
   const TrainState* st;
   int dbg;  // ablation switches for tools/ablate_rowgemm.hip (0 in production): 1 = no epilogue, 2 = no MFMA, 4 = no loads
@@ -65,6 +66,7 @@ struct WgradArgs {
   int64_t slab_stride;
   int M, nslabs, n_layers;
   const TrainState* st;
+  int dbg;                // ablation switches (tools/ablate_rowgemm.hip): 1 = no stores, 2 = no MFMA, 4 = no loads
   const uint16_t* zeros;  // >= 256 bytes of zeros (source of the DMA for rows past the end of a slab)
 };
 
@@ -92,6 +94,7 @@ struct LossArgs {
   float* fc3_partials;   // [blocks][fc3_stride]
   int64_t fc3_stride;
   float* stat_partials;  // [blocks][4]
+  float* bias_partials;  // [blocks][512] column sums of dZ
 };
 
 struct GradReduceArgs {
@@ -102,6 +105,10 @@ struct GradReduceArgs {
   int64_t fc3_stride;
   const float* stat_partials;
   int n_loss_blocks;
+  const float* bias_partials;  // [n_layers][bias_layer_stride]
+  int64_t bias_layer_stride;
+  int bias_count[MAX_LAYERS];  // partial rows per layer
+  int n_layers;
   float* grad;
   int64_t n_wide, n_params;
   const TrainState* st;

@@ -83,7 +83,8 @@ def test_training_steps_match_oracle_and_golden(name):
         st = tr.state()
         assert st["iteration"] == it + 1
         assert abs(st["loss"] - rec["loss"]) < 2e-3 * abs(rec["loss"])
-        # schedule bookkeeping is exact
+        # schedule bookkeeping is exact (the device already holds the cool-down decision of the NEXT iteration)
+        orc.sched.check_and_set_cooldown(orc.iteration)
         assert st["max_iterations"] == orc.sched.max_iterations and st["in_cooldown"] == orc.sched.in_cooldown
         assert abs(st["lr"] - orc.sched.lr) <= 1e-15 * max(1.0, abs(orc.sched.lr)) + 1e-18
         if it + 1 < len(g["lr"]):

@@ -27,7 +27,7 @@ int main() {
       RowGemmArgs g{};
       g.In = In; g.W = W; g.bias = v.m ? nullptr : bias; g.add = v.a ? add : nullptr; g.mask = v.m ? mask : nullptr; g.res = nullptr;
       g.out_main = out; g.out_aux = v.x ? aux : nullptr; g.M = M; g.N = 512; g.K = 512; g.relu = v.m ? 0 : 1;
-      g.aux_mode = v.x ? AUX_UNMASKED : AUX_NONE; g.st = nullptr; g.dbg = v.dbg;
+      g.aux_mode = v.x ? AUX_UNMASKED : AUX_NONE; g.st = nullptr; g.dbg = v.dbg; g.bias_partials = nullptr;
       for (int i = 0; i < 20; ++i) launch_rowgemm(g, dim3(4, 40), 0);
       CK(hipEventRecord(e0, 0));
       const int n = 200;
@@ -36,5 +36,29 @@ int main() {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       if (rep) printf("%-28s %7.2f us/launch  (%.0f TFLOP/s equiv)\n", v.name, ms * 1e3 / n, 2.0 * M * 512 * 512 / (ms * 1e-3 / n) / 1e12);
     }
+  // ---- wgrad
+  {
+    const int L = 8;
+    float* slabs; uint16_t* zeros;
+    const int64_t n_wide = (int64_t)L * 262656;
+    CK(hipMalloc(&slabs, 2 * n_wide * 4)); CK(hipMalloc(&zeros, 1024)); CK(hipMemset(zeros, 0, 1024));
+    std::vector<uint16_t*> bufs;
+    for (int i = 0; i < 2 * L; ++i) { uint16_t* b; CK(hipMalloc(&b, (size_t)M * 512 * 2)); CK(hipMemcpy(b, h.data(), h.size() * 2, hipMemcpyHostToDevice)); bufs.push_back(b); }
+    struct V2 { const char* name; int dbg; } v2[] = {{"wgrad full", 0}, {"wgrad no stores", 1}, {"wgrad no MFMA/tr-read", 2}, {"wgrad no loads", 4},
+                                                    {"wgrad no loads no stores", 5}, {"wgrad nothing", 7}};
+    for (int rep = 0; rep < 2; ++rep)
+      for (auto& v : v2) {
+        WgradArgs a{};
+        for (int l = 0; l < L; ++l) { a.dZ[l] = bufs[2 * l]; a.In[l] = bufs[2 * l + 1]; a.w_off[l] = (int64_t)l * 262656; a.b_off[l] = a.w_off[l] + 262144; }
+        a.slabs = slabs; a.slab_stride = n_wide; a.M = M; a.nslabs = 2; a.n_layers = L; a.st = nullptr; a.zeros = zeros; a.dbg = v.dbg;
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(wgrad_kernel, dim3(256), dim3(256), 0, 0, a);
+        CK(hipEventRecord(e0, 0));
+        const int n = 50;
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(wgrad_kernel, dim3(256), dim3(256), 0, 0, a);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("%-28s %7.2f us/launch  (%.0f TFLOP/s equiv)\n", v.name, ms * 1e3 / n, 2.0 * L * M * 512 * 512 / (ms * 1e-3 / n) / 1e12);
+      }
+  }
   return 0;
 }
