@@ -198,7 +198,7 @@ extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
 static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, const TrainState* st, hipStream_t s) {
   ProfScope chain_scope(tr, s, KC_GEMM_FWD);  // one event pair around the whole chain of dependent GEMM launches
   const float* P = tr->pb.d_params;
-  const dim3 grid(4, (n + 127) / 128), blk(256);
+  const dim3 grid(8 * 4 * ((((n + 127) / 128) + 7) / 8)), blk(256);  // N = 512 -> 4 column tiles; see the XCD decode in rowgemm_kernel
   auto gemm = [&](int l, const uint16_t* in, uint16_t* out_main, const uint16_t* res, uint16_t* out_aux) {
     RowGemmArgs g{};
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144;
@@ -263,7 +263,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
   }
 
   // input-gradient chain
-  const dim3 grid(4, (n + 127) / 128), blk(256);
+  const dim3 grid(8 * 4 * ((((n + 127) / 128) + 7) / 8)), blk(256);  // N = 512 -> 4 column tiles; see the XCD decode in rowgemm_kernel
   auto dgrad = [&](int l, int l_out, const uint16_t* add, const uint16_t* mask, uint16_t* out_main, uint16_t* out_aux) {
     RowGemmArgs g{};
     g.bias_partials = tr->bias_partials + (size_t)l_out * tr->bias_layer_stride;

@@ -100,7 +100,14 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wn = w >> 1, wm = w & 1;
-  const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+  // XCD-aware decode of a 1-D grid (workgroup b runs on XCD b % 8): the four 128-column tiles of one 128-row tile
+  // re-read the same In rows, so they are placed on one XCD and share its L2 (placement affects speed only)
+  const int mtiles = (a.M + 127) >> 7;
+  const int per_xcd = (mtiles + 7) >> 3;
+  const int jx = blockIdx.x >> 3;
+  const int mt = (blockIdx.x & 7) * per_xcd + (jx >> 2);
+  if (mt >= mtiles) return;
+  const int n0 = (jx & 3) * 128, m0 = mt * 128;
   const int M = a.M, N = a.N;
   constexpr int K = 512, KT = 8;
 
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
     float sacc = 0.f;
     const int rows = min(64, M - mw);
     for (int row = 0; row < rows; ++row) sacc += bf2f(regB[row * EP + l]);
-    a.bias_partials[(size_t)(blockIdx.y * 2 + wm) * 512 + nw + l] = sacc;
+    a.bias_partials[(size_t)(mt * 2 + wm) * 512 + nw + l] = sacc;
   }
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
