@@ -182,14 +182,22 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
   const uint16_t* in2 = HAS_MASK ? a.mask : a.res;
   constexpr bool HAS_IN2 = HAS_MASK || AUX == AUX_RESIDUAL;
   if (HAS_ADD || HAS_IN2) {
+    // all 8 (+8) row-segment loads are issued back to back (rows past M are clamped; their results are never
+    // stored), then written to LDS: a load inside an `if (m < M)` block gets its own vmcnt(0) and the eight round
+    // trips serialise (measured: +10 us per launch)
+    uint4 ra[8], rb[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int row = it * 8 + (l >> 3), ch = l & 7, m = mw + row;
-      if (m < M) {
-        const size_t o = (size_t)m * N + nw + ch * 8;
-        if (HAS_ADD) *reinterpret_cast<uint4*>(&regA[row * EP + ch * 8]) = *reinterpret_cast<const uint4*>(a.add + o);
-        if (HAS_IN2) *reinterpret_cast<uint4*>(&regB[row * EP + ch * 8]) = *reinterpret_cast<const uint4*>(in2 + o);
-      }
+      const int row = it * 8 + (l >> 3), ch = l & 7;
+      const size_t o = (size_t)min(mw + row, M - 1) * N + nw + ch * 8;
+      if (HAS_ADD) ra[it] = *reinterpret_cast<const uint4*>(a.add + o);
+      if (HAS_IN2) rb[it] = *reinterpret_cast<const uint4*>(in2 + o);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (l >> 3), ch = l & 7;
+      if (HAS_ADD) *reinterpret_cast<uint4*>(&regA[row * EP + ch * 8]) = ra[it];
+      if (HAS_IN2) *reinterpret_cast<uint4*>(&regB[row * EP + ch * 8]) = rb[it];
     }
   }
   __builtin_amdgcn_wave_barrier();

@@ -149,7 +149,8 @@ def cpu_baseline():
     from concurrent.futures import ThreadPoolExecutor
     from oracle import dsac_oracle, head_oracle
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    tcores = min(cores, 32)   # torch-CPU GEMMs of this size slow down badly when oversubscribed (256 threads: 16 s/step)
+    torch.set_num_threads(tcores)
     prob = synth.make_training_problem(seed=3, n_images=20, views_per_image=2, patches_per_view=128)
     cfg = dict(loss_type="tanh", schedule="1cyclepoly", iterations=25000, lr_min=0.0005, lr_max=0.003, warmup_iterations=1000,
                warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, global_batch=BATCH, soft_clamp=50.0,
@@ -176,8 +177,8 @@ def cpu_baseline():
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(one, range(nfr)))
     t_reg = time.perf_counter() - t0
-    return {"value": BATCH / t_train, "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of 5120 patches, oracle/head_oracle.py fp32 on torch-CPU with {cores} threads; "
+    return {"value": BATCH / t_train, "unit": "patches/s", "cores": tcores, "kind": "port",
+            "sample": f"{steps} steps of 5120 patches, oracle/head_oracle.py fp32 on torch-CPU with {tcores} of {cores} host threads; "
                       f"registration: {nfr} frames, oracle/dsac_oracle.cpp, {cores} threads",
             "registration_images_per_s": nfr / t_reg}
 
