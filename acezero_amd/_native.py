@@ -35,12 +35,14 @@ class TrainConfig(C.Structure):
                 ("lr_min", C.c_double), ("lr_max", C.c_double), ("warmup_iterations", C.c_int32), ("warmup_lr", C.c_double),
                 ("cooldown_iterations", C.c_int32), ("cooldown_trigger_percent", C.c_double), ("beta1", C.c_double),
                 ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("refine_calibration", C.c_int32),
-                ("focal_init", C.c_float), ("calib_lr", C.c_double), ("reserved", C.c_int32)]
+                ("focal_init", C.c_float), ("calib_lr", C.c_double), ("pose_refinement", C.c_int32), ("pose_refinement_wait", C.c_int32),
+                ("pose_refinement_lr", C.c_double), ("pose_refinement_weight", C.c_float), ("reserved", C.c_int32)]
 
 
 class ParamBuffers(C.Structure):
     _fields_ = [("d_params", C.c_void_p), ("d_adam_m", C.c_void_p), ("d_adam_v", C.c_void_p), ("d_grad", C.c_void_p),
-                ("n_params", C.c_int64)]
+                ("n_params", C.c_int64), ("d_pose_params", C.c_void_p), ("d_pose_m", C.c_void_p), ("d_pose_v", C.c_void_p),
+                ("n_pose_params", C.c_int64)]
 
 
 class TrainBuffer(C.Structure):
@@ -81,6 +83,7 @@ SYMBOLS = {
     "acez_trainer_last_scene_coords": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "acez_trainer_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "acez_trainer_get_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acez_trainer_get_poses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "acez_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
 }
 

@@ -1,6 +1,7 @@
 // head_api.hip -- C-ABI entry points of the head training / inference path (include/acez.h, group T).
 // Host-side orchestration only: every entry point enqueues kernels of head_kernels.hip on the caller's stream.
 #include "head_kernels.hip"
+#include "pose_kernels.hip"
 #include "acez_common.h"
 #include <vector>
 #include <new>
@@ -37,6 +38,13 @@ struct acez_trainer {
   TrainState* st = nullptr;
   SchedConfig sc;
   std::vector<void*> allocs;
+  // pose refinement (mlp): per-image activations and gradients, allocated by set_buffer (needs n_images)
+  int pose_images = 0, pose_ksplit = 1;
+  float *pa1 = nullptr, *pa2 = nullptr, *pa3 = nullptr, *pr = nullptr, *pf1 = nullptr, *pf2 = nullptr, *pdlt = nullptr, *pose_cur = nullptr;
+  float *pdT = nullptr, *pddelta = nullptr, *pdz2 = nullptr, *pdz1 = nullptr, *pdr = nullptr, *pdzc3 = nullptr, *pdzc2 = nullptr, *pdzc1 = nullptr;
+  float* pose_part = nullptr;
+  float* row_dT = nullptr;
+  int* row_image = nullptr;
   // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -96,6 +104,9 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_REQUIRE(params->n_params == acez_head_num_params(&cfg->head), "n_params does not match the head description");
   ACEZ_REQUIRE(cfg->schedule >= 0 && cfg->schedule <= 2, "unknown schedule");
   ACEZ_REQUIRE(cfg->loss_type >= 0 && cfg->loss_type <= 4, "unknown loss type");
+  ACEZ_REQUIRE(cfg->pose_refinement == 0 || cfg->pose_refinement == 2, "pose_refinement must be 0 (none) or 2 (mlp)");
+  ACEZ_REQUIRE(cfg->pose_refinement == 0 || (params->d_pose_params && params->d_pose_m && params->d_pose_v && params->n_pose_params == ACEZ_POSE_MLP_PARAMS),
+               "pose_refinement mlp needs the pose-network parameter buffers");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     (void)hipGetLastError();
@@ -155,6 +166,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   sc.cooldown_trigger_percent = cfg->cooldown_trigger_percent;
   sc.beta1 = cfg->beta1; sc.beta2 = cfg->beta2; sc.eps = cfg->eps; sc.weight_decay = cfg->weight_decay;
   sc.calib_lr = cfg->calib_lr;
+  sc.pose_refinement = cfg->pose_refinement; sc.pose_wait = cfg->pose_refinement_wait; sc.pose_lr = cfg->pose_refinement_lr;
   hipLaunchKernelGGL(sched_init_kernel, dim3(1), dim3(64), 0, 0, tr->st, sc);
   ACEZ_HIP_CHECK(hipGetLastError());
   ACEZ_HIP_CHECK(hipMemset(tr->zeros, 0, 1024));
@@ -172,6 +184,28 @@ extern "C" int acez_trainer_set_buffer(acez_trainer* tr, const acez_train_buffer
   ACEZ_REQUIRE(buf->d_image_pose_inv && buf->n_images > 0, "empty pose table");
   tr->buf = *buf;
   tr->have_buf = true;
+  if (tr->cfg.pose_refinement == 2 && tr->pose_images < buf->n_images) {
+    ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+    const int I = buf->n_images;
+    int rc = ACEZ_OK;
+    auto A = [&](void** p, size_t bytes) { if (rc == ACEZ_OK) rc = dmalloc(tr, p, bytes); };
+    float** wide[] = {&tr->pa1, &tr->pa2, &tr->pa3, &tr->pr, &tr->pf1, &tr->pf2, &tr->pdz2, &tr->pdz1, &tr->pdr, &tr->pdzc3, &tr->pdzc2, &tr->pdzc1};
+    for (float** p : wide) A((void**)p, (size_t)I * 128 * sizeof(float));
+    A((void**)&tr->pdlt, (size_t)I * 12 * sizeof(float));
+    A((void**)&tr->pdT, (size_t)I * 12 * sizeof(float));
+    A((void**)&tr->pddelta, (size_t)I * 12 * sizeof(float));
+    A((void**)&tr->pose_cur, (size_t)I * 16 * sizeof(float));
+    tr->pose_ksplit = (I + 127) / 128;
+    if (tr->pose_ksplit > 32) tr->pose_ksplit = 32;
+    if (tr->pose_ksplit < 1) tr->pose_ksplit = 1;
+    A((void**)&tr->pose_part, (size_t)tr->pose_ksplit * ACEZ_POSE_MLP_PARAMS * sizeof(float));
+    if (!tr->row_dT) {
+      A((void**)&tr->row_dT, (size_t)tr->max_batch * 12 * sizeof(float));
+      A((void**)&tr->row_image, (size_t)tr->max_batch * sizeof(int));
+    }
+    if (rc != ACEZ_OK) return rc;
+    tr->pose_images = I;
+  }
   return ACEZ_OK;
 }
 
@@ -227,6 +261,74 @@ static void fill_loss_head(acez_trainer* tr, LossArgs& a) {
   a.max_inv_scale = tr->cfg.head.max_inv_scale; a.min_inv_scale = tr->cfg.head.min_inv_scale; a.h_beta = tr->cfg.head.h_beta;
 }
 
+// ---- pose refinement (mlp): flat parameter offsets in PoseNetwork.named_parameters() order
+namespace {
+constexpr int64_t PO_SKIP_W = 0, PO_SKIP_B = 1536, PO_C1_W = 1664, PO_C1_B = 3200, PO_C2_W = 3328, PO_C2_B = 19712, PO_C3_W = 19840,
+                  PO_C3_B = 36224, PO_F1_W = 36352, PO_F1_B = 52736, PO_F2_W = 52864, PO_F2_B = 69248, PO_F3_W = 69376, PO_F3_B = 70912;
+}
+
+static void pose_sgemm(hipStream_t s, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t scm,
+                       int M, int N, int K, const float* bias, const float* add, const float* mask, int relu, const int* active,
+                       int ksplit = 1, int64_t csplit = 0, float* lastcol = nullptr) {
+  SGemmArgs g{};
+  g.A = A; g.sa_m = sam; g.sa_k = sak; g.B = B; g.sb_k = sbk; g.sb_n = sbn; g.C = C; g.sc_m = scm; g.sc_n = 1; g.M = M; g.N = N; g.K = K;
+  g.bias = bias; g.add = add; g.mask = mask; g.relu = relu; g.scale = 1.f; g.ksplit = ksplit; g.c_split = csplit; g.active = active; g.c_lastcol = lastcol;
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 63) / 64, (M + 63) / 64, ksplit), dim3(256), 0, s, g);
+}
+
+// refined poses of all images with the current network: pose_cur [I][16]
+static void pose_forward(acez_trainer* tr, const int* active, hipStream_t s) {
+  const int I = tr->buf.n_images;
+  const float* P = tr->pb.d_pose_params;
+  const float* T0 = tr->buf.d_image_pose_inv;
+  // y = relu(x W^T + b): A = x [I][K], B(k, n) = W[n][k]
+  pose_sgemm(s, T0, 16, 1, P + PO_C1_W, 1, 12, tr->pa1, 128, I, 128, 12, P + PO_C1_B, nullptr, nullptr, 1, active);
+  pose_sgemm(s, tr->pa1, 128, 1, P + PO_C2_W, 1, 128, tr->pa2, 128, I, 128, 128, P + PO_C2_B, nullptr, nullptr, 1, active);
+  pose_sgemm(s, tr->pa2, 128, 1, P + PO_C3_W, 1, 128, tr->pa3, 128, I, 128, 128, P + PO_C3_B, nullptr, nullptr, 1, active);
+  pose_sgemm(s, T0, 16, 1, P + PO_SKIP_W, 1, 12, tr->pr, 128, I, 128, 12, P + PO_SKIP_B, tr->pa3, nullptr, 0, active);  // head_skip(x) + x3
+  pose_sgemm(s, tr->pr, 128, 1, P + PO_F1_W, 1, 128, tr->pf1, 128, I, 128, 128, P + PO_F1_B, nullptr, nullptr, 1, active);
+  pose_sgemm(s, tr->pf1, 128, 1, P + PO_F2_W, 1, 128, tr->pf2, 128, I, 128, 128, P + PO_F2_B, nullptr, nullptr, 1, active);
+  pose_sgemm(s, tr->pf2, 128, 1, P + PO_F3_W, 1, 128, tr->pdlt, 12, I, 12, 128, P + PO_F3_B, nullptr, nullptr, 0, active);
+  hipLaunchKernelGGL(pose_compose_kernel, dim3((I + 255) / 256), dim3(256), 0, s, T0, (const float*)tr->pdlt, tr->cfg.pose_refinement_weight,
+                     tr->pose_cur, I, active);
+}
+
+// gradient of the pose network from the per-row pose gradients of the loss kernel -> d_grad tail
+static void pose_backward(acez_trainer* tr, int n, const int* active, hipStream_t s) {
+  const int I = tr->buf.n_images, Z = tr->pose_ksplit;
+  const float* P = tr->pb.d_pose_params;
+  const float* T0 = tr->buf.d_image_pose_inv;
+  float* part = tr->pose_part;
+  const int64_t NP = ACEZ_POSE_MLP_PARAMS;
+  hipLaunchKernelGGL(pose_grad_reduce_kernel, dim3((I * 64 + 255) / 256), dim3(256), 0, s, (const float*)tr->row_dT, (const int*)tr->row_image, n,
+                     tr->pdT, I, active);
+  hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((I + 255) / 256), dim3(256), 0, s, T0, (const float*)tr->pdlt, tr->cfg.pose_refinement_weight,
+                     (const float*)tr->pdT, tr->pddelta, I, active);
+  // weight gradient dW[o][k] = sum_i dY[i][o] X[i][k] (+ bias via the ones column), split over images into Z partials
+  auto wgrad = [&](const float* dY, int O, const float* X, int64_t xpitch, int Kin, int64_t offW, int64_t offB) {
+    pose_sgemm(s, dY, 1, O, X, xpitch, 1, part + offW, Kin, O, Kin + 1, I, nullptr, nullptr, nullptr, 0, active, Z, NP, part + offB);
+  };
+  // input gradient dX = (dY W) (.) mask: A = dY [I][O], B(k = o, n) = W[o][n]
+  auto dgrad = [&](const float* dY, int O, int64_t offW, int Kin, const float* mask, float* out) {
+    pose_sgemm(s, dY, O, 1, P + offW, Kin, 1, out, Kin, I, Kin, O, nullptr, nullptr, mask, 0, active);
+  };
+  wgrad(tr->pddelta, 12, tr->pf2, 128, 128, PO_F3_W, PO_F3_B);
+  dgrad(tr->pddelta, 12, PO_F3_W, 128, tr->pf2, tr->pdz2);
+  wgrad(tr->pdz2, 128, tr->pf1, 128, 128, PO_F2_W, PO_F2_B);
+  dgrad(tr->pdz2, 128, PO_F2_W, 128, tr->pf1, tr->pdz1);
+  wgrad(tr->pdz1, 128, tr->pr, 128, 128, PO_F1_W, PO_F1_B);
+  dgrad(tr->pdz1, 128, PO_F1_W, 128, nullptr, tr->pdr);
+  dgrad(tr->pdz1, 128, PO_F1_W, 128, tr->pa3, tr->pdzc3);
+  wgrad(tr->pdr, 128, T0, 16, 12, PO_SKIP_W, PO_SKIP_B);
+  wgrad(tr->pdzc3, 128, tr->pa2, 128, 128, PO_C3_W, PO_C3_B);
+  dgrad(tr->pdzc3, 128, PO_C3_W, 128, tr->pa2, tr->pdzc2);
+  wgrad(tr->pdzc2, 128, tr->pa1, 128, 128, PO_C2_W, PO_C2_B);
+  dgrad(tr->pdzc2, 128, PO_C2_W, 128, tr->pa1, tr->pdzc1);
+  wgrad(tr->pdzc1, 128, T0, 16, 12, PO_C1_W, PO_C1_B);
+  hipLaunchKernelGGL(small_reduce_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, s, (const float*)part, NP, Z,
+                     tr->pb.d_grad + tr->n_params + 4, NP, active);
+}
+
 extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, int n, void* stream) {
   ACEZ_REQUIRE(tr && d_indices, "null pointer");
   ACEZ_REQUIRE(tr->have_buf, "acez_trainer_set_buffer has not been called");
@@ -241,6 +343,8 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
                      (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n, st);
   delete psg;
   uint16_t* act = launch_forward(tr, tr->R[0], n, st, s);
+  const bool pose_mlp = tr->cfg.pose_refinement == 2;
+  if (pose_mlp) pose_forward(tr, &tr->st->active, s);
 
   const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
   const int nblk = (n + 31) / 32;
@@ -250,7 +354,8 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.act = act; a.n = n;
     a.idx = d_indices; a.target_px = tr->buf.d_target_px; a.view_idx = tr->buf.d_view_idx;
     a.view_aug_inv = tr->buf.d_view_aug_inv; a.view_K = tr->buf.d_view_K; a.view_Kinv = tr->buf.d_view_Kinv;
-    a.view_image = tr->buf.d_view_image; a.image_pose_inv = tr->buf.d_image_pose_inv;
+    a.view_image = tr->buf.d_view_image; a.image_pose_inv = pose_mlp ? tr->pose_cur : tr->buf.d_image_pose_inv;
+    a.row_dT = pose_mlp ? tr->row_dT : nullptr; a.row_image = pose_mlp ? tr->row_image : nullptr;
     a.loss_type = tr->cfg.loss_type; a.refine_calibration = tr->cfg.refine_calibration;
     a.hard_clamp = tr->cfg.hard_clamp; a.depth_min = tr->cfg.depth_min; a.depth_max = tr->cfg.depth_max;
     a.depth_target = tr->cfg.depth_target; a.inlier_px = tr->cfg.inlier_px_threshold;
@@ -261,6 +366,8 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     ProfScope ps(tr, s, KC_LOSS);
     hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, s, a);
   }
+
+  if (pose_mlp) pose_backward(tr, n, &tr->st->active, s);
 
   // input-gradient chain
   const dim3 grid(8 * 4 * ((((n + 127) / 128) + 7) / 8)), blk(256);  // N = 512 -> 4 column tiles; see the XCD decode in rowgemm_kernel
@@ -327,6 +434,10 @@ extern "C" int acez_train_update(acez_trainer* tr, void* stream) {
   fill_adam_args(tr, a);
   const int nsmall = (int)(((int64_t)tr->L * 512 + (int64_t)tr->no * 513 + 255) / 256);
   { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3(tr->L * 64 + nsmall), dim3(256), 0, s, a); }
+  if (tr->cfg.pose_refinement == 2)
+    hipLaunchKernelGGL(adamw_small_kernel, dim3((ACEZ_POSE_MLP_PARAMS + 255) / 256), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,
+                       tr->pb.d_pose_v, (const float*)(tr->pb.d_grad + tr->n_params + 4), (int64_t)0, 1, (int64_t)ACEZ_POSE_MLP_PARAMS,
+                       (const AdamScalars*)&tr->st->pose_adam, (const int*)&tr->st->pose_enable, (const int*)&tr->st->active);
   ProfScope ps2(tr, s, KC_SCHED);
   hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, tr->st, tr->sc, (const float*)(tr->pb.d_grad + tr->n_params),
                      1.0f / (float)tr->cfg.global_batch, tr->log_loss, tr->log_inl, tr->log_cap);
@@ -413,5 +524,22 @@ extern "C" int acez_trainer_get_profile(acez_trainer* tr, float* h_ms8, int32_t*
   }
   tr->ev_used.clear();
   tr->ev_next = 0;
+  return ACEZ_OK;
+}
+
+extern "C" int acez_trainer_get_poses(acez_trainer* tr, float* h_poses34, void* stream) {
+  ACEZ_REQUIRE(tr && h_poses34, "null pointer");
+  ACEZ_REQUIRE(tr->have_buf, "acez_trainer_set_buffer has not been called");
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int I = tr->buf.n_images;
+  const float* src = tr->buf.d_image_pose_inv;
+  if (tr->cfg.pose_refinement == 2) {
+    pose_forward(tr, nullptr, s);
+    ACEZ_HIP_CHECK(hipGetLastError());
+    src = tr->pose_cur;
+  }
+  ACEZ_HIP_CHECK(hipMemcpy2DAsync(h_poses34, 12 * sizeof(float), src, 16 * sizeof(float), 12 * sizeof(float), I, hipMemcpyDeviceToHost, s));
+  ACEZ_HIP_CHECK(hipStreamSynchronize(s));
   return ACEZ_OK;
 }

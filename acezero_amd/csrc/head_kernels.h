@@ -33,6 +33,10 @@ struct TrainState {
   double calib_g, calib_m, calib_v;
   double beta1_pow, beta2_pow;  // beta^opt_steps
   AdamScalars adam;
+  // pose-refinement network (refine_poses.py): own AdamW
+  int pose_enable, pose_opt_steps;
+  double pose_b1pow, pose_b2pow;
+  AdamScalars pose_adam;
 };
 
 struct SchedConfig {
@@ -41,6 +45,8 @@ struct SchedConfig {
   float soft_clamp, soft_clamp_min;
   double lr_min, lr_max, warmup_lr, cooldown_trigger_percent;
   double beta1, beta2, eps, weight_decay, calib_lr;
+  int pose_refinement, pose_wait;
+  double pose_lr;
 };
 
 struct RowGemmArgs {
@@ -84,7 +90,9 @@ struct LossArgs {
   const float* view_K;
   const float* view_Kinv;
   const int32_t* view_image;
-  const float* image_pose_inv;
+  const float* image_pose_inv;   // [images][16] world->cam poses used by this step (refined ones under pose refinement)
+  float* row_dT;                 // [n][12] d(loss)/d(pose rows 0..2) per batch row, or null
+  int* row_image;                // [n] image of each batch row, or null
   int loss_type, refine_calibration;
   float hard_clamp, depth_min, depth_max, depth_target, inlier_px, inv_batch, focal_init;
   const TrainState* st;

@@ -585,6 +585,17 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
           }
         }
         const float invB = a.inv_batch;
+        if (a.row_dT) {
+          // d(loss)/dT[k][j] = sum_i A[i][k] * dXc[i] * Xh[j], k < 3 (row 3 of T is the constant 0 0 0 1)
+          const float Xh[4] = {X[0], X[1], X[2], 1.f};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float ak = (A[0 * 4 + k] * dXc[0] + A[1 * 4 + k] * dXc[1] + A[2 * 4 + k] * dXc[2]) * invB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a.row_dT[(size_t)m * 12 + k * 4 + j] = ak * Xh[j];
+          }
+          a.row_image[m] = a.view_image[view];
+        }
         float dX[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) dX[k] = (P[0 * 4 + k] * dXc[0] + P[1 * 4 + k] * dXc[1] + P[2 * 4 + k] * dXc[2]) * invB;
@@ -897,6 +908,19 @@ __device__ void sched_prepare(TrainState* st, const SchedConfig& c) {
     s.step_size = (float)(lr / bc1);
     st->adam = s;
   }
+  if (c.pose_refinement) {
+    st->pose_enable = (it > c.pose_wait) ? 1 : 0;   // ace_trainer.py:634
+    const double b1p = st->pose_b1pow * c.beta1, b2p = st->pose_b2pow * c.beta2;
+    AdamScalars s;
+    s.decay = (float)(1.0 - c.pose_lr * c.weight_decay);
+    s.one_minus_beta1 = (float)(1.0 - c.beta1);
+    s.beta2 = (float)c.beta2;
+    s.one_minus_beta2 = (float)(1.0 - c.beta2);
+    s.bc2_sqrt = (float)sqrt(1.0 - b2p);
+    s.eps = (float)c.eps;
+    s.step_size = (float)(c.pose_lr / (1.0 - b1p));
+    st->pose_adam = s;
+  }
 }
 
 // initial state: lr as left by the torch scheduler constructors (ace_schedule.py:12-70)
@@ -906,6 +930,7 @@ __global__ void sched_init_kernel(TrainState* st, SchedConfig c) {
   st->warmup_epoch = 0; st->cooldown_epoch = 0; st->nan_flag = 0; st->opt_steps = 0; st->crit_count = 0;
   st->calib_steps = 0; st->loss_weight = c.soft_clamp; st->last_loss = 0.f; st->last_inliers = 0.f;
   st->calib_g = 0.0; st->calib_m = 0.0; st->calib_v = 0.0; st->beta1_pow = 1.0; st->beta2_pow = 1.0;
+  st->pose_enable = 0; st->pose_opt_steps = 0; st->pose_b1pow = 1.0; st->pose_b2pow = 1.0;
   if (c.schedule == SCHED_CONSTANT) st->lr = c.lr_min;
   else if (c.schedule == SCHED_1CYCLEPOLY) st->lr = c.lr_max * (c.warmup_lr / c.lr_max);  // LinearLR._initial_step
   else st->lr = onecycle_lr(c, 0);
@@ -926,6 +951,11 @@ __global__ void sched_post_kernel(TrainState* st, SchedConfig c, const float* gr
   st->opt_steps += 1;
   st->beta1_pow *= c.beta1;
   st->beta2_pow *= c.beta2;
+  if (c.pose_refinement && st->pose_enable) {
+    st->pose_opt_steps += 1;
+    st->pose_b1pow *= c.beta1;
+    st->pose_b2pow *= c.beta2;
+  }
   // calibration refiner: its own AdamW on the scalar g (refine_calibration.py:21-26,58-59)
   if (c.refine_calibration) {
     const double g = (double)grad_stats[2];

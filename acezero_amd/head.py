@@ -24,6 +24,23 @@ def layer_names(num_head_blocks):
     return names + ["fc1", "fc2"]
 
 
+POSE_MLP_PARAMS = 70924
+POSE_LAYERS = [("head_skip", 128, 12), ("conv1", 128, 12), ("conv2", 128, 128), ("conv3", 128, 128), ("fc1", 128, 128),
+               ("fc2", 128, 128), ("fc3", 12, 128)]   # PoseNetwork(0, 128).named_parameters() order (refine_poses.py:21-51)
+
+
+def init_pose_network(seed):
+    """nn.Conv2d default initialisation (kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and
+    bias) of PoseNetwork(0, 128), flat in named_parameters() order."""
+    g = torch.Generator().manual_seed(int(seed))
+    parts = []
+    for _, o, k in POSE_LAYERS:
+        bound = 1.0 / math.sqrt(k)
+        parts.append((torch.rand(o * k, generator=g) * 2 - 1) * bound)
+        parts.append((torch.rand(o, generator=g) * 2 - 1) * bound)
+    return torch.cat(parts).float()
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -40,7 +57,8 @@ class HeadTrainer:
                  depth_min=0.1, depth_max=1000.0, depth_target=10.0, inlier_px_threshold=10.0, schedule="circle",
                  iterations=25000, lr_min=0.0005, lr_max=0.005, warmup_iterations=1000, warmup_lr=0.0005,
                  cooldown_iterations=5000, cooldown_trigger_percent=0.7, refine_calibration=False, focal_init=0.0,
-                 calib_lr=0.001, homogeneous_min_scale=0.01, homogeneous_max_scale=4.0, device=None):
+                 calib_lr=0.001, pose_refinement="none", pose_refinement_wait=0, pose_refinement_lr=0.001,
+                 pose_refinement_weight=0.1, pose_seed=0, homogeneous_min_scale=0.01, homogeneous_max_scale=4.0, device=None):
         if not torch.cuda.is_available():
             raise RuntimeError("HeadTrainer needs a GPU: the head kernels are HIP only (no CPU fallback)")
         self.lib = N.lib()
@@ -63,7 +81,17 @@ class HeadTrainer:
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros_like(self.params)
         self.adam_v = torch.zeros_like(self.params)
-        self.grad = torch.zeros(self.n_params + 4, dtype=torch.float32, device=dev)  # + {loss, inliers, dfocal, pad}
+        if pose_refinement not in ("none", "mlp"):
+            raise ValueError("pose_refinement must be 'none' or 'mlp' ('naive' is not built)")
+        self.pose_mlp = pose_refinement == "mlp"
+        self.n_pose = POSE_MLP_PARAMS if self.pose_mlp else 0
+        # gradient bucket: head gradients, {loss, inliers, dfocal, pad}, then the pose-network gradients
+        self.grad = torch.zeros(self.n_params + 4 + self.n_pose, dtype=torch.float32, device=dev)
+        self.pose_params = self.pose_m = self.pose_v = None
+        if self.pose_mlp:
+            self.pose_params = init_pose_network(pose_seed).to(dev)
+            self.pose_m = torch.zeros_like(self.pose_params)
+            self.pose_v = torch.zeros_like(self.pose_params)
         self.max_batch = int(max_batch)
         self.global_batch = int(global_batch or max_batch)
         cfg = N.TrainConfig()
@@ -78,7 +106,11 @@ class HeadTrainer:
         cfg.cooldown_iterations, cfg.cooldown_trigger_percent = int(cooldown_iterations), cooldown_trigger_percent
         cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay = 0.9, 0.999, 1e-8, 1e-2  # torch.optim.AdamW defaults
         cfg.refine_calibration, cfg.focal_init, cfg.calib_lr = int(refine_calibration), float(focal_init), calib_lr
-        pb = N.ParamBuffers(_ptr(self.params), _ptr(self.adam_m), _ptr(self.adam_v), _ptr(self.grad), self.n_params)
+        cfg.pose_refinement = 2 if self.pose_mlp else 0
+        cfg.pose_refinement_wait, cfg.pose_refinement_lr = int(pose_refinement_wait), float(pose_refinement_lr)
+        cfg.pose_refinement_weight = float(pose_refinement_weight)
+        pb = N.ParamBuffers(_ptr(self.params), _ptr(self.adam_m), _ptr(self.adam_v), _ptr(self.grad), self.n_params,
+                            _ptr(self.pose_params), _ptr(self.pose_m), _ptr(self.pose_v), self.n_pose)
         h = C.c_void_p()
         N.check(self.lib.acez_trainer_create(C.byref(h), C.byref(cfg), C.byref(pb), self.device.index))
         self._h = h
@@ -197,6 +229,13 @@ class HeadTrainer:
         cnt = np.zeros(8, np.int32)
         N.check(self.lib.acez_trainer_get_profile(self._h, ms.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
+
+    def current_poses(self):
+        """Refined world->cam poses [n_images,3,4] (PoseRefiner.get_all_current_poses, refine_poses.py:184-210)."""
+        n = int(self._buf["image_pose_inv"].shape[0])
+        out = np.zeros((n, 3, 4), np.float32)
+        N.check(self.lib.acez_trainer_get_poses(self._h, out.ctypes.data_as(C.c_void_p), _stream()))
+        return out
 
     # ---------------------------------------------------------------- inference
     def get_scene_coordinates(self, features):

@@ -157,6 +157,11 @@ typedef struct acez_train_config {
   int32_t refine_calibration;
   float focal_init;            /* CalibrationRefiner.focal_length_init                                   */
   double calib_lr;
+  /* pose refinement (refine_poses.py): 0 = none, 2 = mlp (PoseNetwork(0,128) + Gram-Schmidt); naive is not built */
+  int32_t pose_refinement;
+  int32_t pose_refinement_wait;   /* train_ace.py:220                                                     */
+  double pose_refinement_lr;      /* train_ace.py:223, 1e-3                                               */
+  float pose_refinement_weight;   /* train_ace.py:216, 0.1                                                */
   int32_t reserved;
 } acez_train_config;
 
@@ -172,7 +177,15 @@ typedef struct acez_param_buffers {
                        this is the bucket a data-parallel host all-reduces between
                        acez_train_backward and acez_train_update */
   int64_t n_params; /* must equal acez_head_num_params(head)                 */
+  /* pose-refinement network, flat in PoseNetwork.named_parameters() order (head_skip, conv1..3, fc1..3; 70 924
+   * floats); only read when cfg.pose_refinement == 2. Its gradient is appended to d_grad after the 4 statistics,
+   * so d_grad holds n_params + 4 + n_pose_params floats and one all-reduce still covers everything. */
+  float* d_pose_params;
+  float* d_pose_m;
+  float* d_pose_v;
+  int64_t n_pose_params; /* ACEZ_POSE_MLP_PARAMS or 0 */
 } acez_param_buffers;
+#define ACEZ_POSE_MLP_PARAMS 70924
 
 /* The training buffer of ace_trainer.py:330-340, with the per-image data stored once per view
  * (image x augmentation pass) instead of once per patch. */
@@ -233,6 +246,10 @@ int acez_trainer_last_scene_coords(acez_trainer* tr, float* h_xyz, int n, void* 
  * 8 kernel classes {sched, gather, gemm_fwd, loss, gemm_dgrad, wgrad, grad_reduce, adamw}, then clears the record. */
 int acez_trainer_set_profiling(acez_trainer* tr, int enable);
 int acez_trainer_get_profile(acez_trainer* tr, float* h_ms8, int32_t* h_counts8);
+
+/* Current refined world->cam poses of all images, f32 [n_images][3][4] (PoseRefiner.get_all_current_poses,
+ * refine_poses.py:184-210); the original poses when pose refinement is off. Synchronous. */
+int acez_trainer_get_poses(acez_trainer* tr, float* h_poses34, void* stream);
 
 /* Head inference (Regressor.get_scene_coordinates, ace_network.py:262-263) on n feature rows:
  *   d_features bf16 [n][512]  ->  d_out_xyz f32 [n][3].   Asynchronous. */

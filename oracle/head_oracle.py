@@ -251,6 +251,79 @@ class HeadOracle:
         return g
 
 
+POSE_LAYERS = [("head_skip", 128, 12), ("conv1", 128, 12), ("conv2", 128, 128), ("conv3", 128, 128), ("fc1", 128, 128),
+               ("fc2", 128, 128), ("fc3", 12, 128)]   # PoseNetwork(0, 128).named_parameters() order (refine_poses.py:21-51)
+
+
+def special_gramschmidt(M):
+    """roma.special_gramschmidt (roma 1.4.1, not vendored in the reference: restated from its documentation --
+    Gram-Schmidt on the first two columns, third column = cross product)."""
+    x, y = M[..., 0], M[..., 1]
+    x = x / torch.norm(x, dim=-1, keepdim=True)
+    y = y - torch.sum(x * y, dim=-1, keepdim=True) * x
+    y = y / torch.norm(y, dim=-1, keepdim=True)
+    z = torch.cross(x, y, dim=-1)
+    return torch.stack((x, y, z), dim=-1)
+
+
+class PoseMLPOracle:
+    """refine_poses.py `mlp` strategy evaluated once per image, torch autograd for the backward pass."""
+
+    def __init__(self, flat, update_weight=0.1):
+        self.flat = flat.clone().requires_grad_(True)
+        self.w = update_weight
+
+    def _views(self):
+        out, o = {}, 0
+        for name, O, K in POSE_LAYERS:
+            out[name + ".weight"] = self.flat[o:o + O * K].view(O, K); o += O * K
+            out[name + ".bias"] = self.flat[o:o + O]; o += O
+        return out
+
+    def forward(self, poses44):
+        """poses44 [I,4,4] world->cam -> refined [I,4,4] (refine_poses.py:53-72,152-176,236-244)."""
+        v = self._views()
+        x0 = poses44[:, :3].reshape(-1, 12)
+        lin = lambda x, n: x @ v[n + ".weight"].t() + v[n + ".bias"]
+        x = torch.relu(lin(x0, "conv1")); x = torch.relu(lin(x, "conv2")); x = torch.relu(lin(x, "conv3"))
+        res = lin(x0, "head_skip") + x
+        d = lin(torch.relu(lin(torch.relu(lin(res, "fc1")), "fc2")), "fc3")
+        upd = (x0 + self.w * d).view(-1, 3, 4)
+        R = special_gramschmidt(upd[:, :3, :3])
+        out = poses44.clone()
+        out = torch.cat([torch.cat([R, upd[:, :3, 3:4]], dim=2), poses44[:, 3:4, :]], dim=1)
+        return out
+
+
+def loss_autograd(head, s, batch, cfg, iteration, poses44_rows, focal_scale=1.0):
+    """ace_trainer.py:521-613 with torch ops and autograd (used where gradients wrt the poses are needed).
+    s [B,no] requires grad; poses44_rows [B,4,4] may require grad. Returns (loss_sum tensor, inliers)."""
+    B = s.shape[0]
+    X, _ = head.dehomogenise(s)
+    tu_tv = batch["target_px"]
+    P = torch.bmm(batch["aug_inv"], poses44_rows)
+    Xh = torch.cat([X, torch.ones(B, 1)], dim=1)
+    Xc = torch.bmm(P, Xh[:, :, None])[:, :, 0]
+    K = batch["K"].clone()
+    if cfg.get("refine_calibration", False):
+        raise NotImplementedError
+    pp = torch.bmm(K, Xc[:, :, None])[:, :, 0]
+    pz = pp[:, 2].clamp(min=float(cfg["depth_min"]))
+    uv = pp[:, :2] / pz[:, None]
+    e = (uv - tu_tv).abs().sum(dim=1)
+    invalid = (Xc[:, 2] < cfg["depth_min"]) | (e > cfg["hard_clamp"]) | (Xc[:, 2] > cfg["depth_max"])
+    valid = ~invalid
+    w = float(cfg["soft_clamp"])
+    assert cfg["loss_type"] == "tanh"
+    lv = w * torch.tanh(e / w)
+    px_h = torch.cat([tu_tv, torch.ones(B, 1)], dim=1)
+    tgt = float(cfg["depth_target"]) * torch.bmm(batch["Kinv"], px_h[:, :, None])[:, :, 0]
+    li = (tgt - Xc).abs().sum(dim=1)
+    loss_sum = torch.where(valid, lv, li).sum()
+    inl = float((valid & (e < cfg["inlier_px_threshold"])).sum())
+    return loss_sum, inl
+
+
 class ScheduleOracle:
     """ace_schedule.py restated with the chainable LR recurrences of torch.optim.lr_scheduler (LinearLR,
     OneCycleLR) in Python floats, plus single-tensor AdamW (torch.optim.AdamW defaults)."""
@@ -347,12 +420,34 @@ class ScheduleOracle:
 class TrainerOracle:
     """training_step of ace_trainer.py:499-679 on explicit per-patch inputs."""
 
-    def __init__(self, flat_params, mean, cfg, mode="fp32"):
+    def __init__(self, flat_params, mean, cfg, mode="fp32", pose_flat=None, image_pose_inv=None):
         self.cfg = cfg
         self.head = HeadOracle(flat_params, mean, cfg.get("num_head_blocks", 1), cfg.get("use_homogeneous", True), mode)
         self.sched = ScheduleOracle(cfg, flat_params.numel())
         self.iteration = 0
         self.log = []
+        self.pose = None
+        if cfg.get("pose_refinement", "none") == "mlp":
+            self.pose = PoseMLPOracle(pose_flat, cfg.get("pose_refinement_weight", 0.1))
+            self.image_pose_inv = torch.as_tensor(image_pose_inv, dtype=torch.float32)
+            self.pose_m = torch.zeros_like(pose_flat)
+            self.pose_v = torch.zeros_like(pose_flat)
+            self.pose_steps = 0
+
+    def current_poses(self):
+        with torch.no_grad():
+            return self.pose.forward(self.image_pose_inv)[:, :3].clone()
+
+    def _pose_adamw(self, g, lr=0.001):
+        self.pose_steps += 1
+        b1, b2, eps, wd = 0.9, 0.999, 1e-8, 1e-2
+        with torch.no_grad():
+            p = self.pose.flat
+            p.mul_(1 - lr * wd)
+            self.pose_m.lerp_(g, 1 - b1)
+            self.pose_v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (self.pose_v.sqrt() / math.sqrt(1 - b2 ** self.pose_steps)).add_(eps)
+            p.addcdiv_(self.pose_m, denom, value=-(lr / (1 - b1 ** self.pose_steps)))
 
     def step(self, feats, batch):
         cfg, sch = self.cfg, self.sched
@@ -360,16 +455,32 @@ class TrainerOracle:
         if self.iteration >= sch.max_iterations:
             return None
         s, tape = self.head.forward(feats)
-        out = self.head.loss_and_ds(s, batch, cfg, self.iteration, focal_scale=1.0 + sch.calib_g)
+        pose_grad = None
+        if self.pose is None:
+            out = self.head.loss_and_ds(s, batch, cfg, self.iteration, focal_scale=1.0 + sch.calib_g)
+        else:
+            # refined poses (refine_poses.py:236-244), gradients wrt the fc3 outputs and the pose network by autograd
+            self.pose.flat.grad = None
+            poses_all = self.pose.forward(self.image_pose_inv)
+            rows = poses_all[batch["pose_idx"].long().view(-1)]
+            sl = s.detach().clone().requires_grad_(True)
+            loss_sum, inl = loss_autograd(self.head, sl, batch, cfg, self.iteration, rows)
+            (loss_sum / cfg["global_batch"]).backward()
+            pose_grad = self.pose.flat.grad.detach().clone()
+            with torch.no_grad():
+                X = self.head.dehomogenise(sl)[0]
+            out = {"loss_sum": float(loss_sum), "inliers": inl, "ds": sl.grad.detach(), "focal_grad": 0.0, "X": X.detach()}
         grad = self.head.backward(tape, out["ds"])
         loss = out["loss_sum"] / cfg["global_batch"]
         inl = out["inliers"] / cfg["global_batch"]
         lr_used = sch.lr
         sch.adamw(self.head.p.flat, grad)
+        if self.pose is not None and self.iteration > cfg.get("pose_refinement_wait", 0):   # ace_trainer.py:634
+            self._pose_adamw(pose_grad, cfg.get("pose_refinement_lr", 0.001))
         if cfg.get("refine_calibration", False):
             sch.calib_step(out["focal_grad"])
         sch.sched_step(inl)
-        rec = {"iteration": self.iteration, "loss": loss, "inliers": inl, "lr": lr_used, "grad": grad, "X": out["X"]}
+        rec = {"iteration": self.iteration, "loss": loss, "inliers": inl, "lr": lr_used, "grad": grad, "X": out["X"], "pose_grad": pose_grad}
         self.log.append({k: rec[k] for k in ("iteration", "loss", "inliers", "lr")})
         self.iteration += 1
         return rec

@@ -24,9 +24,14 @@ sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
 for name in ["torchvision", "torchvision.transforms", "torchvision.transforms.functional", "skimage", "skimage.transform",
-             "skimage.io", "skimage.color", "skimage.draw", "roma", "pyrender", "trimesh", "matplotlib.pyplot",
+             "skimage.io", "skimage.color", "skimage.draw", "pyrender", "trimesh", "matplotlib.pyplot",
              "ace_visualizer", "ace_vis_util"]:
     sys.modules.setdefault(name, MagicMock())
+# roma 1.4.1 (environment.yml:226) is not vendored and not installed: the one function the path calls
+# (refine_poses.py:148) is restated in oracle.head_oracle.special_gramschmidt -- parity unpinned for that call
+import types as _types  # noqa: E402
+_roma = _types.ModuleType("roma")
+sys.modules["roma"] = _roma
 sys.path.insert(0, REF)
 torch.Tensor.cuda = lambda self, *a, **k: self  # refine_calibration.py:42 calls .cuda()
 
@@ -37,6 +42,8 @@ import ace_trainer  # noqa: E402
 import refine_calibration  # noqa: E402
 from acezero_amd import synth  # noqa: E402
 from oracle import head_oracle  # noqa: E402
+import refine_poses  # noqa: E402
+_roma.special_gramschmidt = head_oracle.special_gramschmidt
 
 CONFIGS = {
     # ace_zero's mapping settings (ace_zero.py:105-123): tanh, 1cyclepoly, lr_max 0.003
@@ -51,6 +58,10 @@ CONFIGS = {
     "head_tanh_calib": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
                             warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
                             refine_calibration=True, steps=8),
+    # ace_zero's pose refinement (ace_zero.py:86): PoseNetwork(0,128) + Gram-Schmidt, own AdamW after a wait of 2 iterations
+    "head_tanh_posemlp": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
+                              warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
+                              refine_calibration=False, steps=6, pose_refinement="mlp", pose_refinement_wait=2),
 }
 B = 512
 SEED = 2089
@@ -61,6 +72,8 @@ def full_cfg(c):
     d.update(global_batch=B, soft_clamp=50.0, soft_clamp_min=1.0, circle_schedule=True, hard_clamp=1000.0,
              depth_min=0.1, depth_max=1000.0, depth_target=10.0, inlier_px_threshold=10.0, num_head_blocks=1,
              use_homogeneous=True, calib_lr=0.001)
+    d.setdefault("pose_refinement", "none")
+    d.setdefault("pose_refinement_wait", 0)
     return d
 
 
@@ -68,7 +81,8 @@ def run_reference(cfg, prob, flat0, batches):
     opt = types.SimpleNamespace(
         use_half=False, depth_min=cfg["depth_min"], depth_max=cfg["depth_max"], depth_target=cfg["depth_target"],
         repro_loss_hard_clamp=cfg["hard_clamp"], learning_rate_cooldown_trigger_px_threshold=cfg["inlier_px_threshold"],
-        pose_refinement_wait=0, iterations=cfg["iterations"], learning_rate_schedule=cfg["schedule"],
+        pose_refinement_wait=cfg["pose_refinement_wait"], pose_refinement=cfg["pose_refinement"], pose_refinement_lr=0.001,
+        pose_refinement_weight=0.1, refinement_ortho="gram-schmidt", iterations=cfg["iterations"], learning_rate_schedule=cfg["schedule"],
         learning_rate_min=cfg["lr_min"], learning_rate_max=cfg["lr_max"], learning_rate_warmup_iterations=cfg["warmup_iterations"],
         learning_rate_warmup_learning_rate=cfg["warmup_lr"], learning_rate_cooldown_iterations=cfg["cooldown_iterations"],
         learning_rate_cooldown_trigger_percent_threshold=cfg["cooldown_trigger_percent"])
@@ -104,6 +118,22 @@ def run_reference(cfg, prob, flat0, batches):
         def get_all_original_poses(self): return torch.zeros(1, 3, 4)
         def get_all_current_poses(self): return torch.zeros(1, 3, 4)
     tr.pose_refiner = NoRefiner()
+    if cfg["pose_refinement"] == "mlp":
+        n_img = prob["image_pose_inv"].shape[0]
+        class FakeDS:
+            poses = [torch.from_numpy(np.linalg.inv(prob["image_pose_inv"][i].astype(np.float64)).astype(np.float32)) for i in range(n_img)]
+            def __len__(self): return n_img
+        fake_ds = FakeDS()
+        pr = refine_poses.PoseRefiner(fake_ds, torch.device("cpu"), opt)
+        pr.create_pose_buffer()
+        from acezero_amd.head import init_pose_network, POSE_LAYERS
+        flatp = init_pose_network(SEED + 3)
+        sdp, o = {}, 0
+        for lname, O, K in POSE_LAYERS:
+            sdp[lname + ".weight"] = flatp[o:o + O * K].view(O, K, 1, 1).clone(); o += O * K
+            sdp[lname + ".bias"] = flatp[o:o + O].clone(); o += O
+        pr.pose_network.load_state_dict(sdp)
+        tr.pose_refiner = pr
     if cfg["refine_calibration"]:
         ds = types.SimpleNamespace(get_focal_length=lambda i: float(prob["focal"]), __len__=lambda: 1)
         cr = object.__new__(refine_calibration.CalibrationRefiner)
@@ -114,7 +144,7 @@ def run_reference(cfg, prob, flat0, batches):
     else:
         tr.K_optimizer = None
 
-    rec = {"loss": [], "inliers": [], "lr": [], "max_iterations": [], "focal_scale": []}
+    rec = {"loss": [], "inliers": [], "lr": [], "max_iterations": [], "focal_scale": [], "poses": [], "pose_params": []}
     sched = tr.training_scheduler
     orig_backward, orig_step = sched.backward, sched.step
 
@@ -143,6 +173,9 @@ def run_reference(cfg, prob, flat0, batches):
         ran = len(rec["loss"]) > n_before
         rec["max_iterations"].append(int(sched.max_iterations))
         rec["focal_scale"].append(float(1 + tr.K_optimizer.global_f) if tr.K_optimizer is not None else 1.0)
+        if cfg["pose_refinement"] == "mlp":
+            rec["poses"].append(tr.pose_refiner.get_all_current_poses().numpy().copy())
+            rec["pose_params"].append(torch.cat([p.detach().flatten() for p in tr.pose_refiner.pose_network.parameters()]).numpy().copy())
         if not ran:
             break
         tr.iteration += 1
@@ -173,7 +206,8 @@ def main():
             loss=np.array(rec["loss"], np.float64), inliers=np.array(rec["inliers"], np.float64), lr=np.array(rec["lr"], np.float64),
             max_iterations=np.array(rec["max_iterations"], np.int64), focal_scale=np.array(rec["focal_scale"], np.float64),
             coords0=coords0[:64].astype(np.float32), param_sel=sel, params_after_first=first[sel], params_after_last=snaps[last_it][sel],
-            last_it=np.int64(last_it), steps_run=np.int64(len(rec["loss"])))
+            last_it=np.int64(last_it), steps_run=np.int64(len(rec["loss"])),
+            poses=np.array(rec["poses"], np.float32), pose_params_sel=np.array([p[::97] for p in rec["pose_params"]], np.float32))
         print(name, "steps run", len(rec["loss"]), "loss", rec["loss"][:3], "inl", rec["inliers"][:3], "lr", rec["lr"][:3],
               "max_it", rec["max_iterations"][-1], "focal", rec["focal_scale"][-1])
 

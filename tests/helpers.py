@@ -18,6 +18,9 @@ HEAD_CONFIGS = {
     "head_tanh_calib": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
                             warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
                             refine_calibration=True, steps=8),
+    "head_tanh_posemlp": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
+                              warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
+                              refine_calibration=False, steps=6, pose_refinement="mlp", pose_refinement_wait=2),
 }
 
 
@@ -26,6 +29,8 @@ def full_cfg(c, prob=None):
     d.update(global_batch=B, soft_clamp=50.0, soft_clamp_min=1.0, circle_schedule=True, hard_clamp=1000.0,
              depth_min=0.1, depth_max=1000.0, depth_target=10.0, inlier_px_threshold=10.0, num_head_blocks=1,
              use_homogeneous=True, calib_lr=0.001)
+    d.setdefault("pose_refinement", "none")
+    d.setdefault("pose_refinement_wait", 0)
     if prob is not None:
         d["focal_init"] = float(prob["focal"])
     return d

@@ -25,7 +25,8 @@ def _trainer(prob, flat0, cfg, max_batch=helpers.B, global_batch=None):
                      schedule=cfg["schedule"], iterations=cfg["iterations"], lr_min=cfg["lr_min"], lr_max=cfg["lr_max"],
                      warmup_iterations=cfg["warmup_iterations"], warmup_lr=cfg["warmup_lr"], cooldown_iterations=cfg["cooldown_iterations"],
                      cooldown_trigger_percent=cfg["cooldown_trigger_percent"], refine_calibration=cfg["refine_calibration"],
-                     focal_init=float(prob["focal"]), calib_lr=cfg["calib_lr"])
+                     focal_init=float(prob["focal"]), calib_lr=cfg["calib_lr"], pose_refinement=cfg["pose_refinement"],
+                     pose_refinement_wait=cfg["pose_refinement_wait"], pose_seed=helpers.SEED + 3)
     tr.load_flat(flat0)
     tr.set_buffer(prob["features"], prob["target_px"], prob["view_idx"], prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"],
                   prob["view_image"], prob["image_pose_inv"])
@@ -55,7 +56,9 @@ def test_training_steps_match_oracle_and_golden(name):
     cfg = helpers.full_cfg(helpers.HEAD_CONFIGS[name], prob)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     tr = _trainer(prob, flat0, cfg)
-    orc = head_oracle.TrainerOracle(flat0.clone(), prob["mean"], cfg, mode="bf16")
+    mlp = cfg["pose_refinement"] == "mlp"
+    pose_flat = tr.pose_params.cpu().clone() if mlp else None
+    orc = head_oracle.TrainerOracle(flat0.clone(), prob["mean"], cfg, mode="bf16", pose_flat=pose_flat, image_pose_inv=prob["image_pose_inv"])
     batches = helpers.golden_batches(prob, cfg["steps"])
     n_params = flat0.numel()
     for it, idx in enumerate(batches):
@@ -64,6 +67,11 @@ def test_training_steps_match_oracle_and_golden(name):
         # resynchronise the oracle's weights with the GPU's so that every step is compared in isolation
         orc.head.p.flat.copy_(tr.params.cpu())
         orc.sched.m.copy_(tr.adam_m.cpu()); orc.sched.v.copy_(tr.adam_v.cpu())
+        if mlp:
+            with torch.no_grad():
+                orc.pose.flat.copy_(tr.pose_params.cpu())
+            orc.pose_m.copy_(tr.pose_m.cpu()); orc.pose_v.copy_(tr.pose_v.cpu())
+            np.testing.assert_allclose(tr.current_poses(), orc.current_poses().numpy(), atol=2e-6)
         rec = orc.step(b["features"], b)
         tr.backward(di)
         torch.cuda.synchronize()
@@ -79,6 +87,9 @@ def test_training_steps_match_oracle_and_golden(name):
         assert abs(grad[n_params + 1] / cfg["global_batch"] - rec["inliers"]) <= 2.0 / cfg["global_batch"]
         go = rec["grad"].numpy()
         assert _rel(grad[:n_params], go) < 5e-3, _rel(grad[:n_params], go)
+        if mlp:
+            assert _rel(grad[n_params + 4:], rec["pose_grad"].numpy()) < 5e-3, _rel(grad[n_params + 4:], rec["pose_grad"].numpy())
+            pose_before = tr.pose_params.cpu().numpy().copy()
         tr.update()
         st = tr.state()
         assert st["iteration"] == it + 1
@@ -93,6 +104,13 @@ def test_training_steps_match_oracle_and_golden(name):
         assert _rel(tr.params.cpu().numpy() - flat0.numpy(), orc.head.p.flat.numpy() - flat0.numpy()) < 6e-2
         if cfg["refine_calibration"]:
             assert abs(st["focal_scale"] - (1.0 + orc.sched.calib_g)) < 2e-5
+        if mlp:
+            moved = np.abs(tr.pose_params.cpu().numpy() - pose_before).max()
+            assert (moved > 0) == (it > cfg["pose_refinement_wait"])          # ace_trainer.py:634: strict >
+            if it > cfg["pose_refinement_wait"]:
+                assert _rel(tr.pose_params.cpu().numpy() - pose_before, orc.pose.flat.detach().numpy() - pose_before) < 5e-2
+            if it < g["poses"].shape[0]:
+                np.testing.assert_allclose(tr.current_poses(), g["poses"][it], atol=2e-3)   # vs the reference's PoseRefiner (fp32 head)
     loss, _ = tr.log(0, min(5, int(g["steps_run"])))
     np.testing.assert_allclose(loss, g["loss"][:len(loss)], rtol=3e-2)      # vs the reference (fp32): bf16-level agreement
     assert tr.state()["max_iterations"] == int(g["max_iterations"][-1])
