@@ -1,0 +1,299 @@
+"""Command-line surfaces of the hot path: same flag names and defaults as the reference's train_ace.py (:21-228)
+and register_mapping.py (:47-114), driving the MI355X kernels through libacez.so.
+
+What these entry points do NOT contain is the reference's image pipeline (dataset.py image decoding/augmentation
+and the pre-trained encoder): the encoder features are taken from a file
+
+    train_ace.py        --feature_buffer  buffer.npz     (layout of acez_train_buffer, see save_feature_buffer)
+    register_mapping.py --feature_file    frames.npz     (per-frame encoder features or scene coordinates)
+
+written by whatever fills the buffer (the reference's create_training_buffer with the 6-line hook of
+INTEGRATION.md, or acezero_amd.synth for synthetic scenes). Everything after that point -- the training loop, the
+schedule and early stopping, head checkpoints, pose files -- follows the reference's formats.
+"""
+import argparse
+import logging
+import math
+import time
+from pathlib import Path
+
+import numpy as np
+
+_logger = logging.getLogger("acezero_amd")
+
+
+def _strtobool(x):
+    v = str(x).lower()
+    if v in ("y", "yes", "t", "true", "on", "1"):
+        return True
+    if v in ("n", "no", "f", "false", "off", "0"):
+        return False
+    raise argparse.ArgumentTypeError(f"invalid truth value {x!r}")
+
+
+# (flags, type, default, choices, help) -- train_ace.py:21-228
+TRAIN_FLAGS = [
+    (("--base_seed",), int, 2089, None, "seed of the derived random generators"),
+    (("--pose_files",), str, None, None, "glob of per-image pose files"),
+    (("--use_ace_pose_file",), Path, None, None, "ACE pose file (file qw qx qy qz tx ty tz f conf)"),
+    (("--ace_pose_file_conf_threshold",), float, 1000, None, "ignore pose-file entries below this confidence"),
+    (("--use_pose_seed",), float, -1, None, "map a single image with identity pose"),
+    (("--depth_files",), str, None, None, "glob of depth files"),
+    (("--refine_calibration",), _strtobool, False, None, "optimise the focal length during mapping"),
+    (("--refine_calibration_lr",), float, 0.001, None, "learning rate of the focal-length refinement"),
+    (("--use_heuristic_focal_length",), _strtobool, False, None, "use 70%% of the image diagonal as focal length"),
+    (("--use_external_focal_length",), float, None, None, "externally provided focal length"),
+    (("--image_resolution",), int, 480, None, "short side of the training images"),
+    (("--num_data_workers",), int, 12, None, "data loader workers"),
+    (("--encoder_path",), Path, "<path>", None, "pre-trained encoder weights"),
+    (("--load_weights",), Path, None, None, "head weights to start from"),
+    (("--num_head_blocks",), int, 1, None, "residual blocks of the head"),
+    (("--use_half",), _strtobool, True, None, "16-bit matrix arithmetic (bf16 on MI355X)"),
+    (("--use_homogeneous",), _strtobool, True, None, "homogeneous scene-coordinate output"),
+    (("--learning_rate_min",), float, 0.0005, None, ""),
+    (("--learning_rate_max",), float, 0.005, None, ""),
+    (("--learning_rate_schedule",), str, "circle", ["circle", "constant", "1cyclepoly"], ""),
+    (("--learning_rate_warmup_iterations",), int, 1000, None, ""),
+    (("--learning_rate_warmup_learning_rate",), float, 0.0005, None, ""),
+    (("--learning_rate_cooldown_iterations",), int, 5000, None, ""),
+    (("--learning_rate_cooldown_trigger_px_threshold",), int, 10, None, ""),
+    (("--learning_rate_cooldown_trigger_percent_threshold",), float, 0.7, None, ""),
+    (("--max_training_buffer_size",), int, 8000000, None, ""),
+    (("--max_dataset_passes",), int, 10, None, ""),
+    (("--samples_per_image",), int, 1024, None, ""),
+    (("--training_buffer_cpu",), _strtobool, False, None, "accepted for compatibility; the buffer lives in HBM"),
+    (("--batch_size",), int, 5120, None, ""),
+    (("--iterations",), int, 25000, None, ""),
+    (("--iterations_output",), int, 300, None, ""),
+    (("--repro_loss_hard_clamp",), int, 1000, None, ""),
+    (("--repro_loss_soft_clamp",), int, 50, None, ""),
+    (("--repro_loss_soft_clamp_min",), int, 1, None, ""),
+    (("--repro_loss_type",), str, "dyntanh", ["l1", "l1+sqrt", "l1+log", "tanh", "dyntanh"], ""),
+    (("--repro_loss_schedule",), str, "circle", ["circle", "linear"], ""),
+    (("--depth_min",), float, 0.1, None, ""),
+    (("--depth_target",), float, 10, None, ""),
+    (("--depth_max",), float, 1000, None, ""),
+    (("--use_aug",), _strtobool, True, None, ""),
+    (("--aug_rotation",), int, 15, None, ""),
+    (("--aug_scale",), float, 1.5, None, ""),
+    (("--render_visualization",), _strtobool, False, None, "accepted; rendering is out of scope"),
+    (("--render_target_path",), Path, "renderings", None, ""),
+    (("--use_existing_vis_buffer",), Path, None, None, ""),
+    (("--render_flipped_portrait",), _strtobool, False, None, ""),
+    (("--render_map_error_threshold",), int, 10, None, ""),
+    (("--render_map_depth_filter",), int, 100, None, ""),
+    (("--render_camera_z_offset",), int, 4, None, ""),
+    (("--render_marker_size",), float, 0.03, None, ""),
+    (("--pose_refinement",), str, "none", ["none", "naive", "mlp"], ""),
+    (("--pose_refinement_weight",), float, 0.1, None, ""),
+    (("--pose_refinement_wait",), int, 0, None, ""),
+    (("--pose_refinement_lr",), float, 0.001, None, ""),
+    (("--refinement_ortho",), str, "gram-schmidt", ["gram-schmidt", "procrustes"], ""),
+]
+
+# register_mapping.py:47-114
+REGISTER_FLAGS = [
+    (("--encoder_path",), Path, "<path>", None, "pre-trained encoder weights"),
+    (("--session", "-sid"), None, "", None, "session name appended to the output file"),
+    (("--image_resolution",), int, 480, None, ""),
+    (("--num_data_workers",), int, 12, None, ""),
+    (("--hypotheses", "-hyps"), int, 64, None, "RANSAC hypotheses"),
+    (("--hypotheses_max_tries",), int, 1000000, None, "re-tries of an invalid minimal set"),
+    (("--threshold", "-t"), float, 10, None, "inlier threshold in px"),
+    (("--inlieralpha", "-ia"), float, 100, None, "soft inlier count alpha"),
+    (("--maxpixelerror", "-maxerrr"), float, 100, None, "reprojection errors are clamped to this value"),
+    (("--render_visualization",), _strtobool, False, None, ""),
+    (("--render_target_path",), Path, "renderings", None, ""),
+    (("--render_flipped_portrait",), _strtobool, False, None, ""),
+    (("--render_pose_conf_threshold",), int, 5000, None, ""),
+    (("--render_map_depth_filter",), int, 10, None, ""),
+    (("--render_camera_z_offset",), int, 4, None, ""),
+    (("--base_seed",), int, 1305, None, "torch and RANSAC seed"),
+    (("--confidence_threshold",), float, 1000, None, ""),
+    (("--max_estimates",), int, -1, None, "stop after this many images"),
+    (("--use_external_focal_length",), float, -1, None, ""),
+    (("--render_marker_size",), float, 0.03, None, ""),
+]
+
+
+def _add(parser, table):
+    for flags, typ, default, choices, hlp in table:
+        kw = {"default": default, "help": hlp}
+        if typ is not None:
+            kw["type"] = typ
+        if choices is not None:
+            kw["choices"] = choices
+        parser.add_argument(*flags, **kw)
+
+
+def train_parser():
+    p = argparse.ArgumentParser(description="Fast training of a scene coordinate regression network (MI355X head trainer).",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("rgb_files", type=str, help="glob of the RGB files (recorded in the outputs; pixels are not read here)")
+    p.add_argument("output_map_file", type=Path, help="target file for the trained head")
+    _add(p, TRAIN_FLAGS)
+    p.add_argument("--feature_buffer", type=Path, default=None, help="[additive] .npz training buffer (acez_train_buffer layout)")
+    p.add_argument("--num_gpus", type=int, default=1, help="[additive] informational; multi-GPU runs are launched with torchrun")
+    return p
+
+
+def register_parser():
+    p = argparse.ArgumentParser(description="Estimate camera poses for a set of images (MI355X DSAC*).",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("rgb_files", type=str, help="glob of the RGB files")
+    p.add_argument("network", type=Path, help="head weights of the scene")
+    _add(p, REGISTER_FLAGS)
+    p.add_argument("--feature_file", type=Path, default=None, help="[additive] .npz with per-frame encoder features or scene coordinates")
+    return p
+
+
+# ------------------------------------------------------------------------------------------------------- file formats
+def write_pose_line(f, rgb_file, pose_w2c, confidence, focal_length):
+    """dataset_io.py:159-186: `file qw qx qy qz tx ty tz focal confidence`, world->cam."""
+    from scipy.spatial.transform import Rotation
+    q = Rotation.from_matrix(np.asarray(pose_w2c, np.float64)[:3, :3]).as_quat()
+    t = np.asarray(pose_w2c)[:3, 3]
+    f.write(f"{rgb_file} {q[3]} {q[0]} {q[1]} {q[2]} {t[0]} {t[1]} {t[2]} {focal_length} {confidence}\n")
+
+
+def save_feature_buffer(path, prob, image_files=None):
+    """Write a training buffer (dict in the layout of acezero_amd.synth.make_training_problem) as .npz."""
+    n_img = prob["image_pose_inv"].shape[0]
+    files = image_files if image_files is not None else [f"frame_{i:06d}.png" for i in range(n_img)]
+    np.savez(path, features=prob["features"].astype(np.float16), target_px=prob["target_px"], view_idx=prob["view_idx"],
+             view_aug_inv=prob["view_aug_inv"], view_K=prob["view_K"], view_Kinv=prob["view_Kinv"], view_image=prob["view_image"],
+             image_pose_inv=prob["image_pose_inv"], mean=prob["mean"], focal=np.float32(prob["focal"]), image_files=np.array(files))
+
+
+# ------------------------------------------------------------------------------------------------------------ train
+def train_main(argv=None):
+    import torch
+    from .head import HeadTrainer
+    opt = train_parser().parse_args(argv)
+    logging.basicConfig(level=logging.INFO)
+    if opt.feature_buffer is None:
+        raise SystemExit("train_ace.py (MI355X): the image pipeline (dataset.py + encoder) is the reference's; pass the encoder "
+                         "features with --feature_buffer buffer.npz (see acezero_amd/cli.py and INTEGRATION.md)")
+    if opt.pose_refinement == "naive" or opt.refinement_ortho != "gram-schmidt":
+        raise SystemExit("pose_refinement 'naive' / procrustes orthonormalisation are not built (DESIGN.md section 8)")
+    if opt.batch_size % 512 != 0:
+        raise SystemExit("batch_size must be a multiple of 512 (train_ace.py:138)")
+    buf = np.load(opt.feature_buffer, allow_pickle=False)
+    n = min(int(buf["features"].shape[0]), opt.max_training_buffer_size)
+    focal = float(opt.use_external_focal_length) if opt.use_external_focal_length is not None else float(buf["focal"])
+    tr = HeadTrainer(buf["mean"], num_head_blocks=opt.num_head_blocks, use_homogeneous=opt.use_homogeneous, max_batch=opt.batch_size,
+                     loss_type=opt.repro_loss_type, soft_clamp=opt.repro_loss_soft_clamp, soft_clamp_min=opt.repro_loss_soft_clamp_min,
+                     circle_schedule=opt.repro_loss_schedule == "circle", hard_clamp=opt.repro_loss_hard_clamp, depth_min=opt.depth_min,
+                     depth_max=opt.depth_max, depth_target=opt.depth_target,
+                     inlier_px_threshold=opt.learning_rate_cooldown_trigger_px_threshold, schedule=opt.learning_rate_schedule,
+                     iterations=opt.iterations, lr_min=opt.learning_rate_min, lr_max=opt.learning_rate_max,
+                     warmup_iterations=opt.learning_rate_warmup_iterations, warmup_lr=opt.learning_rate_warmup_learning_rate,
+                     cooldown_iterations=opt.learning_rate_cooldown_iterations,
+                     cooldown_trigger_percent=opt.learning_rate_cooldown_trigger_percent_threshold,
+                     refine_calibration=opt.refine_calibration, focal_init=focal, calib_lr=opt.refine_calibration_lr,
+                     pose_refinement=opt.pose_refinement, pose_refinement_wait=opt.pose_refinement_wait,
+                     pose_refinement_lr=opt.pose_refinement_lr, pose_refinement_weight=opt.pose_refinement_weight,
+                     pose_seed=opt.base_seed + 511)
+    if opt.load_weights is not None:
+        tr.load_state_dict(torch.load(opt.load_weights, map_location="cpu"))
+        _logger.info(f"Loaded weights from: {opt.load_weights}")
+    else:
+        g = torch.Generator().manual_seed(opt.base_seed + 1023)     # ace_trainer.py:66-69 network-initialisation generator
+        bound = 1.0 / math.sqrt(512.0)
+        tr.load_flat((torch.rand(tr.n_params, generator=g) * 2 - 1) * bound)
+    tr.set_buffer(buf["features"][:n].astype(np.float32), buf["target_px"][:n], buf["view_idx"][:n], buf["view_aug_inv"], buf["view_K"],
+                  buf["view_Kinv"], buf["view_image"], buf["image_pose_inv"])
+    _logger.info(f"Training buffer: {n} patches, {buf['image_pose_inv'].shape[0]} images.")
+
+    gen = torch.Generator().manual_seed(opt.base_seed + 8191)       # ace_trainer.py:79-80 training generator
+    log_path = opt.output_map_file.with_suffix(".txt")
+    start = time.time()
+    epoch, launched, done = 0, 0, False
+    orig_poses = np.linalg.inv(buf["image_pose_inv"].astype(np.float64))[:, :3, 3]
+    with open(log_path, "w", 1) as log:
+        while not done:
+            perm = torch.randperm(n, generator=gen).cuda()           # ace_trainer.py:466
+            for b0 in range(0, n - opt.batch_size + 1, opt.batch_size):
+                tr.step(perm[b0:b0 + opt.batch_size])
+                launched += 1
+                if launched % opt.iterations_output == 0 or launched % 64 == 0:
+                    st = tr.state()                                  # the only host synchronisation of the loop
+                    if st["nan"]:
+                        raise SystemExit("Aborting because of NaN loss")          # ace_trainer.py:615-617
+                    if launched % opt.iterations_output == 0:
+                        it = st["iteration"] - 1
+                        elapsed = time.time() - start
+                        _logger.info(f"Iteration: {it:6d}|{st['max_iterations']:6d} / Epoch {epoch:03d}, Loss: {st['loss']:.1f}, "
+                                     f"Batch inliers ({opt.learning_rate_cooldown_trigger_px_threshold}px): "
+                                     f"{st['batch_inliers'] * 100:.1f}%, Time: {elapsed:.0f}s")
+                        cur = np.linalg.inv(np.concatenate([tr.current_poses(), np.tile([[[0, 0, 0, 1.0]]], (len(orig_poses), 1, 1))], 1))[:, :3, 3]
+                        d = np.linalg.norm(cur - orig_poses, axis=1)
+                        row = f"{it} {elapsed} {st['loss']} {st['batch_inliers']} {d.mean()} {d.min()} {d.max()}"
+                        if opt.refine_calibration:
+                            row += f" {st['focal_scale'] * focal}"
+                        log.write(row + "\n")
+                    if st["iteration"] >= st["max_iterations"]:
+                        done = True
+                        break
+            epoch += 1
+    st = tr.state()
+    elapsed = time.time() - start
+    _logger.info(f"Done without errors. Training time: {elapsed:.1f}s, {st['iteration']} iterations, "
+                 f"{st['iteration'] * opt.batch_size / max(elapsed, 1e-9):.0f} patches/s.")
+    # save_model (ace_trainer.py:681-694): half-precision head state_dict
+    opt.output_map_file.parent.mkdir(parents=True, exist_ok=True)
+    torch.save({k: v.detach().cpu().half() for k, v in tr.state_dict().items()}, opt.output_map_file)
+    # save_poses (ace_trainer.py:696-728)
+    pose_file = opt.output_map_file.parent / f"poses_{opt.output_map_file.stem}_preliminary.txt"
+    files = [str(x) for x in buf["image_files"]] if "image_files" in buf.files else [f"{i}" for i in range(len(orig_poses))]
+    f_out = st["focal_scale"] * focal if opt.refine_calibration else focal
+    with open(pose_file, "w") as f:
+        for i, p34 in enumerate(tr.current_poses()):
+            write_pose_line(f, files[i], p34, float("inf"), f_out)
+    _logger.info(f"Saved trained head weights to: {opt.output_map_file}; refined poses to: {pose_file}")
+    return 0
+
+
+# --------------------------------------------------------------------------------------------------------- register
+def register_main(argv=None):
+    import torch
+    from . import dsacstar
+    from .head import HeadTrainer
+    opt = register_parser().parse_args(argv)
+    logging.basicConfig(level=logging.INFO)
+    if opt.feature_file is None:
+        raise SystemExit("register_mapping.py (MI355X): pass the encoder output with --feature_file frames.npz "
+                         "(features [n,H*W,512] + h,w or scene_coordinates [n,3,H,W], focal, ppx, ppy, image_files)")
+    torch.manual_seed(opt.base_seed)
+    data = np.load(opt.feature_file, allow_pickle=False)
+    files = [str(x) for x in data["image_files"]]
+    n = len(files) if opt.max_estimates <= 0 else min(len(files), opt.max_estimates)
+    t0 = time.time()
+    if "scene_coordinates" in data.files:
+        sc = torch.from_numpy(data["scene_coordinates"][:n].astype(np.float32)).cuda()
+    else:
+        sd = torch.load(opt.network, map_location="cpu")
+        nb = sum(1 for k in sd if k.endswith("c0.weight"))
+        head = HeadTrainer(sd["mean"].float().view(3), num_head_blocks=nb, use_homogeneous=sd["fc3.weight"].shape[0] == 4, max_batch=8192,
+                           iterations=1)
+        head.load_state_dict(sd)                                    # fp16 checkpoint -> fp32 masters -> bf16 compute copies
+        h, w = int(data["h"]), int(data["w"])
+        feats = torch.from_numpy(data["features"][:n].astype(np.float32)).cuda().reshape(-1, 512)
+        sc = head.get_scene_coordinates(feats).reshape(n, h, w, 3).permute(0, 3, 1, 2).contiguous()
+    f_ext = opt.use_external_focal_length
+    focal = np.broadcast_to(np.asarray(data["focal"], np.float32), (len(files),)) if f_ext < 0 else np.full(len(files), f_ext, np.float32)
+    ppx = np.broadcast_to(np.asarray(data["ppx"], np.float32), (len(files),))
+    ppy = np.broadcast_to(np.asarray(data["ppy"], np.float32), (len(files),))
+    prm = dict(hyps=opt.hypotheses, thr=opt.threshold, alpha=opt.inlieralpha, max_reproj=opt.maxpixelerror, sub=8, max_tries=opt.hypotheses_max_tries)
+    poses, inl, _ = dsacstar.register_batch(sc, [(focal[i], ppx[i], ppy[i]) for i in range(n)], prm, opt.base_seed, list(range(n)),
+                                            want_masks=False)
+    poses, inl = poses.cpu().numpy(), inl.cpu().numpy()
+    out_dir = Path(opt.network).parent
+    pose_log_file = out_dir / f"poses_{opt.session}.txt"
+    with open(pose_log_file, "w") as f:
+        for i in range(n):
+            _logger.info(f"Frame: {files[i]}, Confidence: {int(inl[i])}")
+            write_pose_line(f, files[i], np.linalg.inv(poses[i].astype(np.float64)), int(inl[i]), float(focal[i]))   # :261-276
+    dt = time.time() - t0
+    _logger.info(f"Registered {n} images in {dt:.2f}s ({n / max(dt, 1e-9):.0f} images/s) -> {pose_log_file}")
+    return 0

@@ -1,0 +1,100 @@
+"""CPU: the command-line surfaces keep every flag, default and choice of the reference (golden captured from the
+reference's argparse by tests/golden/make_cli_golden.py); pose-file lines round-trip through the reference format.
+GPU: a small mapping + registration run end to end through the two scripts."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from acezero_amd import cli, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _surface(parser):
+    out = {}
+    for act in parser._actions:
+        if act.dest == "help":
+            continue
+        d = act.default
+        if isinstance(d, Path):
+            d = str(d)
+        out[act.dest] = {"flags": list(act.option_strings), "default": d, "choices": list(act.choices) if act.choices else None,
+                         "positional": not act.option_strings}
+    return out
+
+
+@pytest.mark.parametrize("name,parser,extra", [("train_ace", cli.train_parser, {"feature_buffer", "num_gpus"}),
+                                               ("register_mapping", cli.register_parser, {"feature_file"})])
+def test_flag_surface_matches_reference(name, parser, extra, golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "cli_flags.json")))[name]
+    mine = _surface(parser())
+    assert set(mine) - set(ref) == extra           # additive flags only
+    for dest, spec in ref.items():
+        assert dest in mine, dest
+        m = mine[dest]
+        assert m["flags"] == spec["flags"] and m["positional"] == spec["positional"], dest
+        assert m["choices"] == spec["choices"], dest
+        assert m["default"] == spec["default"], (dest, m["default"], spec["default"])
+
+
+def test_pose_line_format_roundtrip(tmp_path):
+    from scipy.spatial.transform import Rotation
+    R = Rotation.from_euler("xyz", [0.3, -1.1, 2.0]).as_matrix()
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = [1.5, -2.0, 0.25]
+    p = tmp_path / "poses.txt"
+    with open(p, "w") as f:
+        cli.write_pose_line(f, "a/b.png", T, 1234, 525.0)
+    tok = open(p).read().split()
+    assert len(tok) == 10 and tok[0] == "a/b.png"                      # dataset_io.py:128 asserts 10 tokens
+    qw, qx, qy, qz = [float(x) for x in tok[1:5]]
+    np.testing.assert_allclose(Rotation.from_quat([qx, qy, qz, qw]).as_matrix(), R, atol=1e-12)
+    np.testing.assert_allclose([float(x) for x in tok[5:8]], T[:3, 3])
+    assert float(tok[8]) == 525.0 and float(tok[9]) == 1234
+
+
+def test_missing_feature_file_is_a_clear_error():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_ace.py"), "x/*.png", "/tmp/out.pt"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode != 0 and "--feature_buffer" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_train_then_register_end_to_end(tmp_path):
+    import torch
+    prob = synth.make_training_problem(seed=4, n_images=8, views_per_image=2, patches_per_view=512)
+    buf = tmp_path / "buffer.npz"
+    cli.save_feature_buffer(buf, prob)
+    out = tmp_path / "scene.pt"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_ace.py"), "synthetic/*.png", str(out), "--feature_buffer", str(buf),
+                        "--iterations", "60", "--iterations_output", "20", "--learning_rate_schedule", "1cyclepoly", "--learning_rate_max", "0.003",
+                        "--learning_rate_warmup_iterations", "10", "--learning_rate_cooldown_iterations", "20", "--repro_loss_type", "tanh",
+                        "--batch_size", "1024", "--pose_refinement", "mlp", "--refine_calibration", "True", "--use_external_focal_length", "525"],
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sd = torch.load(out, map_location="cpu")
+    assert sd["res3_conv1.weight"].dtype == torch.float16 and sd["fc3.weight"].shape == (4, 512, 1, 1) and "mean" in sd
+    lines = open(tmp_path / "poses_scene_preliminary.txt").read().strip().split("\n")
+    assert len(lines) == 8 and all(len(l.split()) == 10 and l.split()[-1] == "inf" for l in lines)
+    rows = [l.split() for l in open(tmp_path / "scene.txt").read().strip().split("\n")]
+    assert len(rows) == 3 and len(rows[0]) == 8                         # iter time loss inliers pose_mean pose_min pose_max focal
+    # registration of synthetic scene-coordinate maps through the second script
+    fr = synth.make_registration_frames(seed=6, n_frames=5)
+    ff = tmp_path / "frames.npz"
+    np.savez(ff, scene_coordinates=fr["scene_coords"], focal=np.float32(fr["focal"]), ppx=np.float32(fr["ppx"]), ppy=np.float32(fr["ppy"]),
+             image_files=np.array([f"f{i}.png" for i in range(5)]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "register_mapping.py"), "synthetic/*.png", str(out), "--feature_file", str(ff),
+                        "--session", "test", "--hypotheses", "32", "--hypotheses_max_tries", "16"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l.split() for l in open(tmp_path / "poses_test.txt").read().strip().split("\n")]
+    assert len(lines) == 5
+    from scipy.spatial.transform import Rotation
+    for i, t in enumerate(lines):
+        T = np.eye(4)
+        T[:3, :3] = Rotation.from_quat([float(t[2]), float(t[3]), float(t[4]), float(t[1])]).as_matrix()
+        T[:3, 3] = [float(x) for x in t[5:8]]
+        np.testing.assert_allclose(np.linalg.inv(T)[:3, 3], fr["poses"][i][:3, 3], atol=0.03)   # file stores world->cam
+        assert float(t[9]) > 1000
