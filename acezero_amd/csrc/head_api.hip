@@ -2,6 +2,8 @@
 // Host-side orchestration only: every entry point enqueues kernels of head_kernels.hip on the caller's stream.
 #include "head_kernels.hip"
 #include "pose_kernels.hip"
+#include "head_fused.hip"
+#include <stdlib.h>
 #include "acez_common.h"
 #include <vector>
 #include <new>
@@ -52,6 +54,7 @@ struct acez_trainer {
   std::vector<EvUse> ev_used;
   size_t ev_next = 0;
   int prof_launches = 0;  // launches inside the currently open scope
+  bool fused_fwd = true;  // persistent row-tile forward (head_fused.hip); ACEZ_FUSED_FWD=0 selects the per-layer launches
 };
 
 enum { KC_SCHED = 0, KC_GATHER, KC_GEMM_FWD, KC_LOSS, KC_GEMM_DGRAD, KC_WGRAD, KC_REDUCE, KC_ADAMW, KC_COUNT };
@@ -127,6 +130,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->n_params = params->n_params;
   tr->fc3_stride = ((int64_t)tr->no * 513 + 3) & ~3LL;
   tr->max_batch = cfg->max_batch;
+  if (const char* e = getenv("ACEZ_FUSED_FWD")) tr->fused_fwd = atoi(e) != 0;
   tr->nslabs = 256 / (16 * tr->L);
   if (tr->nslabs < 1) tr->nslabs = 1;
 
@@ -226,6 +230,25 @@ extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
   hipLaunchKernelGGL(recast_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
+}
+
+// persistent row-tile forward: gather (idx may be null) + all wide layers in one launch; returns the fc2 output buffer
+static uint16_t* launch_forward_fused(acez_trainer* tr, const uint16_t* feat, const int64_t* idx, int n, bool keep, const TrainState* st,
+                                      hipStream_t s) {
+  HeadFwdArgs a{};
+  a.feat = feat; a.idx = idx; a.g_in = keep ? tr->R[0] : nullptr; a.n = n; a.n_layers = tr->L; a.Wb = tr->Wb; a.params = tr->pb.d_params; a.st = st;
+  for (int b = 0; b <= tr->nb; ++b) {
+    a.layer[3 * b] = FusedLayer{0, 1, 0, keep ? tr->out[3 * b] : nullptr, nullptr};
+    a.layer[3 * b + 1] = FusedLayer{1, 2, 0, keep ? tr->out[3 * b + 1] : nullptr, nullptr};
+    a.layer[3 * b + 2] = FusedLayer{2, 1, 1, keep ? tr->out[3 * b + 2] : nullptr, keep ? tr->R[b + 1] : nullptr};
+  }
+  const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
+  a.layer[f1] = FusedLayer{0, 1, 0, keep ? tr->out[f1] : nullptr, nullptr};
+  a.layer[f2] = FusedLayer{1, 2, 0, tr->out[f2], nullptr};
+  ProfScope ps(tr, s, KC_GEMM_FWD);
+  hipLaunchKernelGGL(headfwd_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a);
+  tr->prof_launches += tr->L;  // accounted as L layer-GEMMs so that the per-layer average stays comparable
+  return tr->out[f2];
 }
 
 // forward chain on n rows whose input features are in `in0`; returns the fc2 output buffer
@@ -338,11 +361,16 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
   const TrainState* st = tr->st;
   tr->last_n = n;
 
+  uint16_t* act = nullptr;
+  if (tr->fused_fwd) {
+    act = launch_forward_fused(tr, (const uint16_t*)tr->buf.d_features, d_indices, n, true, st, s);
+  } else {
   ProfScope* psg = new ProfScope(tr, s, KC_GATHER);
   hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024), dim3(256), 0, s,
                      (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n, st);
   delete psg;
-  uint16_t* act = launch_forward(tr, tr->R[0], n, st, s);
+  act = launch_forward(tr, tr->R[0], n, st, s);
+  }
   const bool pose_mlp = tr->cfg.pose_refinement == 2;
   if (pose_mlp) pose_forward(tr, &tr->st->active, s);
 
@@ -491,7 +519,8 @@ extern "C" int acez_head_forward(acez_trainer* tr, const void* d_features, int n
   const uint16_t* f = (const uint16_t*)d_features;
   for (int done = 0; done < n; done += tr->max_batch) {
     const int cnt = (n - done < tr->max_batch) ? n - done : tr->max_batch;
-    uint16_t* act = launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
+    uint16_t* act = tr->fused_fwd ? launch_forward_fused(tr, f + (size_t)done * 512, nullptr, cnt, false, nullptr, s)
+                                  : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
     LossArgs a{};
     fill_loss_head(tr, a);
     a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr; a.out_xyz = d_out_xyz + (size_t)done * 3;
