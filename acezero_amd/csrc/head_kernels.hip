@@ -95,7 +95,9 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 
 template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX>
 __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
-  if (a.st && !a.st->active) return;
+  // the schedule's `active` flag is only needed before the stores: reading it up front would put a dependent HBM/L2
+  // round trip (~1 us) in front of every launch of the chain
+  const int active = a.st ? a.st->active : 1;
   __shared__ __attribute__((aligned(16))) uint16_t smem[4][2][128 * 64];
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
   // (tools/ablate_rowgemm.hip), 2x the rest of the kernel. Each wave owns two [64][72] bf16 regions of the
   // (now idle) ring: A = `add` in / aux out, B = mask|res in / main out.
   if (a.dbg & 1) { if (acc[0][0][0] == 1.2345e30f) a.out_main[0] = 1; return; }
+  if (!active) return;  // schedule ended (ace_trainer.py:509-510): nothing is written
   __syncthreads();  // every wave is done reading the ring
   constexpr int EP = 72;
   uint16_t* regA = &smem[0][0][0] + w * (2 * 64 * EP);
@@ -313,7 +316,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* p) {
 }
 
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
-  if (a.st && !a.st->active) return;
+  const int active = a.st ? a.st->active : 1;  // tested before the stores only (see rowgemm_kernel)
   __shared__ __attribute__((aligned(16))) uint16_t smem[4][2][64 * 128];  // 4-slot ring of [dZ | In] stages, 128 KiB
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -398,6 +401,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
   }
 
   if (a.dbg & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
+  if (!active) return;
   float* __restrict__ G = a.slabs + (size_t)slab * a.slab_stride;
   const int h = l >> 5;
 #pragma unroll
@@ -430,6 +434,19 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int m0 = blockIdx.x * 32;
   const int n = a.n, no = a.no;
+
+  // phase B's per-row inputs sit behind a chain of dependent loads (idx -> view -> image): start it now so that its
+  // latency hides under phase A
+  int64_t pre_p = 0;
+  int pre_view = 0, pre_img = 0;
+  float pre_tu = 0.f, pre_tv = 0.f;
+  if (a.idx && t < 32 && m0 + t < n) {
+    pre_p = a.idx[m0 + t];
+    pre_view = a.view_idx[pre_p];
+    pre_img = a.view_image[pre_view];
+    pre_tu = a.target_px[pre_p * 2 + 0];
+    pre_tv = a.target_px[pre_p * 2 + 1];
+  }
 
   // ---- phase A
   {
@@ -506,11 +523,10 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
         a.out_xyz[(size_t)m * 3 + 2] = X[2];
       }
       if (a.idx) {  // training: geometry + loss (skipped for pure inference)
-        const int64_t p = a.idx[m];
-        const float tu = a.target_px[p * 2 + 0], tv = a.target_px[p * 2 + 1];
-        const int view = a.view_idx[p];
+        const float tu = pre_tu, tv = pre_tv;
+        const int view = pre_view;
         const float* A = a.view_aug_inv + (size_t)view * 12;
-        const float* T = a.image_pose_inv + (size_t)a.view_image[view] * 16;
+        const float* T = a.image_pose_inv + (size_t)pre_img * 16;
         float K[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) K[i] = a.view_K[(size_t)view * 9 + i];
@@ -594,7 +610,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) a.row_dT[(size_t)m * 12 + k * 4 + j] = ak * Xh[j];
           }
-          a.row_image[m] = a.view_image[view];
+          a.row_image[m] = pre_img;
         }
         float dX[3];
 #pragma unroll
