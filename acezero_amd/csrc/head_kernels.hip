@@ -315,12 +315,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* p) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
   const int active = a.st ? a.st->active : 1;  // tested before the stores only (see rowgemm_kernel)
   __shared__ __attribute__((aligned(16))) uint16_t smem[4][2][64 * 128];  // 4-slot ring of [dZ | In] stages, 128 KiB
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wn = w >> 1, wc = w & 1;
+  const int wn = w >> 2, wc = w & 3;  // 8 waves: 2 (n) x 4 (c), each 64 x 32 of the 128 x 128 tile; two waves per SIMD, so one
+                                      // wave's DMA issue (~100 cycles per 1 KiB instruction) overlaps the other's MFMAs
   // XCD-aware decode: the 16 output tiles of one (layer, slab) group re-read the same dZ / In rows (4x each); they
   // are placed on ONE XCD (workgroup b runs on XCD b % 8) so that the re-reads hit that XCD's L2 instead of the
   // fabric. Measured before: 335 MB per launch at ~5 TB/s = the whole kernel time. Placement only affects speed.
@@ -339,47 +340,45 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
   const int me = min(M, mb + rows_per_slab);
   const int KT = (me > mb) ? (me - mb + 63) >> 6 : 0;
 
-  // DMA instruction j (0..3) of this wave covers stage rows (w*4+j)*4 .. +3; this lane: row + (l>>4), physical
+  // DMA instruction j (0..1) of this wave covers stage rows (w*2+j)*4 .. +3; this lane: row + (l>>4), physical
   // 16-byte chunk l&15, which must receive the logical chunk whose 32-byte segment index is XOR-swizzled
   const int prow = l >> 4, pq = l & 15;
-  int srow[4];
-  int lchunk[4];
+  int srow[2];
+  int lchunk[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    srow[j] = (w * 4 + j) * 4 + prow;
+  for (int j = 0; j < 2; ++j) {
+    srow[j] = (w * 2 + j) * 4 + prow;
     lchunk[j] = ((((pq >> 1) ^ ((srow[j] & 3) << 1)) << 1) | (pq & 1)) * 8;  // element offset of the source chunk
   }
   auto issue = [&](int kt) {
     const int slot = kt & 3;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
       const int m = mb + kt * 64 + srow[j];
       const bool ok = m < me;
       // rows past the slab end must contribute zeros: they are fetched from a zero page
       const uint16_t* gz = ok ? Z + (size_t)m * 512 + n0 + lchunk[j] : a.zeros + pq * 8;
       const uint16_t* gx = ok ? X + (size_t)m * 512 + c0 + lchunk[j] : a.zeros + pq * 8;
-      __builtin_amdgcn_global_load_lds((gvoid_t*)gz, (lvoid_t*)&smem[slot][0][(w * 4 + j) * 4 * 128], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gvoid_t*)gx, (lvoid_t*)&smem[slot][1][(w * 4 + j) * 4 * 128], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)gz, (lvoid_t*)&smem[slot][0][(w * 2 + j) * 4 * 128], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)gx, (lvoid_t*)&smem[slot][1][(w * 2 + j) * 4 * 128], 16, 0, 0);
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int offA[2] = {tr_base(wn * 64, l), tr_base(wn * 64 + 32, l)};
-  const int offB[2] = {tr_base(wc * 64, l), tr_base(wc * 64 + 32, l)};
+  const int offB = tr_base(wc * 32, l);
   if (!(a.dbg & 4)) for (int kt = 0; kt < 4 && kt < KT; ++kt) issue(kt);
   for (int kt = 0; kt < KT; ++kt) {
-    // stages issued so far: 0..3 at kt = 0, 0..kt+2 afterwards; each wave has 8 DMA instructions per stage in flight
+    // stages issued so far: 0..3 at kt = 0, 0..kt+2 afterwards; each wave has 4 DMA instructions per stage in flight
     const int later = (kt == 0) ? min(3, KT - 1) : min(2, KT - 1 - kt);
-    if (later >= 3) ACEZ_VMCNT(24);
-    else if (later == 2) ACEZ_VMCNT(16);
-    else if (later == 1) ACEZ_VMCNT(8);
+    if (later >= 3) ACEZ_VMCNT(12);
+    else if (later == 2) ACEZ_VMCNT(8);
+    else if (later == 1) ACEZ_VMCNT(4);
     else ACEZ_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     if (kt >= 1 && kt + 3 < KT && !(a.dbg & 4)) issue(kt + 3);
@@ -387,33 +386,26 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     const int slot = kt & 3;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = tr_frag(&smem[slot][0][offA[i] + kk * 16 * 128]);
-        fb[i] = tr_frag(&smem[slot][1][offB[i] + kk * 16 * 128]);
-      }
+      for (int i = 0; i < 2; ++i) fa[i] = tr_frag(&smem[slot][0][offA[i] + kk * 16 * 128]);
+      const bf16x8 fb = tr_frag(&smem[slot][1][offB + kk * 16 * 128]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb, acc[i], 0, 0, 0);
     }
   }
 
-  if (a.dbg & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
+  if (a.dbg & 1) { if (acc[0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
   if (!active) return;
   float* __restrict__ G = a.slabs + (size_t)slab * a.slab_stride;
   const int h = l >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    const int c = c0 + wc * 32 + (l & 31);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = c0 + wc * 64 + j * 32 + (l & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        G[a.w_off[layer] + (size_t)n * 512 + c] = acc[i][j][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      G[a.w_off[layer] + (size_t)n * 512 + c] = acc[i][r];
     }
   }
 }
