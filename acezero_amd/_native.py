@@ -48,7 +48,8 @@ class ParamBuffers(C.Structure):
 class TrainBuffer(C.Structure):
     _fields_ = [("d_features", C.c_void_p), ("d_target_px", C.c_void_p), ("d_view_idx", C.c_void_p), ("n_patches", C.c_int64),
                 ("d_view_aug_inv", C.c_void_p), ("d_view_K", C.c_void_p), ("d_view_Kinv", C.c_void_p),
-                ("d_view_image", C.c_void_p), ("n_views", C.c_int32), ("d_image_pose_inv", C.c_void_p), ("n_images", C.c_int32)]
+                ("d_view_image", C.c_void_p), ("n_views", C.c_int32), ("d_image_pose_inv", C.c_void_p), ("n_images", C.c_int32),
+                ("d_target_crds", C.c_void_p)]
 
 
 class TrainState(C.Structure):

@@ -156,13 +156,14 @@ def write_pose_line(f, rgb_file, pose_w2c, confidence, focal_length):
     f.write(f"{rgb_file} {q[3]} {q[0]} {q[1]} {q[2]} {t[0]} {t[1]} {t[2]} {focal_length} {confidence}\n")
 
 
-def save_feature_buffer(path, prob, image_files=None):
+def save_feature_buffer(path, prob, image_files=None, with_depth_targets=False):
     """Write a training buffer (dict in the layout of acezero_amd.synth.make_training_problem) as .npz."""
     n_img = prob["image_pose_inv"].shape[0]
     files = image_files if image_files is not None else [f"frame_{i:06d}.png" for i in range(n_img)]
     np.savez(path, features=prob["features"].astype(np.float16), target_px=prob["target_px"], view_idx=prob["view_idx"],
              view_aug_inv=prob["view_aug_inv"], view_K=prob["view_K"], view_Kinv=prob["view_Kinv"], view_image=prob["view_image"],
-             image_pose_inv=prob["image_pose_inv"], mean=prob["mean"], focal=np.float32(prob["focal"]), image_files=np.array(files))
+             image_pose_inv=prob["image_pose_inv"], mean=prob["mean"], focal=np.float32(prob["focal"]), image_files=np.array(files),
+             **({"target_crds": prob["target_crds"]} if with_depth_targets else {}))
 
 
 # ------------------------------------------------------------------------------------------------------------ train
@@ -202,7 +203,8 @@ def train_main(argv=None):
         bound = 1.0 / math.sqrt(512.0)
         tr.load_flat((torch.rand(tr.n_params, generator=g) * 2 - 1) * bound)
     tr.set_buffer(buf["features"][:n].astype(np.float32), buf["target_px"][:n], buf["view_idx"][:n], buf["view_aug_inv"], buf["view_K"],
-                  buf["view_Kinv"], buf["view_image"], buf["image_pose_inv"])
+                  buf["view_Kinv"], buf["view_image"], buf["image_pose_inv"],
+                  target_crds=buf["target_crds"][:n] if "target_crds" in buf.files else None)   # present = use_depth (ace_trainer.py:86-92)
     _logger.info(f"Training buffer: {n} patches, {buf['image_pose_inv'].shape[0]} images.")
 
     gen = torch.Generator().manual_seed(opt.base_seed + 8191)       # ace_trainer.py:79-80 training generator

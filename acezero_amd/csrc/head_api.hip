@@ -382,7 +382,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     LossArgs a{};
     fill_loss_head(tr, a);
     a.act = act; a.n = n;
-    a.idx = d_indices; a.target_px = tr->buf.d_target_px; a.view_idx = tr->buf.d_view_idx;
+    a.idx = d_indices; a.target_px = tr->buf.d_target_px; a.target_crds = tr->buf.d_target_crds; a.view_idx = tr->buf.d_view_idx;
     a.view_aug_inv = tr->buf.d_view_aug_inv; a.view_K = tr->buf.d_view_K; a.view_Kinv = tr->buf.d_view_Kinv;
     a.view_image = tr->buf.d_view_image; a.image_pose_inv = pose_mlp ? tr->pose_cur : tr->buf.d_image_pose_inv;
     a.row_dT = pose_mlp ? tr->row_dT : nullptr; a.row_image = pose_mlp ? tr->row_image : nullptr;

@@ -85,6 +85,7 @@ struct LossArgs {
   // training only (idx == null -> inference)
   const int64_t* idx;
   const float* target_px;
+  const float* target_crds;      // [patches][3] ground-truth scene coordinates (zeros = none) or null: use_depth mode
   const int32_t* view_idx;
   const float* view_aug_inv;
   const float* view_K;

@@ -550,8 +550,20 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
         const float u = pp[0] / pz, v = pp[1] / pz;
         const float du = u - tu, dv = v - tv;
         const float e = fabsf(du) + fabsf(dv);                     // L1 norm :552
-        const bool invalid = (Xc[2] < a.depth_min) || (e > a.hard_clamp) || (Xc[2] > a.depth_max);  // :558-565
-        float dXc[3];
+        bool invalid = (Xc[2] < a.depth_min) || (e > a.hard_clamp) || (Xc[2] > a.depth_max);  // :558-565
+        // depth-supervised mapping (use_depth, ace_trainer.py:567-574): a prediction further than 10 cm from an available
+        // ground-truth scene coordinate is treated as invalid too
+        float tcd[3] = {0.f, 0.f, 0.f}, tdist = 0.f;
+        bool tavail = false;
+        if (a.target_crds) {
+          const float* tc = a.target_crds + pre_p * 3;
+          tavail = (fabsf(tc[0]) + fabsf(tc[1]) + fabsf(tc[2])) > 0.00001f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) tcd[k] = tc[k] - X[k];
+          tdist = sqrtf(tcd[0] * tcd[0] + tcd[1] * tcd[1] + tcd[2] * tcd[2]);
+          if (tavail && tdist > 0.1f) invalid = true;
+        }
+        float dXc[3], dXs[3] = {0.f, 0.f, 0.f};
         if (!invalid) {
           float ge;
           const float wgt = a.st->loss_weight;
@@ -581,6 +593,15 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
           if (a.refine_calibration) fgrad = (dp[0] * Xc[0] + dp[1] * Xc[1]) * a.focal_init * kscale;
 #pragma unroll
           for (int j = 0; j < 3; ++j) dXc[j] = K[0 * 3 + j] * dp[0] + K[1 * 3 + j] * dp[1] + K[2 * 3 + j] * dp[2];
+        } else if (a.target_crds) {
+          // use_depth (ace_trainer.py:601-609): L2 distance to the ground-truth coordinate where there is one, nothing otherwise
+          dXc[0] = dXc[1] = dXc[2] = 0.f;
+          if (tavail) {
+            loss = tdist;
+            const float inv = tdist > 0.f ? 1.f / tdist : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dXs[k] = -tcd[k] * inv;
+          }
         } else {
           // proxy target at constant depth, ace_trainer.py:592-600
           const float* Ki = a.view_Kinv + (size_t)view * 9;
@@ -606,7 +627,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
         }
         float dX[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dX[k] = (P[0 * 4 + k] * dXc[0] + P[1 * 4 + k] * dXc[1] + P[2 * 4 + k] * dXc[2]) * invB;
+        for (int k = 0; k < 3; ++k) dX[k] = (P[0 * 4 + k] * dXc[0] + P[1 * 4 + k] * dXc[1] + P[2 * 4 + k] * dXc[2] + dXs[k]) * invB;
         fgrad *= invB;
         if (a.use_homogeneous) {
           ds[0] = dX[0] / hval;

@@ -163,7 +163,7 @@ class HeadTrainer:
         N.check(self.lib.acez_trainer_sync_weights(self._h, _stream()))
 
     # ---------------------------------------------------------------- training buffer
-    def set_buffer(self, features, target_px, view_idx, view_aug_inv, view_K, view_Kinv, view_image, image_pose_inv):
+    def set_buffer(self, features, target_px, view_idx, view_aug_inv, view_K, view_Kinv, view_image, image_pose_inv, target_crds=None):
         """All arguments are arrays/tensors in the de-duplicated layout of acez_train_buffer (include/acez.h)."""
         dev = self.device
         t = lambda x, dt: torch.as_tensor(x).to(device=dev, dtype=dt).contiguous()
@@ -172,12 +172,13 @@ class HeadTrainer:
             "view_aug_inv": t(view_aug_inv, torch.float32), "view_K": t(view_K, torch.float32),
             "view_Kinv": t(view_Kinv, torch.float32), "view_image": t(view_image, torch.int32),
             "image_pose_inv": t(image_pose_inv, torch.float32),
+            "target_crds": t(target_crds, torch.float32) if target_crds is not None else None,   # use_depth mode
         }
         b = self._buf
         assert b["features"].shape[1] == 512
         tb = N.TrainBuffer(_ptr(b["features"]), _ptr(b["target_px"]), _ptr(b["view_idx"]), b["features"].shape[0],
                            _ptr(b["view_aug_inv"]), _ptr(b["view_K"]), _ptr(b["view_Kinv"]), _ptr(b["view_image"]),
-                           b["view_aug_inv"].shape[0], _ptr(b["image_pose_inv"]), b["image_pose_inv"].shape[0])
+                           b["view_aug_inv"].shape[0], _ptr(b["image_pose_inv"]), b["image_pose_inv"].shape[0], _ptr(b["target_crds"]))
         N.check(self.lib.acez_trainer_set_buffer(self._h, C.byref(tb)))
 
     @property

@@ -76,6 +76,8 @@ def make_training_problem(seed=2089, n_images=10, views_per_image=2, patches_per
         "features": feats.astype(np.float32), "target_px": target_px, "view_idx": view_idx,
         "view_aug_inv": view_aug_inv, "view_K": view_K, "view_Kinv": view_Kinv, "view_image": view_image,
         "image_pose_inv": image_pose_inv, "mean": mean, "gt_coords": gt, "focal": np.float32(focal),
+        # ground-truth scene coordinates as the depth-based targets of ace_trainer.py:338 (a quarter of them "missing" = zeros)
+        "target_crds": np.where((np.arange(n) % 4 == 3)[:, None], 0.0, gt).astype(np.float32),
     }
 
 
@@ -86,7 +88,7 @@ def expand_per_patch(prob, idx):
     return {
         "features": prob["features"][idx], "target_px": prob["target_px"][idx], "aug_inv": prob["view_aug_inv"][v],
         "pose_inv": prob["image_pose_inv"][img], "K": prob["view_K"][v], "Kinv": prob["view_Kinv"][v],
-        "pose_idx": img.astype(np.int16),
+        "pose_idx": img.astype(np.int16), "target_crds": prob["target_crds"][idx],
     }
 
 

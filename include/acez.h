@@ -201,6 +201,9 @@ typedef struct acez_train_buffer {
   int32_t n_views;
   const float* d_image_pose_inv; /* f32 [n_images][4][4] world->cam poses_inv (ace_trainer.py:332)      */
   int32_t n_images;
+  const float* d_target_crds;  /* f32 [n_patches][3] ground-truth scene coordinates from depth, zeros where none
+                                  (ace_trainer.py:338); non-NULL selects the use_depth variant of the step
+                                  (ace_trainer.py:567-574,601-609), NULL the constant-depth proxy target */
 } acez_train_buffer;
 
 typedef struct acez_train_state {

@@ -159,6 +159,12 @@ class HeadOracle:
         du, dv = u - tu, v - tv
         e = du.abs() + dv.abs()  # :552
         invalid = (Xc[:, 2] < dmin) | (e > float(cfg["hard_clamp"])) | (Xc[:, 2] > dmax)  # :558-565
+        use_depth = "target_crds" in batch and batch["target_crds"] is not None and cfg.get("use_depth", False)
+        if use_depth:   # ace_trainer.py:567-574
+            tcd = batch["target_crds"] - X
+            tdist = torch.linalg.norm(tcd, dim=1)
+            tavail = batch["target_crds"].abs().sum(dim=1) > 0.00001
+            invalid = invalid | ((tdist > 0.1) & tavail)
         valid = ~invalid
         # loss weight (ace_loss.py:55-69)
         lt = cfg["loss_type"]
@@ -194,9 +200,15 @@ class HeadOracle:
         d = tgt - Xc
         li = d.abs().sum(dim=1)
         dXc_inv = -torch.sign(d)
+        dXs = torch.zeros_like(X)
+        if use_depth:   # ace_trainer.py:601-609: L2 distance to the GT coordinate where available, nothing otherwise
+            li = torch.where(tavail, tdist, torch.zeros_like(tdist))
+            dXc_inv = torch.zeros_like(dXc_inv)
+            inv = torch.where(tdist > 0, 1.0 / tdist, torch.zeros_like(tdist))
+            dXs = torch.where((invalid & tavail)[:, None], -tcd * inv[:, None], dXs)
         loss_rows = torch.where(valid, lv, li)
         dXc = torch.where(valid[:, None], dXc_valid, dXc_inv)
-        dX = torch.bmm(P[:, :, :3].transpose(1, 2), dXc[:, :, None])[:, :, 0] * invB
+        dX = (torch.bmm(P[:, :, :3].transpose(1, 2), dXc[:, :, None])[:, :, 0] + dXs) * invB
         focal_grad = 0.0
         if kscale is not None:
             fg = torch.where(valid, (dp[:, 0] * Xc[:, 0] + dp[:, 1] * Xc[:, 1]) * float(cfg["focal_init"]) * kscale, torch.zeros_like(e))

@@ -62,6 +62,10 @@ CONFIGS = {
     "head_tanh_posemlp": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
                               warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
                               refine_calibration=False, steps=6, pose_refinement="mlp", pose_refinement_wait=2),
+    # depth-supervised mapping (the seed stage of ace_zero: use_depth, ace_trainer.py:567-574,601-609)
+    "head_tanh_depth": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
+                            warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
+                            refine_calibration=False, steps=6, use_depth=True),
 }
 B = 512
 SEED = 2089
@@ -74,6 +78,7 @@ def full_cfg(c):
              use_homogeneous=True, calib_lr=0.001)
     d.setdefault("pose_refinement", "none")
     d.setdefault("pose_refinement_wait", 0)
+    d.setdefault("use_depth", False)
     return d
 
 
@@ -101,7 +106,7 @@ def run_reference(cfg, prob, flat0, batches):
     tr.options = opt
     tr.iteration = 0
     tr.epoch = 0
-    tr.use_depth = False
+    tr.use_depth = bool(cfg["use_depth"])
     tr.iterations_output = 10 ** 9
     tr.ace_visualizer = None
     tr.training_start = time.time()
@@ -169,7 +174,7 @@ def run_reference(cfg, prob, flat0, batches):
                 coords0 = head(f).permute(0, 2, 3, 1).flatten(0, 2).clone().numpy()
         n_before = len(rec["loss"])
         ace_trainer.TrainerACE.training_step(tr, t["features"], t["target_px"], t["aug_inv"], t["pose_inv"], t["K"], t["Kinv"],
-                                             torch.zeros(B, 3), t["pose_idx"][:, None])
+                                             t["target_crds"] if cfg["use_depth"] else torch.zeros(B, 3), t["pose_idx"][:, None])
         ran = len(rec["loss"]) > n_before
         rec["max_iterations"].append(int(sched.max_iterations))
         rec["focal_scale"].append(float(1 + tr.K_optimizer.global_f) if tr.K_optimizer is not None else 1.0)

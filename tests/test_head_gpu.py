@@ -29,7 +29,7 @@ def _trainer(prob, flat0, cfg, max_batch=helpers.B, global_batch=None):
                      pose_refinement_wait=cfg["pose_refinement_wait"], pose_seed=helpers.SEED + 3)
     tr.load_flat(flat0)
     tr.set_buffer(prob["features"], prob["target_px"], prob["view_idx"], prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"],
-                  prob["view_image"], prob["image_pose_inv"])
+                  prob["view_image"], prob["image_pose_inv"], target_crds=prob["target_crds"] if cfg.get("use_depth") else None)
     return tr
 
 
