@@ -109,9 +109,10 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_REQUIRE(params->n_params == acez_head_num_params(&cfg->head), "n_params does not match the head description");
   ACEZ_REQUIRE(cfg->schedule >= 0 && cfg->schedule <= 2, "unknown schedule");
   ACEZ_REQUIRE(cfg->loss_type >= 0 && cfg->loss_type <= 4, "unknown loss type");
-  ACEZ_REQUIRE(cfg->pose_refinement == 0 || cfg->pose_refinement == 2, "pose_refinement must be 0 (none) or 2 (mlp)");
-  ACEZ_REQUIRE(cfg->pose_refinement == 0 || (params->d_pose_params && params->d_pose_m && params->d_pose_v && params->n_pose_params == ACEZ_POSE_MLP_PARAMS),
-               "pose_refinement mlp needs the pose-network parameter buffers");
+  ACEZ_REQUIRE(cfg->pose_refinement >= 0 && cfg->pose_refinement <= 2, "pose_refinement must be 0 (none), 1 (naive) or 2 (mlp)");
+  ACEZ_REQUIRE(cfg->pose_refinement == 0 || (params->d_pose_params && params->d_pose_m && params->d_pose_v), "pose refinement needs the pose parameter buffers");
+  ACEZ_REQUIRE(cfg->pose_refinement != 2 || params->n_pose_params == ACEZ_POSE_MLP_PARAMS, "mlp: n_pose_params must be ACEZ_POSE_MLP_PARAMS");
+  ACEZ_REQUIRE(cfg->pose_refinement != 1 || (params->n_pose_params > 0 && params->n_pose_params % 12 == 0), "naive: n_pose_params must be 12 * n_images");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     (void)hipGetLastError();
@@ -190,6 +191,24 @@ extern "C" int acez_trainer_set_buffer(acez_trainer* tr, const acez_train_buffer
   ACEZ_REQUIRE(buf->d_image_pose_inv && buf->n_images > 0, "empty pose table");
   tr->buf = *buf;
   tr->have_buf = true;
+  if (tr->cfg.pose_refinement == 1) {
+    ACEZ_REQUIRE(tr->pb.n_pose_params == (int64_t)buf->n_images * 12, "naive pose refinement: n_pose_params != 12 * n_images");
+    if (tr->pose_images < buf->n_images) {
+      ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+      int rc = ACEZ_OK;
+      auto A = [&](void** p, size_t bytes) { if (rc == ACEZ_OK) rc = dmalloc(tr, p, bytes); };
+      A((void**)&tr->pdT, (size_t)buf->n_images * 12 * sizeof(float));
+      A((void**)&tr->pose_cur, (size_t)buf->n_images * 16 * sizeof(float));
+      A((void**)&tr->pa1, (size_t)buf->n_images * 16 * sizeof(float));   // zero table standing in for T0
+      if (!tr->row_dT) {
+        A((void**)&tr->row_dT, (size_t)tr->max_batch * 12 * sizeof(float));
+        A((void**)&tr->row_image, (size_t)tr->max_batch * sizeof(int));
+      }
+      if (rc != ACEZ_OK) return rc;
+      ACEZ_HIP_CHECK(hipMemset(tr->pa1, 0, (size_t)buf->n_images * 16 * sizeof(float)));
+      tr->pose_images = buf->n_images;
+    }
+  }
   if (tr->cfg.pose_refinement == 2 && tr->pose_images < buf->n_images) {
     ACEZ_HIP_CHECK(hipSetDevice(tr->device));
     const int I = buf->n_images;
@@ -373,8 +392,12 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
   delete psg;
   act = launch_forward(tr, tr->R[0], n, st, s);
   }
-  const bool pose_mlp = tr->cfg.pose_refinement == 2;
-  if (pose_mlp) pose_forward(tr, &tr->st->active, s);
+  const bool pose_naive = tr->cfg.pose_refinement == 1;
+  const bool pose_mlp = tr->cfg.pose_refinement == 2 || pose_naive;   // both need the refined-pose table and per-row pose gradients
+  if (tr->cfg.pose_refinement == 2) pose_forward(tr, &tr->st->active, s);
+  if (pose_naive)   // refine_poses.py:224-234: the poses themselves are the parameters; P = 0 + 1 * params, then Gram-Schmidt
+    hipLaunchKernelGGL(pose_compose_kernel, dim3((tr->buf.n_images + 255) / 256), dim3(256), 0, s, (const float*)tr->pa1,
+                       (const float*)tr->pb.d_pose_params, 1.0f, tr->pose_cur, tr->buf.n_images, (const int*)&tr->st->active);
 
   const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
   const int nblk = (n + 31) / 32;
@@ -397,7 +420,14 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, s, a);
   }
 
-  if (pose_mlp) pose_backward(tr, n, &tr->st->active, s);
+  if (tr->cfg.pose_refinement == 2) pose_backward(tr, n, &tr->st->active, s);
+  if (pose_naive) {
+    const int I = tr->buf.n_images;
+    hipLaunchKernelGGL(pose_grad_reduce_kernel, dim3((I * 64 + 255) / 256), dim3(256), 0, s, (const float*)tr->row_dT, (const int*)tr->row_image, n,
+                       tr->pdT, I, (const int*)&tr->st->active);
+    hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((I + 255) / 256), dim3(256), 0, s, (const float*)tr->pa1, (const float*)tr->pb.d_pose_params, 1.0f,
+                       (const float*)tr->pdT, tr->pb.d_grad + tr->n_params + 4, I, (const int*)&tr->st->active);
+  }
 
   // input-gradient chain
   const dim3 grid(8 * 4 * ((((n + 127) / 128) + 7) / 8)), blk(256);  // N = 512 -> 4 column tiles; see the XCD decode in rowgemm_kernel
@@ -464,9 +494,9 @@ extern "C" int acez_train_update(acez_trainer* tr, void* stream) {
   fill_adam_args(tr, a);
   const int nsmall = (int)(((int64_t)tr->L * 512 + (int64_t)tr->no * 513 + 255) / 256);
   { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3(tr->L * 64 + nsmall), dim3(256), 0, s, a); }
-  if (tr->cfg.pose_refinement == 2)
-    hipLaunchKernelGGL(adamw_small_kernel, dim3((ACEZ_POSE_MLP_PARAMS + 255) / 256), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,
-                       tr->pb.d_pose_v, (const float*)(tr->pb.d_grad + tr->n_params + 4), (int64_t)0, 1, (int64_t)ACEZ_POSE_MLP_PARAMS,
+  if (tr->cfg.pose_refinement != 0)
+    hipLaunchKernelGGL(adamw_small_kernel, dim3((unsigned)((tr->pb.n_pose_params + 255) / 256)), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,
+                       tr->pb.d_pose_v, (const float*)(tr->pb.d_grad + tr->n_params + 4), (int64_t)0, 1, tr->pb.n_pose_params,
                        (const AdamScalars*)&tr->st->pose_adam, (const int*)&tr->st->pose_enable, (const int*)&tr->st->active);
   ProfScope ps2(tr, s, KC_SCHED);
   hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, tr->st, tr->sc, (const float*)(tr->pb.d_grad + tr->n_params),
@@ -567,6 +597,11 @@ extern "C" int acez_trainer_get_poses(acez_trainer* tr, float* h_poses34, void* 
   const float* src = tr->buf.d_image_pose_inv;
   if (tr->cfg.pose_refinement == 2) {
     pose_forward(tr, nullptr, s);
+    ACEZ_HIP_CHECK(hipGetLastError());
+    src = tr->pose_cur;
+  } else if (tr->cfg.pose_refinement == 1) {
+    hipLaunchKernelGGL(pose_compose_kernel, dim3((I + 255) / 256), dim3(256), 0, s, (const float*)tr->pa1, (const float*)tr->pb.d_pose_params, 1.0f,
+                       tr->pose_cur, I, (const int*)nullptr);
     ACEZ_HIP_CHECK(hipGetLastError());
     src = tr->pose_cur;
   }

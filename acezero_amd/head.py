@@ -58,7 +58,8 @@ class HeadTrainer:
                  iterations=25000, lr_min=0.0005, lr_max=0.005, warmup_iterations=1000, warmup_lr=0.0005,
                  cooldown_iterations=5000, cooldown_trigger_percent=0.7, refine_calibration=False, focal_init=0.0,
                  calib_lr=0.001, pose_refinement="none", pose_refinement_wait=0, pose_refinement_lr=0.001,
-                 pose_refinement_weight=0.1, pose_seed=0, homogeneous_min_scale=0.01, homogeneous_max_scale=4.0, device=None):
+                 pose_refinement_weight=0.1, pose_seed=0, initial_poses=None, homogeneous_min_scale=0.01, homogeneous_max_scale=4.0,
+                 device=None):
         if not torch.cuda.is_available():
             raise RuntimeError("HeadTrainer needs a GPU: the head kernels are HIP only (no CPU fallback)")
         self.lib = N.lib()
@@ -81,15 +82,19 @@ class HeadTrainer:
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros_like(self.params)
         self.adam_v = torch.zeros_like(self.params)
-        if pose_refinement not in ("none", "mlp"):
-            raise ValueError("pose_refinement must be 'none' or 'mlp' ('naive' is not built)")
+        if pose_refinement not in ("none", "naive", "mlp"):
+            raise ValueError("pose_refinement must be 'none', 'naive' or 'mlp'")
         self.pose_mlp = pose_refinement == "mlp"
-        self.n_pose = POSE_MLP_PARAMS if self.pose_mlp else 0
+        self.pose_naive = pose_refinement == "naive"
+        if self.pose_naive and initial_poses is None:
+            raise ValueError("pose_refinement='naive' needs initial_poses [n_images,3,4] (world->cam), the learnable parameters")
+        self.n_pose = POSE_MLP_PARAMS if self.pose_mlp else (12 * len(initial_poses) if self.pose_naive else 0)
         # gradient bucket: head gradients, {loss, inliers, dfocal, pad}, then the pose-network gradients
         self.grad = torch.zeros(self.n_params + 4 + self.n_pose, dtype=torch.float32, device=dev)
         self.pose_params = self.pose_m = self.pose_v = None
-        if self.pose_mlp:
-            self.pose_params = init_pose_network(pose_seed).to(dev)
+        if self.pose_mlp or self.pose_naive:
+            self.pose_params = (init_pose_network(pose_seed) if self.pose_mlp else
+                                torch.as_tensor(initial_poses, dtype=torch.float32).reshape(-1).clone()).to(dev)
             self.pose_m = torch.zeros_like(self.pose_params)
             self.pose_v = torch.zeros_like(self.pose_params)
         self.max_batch = int(max_batch)
@@ -106,7 +111,7 @@ class HeadTrainer:
         cfg.cooldown_iterations, cfg.cooldown_trigger_percent = int(cooldown_iterations), cooldown_trigger_percent
         cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay = 0.9, 0.999, 1e-8, 1e-2  # torch.optim.AdamW defaults
         cfg.refine_calibration, cfg.focal_init, cfg.calib_lr = int(refine_calibration), float(focal_init), calib_lr
-        cfg.pose_refinement = 2 if self.pose_mlp else 0
+        cfg.pose_refinement = 2 if self.pose_mlp else (1 if self.pose_naive else 0)
         cfg.pose_refinement_wait, cfg.pose_refinement_lr = int(pose_refinement_wait), float(pose_refinement_lr)
         cfg.pose_refinement_weight = float(pose_refinement_weight)
         pb = N.ParamBuffers(_ptr(self.params), _ptr(self.adam_m), _ptr(self.adam_v), _ptr(self.grad), self.n_params,

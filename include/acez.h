@@ -157,7 +157,8 @@ typedef struct acez_train_config {
   int32_t refine_calibration;
   float focal_init;            /* CalibrationRefiner.focal_length_init                                   */
   double calib_lr;
-  /* pose refinement (refine_poses.py): 0 = none, 2 = mlp (PoseNetwork(0,128) + Gram-Schmidt); naive is not built */
+  /* pose refinement (refine_poses.py): 0 = none, 1 = naive (the 3x4 poses are the parameters, :224-234),
+   * 2 = mlp (PoseNetwork(0,128), :152-176); both with Gram-Schmidt orthonormalisation */
   int32_t pose_refinement;
   int32_t pose_refinement_wait;   /* train_ace.py:220                                                     */
   double pose_refinement_lr;      /* train_ace.py:223, 1e-3                                               */
@@ -183,7 +184,7 @@ typedef struct acez_param_buffers {
   float* d_pose_params;
   float* d_pose_m;
   float* d_pose_v;
-  int64_t n_pose_params; /* ACEZ_POSE_MLP_PARAMS or 0 */
+  int64_t n_pose_params; /* mlp: ACEZ_POSE_MLP_PARAMS; naive: 12 * n_images (d_pose_params = the [n_images][3][4] poses); none: 0 */
 } acez_param_buffers;
 #define ACEZ_POSE_MLP_PARAMS 70924
 

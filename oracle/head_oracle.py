@@ -307,6 +307,18 @@ class PoseMLPOracle:
         return out
 
 
+class PoseNaiveOracle:
+    """refine_poses.py `naive` strategy (:224-234): the [I,3,4] world->cam poses are the parameters."""
+
+    def __init__(self, flat):
+        self.flat = flat.clone().requires_grad_(True)
+
+    def forward(self, poses44):
+        cur = self.flat.view(-1, 3, 4)
+        R = special_gramschmidt(cur[:, :3, :3])
+        return torch.cat([torch.cat([R, cur[:, :3, 3:4]], dim=2), poses44[:, 3:4, :]], dim=1)
+
+
 def loss_autograd(head, s, batch, cfg, iteration, poses44_rows, focal_scale=1.0):
     """ace_trainer.py:521-613 with torch ops and autograd (used where gradients wrt the poses are needed).
     s [B,no] requires grad; poses44_rows [B,4,4] may require grad. Returns (loss_sum tensor, inliers)."""
@@ -439,8 +451,9 @@ class TrainerOracle:
         self.iteration = 0
         self.log = []
         self.pose = None
-        if cfg.get("pose_refinement", "none") == "mlp":
-            self.pose = PoseMLPOracle(pose_flat, cfg.get("pose_refinement_weight", 0.1))
+        if cfg.get("pose_refinement", "none") in ("mlp", "naive"):
+            self.pose = (PoseMLPOracle(pose_flat, cfg.get("pose_refinement_weight", 0.1)) if cfg["pose_refinement"] == "mlp"
+                         else PoseNaiveOracle(pose_flat))
             self.image_pose_inv = torch.as_tensor(image_pose_inv, dtype=torch.float32)
             self.pose_m = torch.zeros_like(pose_flat)
             self.pose_v = torch.zeros_like(pose_flat)

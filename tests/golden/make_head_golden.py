@@ -63,6 +63,9 @@ CONFIGS = {
                               warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
                               refine_calibration=False, steps=6, pose_refinement="mlp", pose_refinement_wait=2),
     # depth-supervised mapping (the seed stage of ace_zero: use_depth, ace_trainer.py:567-574,601-609)
+    "head_tanh_posenaive": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
+                                warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
+                                refine_calibration=False, steps=5, pose_refinement="naive", pose_refinement_wait=0),
     "head_tanh_depth": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
                             warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
                             refine_calibration=False, steps=6, use_depth=True),
@@ -123,7 +126,7 @@ def run_reference(cfg, prob, flat0, batches):
         def get_all_original_poses(self): return torch.zeros(1, 3, 4)
         def get_all_current_poses(self): return torch.zeros(1, 3, 4)
     tr.pose_refiner = NoRefiner()
-    if cfg["pose_refinement"] == "mlp":
+    if cfg["pose_refinement"] in ("mlp", "naive"):
         n_img = prob["image_pose_inv"].shape[0]
         class FakeDS:
             poses = [torch.from_numpy(np.linalg.inv(prob["image_pose_inv"][i].astype(np.float64)).astype(np.float32)) for i in range(n_img)]
@@ -131,6 +134,8 @@ def run_reference(cfg, prob, flat0, batches):
         fake_ds = FakeDS()
         pr = refine_poses.PoseRefiner(fake_ds, torch.device("cpu"), opt)
         pr.create_pose_buffer()
+        tr.pose_refiner = pr
+    if cfg["pose_refinement"] == "mlp":
         from acezero_amd.head import init_pose_network, POSE_LAYERS
         flatp = init_pose_network(SEED + 3)
         sdp, o = {}, 0
@@ -138,7 +143,6 @@ def run_reference(cfg, prob, flat0, batches):
             sdp[lname + ".weight"] = flatp[o:o + O * K].view(O, K, 1, 1).clone(); o += O * K
             sdp[lname + ".bias"] = flatp[o:o + O].clone(); o += O
         pr.pose_network.load_state_dict(sdp)
-        tr.pose_refiner = pr
     if cfg["refine_calibration"]:
         ds = types.SimpleNamespace(get_focal_length=lambda i: float(prob["focal"]), __len__=lambda: 1)
         cr = object.__new__(refine_calibration.CalibrationRefiner)
@@ -178,9 +182,10 @@ def run_reference(cfg, prob, flat0, batches):
         ran = len(rec["loss"]) > n_before
         rec["max_iterations"].append(int(sched.max_iterations))
         rec["focal_scale"].append(float(1 + tr.K_optimizer.global_f) if tr.K_optimizer is not None else 1.0)
-        if cfg["pose_refinement"] == "mlp":
-            rec["poses"].append(tr.pose_refiner.get_all_current_poses().numpy().copy())
-            rec["pose_params"].append(torch.cat([p.detach().flatten() for p in tr.pose_refiner.pose_network.parameters()]).numpy().copy())
+        if cfg["pose_refinement"] in ("mlp", "naive"):
+            rec["poses"].append(tr.pose_refiner.get_all_current_poses().detach().numpy().copy())
+            pp_ = tr.pose_refiner.pose_network.parameters() if cfg["pose_refinement"] == "mlp" else [tr.pose_refiner.pose_buffer]
+            rec["pose_params"].append(torch.cat([p.detach().flatten() for p in pp_]).numpy().copy())
         if not ran:
             break
         tr.iteration += 1
@@ -212,7 +217,7 @@ def main():
             max_iterations=np.array(rec["max_iterations"], np.int64), focal_scale=np.array(rec["focal_scale"], np.float64),
             coords0=coords0[:64].astype(np.float32), param_sel=sel, params_after_first=first[sel], params_after_last=snaps[last_it][sel],
             last_it=np.int64(last_it), steps_run=np.int64(len(rec["loss"])),
-            poses=np.array(rec["poses"], np.float32), pose_params_sel=np.array([p[::97] for p in rec["pose_params"]], np.float32))
+            poses=np.array(rec["poses"], np.float32), pose_params_sel=np.array([p[::(97 if p.size > 1000 else 1)] for p in rec["pose_params"]], np.float32))
         print(name, "steps run", len(rec["loss"]), "loss", rec["loss"][:3], "inl", rec["inliers"][:3], "lr", rec["lr"][:3],
               "max_it", rec["max_iterations"][-1], "focal", rec["focal_scale"][-1])
 

@@ -21,6 +21,9 @@ HEAD_CONFIGS = {
     "head_tanh_posemlp": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
                               warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
                               refine_calibration=False, steps=6, pose_refinement="mlp", pose_refinement_wait=2),
+    "head_tanh_posenaive": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
+                                warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
+                                refine_calibration=False, steps=5, pose_refinement="naive", pose_refinement_wait=0),
     "head_tanh_depth": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
                             warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
                             refine_calibration=False, steps=6, use_depth=True),

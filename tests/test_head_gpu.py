@@ -26,7 +26,8 @@ def _trainer(prob, flat0, cfg, max_batch=helpers.B, global_batch=None):
                      warmup_iterations=cfg["warmup_iterations"], warmup_lr=cfg["warmup_lr"], cooldown_iterations=cfg["cooldown_iterations"],
                      cooldown_trigger_percent=cfg["cooldown_trigger_percent"], refine_calibration=cfg["refine_calibration"],
                      focal_init=float(prob["focal"]), calib_lr=cfg["calib_lr"], pose_refinement=cfg["pose_refinement"],
-                     pose_refinement_wait=cfg["pose_refinement_wait"], pose_seed=helpers.SEED + 3)
+                     pose_refinement_wait=cfg["pose_refinement_wait"], pose_seed=helpers.SEED + 3,
+                     initial_poses=prob["image_pose_inv"][:, :3] if cfg["pose_refinement"] == "naive" else None)
     tr.load_flat(flat0)
     tr.set_buffer(prob["features"], prob["target_px"], prob["view_idx"], prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"],
                   prob["view_image"], prob["image_pose_inv"], target_crds=prob["target_crds"] if cfg.get("use_depth") else None)
@@ -56,7 +57,7 @@ def test_training_steps_match_oracle_and_golden(name):
     cfg = helpers.full_cfg(helpers.HEAD_CONFIGS[name], prob)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     tr = _trainer(prob, flat0, cfg)
-    mlp = cfg["pose_refinement"] == "mlp"
+    mlp = cfg["pose_refinement"] in ("mlp", "naive")
     pose_flat = tr.pose_params.cpu().clone() if mlp else None
     orc = head_oracle.TrainerOracle(flat0.clone(), prob["mean"], cfg, mode="bf16", pose_flat=pose_flat, image_pose_inv=prob["image_pose_inv"])
     batches = helpers.golden_batches(prob, cfg["steps"])

@@ -19,6 +19,8 @@ def test_oracle_fp32_matches_reference_golden(name, golden_dir):
     if cfg["pose_refinement"] == "mlp":
         from acezero_amd.head import init_pose_network
         pose_flat = init_pose_network(helpers.SEED + 3)
+    if cfg["pose_refinement"] == "naive":
+        pose_flat = torch.from_numpy(prob["image_pose_inv"][:, :3].reshape(-1).copy())
     tr = head_oracle.TrainerOracle(flat0.clone(), prob["mean"], cfg, mode="fp32", pose_flat=pose_flat, image_pose_inv=prob["image_pose_inv"])
     losses, inl, lrs, maxit, focal = [], [], [], [], []
     snaps = {}
@@ -33,10 +35,11 @@ def test_oracle_fp32_matches_reference_golden(name, golden_dir):
         if rec is None:
             break
         losses.append(rec["loss"]); inl.append(rec["inliers"]); lrs.append(rec["lr"])
-        if cfg["pose_refinement"] == "mlp":
-            # refined poses and the pose network after this step vs the reference's PoseRefiner
+        if cfg["pose_refinement"] in ("mlp", "naive"):
+            # refined poses and the pose parameters after this step vs the reference's PoseRefiner
             np.testing.assert_allclose(tr.current_poses().numpy(), g["poses"][it], atol=5e-5 if it < 4 else 5e-4)
-            np.testing.assert_allclose(tr.pose.flat.detach().numpy()[::97], g["pose_params_sel"][it], atol=2e-6 if it < 3 else 3e-3)
+            stride = 97 if tr.pose.flat.numel() > 1000 else 1
+            np.testing.assert_allclose(tr.pose.flat.detach().numpy()[::stride], g["pose_params_sel"][it], atol=2e-6 if it < 3 else 3e-3)
         snaps[it] = tr.head.p.flat.clone().numpy()
     assert len(losses) == int(g["steps_run"])
     np.testing.assert_allclose(lrs, g["lr"], rtol=1e-12)
