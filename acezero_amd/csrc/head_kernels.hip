@@ -411,20 +411,22 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// loss kernel (32 rows per workgroup):
+// loss kernel (LOSS_ROWS = 8 rows per single-wave workgroup: 640 workgroups at batch 5120 keep every CU busy and
+// give the latency-bound phases 8 waves per SIMD to hide behind):
 //   A  fc3 forward, one wave per row, fp32 accumulate
 //   B  one thread per row: de-homogenise, project, masks, robust loss and d(loss)/d(fc3 outputs)
 //   C  one thread per channel pair: fc3 weight-gradient partials and the masked input gradient dZ
 // ---------------------------------------------------------------------------------------------------
+constexpr int LOSS_ROWS = 8;
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
-__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
+__global__ __launch_bounds__(64) void loss_kernel(LossArgs a) {
   if (a.st && !a.st->active) return;
-  __shared__ float s_s[32][4];
-  __shared__ float s_ds[32][4];
-  __shared__ float s_red[32][4];
-  const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  const int m0 = blockIdx.x * 32;
+  __shared__ float s_s[LOSS_ROWS][4];
+  __shared__ float s_ds[LOSS_ROWS][4];
+  __shared__ float s_red[LOSS_ROWS][4];
+  const int t = threadIdx.x, l = t;
+  const int m0 = blockIdx.x * LOSS_ROWS;
   const int n = a.n, no = a.no;
 
   // phase B's per-row inputs sit behind a chain of dependent loads (idx -> view -> image): start it now so that its
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   int64_t pre_p = 0;
   int pre_view = 0, pre_img = 0;
   float pre_tu = 0.f, pre_tv = 0.f;
-  if (a.idx && t < 32 && m0 + t < n) {
+  if (a.idx && t < LOSS_ROWS && m0 + t < n) {
     pre_p = a.idx[m0 + t];
     pre_view = a.view_idx[pre_p];
     pre_img = a.view_image[pre_view];
@@ -455,8 +457,8 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
       }
     }
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = w * 8 + rr, m = m0 + r;
+    for (int rr = 0; rr < LOSS_ROWS; ++rr) {
+      const int r = rr, m = m0 + r;
       float x[8];
       if (m < n) {
         const uint4 v = *reinterpret_cast<const uint4*>(a.act + (size_t)m * 512 + l * 8);
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   __syncthreads();
 
   // ---- phase B
-  if (t < 32) {
+  if (t < LOSS_ROWS) {
     const int r = t, m = m0 + r;
     float loss = 0.f, inl = 0.f, fgrad = 0.f, ds[4] = {0.f, 0.f, 0.f, 0.f};
     if (m < n) {
@@ -652,57 +654,74 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   __syncthreads();
   if (!a.idx) return;  // inference: no gradients
 
-  if (t < 3) {  // fixed-order sum over the 32 rows -> one partial per workgroup
+  if (t < 3) {  // fixed-order sum over the rows -> one partial per workgroup
     float acc = 0.f;
-    for (int r = 0; r < 32; ++r) acc += s_red[r][t];
+    for (int r = 0; r < LOSS_ROWS; ++r) acc += s_red[r][t];
     a.stat_partials[(size_t)blockIdx.x * 4 + t] = acc;
   }
 
-  // ---- phase C: thread t owns channels 2t, 2t+1
+  // ---- phase C: lane t owns channels 8t .. 8t+7 (16-byte row segments in and out)
   {
-    float w3[4][2], gw[4][2], bsum0 = 0.f, bsum1 = 0.f;
+    float w3[4][8], gw[4][8], bsum[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j < no) {
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(a.W3 + (size_t)j * 512 + 2 * t);
-        w3[j][0] = __uint_as_float(v << 16);
-        w3[j][1] = __uint_as_float(v & 0xffff0000u);
+        const uint4 v = *reinterpret_cast<const uint4*>(a.W3 + (size_t)j * 512 + 8 * t);
+        unpack4(make_uint2(v.x, v.y), &w3[j][0]);
+        unpack4(make_uint2(v.z, v.w), &w3[j][4]);
       } else {
-        w3[j][0] = w3[j][1] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w3[j][e] = 0.f;
       }
-      gw[j][0] = gw[j][1] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gw[j][e] = 0.f;
     }
-#pragma unroll 8
-    for (int r = 0; r < 32; ++r) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < LOSS_ROWS; ++r) {
       const int m = min(m0 + r, n - 1);  // rows past the end carry ds == 0 and are not stored
-      const uint32_t v = *reinterpret_cast<const uint32_t*>(a.act + (size_t)m * 512 + 2 * t);
-      const float x0 = __uint_as_float(v << 16), x1 = __uint_as_float(v & 0xffff0000u);
-      float d0 = 0.f, d1 = 0.f;
+      const uint4 v = *reinterpret_cast<const uint4*>(a.act + (size_t)m * 512 + 8 * t);
+      float x[8], d[8];
+      unpack4(make_uint2(v.x, v.y), &x[0]);
+      unpack4(make_uint2(v.z, v.w), &x[4]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float dsj = s_ds[r][j];
-        d0 = fmaf(dsj, w3[j][0], d0);
-        d1 = fmaf(dsj, w3[j][1], d1);
-        gw[j][0] = fmaf(dsj, x0, gw[j][0]);
-        gw[j][1] = fmaf(dsj, x1, gw[j][1]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          d[e] = fmaf(dsj, w3[j][e], d[e]);
+          gw[j][e] = fmaf(dsj, x[e], gw[j][e]);
+        }
       }
-      if (!(x0 > 0.f)) d0 = 0.f;  // relu mask of the fc2 output
-      if (!(x1 > 0.f)) d1 = 0.f;
-      const uint32_t pk = pack2(d0, d1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (!(x[e] > 0.f)) d[e] = 0.f;  // relu mask of the fc2 output
+      const uint2 lo = pack4(d[0], d[1], d[2], d[3]), hi = pack4(d[4], d[5], d[6], d[7]);
       if (m0 + r < n) {
-        *reinterpret_cast<uint32_t*>(a.dZ + (size_t)m * 512 + 2 * t) = pk;
-        bsum0 += __uint_as_float(pk << 16);
-        bsum1 += __uint_as_float(pk & 0xffff0000u);
+        *reinterpret_cast<uint4*>(a.dZ + (size_t)m * 512 + 8 * t) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        float q[8];
+        unpack4(lo, &q[0]);
+        unpack4(hi, &q[4]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += q[e];   // bias gradient of fc2: the bf16-rounded values, in row order
       }
     }
-    *reinterpret_cast<float2*>(a.bias_partials + (size_t)blockIdx.x * 512 + 2 * t) = make_float2(bsum0, bsum1);
+    float* bp = a.bias_partials + (size_t)blockIdx.x * 512 + 8 * t;
+    *reinterpret_cast<float4*>(bp) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+    *reinterpret_cast<float4*>(bp + 4) = make_float4(bsum[4], bsum[5], bsum[6], bsum[7]);
     float* gp = a.fc3_partials + (size_t)blockIdx.x * a.fc3_stride;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (j < no) *reinterpret_cast<float2*>(gp + (size_t)j * 512 + 2 * t) = make_float2(gw[j][0], gw[j][1]);
+      if (j < no) {
+        *reinterpret_cast<float4*>(gp + (size_t)j * 512 + 8 * t) = make_float4(gw[j][0], gw[j][1], gw[j][2], gw[j][3]);
+        *reinterpret_cast<float4*>(gp + (size_t)j * 512 + 8 * t + 4) = make_float4(gw[j][4], gw[j][5], gw[j][6], gw[j][7]);
+      }
     if (t < no) {
       float acc = 0.f;
-      for (int r = 0; r < 32; ++r) acc += s_ds[r][t];
+      for (int r = 0; r < LOSS_ROWS; ++r) acc += s_ds[r][t];
       gp[(size_t)no * 512 + t] = acc;
     }
   }
