@@ -415,7 +415,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.inv_batch = 1.0f / (float)tr->cfg.global_batch; a.focal_init = tr->cfg.focal_init;
     a.st = st; a.out_xyz = tr->xyz; a.dZ = tr->dZ[f2];
     a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
-    a.bias_partials = tr->bias_partials + (size_t)f2 * tr->bias_layer_stride;
+    a.bias_partials = tr->bias_partials + (size_t)f2 * tr->bias_layer_stride; a.dbg = 0;
     ProfScope ps(tr, s, KC_LOSS);
     hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(64), 0, s, a);
   }

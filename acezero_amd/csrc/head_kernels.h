@@ -104,6 +104,7 @@ struct LossArgs {
   int64_t fc3_stride;
   float* stat_partials;  // [blocks][4]
   float* bias_partials;  // [blocks][512] column sums of dZ
+  int dbg;               // ablation (tools/ablate_rowgemm.hip): 1 = stop after phase A, 2 = stop after phase B
 };
 
 struct GradReduceArgs {

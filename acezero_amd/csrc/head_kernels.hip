@@ -488,6 +488,7 @@ __global__ __launch_bounds__(64) void loss_kernel(LossArgs a) {
     }
   }
   __syncthreads();
+  if (a.dbg == 1) return;
 
   // ---- phase B
   if (t < LOSS_ROWS) {
@@ -653,6 +654,7 @@ __global__ __launch_bounds__(64) void loss_kernel(LossArgs a) {
   }
   __syncthreads();
   if (!a.idx) return;  // inference: no gradients
+  if (a.dbg == 2) return;
 
   if (t < 3) {  // fixed-order sum over the rows -> one partial per workgroup
     float acc = 0.f;

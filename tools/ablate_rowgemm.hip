@@ -60,5 +60,38 @@ int main() {
         if (rep) printf("%-28s %7.2f us/launch  (%.0f TFLOP/s equiv)\n", v.name, ms * 1e3 / n, 2.0 * L * M * 512 * 512 / (ms * 1e-3 / n) / 1e12);
       }
   }
+  // ---- loss kernel phases
+  {
+    const int n = M, no = 4, nblk = (n + LOSS_ROWS - 1) / LOSS_ROWS;
+    int64_t* idx; float *tpx, *aug, *Kk, *Ki, *pose, *b3, *fc3p, *statp, *biasp, *xyz; int *vidx, *vimg; uint16_t* W3; TrainState* st;
+    CK(hipMalloc(&idx, n * 8)); CK(hipMalloc(&tpx, n * 8)); CK(hipMalloc(&vidx, n * 4)); CK(hipMalloc(&aug, 2000 * 48)); CK(hipMalloc(&Kk, 2000 * 36));
+    CK(hipMalloc(&Ki, 2000 * 36)); CK(hipMalloc(&vimg, 2000 * 4)); CK(hipMalloc(&pose, 1000 * 64)); CK(hipMalloc(&b3, 16)); CK(hipMalloc(&W3, 4 * 512 * 2));
+    CK(hipMalloc(&fc3p, (size_t)nblk * 2052 * 4)); CK(hipMalloc(&statp, nblk * 16)); CK(hipMalloc(&biasp, (size_t)nblk * 512 * 4)); CK(hipMalloc(&xyz, n * 12));
+    CK(hipMalloc(&st, sizeof(TrainState)));
+    std::vector<int64_t> hi(n); for (int i = 0; i < n; ++i) hi[i] = i; CK(hipMemcpy(idx, hi.data(), n * 8, hipMemcpyHostToDevice));
+    std::vector<int> hv(n); for (int i = 0; i < n; ++i) hv[i] = (i * 7) % 2000; CK(hipMemcpy(vidx, hv.data(), n * 4, hipMemcpyHostToDevice));
+    std::vector<int> hm(2000); for (int i = 0; i < 2000; ++i) hm[i] = i / 2; CK(hipMemcpy(vimg, hm.data(), 8000, hipMemcpyHostToDevice));
+    std::vector<float> ones(2000 * 16, 0.5f); CK(hipMemcpy(aug, ones.data(), 2000 * 48, hipMemcpyHostToDevice)); CK(hipMemcpy(Kk, ones.data(), 2000 * 36, hipMemcpyHostToDevice));
+    CK(hipMemcpy(Ki, ones.data(), 2000 * 36, hipMemcpyHostToDevice)); CK(hipMemcpy(pose, ones.data(), 1000 * 64, hipMemcpyHostToDevice));
+    CK(hipMemset(tpx, 0, n * 8)); CK(hipMemset(b3, 0, 16)); CK(hipMemcpy(W3, h.data(), 4 * 512 * 2, hipMemcpyHostToDevice));
+    TrainState hs{}; hs.active = 1; hs.loss_weight = 50.f; CK(hipMemcpy(st, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    const char* names[] = {"loss full", "loss phase A only", "loss phases A+B"};
+    for (int rep = 0; rep < 2; ++rep)
+      for (int dbg = 0; dbg < 3; ++dbg) {
+        LossArgs a{};
+        a.act = In; a.W3 = W3; a.b3 = b3; a.n = n; a.no = no; a.use_homogeneous = 1; a.max_inv_scale = 0.25f; a.min_inv_scale = 100.f; a.h_beta = 0.924f;
+        a.idx = idx; a.target_px = tpx; a.target_crds = nullptr; a.view_idx = vidx; a.view_aug_inv = aug; a.view_K = Kk; a.view_Kinv = Ki; a.view_image = vimg;
+        a.image_pose_inv = pose; a.row_dT = nullptr; a.row_image = nullptr; a.loss_type = 0; a.refine_calibration = 0; a.hard_clamp = 1000.f; a.depth_min = 0.1f;
+        a.depth_max = 1000.f; a.depth_target = 10.f; a.inlier_px = 10.f; a.inv_batch = 1.f / n; a.focal_init = 525.f; a.st = st; a.out_xyz = xyz; a.dZ = out;
+        a.fc3_partials = fc3p; a.fc3_stride = 2052; a.stat_partials = statp; a.bias_partials = biasp; a.dbg = dbg == 0 ? 0 : dbg;
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(64), 0, 0, a);
+        CK(hipEventRecord(e0, 0));
+        const int nn = 100;
+        for (int i = 0; i < nn; ++i) hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(64), 0, 0, a);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("%-28s %7.2f us/launch\n", names[dbg], ms * 1e3 / nn);
+      }
+  }
   return 0;
 }
