@@ -57,6 +57,7 @@ struct acez_trainer {
   // persistent row-tile forward (head_fused.hip). Measured on MI355X: 115 us for the 8 layers vs 85 us for 8 rowgemm
   // launches -> off by default; ACEZ_FUSED_FWD=1 selects it.
   bool fused_fwd = false;
+  int gemm_tile = 80;  // rows per rowgemm workgroup: 80 (256 workgroups at batch 5120) or 128; ACEZ_GEMM_TILE overrides
 };
 
 enum { KC_SCHED = 0, KC_GATHER, KC_GEMM_FWD, KC_LOSS, KC_GEMM_DGRAD, KC_WGRAD, KC_REDUCE, KC_ADAMW, KC_COUNT };
@@ -134,6 +135,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->fc3_stride = ((int64_t)tr->no * 513 + 3) & ~3LL;
   tr->max_batch = cfg->max_batch;
   if (const char* e = getenv("ACEZ_FUSED_FWD")) tr->fused_fwd = atoi(e) != 0;
+  if (const char* e = getenv("ACEZ_GEMM_TILE")) tr->gemm_tile = atoi(e) == 128 ? 128 : 80;
   tr->nslabs = 256 / (16 * tr->L);
   if (tr->nslabs < 1) tr->nslabs = 1;
 
@@ -276,13 +278,12 @@ static uint16_t* launch_forward_fused(acez_trainer* tr, const uint16_t* feat, co
 static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, const TrainState* st, hipStream_t s) {
   ProfScope chain_scope(tr, s, KC_GEMM_FWD);  // one event pair around the whole chain of dependent GEMM launches
   const float* P = tr->pb.d_params;
-  const dim3 grid(8 * 4 * ((((n + 127) / 128) + 7) / 8)), blk(256);  // N = 512 -> 4 column tiles; see the XCD decode in rowgemm_kernel
   auto gemm = [&](int l, const uint16_t* in, uint16_t* out_main, const uint16_t* res, uint16_t* out_aux) {
     RowGemmArgs g{};
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144;
     g.add = nullptr; g.mask = nullptr; g.res = res; g.out_main = out_main; g.out_aux = out_aux;
     g.M = n; g.N = 512; g.K = 512; g.relu = 1; g.aux_mode = res ? AUX_RESIDUAL : AUX_NONE; g.st = st; g.dbg = 0; g.bias_partials = nullptr;
-    launch_rowgemm(g, grid, s);
+    launch_rowgemm(g, tr->gemm_tile, s);
     ++tr->prof_launches;
   };
   const uint16_t* r = in0;
@@ -430,14 +431,13 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
   }
 
   // input-gradient chain
-  const dim3 grid(8 * 4 * ((((n + 127) / 128) + 7) / 8)), blk(256);  // N = 512 -> 4 column tiles; see the XCD decode in rowgemm_kernel
   auto dgrad = [&](int l, int l_out, const uint16_t* add, const uint16_t* mask, uint16_t* out_main, uint16_t* out_aux) {
     RowGemmArgs g{};
     g.bias_partials = tr->bias_partials + (size_t)l_out * tr->bias_layer_stride;
     g.In = tr->dZ[l]; g.W = tr->WbT + (size_t)l * 262144; g.bias = nullptr; g.add = add; g.mask = mask; g.res = nullptr;
     g.out_main = out_main; g.out_aux = out_aux; g.M = n; g.N = 512; g.K = 512; g.relu = 0;
     g.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE; g.st = st; g.dbg = 0;
-    launch_rowgemm(g, grid, s);
+    launch_rowgemm(g, tr->gemm_tile, s);
     ++tr->prof_launches;
   };
   ProfScope* dchain = new ProfScope(tr, s, KC_GEMM_DGRAD);
@@ -476,7 +476,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials; a.n_loss_blocks = nblk; a.grad = tr->pb.d_grad;
     a.n_wide = tr->n_wide; a.n_params = tr->n_params; a.st = st;
     a.bias_partials = tr->bias_partials; a.bias_layer_stride = tr->bias_layer_stride; a.n_layers = tr->L;
-    for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2) ? nblk : 2 * ((n + 127) / 128);
+    for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2) ? nblk : (tr->gemm_tile == 80 ? (n + 79) / 80 : 2 * ((n + 127) / 128));
     const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
     const int64_t tail_blocks = (((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4) * 64 + 255) / 256;
     ProfScope ps(tr, s, KC_REDUCE);

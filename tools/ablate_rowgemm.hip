@@ -22,19 +22,21 @@ int main() {
       {"full dgrad (mask+add+aux)", 0, true, true, true}, {"no epilogue", 1, false, false, false},
       {"no MFMA/ds_read", 2, false, false, false}, {"no loads", 4, false, false, false}, {"no loads, no epilogue", 5, false, false, false},
       {"nothing (launch only)", 7, false, false, false}};
+  for (int tile : {128, 80})
   for (int rep = 0; rep < 2; ++rep)
     for (auto& v : vars) {
+      if (tile == 80 && v.dbg) continue;
       RowGemmArgs g{};
       g.In = In; g.W = W; g.bias = v.m ? nullptr : bias; g.add = v.a ? add : nullptr; g.mask = v.m ? mask : nullptr; g.res = nullptr;
       g.out_main = out; g.out_aux = v.x ? aux : nullptr; g.M = M; g.N = 512; g.K = 512; g.relu = v.m ? 0 : 1;
       g.aux_mode = v.x ? AUX_UNMASKED : AUX_NONE; g.st = nullptr; g.dbg = v.dbg; g.bias_partials = nullptr;
-      for (int i = 0; i < 20; ++i) launch_rowgemm(g, dim3(160), 0);
+      for (int i = 0; i < 20; ++i) launch_rowgemm(g, tile, 0);
       CK(hipEventRecord(e0, 0));
       const int n = 200;
-      for (int i = 0; i < n; ++i) launch_rowgemm(g, dim3(160), 0);
+      for (int i = 0; i < n; ++i) launch_rowgemm(g, tile, 0);
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      if (rep) printf("%-28s %7.2f us/launch  (%.0f TFLOP/s equiv)\n", v.name, ms * 1e3 / n, 2.0 * M * 512 * 512 / (ms * 1e-3 / n) / 1e12);
+      if (rep) printf("tile %3d %-28s %7.2f us/launch  (%.0f TFLOP/s equiv)\n", tile, v.name, ms * 1e3 / n, 2.0 * M * 512 * 512 / (ms * 1e-3 / n) / 1e12);
     }
   // ---- wgrad
   {
