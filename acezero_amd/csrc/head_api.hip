@@ -478,7 +478,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.bias_partials = tr->bias_partials; a.bias_layer_stride = tr->bias_layer_stride; a.n_layers = tr->L;
     for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2) ? nblk : (tr->gemm_tile == 80 ? (n + 79) / 80 : 2 * ((n + 127) / 128));
     const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
-    const int64_t tail_blocks = (((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4) * 64 + 255) / 256;
+    const int64_t tail_blocks = ((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4 + 31) / 32;
     ProfScope ps(tr, s, KC_REDUCE);
     hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, a);
   }

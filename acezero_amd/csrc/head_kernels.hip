@@ -926,35 +926,41 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
     *reinterpret_cast<float4*>(a.grad + i4) = acc;
     return;
   }
-  // tail: one wavefront per output -- the biases of the wide layers (column-sum partials written where each dZ is
-  // produced), fc3 weights/bias, then the 4 statistics. Lane-strided partial sums followed by the fixed butterfly
-  // order: deterministic.
-  const int lane = threadIdx.x & 63;
-  const int64_t k = ((int64_t)(blockIdx.x - wide_blocks) * 256 + threadIdx.x) >> 6;
+  // tail: the biases of the wide layers (column-sum partials written where each dZ is produced), fc3 weights/bias, then
+  // the 4 statistics. A workgroup reduces 32 consecutive outputs: thread (k = t & 31, group = t >> 5) sums the partial
+  // rows b = group, group + 8, ... (32 lanes read 128 contiguous bytes of one partial row), the 8 group sums are
+  // combined in a fixed order through LDS: deterministic.
+  __shared__ float s_part[8][33];
+  const int t = threadIdx.x, kl = t & 31, grp = t >> 5;
+  const int64_t k = (int64_t)(blockIdx.x - wide_blocks) * 32 + kl;
   const int64_t n_bias = (int64_t)a.n_layers * 512;
   const int64_t n_fc3 = a.n_params - a.n_wide;
-  if (k >= n_bias + n_fc3 + 4) return;
   float acc = 0.f;
-  int64_t dst;
+  int64_t dst = -1;
   if (k < n_bias) {
     const int layer = (int)(k >> 9), c = (int)(k & 511);
     const float* p = a.bias_partials + (size_t)layer * a.bias_layer_stride + c;
     const int cnt = a.bias_count[layer];
-    for (int b = lane; b < cnt; b += 64) acc += p[(size_t)b * 512];
+    for (int bb = grp; bb < cnt; bb += 8) acc += p[(size_t)bb * 512];
     dst = (int64_t)layer * 262656 + 262144 + c;
   } else if (k < n_bias + n_fc3) {
     const int64_t kk = k - n_bias;
-    for (int b = lane; b < a.n_loss_blocks; b += 64) acc += a.fc3_partials[(size_t)b * a.fc3_stride + kk];
+    for (int bb = grp; bb < a.n_loss_blocks; bb += 8) acc += a.fc3_partials[(size_t)bb * a.fc3_stride + kk];
     dst = a.n_wide + kk;
-  } else {
+  } else if (k < n_bias + n_fc3 + 4) {
     const int64_t kk = k - n_bias - n_fc3;
     if (kk < 3)
-      for (int b = lane; b < a.n_loss_blocks; b += 64) acc += a.stat_partials[(size_t)b * 4 + kk];
+      for (int bb = grp; bb < a.n_loss_blocks; bb += 8) acc += a.stat_partials[(size_t)bb * 4 + kk];
     dst = a.n_params + kk;
   }
+  s_part[grp][kl] = acc;
+  __syncthreads();
+  if (grp == 0 && dst >= 0) {
+    float tot = s_part[0][kl];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if (lane == 0) a.grad[dst] = acc;
+    for (int g = 1; g < 8; ++g) tot += s_part[g][kl];
+    a.grad[dst] = tot;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
