@@ -153,7 +153,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->dR[0], act_bytes);
   A((void**)&tr->dR[1], act_bytes);
   A((void**)&tr->slabs, (size_t)tr->nslabs * tr->n_wide * sizeof(float));
-  const int max_blocks = (tr->max_batch + LOSS_ROWS - 1) / LOSS_ROWS;
+  const int max_blocks = (tr->max_batch + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS);
   A((void**)&tr->fc3_partials, (size_t)max_blocks * tr->fc3_stride * sizeof(float));
   A((void**)&tr->stat_partials, (size_t)max_blocks * 4 * sizeof(float));
   tr->bias_layer_stride = (int64_t)max_blocks * 512;
@@ -401,7 +401,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
                        (const float*)tr->pb.d_pose_params, 1.0f, tr->pose_cur, tr->buf.n_images, (const int*)&tr->st->active);
 
   const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
-  const int nblk = (n + LOSS_ROWS - 1) / LOSS_ROWS;
+  const int nblk = (n + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS);
   {
     LossArgs a{};
     fill_loss_head(tr, a);
@@ -418,7 +418,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
     a.bias_partials = tr->bias_partials + (size_t)f2 * tr->bias_layer_stride; a.dbg = 0;
     ProfScope ps(tr, s, KC_LOSS);
-    hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, s, a);
   }
 
   if (tr->cfg.pose_refinement == 2) pose_backward(tr, n, &tr->st->active, s);
@@ -478,7 +478,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.bias_partials = tr->bias_partials; a.bias_layer_stride = tr->bias_layer_stride; a.n_layers = tr->L;
     for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2) ? nblk : (tr->gemm_tile == 80 ? (n + 79) / 80 : 2 * ((n + 127) / 128));
     const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
-    const int64_t tail_blocks = ((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4 + 31) / 32;
+    const int64_t tail_blocks = (((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4) * 64 + 255) / 256;
     ProfScope ps(tr, s, KC_REDUCE);
     hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, a);
   }
@@ -556,7 +556,7 @@ extern "C" int acez_head_forward(acez_trainer* tr, const void* d_features, int n
     LossArgs a{};
     fill_loss_head(tr, a);
     a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr; a.out_xyz = d_out_xyz + (size_t)done * 3;
-    hipLaunchKernelGGL(loss_kernel, dim3((cnt + LOSS_ROWS - 1) / LOSS_ROWS), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(loss_kernel, dim3((cnt + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS)), dim3(256), 0, s, a);
   }
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;

@@ -589,8 +589,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// loss kernel (LOSS_ROWS = 8 rows per single-wave workgroup: 640 workgroups at batch 5120 keep every CU busy and
-// give the latency-bound phases 8 waves per SIMD to hide behind):
+// loss kernel (32 rows per workgroup = four independent wavefronts of LOSS_ROWS = 8 rows):
 //   A  fc3 forward, one wave per row, fp32 accumulate
 //   B  one thread per row: de-homogenise, project, masks, robust loss and d(loss)/d(fc3 outputs)
 //   C  one thread per channel pair: fc3 weight-gradient partials and the masked input gradient dZ
@@ -598,13 +597,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
 constexpr int LOSS_ROWS = 8;
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
-__global__ __launch_bounds__(64) void loss_kernel(LossArgs a) {
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   if (a.st && !a.st->active) return;
-  __shared__ float s_s[LOSS_ROWS][4];
-  __shared__ float s_ds[LOSS_ROWS][4];
-  __shared__ float s_red[LOSS_ROWS][4];
-  const int t = threadIdx.x, l = t;
-  const int m0 = blockIdx.x * LOSS_ROWS;
+  // four independent wavefronts of LOSS_ROWS = 8 rows each; only the gradient partials are combined across them (in
+  // wave order) so that a workgroup emits ONE partial per 32 rows
+  __shared__ float s_s_all[4][LOSS_ROWS][4];
+  __shared__ float s_ds_all[4][LOSS_ROWS][4];
+  __shared__ float s_red_all[4][LOSS_ROWS][4];
+  __shared__ float s_comb[3][40][64];   // waves 1..3 -> wave 0
+  const int wv = threadIdx.x >> 6;
+  float (*s_s)[4] = s_s_all[wv];
+  float (*s_ds)[4] = s_ds_all[wv];
+  float (*s_red)[4] = s_red_all[wv];
+  const int t = threadIdx.x & 63, l = t;
+  const int m0 = (blockIdx.x * 4 + wv) * LOSS_ROWS;
   const int n = a.n, no = a.no;
 
   // phase B's per-row inputs sit behind a chain of dependent loads (idx -> view -> image): start it now so that its
@@ -665,7 +671,8 @@ __global__ __launch_bounds__(64) void loss_kernel(LossArgs a) {
       }
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   if (a.dbg == 1) return;
 
   // ---- phase B
@@ -830,15 +837,14 @@ __global__ __launch_bounds__(64) void loss_kernel(LossArgs a) {
     for (int j = 0; j < 4; ++j) s_ds[r][j] = ds[j];
     s_red[r][0] = loss; s_red[r][1] = inl; s_red[r][2] = fgrad; s_red[r][3] = 0.f;
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   if (!a.idx) return;  // inference: no gradients
   if (a.dbg == 2) return;
 
-  if (t < 3) {  // fixed-order sum over the rows -> one partial per workgroup
-    float acc = 0.f;
-    for (int r = 0; r < LOSS_ROWS; ++r) acc += s_red[r][t];
-    a.stat_partials[(size_t)blockIdx.x * 4 + t] = acc;
-  }
+  float stat = 0.f;
+  if (t < 3)
+    for (int r = 0; r < LOSS_ROWS; ++r) stat += s_red[r][t];   // fixed-order sum over this wave's rows
 
   // ---- phase C: lane t owns channels 8t .. 8t+7 (16-byte row segments in and out)
   {
@@ -889,20 +895,46 @@ __global__ __launch_bounds__(64) void loss_kernel(LossArgs a) {
         for (int e = 0; e < 8; ++e) bsum[e] += q[e];   // bias gradient of fc2: the bf16-rounded values, in row order
       }
     }
-    float* bp = a.bias_partials + (size_t)blockIdx.x * 512 + 8 * t;
-    *reinterpret_cast<float4*>(bp) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
-    *reinterpret_cast<float4*>(bp + 4) = make_float4(bsum[4], bsum[5], bsum[6], bsum[7]);
-    float* gp = a.fc3_partials + (size_t)blockIdx.x * a.fc3_stride;
+    float fb3 = 0.f;
+    if (t < no)
+      for (int r = 0; r < LOSS_ROWS; ++r) fb3 += s_ds[r][t];
+    // combine the four waves in wave order: ((w0 + w1) + w2) + w3
+    if (wv > 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < no) {
-        *reinterpret_cast<float4*>(gp + (size_t)j * 512 + 8 * t) = make_float4(gw[j][0], gw[j][1], gw[j][2], gw[j][3]);
-        *reinterpret_cast<float4*>(gp + (size_t)j * 512 + 8 * t + 4) = make_float4(gw[j][4], gw[j][5], gw[j][6], gw[j][7]);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_comb[wv - 1][j * 8 + e][t] = gw[j][e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s_comb[wv - 1][32 + e][t] = bsum[e];
+    }
+    __shared__ float s_small[3][8];
+    if (wv > 0 && t < 4) s_small[wv - 1][t] = stat;
+    if (wv > 0 && t < no) s_small[wv - 1][4 + t] = fb3;
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gw[j][e] += s_comb[u][j * 8 + e][t];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += s_comb[u][32 + e][t];
+        if (t < 3) stat += s_small[u][t];
+        if (t < no) fb3 += s_small[u][4 + t];
       }
-    if (t < no) {
-      float acc = 0.f;
-      for (int r = 0; r < LOSS_ROWS; ++r) acc += s_ds[r][t];
-      gp[(size_t)no * 512 + t] = acc;
+      float* bp = a.bias_partials + (size_t)blockIdx.x * 512 + 8 * t;
+      *reinterpret_cast<float4*>(bp) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+      *reinterpret_cast<float4*>(bp + 4) = make_float4(bsum[4], bsum[5], bsum[6], bsum[7]);
+      float* gp = a.fc3_partials + (size_t)blockIdx.x * a.fc3_stride;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < no) {
+          *reinterpret_cast<float4*>(gp + (size_t)j * 512 + 8 * t) = make_float4(gw[j][0], gw[j][1], gw[j][2], gw[j][3]);
+          *reinterpret_cast<float4*>(gp + (size_t)j * 512 + 8 * t + 4) = make_float4(gw[j][4], gw[j][5], gw[j][6], gw[j][7]);
+        }
+      if (t < no) gp[(size_t)no * 512 + t] = fb3;
+      if (t < 3) a.stat_partials[(size_t)blockIdx.x * 4 + t] = stat;
     }
   }
 }
@@ -926,41 +958,36 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
     *reinterpret_cast<float4*>(a.grad + i4) = acc;
     return;
   }
-  // tail: the biases of the wide layers (column-sum partials written where each dZ is produced), fc3 weights/bias, then
-  // the 4 statistics. A workgroup reduces 32 consecutive outputs: thread (k = t & 31, group = t >> 5) sums the partial
-  // rows b = group, group + 8, ... (32 lanes read 128 contiguous bytes of one partial row), the 8 group sums are
-  // combined in a fixed order through LDS: deterministic.
-  __shared__ float s_part[8][33];
-  const int t = threadIdx.x, kl = t & 31, grp = t >> 5;
-  const int64_t k = (int64_t)(blockIdx.x - wide_blocks) * 32 + kl;
+  // tail: one wavefront per output -- the biases of the wide layers (column-sum partials written where each dZ is
+  // produced), fc3 weights/bias, then the 4 statistics. Lane-strided partial sums followed by the fixed butterfly
+  // order: deterministic. (A two-level "32 outputs x 8 groups" variant with coalesced reads measured 2-4x slower: its
+  // 80-deep dependent add chains are latency bound.)
+  const int lane = threadIdx.x & 63;
+  const int64_t k = ((int64_t)(blockIdx.x - wide_blocks) * 256 + threadIdx.x) >> 6;
   const int64_t n_bias = (int64_t)a.n_layers * 512;
   const int64_t n_fc3 = a.n_params - a.n_wide;
+  if (k >= n_bias + n_fc3 + 4) return;
   float acc = 0.f;
-  int64_t dst = -1;
+  int64_t dst;
   if (k < n_bias) {
     const int layer = (int)(k >> 9), c = (int)(k & 511);
     const float* p = a.bias_partials + (size_t)layer * a.bias_layer_stride + c;
     const int cnt = a.bias_count[layer];
-    for (int bb = grp; bb < cnt; bb += 8) acc += p[(size_t)bb * 512];
+    for (int b = lane; b < cnt; b += 64) acc += p[(size_t)b * 512];
     dst = (int64_t)layer * 262656 + 262144 + c;
   } else if (k < n_bias + n_fc3) {
     const int64_t kk = k - n_bias;
-    for (int bb = grp; bb < a.n_loss_blocks; bb += 8) acc += a.fc3_partials[(size_t)bb * a.fc3_stride + kk];
+    for (int b = lane; b < a.n_loss_blocks; b += 64) acc += a.fc3_partials[(size_t)b * a.fc3_stride + kk];
     dst = a.n_wide + kk;
-  } else if (k < n_bias + n_fc3 + 4) {
+  } else {
     const int64_t kk = k - n_bias - n_fc3;
     if (kk < 3)
-      for (int bb = grp; bb < a.n_loss_blocks; bb += 8) acc += a.stat_partials[(size_t)bb * 4 + kk];
+      for (int b = lane; b < a.n_loss_blocks; b += 64) acc += a.stat_partials[(size_t)b * 4 + kk];
     dst = a.n_params + kk;
   }
-  s_part[grp][kl] = acc;
-  __syncthreads();
-  if (grp == 0 && dst >= 0) {
-    float tot = s_part[0][kl];
 #pragma unroll
-    for (int g = 1; g < 8; ++g) tot += s_part[g][kl];
-    a.grad[dst] = tot;
-  }
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) a.grad[dst] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------

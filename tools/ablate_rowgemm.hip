@@ -64,7 +64,7 @@ int main() {
   }
   // ---- loss kernel phases
   {
-    const int n = M, no = 4, nblk = (n + LOSS_ROWS - 1) / LOSS_ROWS;
+    const int n = M, no = 4, nblk = (n + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS);
     int64_t* idx; float *tpx, *aug, *Kk, *Ki, *pose, *b3, *fc3p, *statp, *biasp, *xyz; int *vidx, *vimg; uint16_t* W3; TrainState* st;
     CK(hipMalloc(&idx, n * 8)); CK(hipMalloc(&tpx, n * 8)); CK(hipMalloc(&vidx, n * 4)); CK(hipMalloc(&aug, 2000 * 48)); CK(hipMalloc(&Kk, 2000 * 36));
     CK(hipMalloc(&Ki, 2000 * 36)); CK(hipMalloc(&vimg, 2000 * 4)); CK(hipMalloc(&pose, 1000 * 64)); CK(hipMalloc(&b3, 16)); CK(hipMalloc(&W3, 4 * 512 * 2));
@@ -86,10 +86,10 @@ int main() {
         a.image_pose_inv = pose; a.row_dT = nullptr; a.row_image = nullptr; a.loss_type = 0; a.refine_calibration = 0; a.hard_clamp = 1000.f; a.depth_min = 0.1f;
         a.depth_max = 1000.f; a.depth_target = 10.f; a.inlier_px = 10.f; a.inv_batch = 1.f / n; a.focal_init = 525.f; a.st = st; a.out_xyz = xyz; a.dZ = out;
         a.fc3_partials = fc3p; a.fc3_stride = 2052; a.stat_partials = statp; a.bias_partials = biasp; a.dbg = dbg == 0 ? 0 : dbg;
-        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(64), 0, 0, a);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, 0, a);
         CK(hipEventRecord(e0, 0));
         const int nn = 100;
-        for (int i = 0; i < nn; ++i) hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(64), 0, 0, a);
+        for (int i = 0; i < nn; ++i) hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, 0, a);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) printf("%-28s %7.2f us/launch\n", names[dbg], ms * 1e3 / nn);
