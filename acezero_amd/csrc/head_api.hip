@@ -468,7 +468,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.n_layers = tr->L; a.st = st; a.zeros = tr->zeros; a.dbg = 0;
     ProfScope ps(tr, s, KC_WGRAD);
     const int groups = tr->L * tr->nslabs;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(128 * ((groups + 7) / 8)), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
   }
   {
     GradReduceArgs a{};

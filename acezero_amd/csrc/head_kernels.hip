@@ -92,6 +92,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chu
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 #define ACEZ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define ACEZ_VMCNT_C(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")   // n: integral constant expression
 
 template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX>
 __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
@@ -493,16 +494,25 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* p) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
+constexpr int WGRAD_LOADERS = 8;                    // loader waves per workgroup (beside the 4 multiplier waves)
+constexpr int WGRAD_THREADS = 256 + 64 * WGRAD_LOADERS;
+__global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
   const int active = a.st ? a.st->active : 1;  // tested before the stores only (see rowgemm_kernel)
   __shared__ __attribute__((aligned(16))) uint16_t smem[4][2][64 * 128];  // 4-slot ring of [dZ | In] stages, 128 KiB
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wn = w >> 2, wc = w & 3;  // 8 waves: 2 (n) x 4 (c), each 64 x 32 of the 128 x 128 tile; two waves per SIMD, so one
-                                      // wave's DMA issue (~100 cycles per 1 KiB instruction) overlaps the other's MFMAs
+  // Role split: waves 0..3 multiply (2 x 2 grid of 64 x 64 sub-tiles: 4 fragment reads feed 4 MFMAs), waves 4..7 only
+  // issue the LDS-DMA. A wave's instruction stream is in-order: with every wave loading AND multiplying, the ~0.4 us a
+  // stage's DMA instructions need to get through the memory pipeline was added to the MFMA time instead of hidden
+  // behind it (ablation: 18 us loads-only + 23 us MFMA-only = 41 us). Waves w and w + 4 share a SIMD, so every SIMD
+  // has one multiplier and one loader.
+  const bool loader = w >= 4;
+  const int cw = w & 3, wn = cw >> 1, wc = cw & 1;
+  const int lw = w - 4;                         // loader index
+  constexpr int GPL = 16 / WGRAD_LOADERS;       // 4-row DMA groups (x 2 operands) per loader and stage
   // XCD-aware decode: the 16 output tiles of one (layer, slab) group re-read the same dZ / In rows (4x each); they
   // are placed on ONE XCD (workgroup b runs on XCD b % 8) so that the re-reads hit that XCD's L2 instead of the
-  // fabric. Measured before: 335 MB per launch at ~5 TB/s = the whole kernel time. Placement only affects speed.
+  // fabric. Placement only affects speed.
   const int b = blockIdx.x;
   const int xcd = b & 7, jx = b >> 3;
   const int group = xcd + 8 * (jx >> 4), tile = jx & 15;
@@ -518,74 +528,88 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
   const int me = min(M, mb + rows_per_slab);
   const int KT = (me > mb) ? (me - mb + 63) >> 6 : 0;
 
-  // DMA instruction j (0..1) of this wave covers stage rows (w*2+j)*4 .. +3; this lane: row + (l>>4), physical
-  // 16-byte chunk l&15, which must receive the logical chunk whose 32-byte segment index is XOR-swizzled
+  // DMA instruction j (0..3) of loader wave cw covers stage rows (cw*4+j)*4 .. +3 of both operands; this lane: row + (l>>4),
+  // physical 16-byte chunk l&15, which must receive the logical chunk whose 32-byte segment index is XOR-swizzled
   const int prow = l >> 4, pq = l & 15;
-  int srow[2];
-  int lchunk[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    srow[j] = (w * 2 + j) * 4 + prow;
-    lchunk[j] = ((((pq >> 1) ^ ((srow[j] & 3) << 1)) << 1) | (pq & 1)) * 8;  // element offset of the source chunk
-  }
   auto issue = [&](int kt) {
     const int slot = kt & 3;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = mb + kt * 64 + srow[j];
+    for (int j = 0; j < GPL; ++j) {
+      const int srow = (lw * GPL + j) * 4 + prow;
+      const int lchunk = ((((pq >> 1) ^ ((srow & 3) << 1)) << 1) | (pq & 1)) * 8;  // element offset of the source chunk
+      const int m = mb + kt * 64 + srow;
       const bool ok = m < me;
       // rows past the slab end must contribute zeros: they are fetched from a zero page
-      const uint16_t* gz = ok ? Z + (size_t)m * 512 + n0 + lchunk[j] : a.zeros + pq * 8;
-      const uint16_t* gx = ok ? X + (size_t)m * 512 + c0 + lchunk[j] : a.zeros + pq * 8;
-      __builtin_amdgcn_global_load_lds((gvoid_t*)gz, (lvoid_t*)&smem[slot][0][(w * 2 + j) * 4 * 128], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gvoid_t*)gx, (lvoid_t*)&smem[slot][1][(w * 2 + j) * 4 * 128], 16, 0, 0);
+      const uint16_t* gz = ok ? Z + (size_t)m * 512 + n0 + lchunk : a.zeros + pq * 8;
+      const uint16_t* gx = ok ? X + (size_t)m * 512 + c0 + lchunk : a.zeros + pq * 8;
+      __builtin_amdgcn_global_load_lds((gvoid_t*)gz, (lvoid_t*)&smem[slot][0][(lw * GPL + j) * 4 * 128], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)gx, (lvoid_t*)&smem[slot][1][(lw * GPL + j) * 4 * 128], 16, 0, 0);
     }
   };
 
-  f32x16 acc[2];
+  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int offA[2] = {tr_base(wn * 64, l), tr_base(wn * 64 + 32, l)};
-  const int offB = tr_base(wc * 32, l);
-  if (!(a.dbg & 4)) for (int kt = 0; kt < 4 && kt < KT; ++kt) issue(kt);
+  const int offB[2] = {tr_base(wc * 64, l), tr_base(wc * 64 + 32, l)};
+  // Two separate loops (one per role) with the same number of barriers: sharing one loop body makes the compiler
+  // carry the 64 accumulator registers through the loader's control flow (moves on every iteration).
+  if (loader) {
+    if (a.dbg & 4) {
+      for (int kt = 0; kt < KT; ++kt) __builtin_amdgcn_s_barrier();
+      return;
+    }
+    for (int kt = 0; kt < 4 && kt < KT; ++kt) issue(kt);
+    for (int kt = 0; kt < KT; ++kt) {
+      // stages issued so far: 0..3 at kt = 0, 0..kt+2 afterwards; a loader wave has 2 * GPL DMA instructions per stage in flight
+      const int later = (kt == 0) ? min(3, KT - 1) : min(2, KT - 1 - kt);
+      if (later >= 3) ACEZ_VMCNT_C(6 * GPL);
+      else if (later == 2) ACEZ_VMCNT_C(4 * GPL);
+      else if (later == 1) ACEZ_VMCNT_C(2 * GPL);
+      else ACEZ_VMCNT(0);
+      __builtin_amdgcn_s_barrier();  // stage kt has landed; the multipliers are done with stage kt - 1
+      if (kt >= 1 && kt + 3 < KT) issue(kt + 3);
+    }
+    return;
+  }
   for (int kt = 0; kt < KT; ++kt) {
-    // stages issued so far: 0..3 at kt = 0, 0..kt+2 afterwards; each wave has 4 DMA instructions per stage in flight
-    const int later = (kt == 0) ? min(3, KT - 1) : min(2, KT - 1 - kt);
-    if (later >= 3) ACEZ_VMCNT(12);
-    else if (later == 2) ACEZ_VMCNT(8);
-    else if (later == 1) ACEZ_VMCNT(4);
-    else ACEZ_VMCNT(0);
     __builtin_amdgcn_s_barrier();
-    if (kt >= 1 && kt + 3 < KT && !(a.dbg & 4)) issue(kt + 3);
     if (a.dbg & 2) continue;
     const int slot = kt & 3;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fa[2];
+      bf16x8 fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) fa[i] = tr_frag(&smem[slot][0][offA[i] + kk * 16 * 128]);
-      const bf16x8 fb = tr_frag(&smem[slot][1][offB + kk * 16 * 128]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb, acc[i], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) fb[j] = tr_frag(&smem[slot][1][offB[j] + kk * 16 * 128]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   }
 
-  if (a.dbg & 1) { if (acc[0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
+  if (a.dbg & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
   if (!active) return;
   float* __restrict__ G = a.slabs + (size_t)slab * a.slab_stride;
   const int h = l >> 5;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = c0 + wc * 32 + (l & 31);
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      G[a.w_off[layer] + (size_t)n * 512 + c] = acc[i][r];
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + (l & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        G[a.w_off[layer] + (size_t)n * 512 + c] = acc[i][j][r];
+      }
     }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------

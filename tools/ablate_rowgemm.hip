@@ -53,10 +53,10 @@ int main() {
         WgradArgs a{};
         for (int l = 0; l < L; ++l) { a.dZ[l] = bufs[2 * l]; a.In[l] = bufs[2 * l + 1]; a.w_off[l] = (int64_t)l * 262656; a.b_off[l] = a.w_off[l] + 262144; }
         a.slabs = slabs; a.slab_stride = n_wide; a.M = M; a.nslabs = 2; a.n_layers = L; a.st = nullptr; a.zeros = zeros; a.dbg = v.dbg;
-        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(wgrad_kernel, dim3(256), dim3(512), 0, 0, a);
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(wgrad_kernel, dim3(256), dim3(WGRAD_THREADS), 0, 0, a);
         CK(hipEventRecord(e0, 0));
         const int n = 50;
-        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(wgrad_kernel, dim3(256), dim3(512), 0, 0, a);
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(wgrad_kernel, dim3(256), dim3(WGRAD_THREADS), 0, 0, a);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) printf("%-28s %7.2f us/launch  (%.0f TFLOP/s equiv)\n", v.name, ms * 1e3 / n, 2.0 * L * M * 512 * 512 / (ms * 1e-3 / n) / 1e12);
