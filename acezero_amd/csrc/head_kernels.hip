@@ -277,18 +277,28 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // rowgemm80: the same GEMM + epilogues re-tiled to 80 rows x 128 columns so that a 5120-row batch gives 64 x 4 = 256
-// workgroups = one per CU (the 128 x 128 tiling fills only 160 of the 256 CUs). MFMA v_mfma_f32_16x16x32_bf16; wave w
-// owns output columns 32w .. 32w+31 (2 column fragments x 5 row fragments = 10 accumulator tiles). Stage = [W 128 x 64 |
-// In 96 x 64] (the In tile is padded to 96 rows so that every wave issues the same 7 DMA instructions per stage),
-// 4-slot ring = 112 KiB. The epilogue exchanges the whole 80 x 128 tile through LDS: every global access is a full
-// 256-byte row.
+// workgroups = one per CU (the 128 x 128 tiling fills only 160 of the 256 CUs). MFMA v_mfma_f32_16x16x32_bf16.
+// Eight waves with fixed roles (waves w and w + 4 share a SIMD):
+//   waves 0..3  multiply: wave w owns output columns 32w .. 32w+31 (2 column fragments x 5 row fragments = 10
+//               accumulator tiles) and never touches global memory inside the K loop;
+//   waves 4..7  only issue LDS-DMA: the 8 K-stages [W 128 x 64 | In 96 x 64] into a 4-slot ring (112 KiB, 7 DMA
+//               instructions per loader and stage) and then the epilogue's input tiles (`add`, `mask` / `res`) into two
+//               [80][128] staging tiles, so that their latency is hidden behind the K loop too.
+// A wave's instruction stream is in-order: when every wave both loaded and multiplied, the time its DMA instructions
+// spent getting through the memory pipeline was added to its MFMA time.
+// The epilogue exchanges the whole 80 x 128 tile through the staging tiles (16-byte chunk index XOR row & 15: conflict
+// free both for the accumulator layout and for the row-wise copy), so every global access is a full 256-byte row.
 // ---------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+__device__ __forceinline__ int st_off(int row, int col) { return row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7)); }
+
 template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX>
-__global__ __launch_bounds__(256, 1) void rowgemm80_kernel(RowGemmArgs a) {
+__global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
   const int active = a.st ? a.st->active : 1;
   constexpr int STAGE = (128 + 96) * 64;  // elements per ring slot
-  __shared__ __attribute__((aligned(16))) uint16_t smem[4 * STAGE];
+  __shared__ __attribute__((aligned(16))) uint16_t smem[4 * STAGE + 2 * 80 * 128];
+  uint16_t* const stA = smem + 4 * STAGE;   // `add` in / aux out
+  uint16_t* const stB = stA + 80 * 128;     // mask | res in / main out
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int mtiles = (a.M + 79) / 80;
@@ -299,148 +309,167 @@ __global__ __launch_bounds__(256, 1) void rowgemm80_kernel(RowGemmArgs a) {
   const int n0 = (jx & 3) * 128, m0 = mt * 80;
   const int M = a.M, N = a.N;
   constexpr int K = 512, KT = 8;
-
-  // DMA: W instructions 4w .. 4w+3 (8 rows each), In instructions 3w .. 3w+2; lane: row + (l>>3), slot l&7
-  const uint16_t* gW[4];
-  const uint16_t* gI[3];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (w * 4 + j) * 8 + (l >> 3);
-    gW[j] = a.W + (size_t)(n0 + row) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8;
-  }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int row = (w * 3 + j) * 8 + (l >> 3);
-    gI[j] = a.In + (size_t)min(m0 + row, M - 1) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8;
-  }
-  auto issue = [&](int kt) {
-    uint16_t* slot = smem + (kt & 3) * STAGE;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + kt * 64), (lvoid_t*)(slot + (w * 4 + j) * 8 * 64), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)(slot + 128 * 64 + (w * 3 + j) * 8 * 64), 16, 0, 0);
-  };
-  issue(0); issue(1); issue(2); issue(3);
-
-  f32x4 acc[2][5];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
-  const int fr = l & 15, fq = l >> 4;
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    if (kt == 0) ACEZ_VMCNT(21);
-    else if (kt <= 5) ACEZ_VMCNT(14);
-    else if (kt == 6) ACEZ_VMCNT(7);
-    else ACEZ_VMCNT(0);
-    __builtin_amdgcn_s_barrier();
-    if (kt >= 1 && kt + 3 < KT) issue(kt + 3);
-    const uint16_t* sW = smem + (kt & 3) * STAGE;
-    const uint16_t* sI = sW + 128 * 64;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int c = kk * 4 + fq;
-      bf16x8 fa[2], fb[5];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz(w * 32 + i * 16 + fr, c)]);
-#pragma unroll
-      for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz(j * 16 + fr, c)]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-  }
-  if (!active) return;
-  __syncthreads();  // every wave is done reading the ring
-
-  // ---- epilogue through LDS: A = `add` in / aux out, B = mask|res in / main out, both [80][EP]
-  constexpr int EP = 136;
-  uint16_t* regA = smem;
-  uint16_t* regB = smem + 80 * EP;
-  const uint16_t* in2 = HAS_MASK ? a.mask : a.res;
   constexpr bool HAS_IN2 = HAS_MASK || AUX == AUX_RESIDUAL;
-  if (HAS_ADD || HAS_IN2) {
-    uint4 ra[5], rb[5];
+  constexpr int E = 5 * ((HAS_ADD ? 1 : 0) + (HAS_IN2 ? 1 : 0));  // epilogue-input DMA instructions per loader
+
+  if (w >= 4) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = w - 4;
+    if (a.dbg & 4) {
+      for (int kt = 0; kt < KT + 1; ++kt) __builtin_amdgcn_s_barrier();
+    } else {
+      // W instructions 4lw .. 4lw+3 (8 rows each), In instructions 3lw .. 3lw+2; lane: row + (l>>3), slot l&7
+      const uint16_t* gW[4];
+      const uint16_t* gI[3];
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
-      const int q = t + 256 * it, row = q >> 4, ch = q & 15;
-      const size_t o = (size_t)min(m0 + row, M - 1) * N + n0 + ch * 8;
-      if (HAS_ADD) ra[it] = *reinterpret_cast<const uint4*>(a.add + o);
-      if (HAS_IN2) rb[it] = *reinterpret_cast<const uint4*>(in2 + o);
+      for (int j = 0; j < 4; ++j) {
+        const int row = (lw * 4 + j) * 8 + (l >> 3);
+        gW[j] = a.W + (size_t)(n0 + row) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int row = (lw * 3 + j) * 8 + (l >> 3);
+        gI[j] = a.In + (size_t)min(m0 + row, M - 1) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8;
+      }
+      auto issue = [&](int kt) {
+        uint16_t* slot = smem + (kt & 3) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + kt * 64), (lvoid_t*)(slot + (lw * 4 + j) * 8 * 64), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)(slot + 128 * 64 + (lw * 3 + j) * 8 * 64), 16, 0, 0);
+      };
+      // epilogue inputs: 4-row groups 5lw .. 5lw+4 of the [80][128] tile; lane: row + (l>>4), physical chunk l&15 receives
+      // the logical chunk (l&15) ^ (row & 15)
+      auto issue_tile = [&](const uint16_t* src, uint16_t* dst) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int row = (lw * 5 + j) * 4 + (l >> 4);
+          const uint16_t* g = src + (size_t)min(m0 + row, M - 1) * N + n0 + (((l & 15) ^ (row & 15)) << 3);
+          __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(dst + (lw * 5 + j) * 4 * 128), 16, 0, 0);
+        }
+      };
+      issue(0); issue(1); issue(2); issue(3);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        // in-order completion: everything younger than stage kt may still be in flight
+        if (kt == 0) ACEZ_VMCNT(21);
+        else if (kt <= 4) ACEZ_VMCNT(14);
+        else if (kt == 5) ACEZ_VMCNT_C(14 + E);
+        else if (kt == 6) ACEZ_VMCNT_C(7 + E);
+        else ACEZ_VMCNT_C(E);
+        __builtin_amdgcn_s_barrier();   // stage kt has landed; the multipliers are done with stage kt - 1
+        if (kt >= 1 && kt + 3 < KT) issue(kt + 3);
+        if (kt == 4) {
+          if (HAS_ADD) issue_tile(a.add, stA);
+          if (HAS_IN2) issue_tile(HAS_MASK ? a.mask : a.res, stB);
+        }
+      }
+      ACEZ_VMCNT(0);
+      __builtin_amdgcn_s_barrier();     // epilogue inputs have landed
+    }
+    if ((a.dbg & 1) || !active) return;
+    __builtin_amdgcn_s_barrier();       // the multipliers have written the output tiles
+  } else {
+    // ------------------------------------------------------------------ multiplier waves
+    f32x4 acc[2][5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    const int fr = l & 15, fq = l >> 4;
+    float4 bias[2];
+    if (BIAS_RELU) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) bias[i] = *reinterpret_cast<const float4*>(a.bias + n0 + w * 32 + i * 16 + 4 * fq);
     }
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
-      const int q = t + 256 * it, row = q >> 4, ch = q & 15;
-      if (HAS_ADD) *reinterpret_cast<uint4*>(&regA[row * EP + ch * 8]) = ra[it];
-      if (HAS_IN2) *reinterpret_cast<uint4*>(&regB[row * EP + ch * 8]) = rb[it];
+    for (int kt = 0; kt < KT; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      if (a.dbg & 2) continue;
+      const uint16_t* sW = smem + (kt & 3) * STAGE;
+      const uint16_t* sI = sW + 128 * 64;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int c = kk * 4 + fq;
+        bf16x8 fa[2], fb[5];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz(w * 32 + i * 16 + fr, c)]);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz(j * 16 + fr, c)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
     }
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();       // epilogue inputs have landed
+    if ((a.dbg & 1) || !active) return;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int ml = j * 16 + fr;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int nl = w * 32 + i * 16 + 4 * fq;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        uint16_t* pa = &stA[st_off(ml, nl)];
+        uint16_t* pb = &stB[st_off(ml, nl)];
+        if (BIAS_RELU) {
+          v[0] += bias[i].x; v[1] += bias[i].y; v[2] += bias[i].z; v[3] += bias[i].w;
+        }
+        if (HAS_ADD) {
+          float ad[4];
+          unpack4(*reinterpret_cast<const uint2*>(pa), ad);
+          v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
+        }
+        if (BIAS_RELU) {
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
+        uint2 y = pack4(v[0], v[1], v[2], v[3]);
+        if (AUX == AUX_RESIDUAL) {
+          float yf[4], rf[4];
+          unpack4(y, yf);
+          unpack4(*reinterpret_cast<const uint2*>(pb), rf);
+          *reinterpret_cast<uint2*>(pa) = pack4(yf[0] + rf[0], yf[1] + rf[1], yf[2] + rf[2], yf[3] + rf[3]);
+        } else if (AUX == AUX_UNMASKED) {
+          *reinterpret_cast<uint2*>(pa) = y;
+        }
+        if (HAS_MASK) {
+          const uint2 mk = *reinterpret_cast<const uint2*>(pb);
+          const uint32_t m0b = mk.x & 0xffffu, m1b = mk.x >> 16, m2b = mk.y & 0xffffu, m3b = mk.y >> 16;
+          uint32_t lo = y.x, hi = y.y;
+          if (!(m0b != 0 && m0b < 0x8000u)) lo &= 0xffff0000u;
+          if (!(m1b != 0 && m1b < 0x8000u)) lo &= 0x0000ffffu;
+          if (!(m2b != 0 && m2b < 0x8000u)) hi &= 0xffff0000u;
+          if (!(m3b != 0 && m3b < 0x8000u)) hi &= 0x0000ffffu;
+          y.x = lo; y.y = hi;
+        }
+        *reinterpret_cast<uint2*>(pb) = y;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // output tiles complete
   }
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    const int ml = j * 16 + fr;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int nl = w * 32 + i * 16 + 4 * fq;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      uint16_t* pa = &regA[ml * EP + nl];
-      uint16_t* pb = &regB[ml * EP + nl];
-      if (BIAS_RELU) {
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (HAS_ADD) {
-        float ad[4];
-        unpack4(*reinterpret_cast<const uint2*>(pa), ad);
-        v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
-      }
-      if (BIAS_RELU) {
-        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-      }
-      uint2 y = pack4(v[0], v[1], v[2], v[3]);
-      if (AUX == AUX_RESIDUAL) {
-        float yf[4], rf[4];
-        unpack4(y, yf);
-        unpack4(*reinterpret_cast<const uint2*>(pb), rf);
-        *reinterpret_cast<uint2*>(pa) = pack4(yf[0] + rf[0], yf[1] + rf[1], yf[2] + rf[2], yf[3] + rf[3]);
-      } else if (AUX == AUX_UNMASKED) {
-        *reinterpret_cast<uint2*>(pa) = y;
-      }
-      if (HAS_MASK) {
-        const uint2 mk = *reinterpret_cast<const uint2*>(pb);
-        const uint32_t m0b = mk.x & 0xffffu, m1b = mk.x >> 16, m2b = mk.y & 0xffffu, m3b = mk.y >> 16;
-        uint32_t lo = y.x, hi = y.y;
-        if (!(m0b != 0 && m0b < 0x8000u)) lo &= 0xffff0000u;
-        if (!(m1b != 0 && m1b < 0x8000u)) lo &= 0x0000ffffu;
-        if (!(m2b != 0 && m2b < 0x8000u)) hi &= 0xffff0000u;
-        if (!(m3b != 0 && m3b < 0x8000u)) hi &= 0x0000ffffu;
-        y.x = lo; y.y = hi;
-      }
-      *reinterpret_cast<uint2*>(pb) = y;
-    }
-  }
-  __syncthreads();
-  if (HAS_MASK && a.bias_partials && t < 128) {
-    // bias gradient partial of this 80-row tile: column sums of the bf16 tile in row order
+  // ------------------------------------------------------------------ all eight waves: copy the tiles out
+  if (HAS_MASK && a.bias_partials && t >= 384) {
+    // bias gradient partial of this 80-row tile: column sums of the bf16 tile in row order (waves 6, 7)
+    const int col = t - 384;
     float sacc = 0.f;
     const int rows = min(80, M - m0);
-    for (int row = 0; row < rows; ++row) sacc += bf2f(regB[row * EP + t]);
-    a.bias_partials[(size_t)mt * 512 + n0 + t] = sacc;
+    for (int row = 0; row < rows; ++row) sacc += bf2f(stB[st_off(row, col)]);
+    a.bias_partials[(size_t)mt * 512 + n0 + col] = sacc;
   }
 #pragma unroll
-  for (int it = 0; it < 5; ++it) {
-    const int q = t + 256 * it, row = q >> 4, ch = q & 15, m = m0 + row;
-    if (m < M) {
+  for (int it = 0; it < 3; ++it) {
+    const int q = t + 512 * it, row = q >> 4, ch = q & 15, m = m0 + row;
+    if (q < 1280 && m < M) {
       const size_t o = (size_t)m * N + n0 + ch * 8;
-      *reinterpret_cast<uint4*>(a.out_main + o) = *reinterpret_cast<const uint4*>(&regB[row * EP + ch * 8]);
-      if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o) = *reinterpret_cast<const uint4*>(&regA[row * EP + ch * 8]);
+      const int so = row * 128 + ((ch ^ (row & 15)) << 3);
+      *reinterpret_cast<uint4*>(a.out_main + o) = *reinterpret_cast<const uint4*>(&stB[so]);
+      if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o) = *reinterpret_cast<const uint4*>(&stA[so]);
     }
   }
 }
@@ -453,7 +482,7 @@ static inline void launch_rowgemm(const RowGemmArgs& g, int tile, hipStream_t s)
   const dim3 grid(8 * 4 * ((mtiles + 7) / 8));  // N = 512 -> 4 column tiles; XCD-aware decode inside the kernels
 #define ACEZ_RG(...)                                                                               \
   do {                                                                                             \
-    if (tile == 80) hipLaunchKernelGGL((rowgemm80_kernel<__VA_ARGS__>), grid, blk, 0, s, g);       \
+    if (tile == 80) hipLaunchKernelGGL((rowgemm80_kernel<__VA_ARGS__>), grid, dim3(512), 0, s, g); \
     else hipLaunchKernelGGL((rowgemm_kernel<__VA_ARGS__>), grid, blk, 0, s, g);                    \
   } while (0)
   if (br && g.aux_mode == AUX_NONE) ACEZ_RG(true, false, false, AUX_NONE);
