@@ -38,6 +38,7 @@ struct acez_trainer {
   float *log_loss = nullptr, *log_inl = nullptr;
   int log_cap = 0;
   TrainState* st = nullptr;
+  bool post_pending = false;   // acez_train_update has run; its schedule bookkeeping rides with the next step's gather (flush_post)
   SchedConfig sc;
   std::vector<void*> allocs;
   // pose refinement (mlp): per-image activations and gradients, allocated by set_buffer (needs n_images)
@@ -374,6 +375,23 @@ static void pose_backward(acez_trainer* tr, int n, const int* active, hipStream_
                      tr->pb.d_grad + tr->n_params + 4, NP, active);
 }
 
+static PostArgs post_args(acez_trainer* tr) {
+  PostArgs p;
+  p.st = tr->st; p.c = tr->sc; p.grad_stats = (const float*)(tr->pb.d_grad + tr->n_params);
+  p.inv_global_batch = 1.0f / (float)tr->cfg.global_batch; p.log_loss = tr->log_loss; p.log_inl = tr->log_inl; p.log_cap = tr->log_cap;
+  return p;
+}
+
+// The schedule bookkeeping that closes a step (sched_post) is deferred: normally it is executed by an extra workgroup of
+// the next step's gather launch. Every entry point that reads the schedule state or the log flushes it first.
+static void flush_post(acez_trainer* tr, hipStream_t s) {
+  if (!tr->post_pending) return;
+  tr->post_pending = false;
+  ProfScope ps(tr, s, KC_SCHED);
+  const PostArgs p = post_args(tr);
+  hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap);
+}
+
 extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, int n, void* stream) {
   ACEZ_REQUIRE(tr && d_indices, "null pointer");
   ACEZ_REQUIRE(tr->have_buf, "acez_trainer_set_buffer has not been called");
@@ -385,11 +403,18 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
 
   uint16_t* act = nullptr;
   if (tr->fused_fwd) {
+    flush_post(tr, s);
     act = launch_forward_fused(tr, (const uint16_t*)tr->buf.d_features, d_indices, n, true, st, s);
   } else {
   ProfScope* psg = new ProfScope(tr, s, KC_GATHER);
-  hipLaunchKernelGGL(gather_kernel, dim3((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024), dim3(256), 0, s,
-                     (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n, st);
+  const int gblocks = (n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024;
+  if (tr->post_pending) {   // gather of this step + the schedule bookkeeping of the previous one, in one launch
+    tr->post_pending = false;
+    hipLaunchKernelGGL(step_begin_kernel, dim3(gblocks + 1), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n,
+                       post_args(tr));
+  } else {
+    hipLaunchKernelGGL(gather_kernel, dim3(gblocks), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n, st);
+  }
   delete psg;
   act = launch_forward(tr, tr->R[0], n, st, s);
   }
@@ -498,9 +523,7 @@ extern "C" int acez_train_update(acez_trainer* tr, void* stream) {
     hipLaunchKernelGGL(adamw_small_kernel, dim3((unsigned)((tr->pb.n_pose_params + 255) / 256)), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,
                        tr->pb.d_pose_v, (const float*)(tr->pb.d_grad + tr->n_params + 4), (int64_t)0, 1, tr->pb.n_pose_params,
                        (const AdamScalars*)&tr->st->pose_adam, (const int*)&tr->st->pose_enable, (const int*)&tr->st->active);
-  ProfScope ps2(tr, s, KC_SCHED);
-  hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, tr->st, tr->sc, (const float*)(tr->pb.d_grad + tr->n_params),
-                     1.0f / (float)tr->cfg.global_batch, tr->log_loss, tr->log_inl, tr->log_cap);
+  tr->post_pending = true;   // sched_post: with the next step's gather, or at the next state read-out (flush_post)
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
 }
@@ -514,6 +537,7 @@ extern "C" int acez_train_step(acez_trainer* tr, const int64_t* d_indices, int n
 extern "C" int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out, void* stream) {
   ACEZ_REQUIRE(tr && h_out, "null pointer");
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  flush_post(tr, (hipStream_t)stream);
   TrainState hs;
   ACEZ_HIP_CHECK(hipMemcpyAsync(&hs, tr->st, sizeof(TrainState), hipMemcpyDeviceToHost, (hipStream_t)stream));
   ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
@@ -528,6 +552,7 @@ extern "C" int acez_trainer_get_log(acez_trainer* tr, int first, int count, floa
   ACEZ_REQUIRE(first >= 0 && count >= 0 && first + count <= tr->log_cap, "log range out of bounds");
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   hipStream_t s = (hipStream_t)stream;
+  flush_post(tr, s);
   if (h_loss) ACEZ_HIP_CHECK(hipMemcpyAsync(h_loss, tr->log_loss + first, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, s));
   if (h_inliers) ACEZ_HIP_CHECK(hipMemcpyAsync(h_inliers, tr->log_inl + first, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, s));
   ACEZ_HIP_CHECK(hipStreamSynchronize(s));

@@ -24,11 +24,12 @@ struct TrainState {
   int cooldown_epoch;  // last_epoch of the cool-down LinearLR
   int nan_flag;
   int opt_steps;       // AdamW state['step']
-  int crit_count;
+  int crit_count;      // entries of the cool-down criterion ring in use (<= 100)
+  int crit_pos;        // next slot of the ring to overwrite
   int calib_steps;
   float loss_weight;   // soft clamp of this iteration
   float last_loss, last_inliers;
-  float crit_buf[100];  // cooldown_criterium_buffer
+  float crit_buf[100];  // cooldown_criterium_buffer (ace_schedule.py:44,121-125) as a ring: only its minimum is ever used
   double lr;            // param_group['lr']
   double calib_g, calib_m, calib_v;
   double beta1_pow, beta2_pow;  // beta^opt_steps

@@ -454,14 +454,6 @@ __global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
     __builtin_amdgcn_s_barrier();       // output tiles complete
   }
   // ------------------------------------------------------------------ all eight waves: copy the tiles out
-  if (HAS_MASK && a.bias_partials && t >= 384) {
-    // bias gradient partial of this 80-row tile: column sums of the bf16 tile in row order (waves 6, 7)
-    const int col = t - 384;
-    float sacc = 0.f;
-    const int rows = min(80, M - m0);
-    for (int row = 0; row < rows; ++row) sacc += bf2f(stB[st_off(row, col)]);
-    a.bias_partials[(size_t)mt * 512 + n0 + col] = sacc;
-  }
 #pragma unroll
   for (int it = 0; it < 3; ++it) {
     const int q = t + 512 * it, row = q >> 4, ch = q & 15, m = m0 + row;
@@ -471,6 +463,23 @@ __global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
       *reinterpret_cast<uint4*>(a.out_main + o) = *reinterpret_cast<const uint4*>(&stB[so]);
       if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o) = *reinterpret_cast<const uint4*>(&stA[so]);
     }
+  }
+  if (HAS_MASK && a.bias_partials) {
+    // bias gradient partial of this 80-row tile = column sums of the bf16 output tile: four 20-row groups in parallel,
+    // combined in a fixed order (the ring is free by now)
+    const int col = t & 127, g = t >> 7;
+    const int rows = min(80, M - m0);
+    float sacc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 20; ++r) {
+      const int row = g * 20 + r;
+      const float v = bf2f(stB[st_off(row, col)]);
+      sacc += (row < rows) ? v : 0.f;
+    }
+    float* red = reinterpret_cast<float*>(smem);
+    red[g * 128 + col] = sacc;
+    __syncthreads();
+    if (t < 128) a.bias_partials[(size_t)mt * 512 + n0 + t] = ((red[t] + red[128 + t]) + red[256 + t]) + red[384 + t];
   }
 }
 
@@ -1180,16 +1189,14 @@ __device__ double onecycle_lr(const SchedConfig& c, int step_num) {
   return end + (start - end) / 2.0 * cos_out;
 }
 
-__device__ void sched_prepare(TrainState* st, const SchedConfig& c) {
+__device__ void sched_prepare(TrainState* st, const SchedConfig& c, float crit_min) {
   // everything the kernels of iteration `st->iteration` need: cool-down decision, active flag, loss weight, AdamW scalars
   const int it = st->iteration;
   // check_and_set_cooldown(iteration)   ace_schedule.py:72-101
   if (c.schedule == SCHED_1CYCLEPOLY && !st->in_cooldown && it >= c.warmup_iterations) {
     const bool by_duration = it >= (st->max_iterations - c.cooldown_iterations);
-    double mn = 1e300;
     const int cnt = st->crit_count;
-    for (int i = 0; i < cnt; ++i) mn = fmin(mn, (double)st->crit_buf[i]);
-    const bool dynamic = (cnt > 0) && (mn > c.cooldown_trigger_percent);
+    const bool dynamic = (cnt > 0) && ((double)crit_min > c.cooldown_trigger_percent);   // min(buffer) > trigger, ace_schedule.py:86-90
     if (by_duration || dynamic) {
       st->in_cooldown = 1;
       st->cooldown_epoch = 0;
@@ -1241,22 +1248,37 @@ __device__ void sched_prepare(TrainState* st, const SchedConfig& c) {
 __global__ void sched_init_kernel(TrainState* st, SchedConfig c) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   st->active = 0; st->iteration = 0; st->max_iterations = c.iterations; st->in_cooldown = 0;
-  st->warmup_epoch = 0; st->cooldown_epoch = 0; st->nan_flag = 0; st->opt_steps = 0; st->crit_count = 0;
+  st->warmup_epoch = 0; st->cooldown_epoch = 0; st->nan_flag = 0; st->opt_steps = 0; st->crit_count = 0; st->crit_pos = 0;
   st->calib_steps = 0; st->loss_weight = c.soft_clamp; st->last_loss = 0.f; st->last_inliers = 0.f;
   st->calib_g = 0.0; st->calib_m = 0.0; st->calib_v = 0.0; st->beta1_pow = 1.0; st->beta2_pow = 1.0;
   st->pose_enable = 0; st->pose_opt_steps = 0; st->pose_b1pow = 1.0; st->pose_b2pow = 1.0;
   if (c.schedule == SCHED_CONSTANT) st->lr = c.lr_min;
   else if (c.schedule == SCHED_1CYCLEPOLY) st->lr = c.lr_max * (c.warmup_lr / c.lr_max);  // LinearLR._initial_step
   else st->lr = onecycle_lr(c, 0);
-  sched_prepare(st, c);
+  sched_prepare(st, c, 0.f);
 }
 
-__global__ void sched_post_kernel(TrainState* st, SchedConfig c, const float* grad_stats, float inv_global_batch,
-                                  float* log_loss, float* log_inl, int log_cap) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Executed by ONE full wavefront (all 64 lanes must call it): the lanes cooperate on the minimum of the cool-down
+// criterion ring, lane 0 does the scalar bookkeeping.
+__device__ void sched_post_wave(TrainState* st, const SchedConfig& c, const float* grad_stats, float inv_global_batch,
+                                float* log_loss, float* log_inl, int log_cap) {
   if (!st->active) return;  // the schedule has ended: state is frozen (ace_trainer.py:509-510)
+  const int lane = threadIdx.x & 63;
   const float loss = grad_stats[0] * inv_global_batch;
   const float inl = grad_stats[1] * inv_global_batch;
+  // minimum of the ring as it will be after this step's push: the entries that stay, and the new value
+  float crit_min = inl;
+  {
+    const int cnt = st->crit_count, pos = st->crit_pos;
+#pragma unroll
+    for (int i = lane; i < 128; i += 64) {
+      const bool keep = i < cnt && !(cnt == 100 && i == pos);
+      if (keep) crit_min = fminf(crit_min, st->crit_buf[i]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) crit_min = fminf(crit_min, __shfl_xor(crit_min, off));
+  }
+  if (lane != 0) return;
   st->last_loss = loss;
   st->last_inliers = inl;
   if (loss != loss) st->nan_flag = 1;   // ace_trainer.py:615-617
@@ -1303,17 +1325,49 @@ __global__ void sched_post_kernel(TrainState* st, SchedConfig c, const float* gr
         st->lr = st->lr * (1.0 + (ef - sf) / ((double)c.warmup_iterations * sf + (double)(e - 1) * (ef - sf)));
     }
     // rolling buffer of the last 100 batch_inliers
-    if (st->crit_count < 100) st->crit_buf[st->crit_count++] = inl;
-    else {
-      for (int i = 0; i < 99; ++i) st->crit_buf[i] = st->crit_buf[i + 1];
-      st->crit_buf[99] = inl;
-    }
+    const int pos = st->crit_pos;
+    st->crit_buf[pos] = inl;
+    st->crit_pos = (pos + 1 == 100) ? 0 : pos + 1;
+    if (st->crit_count < 100) st->crit_count += 1;
   } else if (c.schedule == SCHED_CIRCLE) {
     const int e = ++st->warmup_epoch;
     st->lr = onecycle_lr(c, e);
   }
   st->iteration = it + 1;   // ace_trainer.py:495
-  sched_prepare(st, c);     // bookkeeping of the NEXT iteration, so that a step needs a single schedule launch
+  sched_prepare(st, c, crit_min);   // bookkeeping of the NEXT iteration, so that a step needs a single schedule launch
+}
+
+__global__ __launch_bounds__(64) void sched_post_kernel(TrainState* st, SchedConfig c, const float* grad_stats, float inv_global_batch,
+                                                        float* log_loss, float* log_inl, int log_cap) {
+  sched_post_wave(st, c, grad_stats, inv_global_batch, log_loss, log_inl, log_cap);
+}
+
+// step_begin: the batch gather of iteration i + 1 and, in ONE extra single-wave workgroup, the schedule bookkeeping that
+// closes iteration i (the two are independent: the gather does not look at the schedule state; a gather into the scratch
+// rows of an inactive step is harmless). Saves a dependent single-thread launch per step.
+struct PostArgs {
+  TrainState* st;
+  SchedConfig c;
+  const float* grad_stats;
+  float inv_global_batch;
+  float* log_loss;
+  float* log_inl;
+  int log_cap;
+};
+__global__ __launch_bounds__(256) void step_begin_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
+                                                         uint16_t* __restrict__ out, int n, PostArgs p) {
+  if (blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x < 64) sched_post_wave(p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = ((gridDim.x - 1) * blockDim.x) >> 6;
+  for (int r = wave; r < n; r += nwaves) {
+    const int64_t src = idx[r];
+    const uint4 v = *reinterpret_cast<const uint4*>(feat + src * 512 + lane * 8);
+    *reinterpret_cast<uint4*>(out + (size_t)r * 512 + lane * 8) = v;
+  }
 }
 
 // cos(pi x) for x in [0,1] with basic operations only (Taylor around the nearest multiple of 1/2).

@@ -16,20 +16,20 @@ int main() {
   CK(hipMemcpy(In, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W, h.data(), 512 * 512 * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(mask, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(add, h.data(), h.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemset(bias, 0, 512 * 4));
+  float* bpart; CK(hipMalloc(&bpart, 64 * 2 * 512 * 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   struct V { const char* name; int dbg; bool m, a, x; } vars[] = {
       {"full fwd (bias+relu)", 0, false, false, false}, {"full dgrad (mask)", 0, true, false, false},
       {"full dgrad (mask+add+aux)", 0, true, true, true}, {"no epilogue", 1, false, false, false},
       {"no MFMA/ds_read", 2, false, false, false}, {"no loads", 4, false, false, false}, {"no loads, no epilogue", 5, false, false, false},
       {"nothing (launch only)", 7, false, false, false}};
-  for (int tile : {128, 80})
+  for (int tile : {80})
   for (int rep = 0; rep < 2; ++rep)
     for (auto& v : vars) {
-      if (tile == 80 && v.dbg) continue;
       RowGemmArgs g{};
       g.In = In; g.W = W; g.bias = v.m ? nullptr : bias; g.add = v.a ? add : nullptr; g.mask = v.m ? mask : nullptr; g.res = nullptr;
       g.out_main = out; g.out_aux = v.x ? aux : nullptr; g.M = M; g.N = 512; g.K = 512; g.relu = v.m ? 0 : 1;
-      g.aux_mode = v.x ? AUX_UNMASKED : AUX_NONE; g.st = nullptr; g.dbg = v.dbg; g.bias_partials = nullptr;
+      g.aux_mode = v.x ? AUX_UNMASKED : AUX_NONE; g.st = nullptr; g.dbg = v.dbg; g.bias_partials = v.m ? bpart : nullptr;
       for (int i = 0; i < 20; ++i) launch_rowgemm(g, tile, 0);
       CK(hipEventRecord(e0, 0));
       const int n = 200;
