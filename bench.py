@@ -227,7 +227,7 @@ def main():
             "registration": {"metric": "DSAC* images-registered/sec", "value": nreg * world / dt_reg, "unit": "images/s",
                              "frames": nreg * world, "hypotheses": 32, "max_tries": 16, "frac_frames_registered": reg_ok,
                              "note": "RANSAC only, 60x80 scene coordinates resident in HBM"},
-            "roofline": {"bound": "mfma", "kernel": "rowgemm_kernel (5120x512x512 bf16, fwd + dgrad launches)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "rowgemm80_kernel (5120x512x512 bf16, fwd + dgrad launches)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": gemm_n,
                          "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()},
