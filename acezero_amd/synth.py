@@ -92,6 +92,25 @@ def expand_per_patch(prob, idx):
     }
 
 
+def make_gray_images(seed=77, n=2, h=480, w=640):
+    """Normalised grayscale frames [n,1,h,w] float32 as the dataset hands them to the network: smooth random texture,
+    (x/255 - 0.4) / 0.25 (dataset.py:150-153)."""
+    rng = np.random.default_rng(seed)
+    ys = np.arange(h, dtype=np.float64)[:, None]
+    xs = np.arange(w, dtype=np.float64)[None, :]
+    out = np.zeros((n, 1, h, w), np.float32)
+    for i in range(n):
+        img = np.zeros((h, w))
+        for _ in range(12):
+            fx, fy = rng.uniform(0.005, 0.25, size=2)
+            ph = rng.uniform(0, 2 * math.pi)
+            img += rng.uniform(0.3, 1.0) * np.sin(2 * math.pi * (fx * xs + fy * ys) + ph)
+        img = (img - img.min()) / (img.max() - img.min() + 1e-9)          # [0,1]
+        img = np.round(img * 255.0) / 255.0 + 0.0                        # 8-bit grey levels
+        out[i, 0] = ((img - 0.4) / 0.25).astype(np.float32)
+    return out
+
+
 def make_registration_frames(seed=1305, n_frames=8, h=60, w=80, focal=525.0, subsampling=8, noise_sigma=0.02,
                              outlier_ratio=0.3):
     """Scene-coordinate maps [n,3,h,w] float32 for cameras in a box room + ground-truth cam->world poses.

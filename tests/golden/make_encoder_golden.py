@@ -1,0 +1,39 @@
+"""Generate tests/golden/encoder_small.npz by running the REFERENCE's own ace_network.Encoder on CPU (fp32).
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_encoder_golden.py
+
+Weights and the input image come from seeded numpy generators (oracle.encoder_oracle.init_weights, synth_image below), so
+the fixture only holds the reference's OUTPUT features (fp32) for two small frames, plus a checksum of the inputs.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import ace_network  # noqa: E402
+from oracle import encoder_oracle  # noqa: E402
+from acezero_amd import synth  # noqa: E402
+
+
+def main():
+    torch.set_num_threads(4)
+    sd = encoder_oracle.init_weights(seed=4099)
+    enc = ace_network.Encoder(out_channels=512)
+    enc.load_state_dict(sd)
+    enc.eval()
+    img = torch.from_numpy(synth.make_gray_images(seed=77, n=2, h=64, w=96))
+    with torch.no_grad():
+        out = enc(img)
+    path = os.path.join(ROOT, "tests", "golden", "encoder_small.npz")
+    np.savez_compressed(path, features=out.numpy().astype(np.float32), image_sum=np.float64(img.double().sum().item()),
+                        weight_sum=np.float64(sum(v.double().sum().item() for v in sd.values())))
+    print("wrote", path, out.shape, float(out.abs().mean()))
+
+
+if __name__ == "__main__":
+    main()
