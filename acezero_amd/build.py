@@ -19,6 +19,7 @@ STAMP = os.path.join(HERE, ".libacez.stamp")
 UNITS = {
     "acez_common.hip": [],
     "head_api.hip": [],
+    "encoder_api.hip": [],
     "ransac_api.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,415 @@
+// encoder_api.hip -- the ACE feature encoder (ace_network.py:14-59) on gfx950 and its C ABI (include/acez.h).
+//
+// the encoder is the step right before both hot paths (it fills the training buffer and it
+// produces the features the head turns into scene coordinates at registration time).
+//
+// Data layout: activations NHWC bf16 ([frame][y][x][channel]; a pixel's channels are contiguous, so a pixel is a "row" of
+// an implicit GEMM and the final [F*h*w][512] tensor is exactly the row layout of the training buffer / acez_head_forward).
+// Weights: bf16 [Co][Kp], k = (ky*3 + kx) * Ci + ci, Kp = K rounded up to 64 (zero padded).
+//
+//   conv1 (1 -> 32, 3x3)    direct kernel, one thread per pixel (0.3 % of the FLOPs, HBM-bound: 64 B out per pixel)
+//   every other layer       convgemm_kernel: implicit GEMM Out[p][co] = act(sum_k In[pix(p, tap(k))][ci(k)] * W[co][k] + b)
+//                           on v_mfma_f32_16x16x32_bf16, same structure as rowgemm80 (head_kernels.hip): 80-row x NT-column
+//                           tiles, 4 multiplier waves + 4 loader waves, 4-slot LDS-DMA ring of 64-wide K stages. The
+//                           im2col never exists in memory: a loader lane computes, per stage, the source address of its
+//                           16-byte chunk (8 input channels of one tap of one pixel) or points at a zero page for the
+//                           padding border / K padding / rows past the end.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/acez.h"
+#include "acez_common.h"
+#include "gemm_common.h"
+
+namespace acez {
+
+struct ConvGemmArgs {
+  const uint16_t* In;     // NHWC bf16 [F][Hi][Wi][Ci]
+  const uint16_t* W;      // bf16 [Co][Kp]
+  const float* bias;      // [Co]
+  const uint16_t* add;    // [M][Co] bf16 or null: added (fp32) after the activation, before the single bf16 store
+  uint16_t* out;          // [M][Co]
+  const uint16_t* zeros;  // >= 128 bytes of zeros: DMA source of every padded chunk
+  int Hi, Wi, Ci, ci_shift, Ho, Wo, Co, ksize, stride, pad, K, Kp, M;
+};
+
+// 1 -> 32 channels, 3x3, stride 1, pad 1, ReLU. image fp32 [F][H][W] (rounded to bf16 on the fly), out NHWC bf16.
+__global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ img, const float* __restrict__ w /*[32][9] bf16-rounded*/,
+                                                    const float* __restrict__ bias, uint16_t* __restrict__ out, int H, int W, int64_t npix) {
+  __shared__ float sw[32 * 9 + 32];
+  for (int i = threadIdx.x; i < 32 * 9 + 32; i += 256) sw[i] = i < 288 ? w[i] : bias[i - 288];
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  const int64_t hw = (int64_t)H * W;
+  const int64_t f = p / hw;
+  const int r = (int)(p - f * hw);
+  const int y = r / W, x = r - y * W;
+  float v[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = y + ky - 1, ix = x + kx - 1;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const float t = ok ? img[f * hw + (int64_t)iy * W + ix] : 0.f;
+      v[ky * 3 + kx] = bf2f(f2bf(t));
+    }
+  uint32_t pk[16];
+#pragma unroll
+  for (int c = 0; c < 32; c += 2) {
+    float a0 = sw[288 + c], a1 = sw[288 + c + 1];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      a0 = fmaf(sw[c * 9 + k], v[k], a0);
+      a1 = fmaf(sw[(c + 1) * 9 + k], v[k], a1);
+    }
+    pk[c >> 1] = pack2(fmaxf(a0, 0.f), fmaxf(a1, 0.f));
+  }
+  uint4* o = reinterpret_cast<uint4*>(out + p * 32);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = make_uint4(pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]);
+}
+
+// [80][64] staging tile of the 64-column variant: chunk index XOR row & 7
+__device__ __forceinline__ int st_off64(int row, int col) { return row * 64 + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7)); }
+
+template <int NT, bool RELU, bool HAS_ADD>
+__global__ __launch_bounds__(512) void convgemm_kernel(ConvGemmArgs a) {
+  static_assert(NT == 64 || NT == 128, "column tile");
+  static_assert(!(HAS_ADD && NT == 64), "the residual epilogue exists for 128-column tiles only");
+  constexpr int CF = NT / 64;                 // 16-column fragments per multiplier wave
+  constexpr int WI = NT / 32;                 // W DMA instructions per loader and stage (8 rows each)
+  constexpr int IPS = WI + 3;                 // DMA instructions per loader and stage
+  constexpr int STAGE = (NT + 96) * 64;       // elements per ring slot
+  __shared__ __attribute__((aligned(16))) uint16_t smem[4 * STAGE + 80 * NT];
+  uint16_t* const stO = smem + 4 * STAGE;     // `add` in / output tile
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int M = a.M, Co = a.Co, Kp = a.Kp;
+  const int ntiles = Co / NT;
+  const int mtiles = (M + 79) / 80;
+  const int per_xcd = (mtiles + 7) >> 3;
+  const int jx = blockIdx.x >> 3;
+  const int mt = (blockIdx.x & 7) * per_xcd + jx / ntiles;   // the column tiles of a row tile share an XCD (and its L2)
+  if (mt >= mtiles) return;
+  const int n0 = (jx % ntiles) * NT, m0 = mt * 80;
+  const int KT = Kp >> 6;
+
+  if (w >= 4) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = w - 4;
+    if (HAS_ADD) {
+      // residual / skip tile -> staging (oldest DMA of this wave: complete before any stage it could be confused with)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int row = (lw * 5 + j) * 4 + (l >> 4);
+        const uint16_t* g = a.add + (size_t)min(m0 + row, M - 1) * Co + n0 + (((l & 15) ^ (row & 15)) << 3);
+        __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(stO + (lw * 5 + j) * 4 * 128), 16, 0, 0);
+      }
+    }
+    const uint16_t* gW[WI];
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+      const int row = (lw * WI + j) * 8 + (l >> 3);
+      gW[j] = a.W + (size_t)(n0 + row) * Kp + ((l & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+    // this lane's three rows of the In tile: output pixel -> top-left input pixel of its receptive field
+    const uint16_t* ibase[3];
+    int iy0[3], ix0[3], kc[3];
+    bool pv[3];
+    const int hw = a.Ho * a.Wo;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int row = (lw * 3 + j) * 8 + (l >> 3);
+      const int p = m0 + row;
+      pv[j] = row < 80 && p < M;
+      const int pp = pv[j] ? p : 0;
+      const int f = pp / hw, r = pp - f * hw;
+      const int y = r / a.Wo, x = r - y * a.Wo;
+      iy0[j] = y * a.stride - a.pad;
+      ix0[j] = x * a.stride - a.pad;
+      ibase[j] = a.In + (size_t)f * a.Hi * a.Wi * a.Ci;
+      kc[j] = ((l & 7) ^ ((row >> 1) & 7)) * 8;   // logical K offset of this lane's chunk inside a stage
+    }
+    const uint16_t* zp = a.zeros + (l & 7) * 8;
+    auto issue = [&](int kt) {
+      uint16_t* slot = smem + (kt & 3) * STAGE;
+#pragma unroll
+      for (int j = 0; j < WI; ++j)
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + kt * 64), (lvoid_t*)(slot + (lw * WI + j) * 8 * 64), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int k0 = kt * 64 + kc[j];
+        const int tap = k0 >> a.ci_shift, ci = k0 & (a.Ci - 1);
+        const int ky = (a.ksize == 3) ? (tap * 11) >> 5 : 0;   // tap / 3 for tap < 12
+        const int kx = tap - 3 * ky;
+        const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+        const bool ok = pv[j] && k0 < a.K && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+        const uint16_t* g = ok ? ibase[j] + (((size_t)iy * a.Wi + ix) << a.ci_shift) + ci : zp;
+        __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(slot + NT * 64 + (lw * 3 + j) * 8 * 64), 16, 0, 0);
+      }
+    };
+    for (int kt = 0; kt < 4 && kt < KT; ++kt) issue(kt);
+    for (int kt = 0; kt < KT; ++kt) {
+      // stages issued so far: 0..3 at kt = 0, 0..kt+2 afterwards (in-order completion)
+      const int later = (kt == 0) ? min(3, KT - 1) : min(2, KT - 1 - kt);
+      if (later >= 3) ACEZ_VMCNT_C(3 * IPS);
+      else if (later == 2) ACEZ_VMCNT_C(2 * IPS);
+      else if (later == 1) ACEZ_VMCNT_C(IPS);
+      else ACEZ_VMCNT(0);
+      __builtin_amdgcn_s_barrier();   // stage kt has landed; the multipliers are done with stage kt - 1
+      if (kt >= 1 && kt + 3 < KT) issue(kt + 3);
+    }
+    __builtin_amdgcn_s_barrier();     // the multipliers have left the K loop (ring free)
+    __builtin_amdgcn_s_barrier();     // ... and have written the output tile
+  } else {
+    // ------------------------------------------------------------------ multiplier waves
+    f32x4 acc[CF][5];
+#pragma unroll
+    for (int i = 0; i < CF; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    const int fr = l & 15, fq = l >> 4;
+    float4 bias[CF];
+#pragma unroll
+    for (int i = 0; i < CF; ++i) bias[i] = *reinterpret_cast<const float4*>(a.bias + n0 + w * (NT / 4) + i * 16 + 4 * fq);
+    for (int kt = 0; kt < KT; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      const uint16_t* sW = smem + (kt & 3) * STAGE;
+      const uint16_t* sI = sW + NT * 64;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int c = kk * 4 + fq;
+        bf16x8 fa[CF], fb[5];
+#pragma unroll
+        for (int i = 0; i < CF; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz(w * (NT / 4) + i * 16 + fr, c)]);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz(j * 16 + fr, c)]);
+#pragma unroll
+        for (int i = 0; i < CF; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int ml = j * 16 + fr;
+#pragma unroll
+      for (int i = 0; i < CF; ++i) {
+        const int nl = w * (NT / 4) + i * 16 + 4 * fq;
+        float v[4] = {acc[i][j][0] + bias[i].x, acc[i][j][1] + bias[i].y, acc[i][j][2] + bias[i].z, acc[i][j][3] + bias[i].w};
+        if (RELU) {
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
+        uint16_t* po = &stO[NT == 128 ? st_off(ml, nl) : st_off64(ml, nl)];
+        if (HAS_ADD) {
+          float ad[4];
+          unpack4(*reinterpret_cast<const uint2*>(po), ad);
+          v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
+        }
+        *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // ------------------------------------------------------------------ all eight waves: copy the tile out, full rows
+  constexpr int CH = NT / 8;   // 16-byte chunks per tile row
+#pragma unroll
+  for (int it = 0; it < (80 * CH + 511) / 512; ++it) {
+    const int q = t + 512 * it, row = q / CH, ch = q % CH, m = m0 + row;
+    if (q < 80 * CH && m < M) {
+      const int so = NT == 128 ? row * 128 + ((ch ^ (row & 15)) << 3) : row * 64 + ((ch ^ (row & 7)) << 3);
+      *reinterpret_cast<uint4*>(a.out + (size_t)m * Co + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&stO[so]);
+    }
+  }
+}
+
+static void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s) {
+  const int nt = (g.Co % 128 == 0) ? 128 : 64;
+  const int ntiles = g.Co / nt;
+  const int mtiles = (g.M + 79) / 80;
+  const dim3 grid(8 * ntiles * ((mtiles + 7) / 8)), blk(512);
+  if (nt == 64) {
+    if (g.add || !relu) abort();
+    hipLaunchKernelGGL((convgemm_kernel<64, true, false>), grid, blk, 0, s, g);
+  } else if (g.add) {
+    if (!relu) abort();
+    hipLaunchKernelGGL((convgemm_kernel<128, true, true>), grid, blk, 0, s, g);
+  } else if (relu) {
+    hipLaunchKernelGGL((convgemm_kernel<128, true, false>), grid, blk, 0, s, g);
+  } else {
+    hipLaunchKernelGGL((convgemm_kernel<128, false, false>), grid, blk, 0, s, g);
+  }
+}
+
+}  // namespace acez
+
+using namespace acez;
+
+namespace {
+
+struct LayerDesc {
+  const char* name;
+  int ci, co, k, stride;
+};
+// Encoder.__init__ order (ace_network.py:26-40); co of the last two layers is the configurable feature size
+const LayerDesc kLayers[ACEZ_ENCODER_LAYERS] = {
+    {"conv1", 1, 32, 3, 1},         {"conv2", 32, 64, 3, 2},        {"conv3", 64, 128, 3, 2},       {"conv4", 128, 256, 3, 2},
+    {"res1_conv1", 256, 256, 3, 1}, {"res1_conv2", 256, 256, 1, 1}, {"res1_conv3", 256, 256, 3, 1}, {"res2_conv1", 256, 512, 3, 1},
+    {"res2_conv2", 512, 512, 1, 1}, {"res2_conv3", 512, 512, 3, 1}, {"res2_skip", 256, 512, 1, 1}};
+
+uint16_t host_f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float host_bf2f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+}  // namespace
+
+struct acez_encoder {
+  int device = 0, out_channels = 512, max_frames = 0, max_h = 0, max_w = 0;
+  float* w1 = nullptr;                 // conv1 weights [32][9] (bf16-rounded values in fp32) followed by nothing
+  float* bias[ACEZ_ENCODER_LAYERS] = {};
+  uint16_t* W[ACEZ_ENCODER_LAYERS] = {};   // bf16 [co][Kp] (layers 1..10)
+  int K[ACEZ_ENCODER_LAYERS] = {}, Kp[ACEZ_ENCODER_LAYERS] = {}, co[ACEZ_ENCODER_LAYERS] = {};
+  uint16_t* zeros = nullptr;
+  uint16_t *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *r4 = nullptr, *x5 = nullptr, *x6 = nullptr, *r7 = nullptr, *x8 = nullptr,
+           *x9 = nullptr, *sk = nullptr;
+  std::vector<void*> allocs;
+};
+
+extern "C" void acez_encoder_destroy(acez_encoder* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  for (void* p : e->allocs) (void)hipFree(p);
+  delete e;
+}
+
+extern "C" int acez_encoder_create(acez_encoder** out, const float* const* h_weights, const float* const* h_biases, int out_channels,
+                                   int max_frames, int max_h, int max_w, int device) {
+  ACEZ_REQUIRE(out && h_weights && h_biases, "null pointer");
+  ACEZ_REQUIRE(out_channels > 0 && out_channels % 128 == 0, "out_channels must be a positive multiple of 128");
+  ACEZ_REQUIRE(max_frames > 0 && max_h >= 8 && max_w >= 8, "bad capacity");
+  for (int i = 0; i < ACEZ_ENCODER_LAYERS; ++i) ACEZ_REQUIRE(h_weights[i] && h_biases[i], "null layer pointer");
+  if (device < 0) ACEZ_HIP_CHECK(hipGetDevice(&device));
+  ACEZ_HIP_CHECK(hipSetDevice(device));
+  acez_encoder* e = new acez_encoder();
+  e->device = device; e->out_channels = out_channels; e->max_frames = max_frames; e->max_h = max_h; e->max_w = max_w;
+  auto A = [&](void** p, size_t bytes) -> hipError_t {
+    hipError_t rc = hipMalloc(p, bytes);
+    if (rc == hipSuccess) e->allocs.push_back(*p);
+    return rc;
+  };
+#define ACEZ_ENC_ALLOC(ptr, bytes)                                   \
+  do {                                                               \
+    hipError_t rc_ = A((void**)&(ptr), (bytes));                     \
+    if (rc_ != hipSuccess) {                                         \
+      acez::set_error("hipMalloc failed: %s", hipGetErrorString(rc_)); \
+      acez_encoder_destroy(e);                                       \
+      return ACEZ_ERR_HIP;                                           \
+    }                                                                \
+  } while (0)
+  ACEZ_ENC_ALLOC(e->zeros, 256);
+  ACEZ_HIP_CHECK(hipMemset(e->zeros, 0, 256));
+  for (int i = 0; i < ACEZ_ENCODER_LAYERS; ++i) {
+    const LayerDesc& L = kLayers[i];
+    const int co = (i >= 9) ? out_channels : L.co;
+    e->co[i] = co;
+    const int K = L.k * L.k * L.ci;
+    e->K[i] = K; e->Kp[i] = (K + 63) / 64 * 64;
+    ACEZ_ENC_ALLOC(e->bias[i], (size_t)co * sizeof(float));
+    ACEZ_HIP_CHECK(hipMemcpy(e->bias[i], h_biases[i], (size_t)co * sizeof(float), hipMemcpyHostToDevice));
+    if (i == 0) {
+      std::vector<float> w(32 * 9);
+      for (int j = 0; j < 32 * 9; ++j) w[j] = host_bf2f(host_f2bf(h_weights[0][j]));   // [co][1][3][3] is already [co][tap]
+      ACEZ_ENC_ALLOC(e->w1, w.size() * sizeof(float));
+      ACEZ_HIP_CHECK(hipMemcpy(e->w1, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+      // torch layout [co][ci][ky][kx] -> [co][(ky*k + kx) * ci_n + ci], zero padded to Kp
+      std::vector<uint16_t> w((size_t)co * e->Kp[i], 0);
+      const int kk = L.k * L.k;
+      for (int o = 0; o < co; ++o)
+        for (int c = 0; c < L.ci; ++c)
+          for (int tp = 0; tp < kk; ++tp)
+            w[(size_t)o * e->Kp[i] + (size_t)tp * L.ci + c] = host_f2bf(h_weights[i][((size_t)o * L.ci + c) * kk + tp]);
+      ACEZ_ENC_ALLOC(e->W[i], w.size() * sizeof(uint16_t));
+      ACEZ_HIP_CHECK(hipMemcpy(e->W[i], w.data(), w.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+  }
+  const size_t F = max_frames;
+  const size_t h2 = (max_h + 1) / 2, w2 = (max_w + 1) / 2, h4 = (h2 + 1) / 2, w4 = (w2 + 1) / 2, h8 = (h4 + 1) / 2, w8 = (w4 + 1) / 2;
+  ACEZ_ENC_ALLOC(e->a1, F * max_h * max_w * 32 * 2);
+  ACEZ_ENC_ALLOC(e->a2, F * h2 * w2 * 64 * 2);
+  ACEZ_ENC_ALLOC(e->a3, F * h4 * w4 * 128 * 2);
+  const size_t px = F * h8 * w8;
+  ACEZ_ENC_ALLOC(e->r4, px * 256 * 2);
+  ACEZ_ENC_ALLOC(e->x5, px * 256 * 2);
+  ACEZ_ENC_ALLOC(e->x6, px * 256 * 2);
+  ACEZ_ENC_ALLOC(e->r7, px * 256 * 2);
+  ACEZ_ENC_ALLOC(e->x8, px * 512 * 2);
+  ACEZ_ENC_ALLOC(e->x9, px * 512 * 2);
+  ACEZ_ENC_ALLOC(e->sk, px * (size_t)out_channels * 2);
+#undef ACEZ_ENC_ALLOC
+  *out = e;
+  return ACEZ_OK;
+}
+
+extern "C" int acez_encoder_output_size(int h, int w, int* out_h, int* out_w) {
+  ACEZ_REQUIRE(out_h && out_w && h > 0 && w > 0, "bad argument");
+  int hh = h, ww = w;
+  for (int i = 0; i < 3; ++i) { hh = (hh + 1) / 2; ww = (ww + 1) / 2; }   // three 3x3 stride-2 pad-1 convolutions
+  *out_h = hh; *out_w = ww;
+  return ACEZ_OK;
+}
+
+extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int n_frames, int h, int w, void* d_features, void* stream) {
+  ACEZ_REQUIRE(e && d_images && d_features, "null pointer");
+  ACEZ_REQUIRE(n_frames > 0 && h >= 8 && w >= 8 && h <= e->max_h && w <= e->max_w, "frame size out of the context's capacity");
+  ACEZ_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int h2 = (h + 1) / 2, w2 = (w + 1) / 2, h4 = (h2 + 1) / 2, w4 = (w2 + 1) / 2, h8 = (h4 + 1) / 2, w8 = (w4 + 1) / 2;
+  for (int f0 = 0; f0 < n_frames; f0 += e->max_frames) {
+    const int F = (n_frames - f0 < e->max_frames) ? n_frames - f0 : e->max_frames;
+    const float* img = d_images + (size_t)f0 * h * w;
+    uint16_t* feat = (uint16_t*)d_features + (size_t)f0 * h8 * w8 * e->out_channels;
+    const int64_t npix = (int64_t)F * h * w;
+    hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, img, (const float*)e->w1, (const float*)e->bias[0], e->a1, h, w,
+                       npix);
+    auto conv = [&](int li, const uint16_t* in, int hi, int wi, uint16_t* outp, int ho, int wo, const uint16_t* add, bool relu) {
+      const LayerDesc& L = kLayers[li];
+      ConvGemmArgs g{};
+      g.In = in; g.W = e->W[li]; g.bias = e->bias[li]; g.add = add; g.out = outp; g.zeros = e->zeros;
+      g.Hi = hi; g.Wi = wi; g.Ci = L.ci; g.ci_shift = __builtin_ctz(L.ci); g.Ho = ho; g.Wo = wo; g.Co = e->co[li];
+      g.ksize = L.k; g.stride = L.stride; g.pad = L.k / 2; g.K = e->K[li]; g.Kp = e->Kp[li]; g.M = F * ho * wo;
+      launch_convgemm(g, relu, s);
+    };
+    conv(1, e->a1, h, w, e->a2, h2, w2, nullptr, true);
+    conv(2, e->a2, h2, w2, e->a3, h4, w4, nullptr, true);
+    conv(3, e->a3, h4, w4, e->r4, h8, w8, nullptr, true);
+    conv(4, e->r4, h8, w8, e->x5, h8, w8, nullptr, true);
+    conv(5, e->x5, h8, w8, e->x6, h8, w8, nullptr, true);
+    conv(6, e->x6, h8, w8, e->r7, h8, w8, e->r4, true);     // res = res + relu(res1_conv3(x))      ace_network.py:50-52
+    conv(7, e->r7, h8, w8, e->x8, h8, w8, nullptr, true);
+    conv(8, e->x8, h8, w8, e->x9, h8, w8, nullptr, true);
+    conv(10, e->r7, h8, w8, e->sk, h8, w8, nullptr, false); // res2_skip(res)                       ace_network.py:58
+    conv(9, e->x9, h8, w8, feat, h8, w8, e->sk, true);      // skip + relu(res2_conv3(x))
+  }
+  ACEZ_HIP_CHECK(hipGetLastError());
+  return ACEZ_OK;
+}

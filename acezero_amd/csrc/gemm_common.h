@@ -1,0 +1,59 @@
+// gemm_common.h -- device helpers shared by the GEMM-shaped kernels (head_kernels.hip, encoder_kernels.hip):
+// bf16 packing, LDS swizzles, LDS-DMA address-space typedefs, counted waits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace acez {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even fp32 -> bf16 (same as torch .to(bfloat16)); NaN stays NaN.
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+// two fp32 -> packed bf16x2, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32 on gfx950; the compiler emits
+// it for the __bf16 conversion). Branch-free: the bit-twiddling f2bf above costs an exec-mask branch per value.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  bf16x2_t v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  uint2 r;
+  r.x = pack2(a, b);
+  r.y = pack2(c, d);
+  return r;
+}
+__device__ __forceinline__ void unpack4(uint2 v, float* o) {
+  o[0] = __uint_as_float(v.x << 16);
+  o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16);
+  o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// [row][64] bf16 K-stage tiles: 16-byte chunk index XOR (row >> 1) & 7 -> the ds_read_b128 fragment reads of 32
+// consecutive rows are conflict-free. Applied to the per-lane SOURCE chunk of the LDS-DMA and, identically, to the reads.
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+// [rows][128] bf16 epilogue staging tiles: chunk index XOR row & 15 (conflict-free for the accumulator layout and for
+// the row-wise copy)
+__device__ __forceinline__ int st_off(int row, int col) { return row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7)); }
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+#define ACEZ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define ACEZ_VMCNT_C(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")   // n: integral constant expression
+
+}  // namespace acez

@@ -259,6 +259,36 @@ int acez_trainer_get_poses(acez_trainer* tr, float* h_poses34, void* stream);
  *   d_features bf16 [n][512]  ->  d_out_xyz f32 [n][3].   Asynchronous. */
 int acez_head_forward(acez_trainer* tr, const void* d_features, int n, float* d_out_xyz, void* stream);
 
+/* =====================================================================================================
+ * E. Feature encoder: ace_network.py:14-59 Encoder.forward
+ *    11 convolutions, two residual blocks, output stride 8 (Regressor.OUTPUT_SUBSAMPLE, ace_network.py:159).
+ * ===================================================================================================== */
+#define ACEZ_ENCODER_LAYERS 11
+/* Layer order of the weight/bias pointer arrays == Encoder.__init__ (ace_network.py:26-40):
+ *   conv1 conv2 conv3 conv4 res1_conv1 res1_conv2 res1_conv3 res2_conv1 res2_conv2 res2_conv3 res2_skip */
+
+typedef struct acez_encoder acez_encoder; /* opaque: bf16 weight matrices + activation workspaces for max_frames frames */
+
+/* h_weights[i]  float32 host pointer, torch Conv2d layout [c_out][c_in][k][k] (state_dict "<name>.weight")
+ * h_biases[i]   float32 host pointer [c_out]                                   (state_dict "<name>.bias")
+ * out_channels  Encoder(out_channels): c_out of res2_conv3 and res2_skip (512 in every shipped encoder)
+ * max_frames / max_h / max_w   capacity of one internal pass; acez_encoder_forward chunks larger batches. */
+int acez_encoder_create(acez_encoder** out, const float* const* h_weights, const float* const* h_biases,
+                        int out_channels, int max_frames, int max_h, int max_w, int device);
+void acez_encoder_destroy(acez_encoder* enc);
+
+/* Spatial size of the feature map for an h x w input: three stride-2, pad-1, 3x3 convolutions. */
+int acez_encoder_output_size(int h, int w, int* out_h, int* out_w);
+
+/* Encoder.forward (ace_network.py:42-59) for n_frames grayscale frames.
+ *   d_images    float32 [n_frames][1][h][w], normalised as dataset.py:150-153 does
+ *   d_features  bfloat16 [n_frames * out_h * out_w][out_channels]: one row per feature-map pixel in (frame, y, x)
+ *               order -- the row layout of acez_train_buffer.d_features and of acez_head_forward's input
+ * bf16 operands, fp32 accumulation (the reference runs this network under fp16 autocast, register_mapping.py:209).
+ * Asynchronous on `stream`. */
+int acez_encoder_forward(acez_encoder* enc, const float* d_images, int n_frames, int h, int w, void* d_features,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif
