@@ -86,6 +86,7 @@ SYMBOLS = {
     "acez_trainer_get_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "acez_trainer_get_poses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "acez_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "acez_head_forward_maps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "acez_encoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int]),
     "acez_encoder_destroy": (None, [C.c_void_p]),

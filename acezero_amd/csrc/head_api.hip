@@ -568,9 +568,7 @@ extern "C" int acez_trainer_last_scene_coords(acez_trainer* tr, float* h_xyz, in
   return ACEZ_OK;
 }
 
-extern "C" int acez_head_forward(acez_trainer* tr, const void* d_features, int n, float* d_out_xyz, void* stream) {
-  ACEZ_REQUIRE(tr && d_features && d_out_xyz, "null pointer");
-  ACEZ_REQUIRE(n > 0, "n must be positive");
+static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, float* d_out, int planar_hw, void* stream) {
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   hipStream_t s = (hipStream_t)stream;
   const uint16_t* f = (const uint16_t*)d_features;
@@ -580,11 +578,25 @@ extern "C" int acez_head_forward(acez_trainer* tr, const void* d_features, int n
                                   : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
     LossArgs a{};
     fill_loss_head(tr, a);
-    a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr; a.out_xyz = d_out_xyz + (size_t)done * 3;
+    a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr;
+    if (planar_hw > 0) { a.out_xyz = d_out; a.planar_hw = planar_hw; a.row_offset = done; }
+    else a.out_xyz = d_out + (size_t)done * 3;
     hipLaunchKernelGGL(loss_kernel, dim3((cnt + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS)), dim3(256), 0, s, a);
   }
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
+}
+
+extern "C" int acez_head_forward(acez_trainer* tr, const void* d_features, int n, float* d_out_xyz, void* stream) {
+  ACEZ_REQUIRE(tr && d_features && d_out_xyz, "null pointer");
+  ACEZ_REQUIRE(n > 0, "n must be positive");
+  return head_forward_impl(tr, d_features, n, d_out_xyz, 0, stream);
+}
+
+extern "C" int acez_head_forward_maps(acez_trainer* tr, const void* d_features, int n_frames, int h, int w, float* d_out_maps, void* stream) {
+  ACEZ_REQUIRE(tr && d_features && d_out_maps, "null pointer");
+  ACEZ_REQUIRE(n_frames > 0 && h > 0 && w > 0 && (int64_t)n_frames * h * w < ((int64_t)1 << 31), "bad frame geometry");
+  return head_forward_impl(tr, d_features, n_frames * h * w, d_out_maps, h * w, stream);
 }
 
 // Per-kernel-class timing (diagnostics for bench.py's roofline leg): when enabled every launch of the following

@@ -99,7 +99,8 @@ struct LossArgs {
   float hard_clamp, depth_min, depth_max, depth_target, inlier_px, inv_batch, focal_init;
   const TrainState* st;
   // outputs
-  float* out_xyz;        // [n][3] or null
+  float* out_xyz;        // [n][3] or null; with planar_hw > 0: [frames][3][planar_hw] maps (row m = frame * planar_hw + pixel)
+  int planar_hw, row_offset;   // row_offset: index of this launch's row 0 in the whole batch (chunked inference)
   uint16_t* dZ;          // [n][512] gradient wrt the fc2 pre-activation
   float* fc3_partials;   // [blocks][fc3_stride]
   int64_t fc3_stride;

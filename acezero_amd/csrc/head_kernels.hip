@@ -719,9 +719,18 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
         X[2] = s2 + a.mean[2];
       }
       if (a.out_xyz) {
-        a.out_xyz[(size_t)m * 3 + 0] = X[0];
-        a.out_xyz[(size_t)m * 3 + 1] = X[1];
-        a.out_xyz[(size_t)m * 3 + 2] = X[2];
+        if (a.planar_hw > 0) {   // Regressor.forward's [B,3,H,W] layout (ace_network.py:265-270), what RANSAC reads
+          const int64_t mg = (int64_t)a.row_offset + m;
+          const int64_t fr = mg / a.planar_hw, px = mg - fr * a.planar_hw;
+          float* o = a.out_xyz + fr * 3 * a.planar_hw + px;
+          o[0] = X[0];
+          o[(size_t)a.planar_hw] = X[1];
+          o[(size_t)2 * a.planar_hw] = X[2];
+        } else {
+          a.out_xyz[(size_t)m * 3 + 0] = X[0];
+          a.out_xyz[(size_t)m * 3 + 1] = X[1];
+          a.out_xyz[(size_t)m * 3 + 2] = X[2];
+        }
       }
       if (a.idx) {  // training: geometry + loss (skipped for pure inference)
         const float tu = pre_tu, tv = pre_tv;

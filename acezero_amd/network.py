@@ -1,0 +1,80 @@
+"""Host mirror of ace_network.Regressor (ace_network.py:150-270) for inference on one MI355X: HIP encoder + HIP head.
+
+    net = Regressor.create_from_split_state_dict(encoder_state_dict, head_state_dict)
+    sc = net(image_B1HW)                       # == Regressor.forward: float32 [B,3,H/8,W/8], stays on the device
+    poses, inliers, masks = net.register(image_B1HW, intrinsics, ransac_params, seed)   # encoder -> head -> RANSAC in HBM
+
+The reference moves the scene coordinates to the CPU and loops over frames (register_mapping.py:209-242); here a batch of
+frames goes through three device-resident stages and only poses / inlier counts come back.
+There is no CPU fallback.
+"""
+import ctypes as C
+import re
+
+import torch
+
+from . import _native as N
+from . import dsacstar
+from .encoder import Encoder, output_size
+from .head import HeadTrainer, _ptr, _stream
+
+
+class Regressor:
+    OUTPUT_SUBSAMPLE = 8  # ace_network.py:159
+
+    def __init__(self, encoder_state_dict, head_state_dict, max_frames=16, max_h=480, max_w=640, device=None):
+        hs = head_state_dict
+        pattern = re.compile(r"^\d+c0\.weight$")                      # ace_network.py:207-208
+        num_head_blocks = sum(1 for k in hs if pattern.match(k))
+        use_homogeneous = hs["fc3.weight"].shape[0] == 4              # ace_network.py:211
+        mean = hs["mean"].detach().float().view(3).cpu() if "mean" in hs else torch.zeros(3)
+        kw = {}
+        if use_homogeneous and "max_scale" in hs:
+            kw = {"homogeneous_max_scale": float(hs["max_scale"]), "homogeneous_min_scale": float(hs["min_scale"])}
+        oh, ow = output_size(max_h, max_w)
+        self.encoder = Encoder.from_state_dict(encoder_state_dict, max_frames=max_frames, max_h=max_h, max_w=max_w, device=device)
+        self.feature_dim = self.encoder.out_channels
+        if self.feature_dim != 512:
+            raise ValueError("the head kernels are built for 512 encoder features (ace_network.py:22 default)")
+        # an inference-only context: max_batch rows per internal pass of the head
+        self.heads = HeadTrainer(mean, num_head_blocks=num_head_blocks, use_homogeneous=use_homogeneous, max_batch=4 * oh * ow,
+                                 device=device, **kw)
+        self.heads.load_state_dict(hs)
+        self.device = self.heads.device
+
+    @classmethod
+    def create_from_split_state_dict(cls, encoder_state_dict, head_state_dict, **kw):
+        return cls(encoder_state_dict, head_state_dict, **kw)
+
+    @classmethod
+    def create_from_state_dict(cls, state_dict, **kw):
+        enc = {k[len("encoder."):]: v for k, v in state_dict.items() if k.startswith("encoder.")}
+        head = {k[len("heads."):]: v for k, v in state_dict.items() if k.startswith("heads.")}
+        return cls(enc, head, **kw)
+
+    def get_features(self, inputs):
+        return self.encoder(inputs)
+
+    def get_scene_coordinates(self, features_bchw):
+        """Head.forward on a [B,512,h,w] feature tensor -> [B,3,h,w] (ace_network.py:262-263)."""
+        b, c, h, w = features_bchw.shape
+        rows = features_bchw.permute(0, 2, 3, 1).reshape(-1, c).to(self.device, torch.bfloat16).contiguous()
+        return self._maps(rows, b, h, w)
+
+    def _maps(self, rows, b, h, w):
+        out = torch.empty((b, 3, h, w), dtype=torch.float32, device=self.device)
+        N.check(N.lib().acez_head_forward_maps(self.heads._h, _ptr(rows), int(b), int(h), int(w), _ptr(out), _stream()))
+        return out
+
+    def forward(self, inputs):
+        b, _, h, w = inputs.shape
+        oh, ow = output_size(h, w)
+        rows = self.encoder.features_rows(inputs)
+        return self._maps(rows, b, oh, ow)
+
+    __call__ = forward
+
+    def register(self, inputs, intrinsics, params, seed, frame_ids=None, want_masks=False):
+        """images -> (poses [B,4,4] cam->world, inlier counts [B], masks): register_mapping.py:201-242 for a batch, all on device."""
+        sc = self.forward(inputs)
+        return dsacstar.register_batch(sc, intrinsics, params, seed, frame_ids, want_masks=want_masks)

@@ -259,6 +259,14 @@ int acez_trainer_get_poses(acez_trainer* tr, float* h_poses34, void* stream);
  *   d_features bf16 [n][512]  ->  d_out_xyz f32 [n][3].   Asynchronous. */
 int acez_head_forward(acez_trainer* tr, const void* d_features, int n, float* d_out_xyz, void* stream);
 
+/* Head.forward for whole frames, written as Regressor.forward's [B,3,H,W] maps (ace_network.py:265-270): the input of
+ * acez_register_rgb_device, so that scene coordinates go encoder -> head -> RANSAC without leaving HBM
+ * (register_mapping.py:209-213 copies them to the CPU instead).
+ *   d_features  bfloat16 [n_frames * h * w][512], rows in (frame, y, x) order (acez_encoder_forward's output)
+ *   d_out_maps  float32  [n_frames][3][h][w] */
+int acez_head_forward_maps(acez_trainer* tr, const void* d_features, int n_frames, int h, int w, float* d_out_maps,
+                           void* stream);
+
 /* =====================================================================================================
  * E. Feature encoder: ace_network.py:14-59 Encoder.forward
  *    11 convolutions, two residual blocks, output stride 8 (Regressor.OUTPUT_SUBSAMPLE, ace_network.py:159).

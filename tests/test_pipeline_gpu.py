@@ -1,0 +1,58 @@
+"""Registration pipeline on the GPU: images -> encoder -> head -> RANSAC without leaving HBM."""
+import numpy as np
+import pytest
+import torch
+
+from acezero_amd import synth
+from oracle import encoder_oracle, head_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _head_state_dict(seed=3):
+    from acezero_amd.head import layer_names
+    flat = head_oracle.init_params(seed, 1, True)
+    sd, o = {}, 0
+    for name in layer_names(1):
+        sd[name + ".weight"] = flat[o:o + 262144].view(512, 512, 1, 1).clone(); o += 262144
+        sd[name + ".bias"] = flat[o:o + 512].clone(); o += 512
+    sd["fc3.weight"] = flat[o:o + 2048].view(4, 512, 1, 1).clone(); o += 2048
+    sd["fc3.bias"] = flat[o:o + 4].clone()
+    sd["mean"] = torch.tensor([1.0, -2.0, 0.5]).view(1, 3, 1, 1)
+    return sd, flat
+
+
+def test_regressor_forward_matches_oracles():
+    from acezero_amd.network import Regressor
+    esd = encoder_oracle.init_weights(seed=4099)
+    hsd, flat = _head_state_dict()
+    img = torch.from_numpy(synth.make_gray_images(seed=21, n=3, h=96, w=128))
+    net = Regressor.create_from_split_state_dict(esd, hsd, max_frames=2, max_h=96, max_w=128)
+    sc = net(img)
+    assert sc.shape == (3, 3, 12, 16) and sc.dtype == torch.float32 and sc.is_cuda
+    # oracle: bf16 encoder -> bf16 head forward
+    rows = encoder_oracle.EncoderOracle(esd, "bf16").features_rows(img)
+    ho = head_oracle.HeadOracle(flat, torch.tensor([1.0, -2.0, 0.5]), 1, True, mode="bf16")
+    ref = ho.scene_coordinates(rows).view(3, 12, 16, 3).permute(0, 3, 1, 2)
+    err = (sc.cpu() - ref).abs().max().item()
+    scale = (ref - torch.tensor([1.0, -2.0, 0.5]).view(1, 3, 1, 1)).abs().max().item()
+    assert err < 2e-2 * scale, (err, scale)
+    # the two-step path (features as a tensor, then the head) gives the same maps as the fused row path
+    sc2 = net.get_scene_coordinates(net.get_features(img))
+    assert torch.equal(sc2, sc)
+
+
+def test_register_images_equals_stagewise_composition():
+    from acezero_amd import dsacstar
+    from acezero_amd.network import Regressor
+    esd = encoder_oracle.init_weights(seed=4099)
+    hsd, _ = _head_state_dict()
+    img = torch.from_numpy(synth.make_gray_images(seed=4, n=2, h=96, w=128))
+    net = Regressor.create_from_split_state_dict(esd, hsd, max_frames=2, max_h=96, max_w=128)
+    params = dict(hyps=16, thr=10.0, alpha=100.0, max_reproj=100.0, sub=8, max_tries=16)
+    intr = [(100.0, 64.0, 48.0)] * 2
+    poses, inl, _ = net.register(img, intr, params, seed=11, frame_ids=[5, 6])
+    sc = net(img)
+    poses2, inl2, _ = dsacstar.register_batch(sc, intr, params, 11, [5, 6], want_masks=False)
+    assert torch.equal(poses, poses2) and torch.equal(inl, inl2)
+    assert poses.shape == (2, 4, 4) and bool(torch.isfinite(poses).all())
