@@ -250,6 +250,83 @@ static void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Training-buffer sampling (ace_trainer.py:404-431): per view, `samples` feature rows are drawn uniformly WITH replacement
+// among the pixels whose mask is set (torch.multinomial(mask, n, replacement=True) on equal weights) and appended to the
+// buffer together with their target pixel 8 * (x + 0.5, y + 0.5) (ace_util.py:7-13) and the view index.
+// The draw is a counter-based stream keyed by (seed, view id, sample): reproducible and independent of batching
+// (torch's multinomial stream cannot be reproduced). One workgroup = one view x a slice of its samples:
+// inclusive prefix counts of the mask in LDS, one wave per sample (binary search, then a 1 KiB row copy).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t smix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t sample_draw(uint64_t seed, uint64_t view_id, uint32_t s) {
+  return (uint32_t)(smix64(smix64(seed ^ (view_id * 0xD1342543DE82EF95ull)) + s) >> 32);
+}
+
+constexpr int SAMPLE_MAX_HW = 24576;   // feature-map pixels per view the LDS prefix array holds (e.g. 128 x 192)
+
+__global__ __launch_bounds__(256) void sample_views_kernel(const uint16_t* __restrict__ feat, const uint8_t* __restrict__ mask, int hw, int ow,
+                                                           int channels, int samples, uint64_t seed, uint64_t first_view_id,
+                                                           int view_index_base, uint16_t* __restrict__ out_feat, float* __restrict__ out_px,
+                                                           int32_t* __restrict__ out_view, int32_t* __restrict__ out_pix) {
+  __shared__ uint16_t pref[SAMPLE_MAX_HW];   // inclusive count of valid pixels up to p (hw <= 24576 < 65536)
+  __shared__ int part[256];
+  const int v = blockIdx.x, t = threadIdx.x;
+  const uint8_t* mk = mask ? mask + (size_t)v * hw : nullptr;
+  const int per = (hw + 255) / 256;
+  const int lo = t * per, hi = min(hw, lo + per);
+  int cnt = 0;
+  for (int p = lo; p < hi; ++p) cnt += mk ? (mk[p] != 0) : 1;
+  part[t] = cnt;
+  __syncthreads();
+  // exclusive scan of the 256 partial counts (Hillis-Steele, 8 rounds)
+  for (int off = 1; off < 256; off <<= 1) {
+    const int x = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += x;
+    __syncthreads();
+  }
+  const int nvalid = part[255];
+  int run = part[t] - cnt;
+  for (int p = lo; p < hi; ++p) {
+    run += mk ? (mk[p] != 0) : 1;
+    pref[p] = (uint16_t)run;
+  }
+  __syncthreads();
+  if (nvalid == 0) return;   // the host never passes such a view (ace_trainer.py:377-378 skips it)
+  const int lane = t & 63, wave = t >> 6;
+  const int per_block = (samples + gridDim.y - 1) / gridDim.y;
+  const int s_lo = blockIdx.y * per_block, s_hi = min(samples, s_lo + per_block);
+  for (int s = s_lo + wave; s < s_hi; s += 4) {
+    const uint32_t r = sample_draw(seed, first_view_id + v, (uint32_t)s);
+    const uint32_t k = (uint32_t)(((uint64_t)r * (uint32_t)nvalid) >> 32);   // uniform in [0, nvalid)
+    // smallest p with pref[p] > k  == the (k+1)-th valid pixel
+    int a = 0, b = hw - 1;
+    while (a < b) {
+      const int m = (a + b) >> 1;
+      if (pref[m] > k) b = m; else a = m + 1;
+    }
+    const int pix = a;
+    const size_t dst = (size_t)v * samples + s;
+    const uint16_t* src = feat + ((size_t)v * hw + pix) * channels;
+    for (int c = lane * 8; c < channels; c += 512)
+      *reinterpret_cast<uint4*>(out_feat + dst * channels + c) = *reinterpret_cast<const uint4*>(src + c);
+    if (lane == 0) {
+      const int y = pix / ow, x = pix - y * ow;
+      out_px[dst * 2 + 0] = 8.0f * ((float)x + 0.5f);
+      out_px[dst * 2 + 1] = 8.0f * ((float)y + 0.5f);
+      out_view[dst] = view_index_base + v;
+      if (out_pix) out_pix[dst] = pix;
+    }
+  }
+}
+
 }  // namespace acez
 
 using namespace acez;
@@ -410,6 +487,24 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
     conv(10, e->r7, h8, w8, e->sk, h8, w8, nullptr, false); // res2_skip(res)                       ace_network.py:58
     conv(9, e->x9, h8, w8, feat, h8, w8, e->sk, true);      // skip + relu(res2_conv3(x))
   }
+  ACEZ_HIP_CHECK(hipGetLastError());
+  return ACEZ_OK;
+}
+
+extern "C" int acez_buffer_sample_views(const void* d_view_features, const uint8_t* d_masks, int n_views, int map_h, int map_w, int channels,
+                                        int samples_per_view, uint64_t seed, uint64_t first_view_id, int32_t view_index_base,
+                                        void* d_out_features, float* d_out_target_px, int32_t* d_out_view_idx, int32_t* d_out_pixel,
+                                        void* stream) {
+  ACEZ_REQUIRE(d_view_features && d_out_features && d_out_target_px && d_out_view_idx, "null pointer");
+  ACEZ_REQUIRE(n_views > 0 && map_h > 0 && map_w > 0 && samples_per_view > 0, "bad shape");
+  ACEZ_REQUIRE(map_h * map_w <= SAMPLE_MAX_HW, "feature map too large for the sampling kernel (24576 pixels)");
+  ACEZ_REQUIRE(channels > 0 && channels % 8 == 0, "channels must be a multiple of 8");
+  const int hw = map_h * map_w;
+  int split = (samples_per_view + 255) / 256;   // ~256 samples per workgroup
+  if (split > 64) split = 64;
+  hipLaunchKernelGGL(sample_views_kernel, dim3(n_views, split), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)d_view_features, d_masks, hw, map_w,
+                     channels, samples_per_view, seed, first_view_id, (int)view_index_base, (uint16_t*)d_out_features, d_out_target_px,
+                     d_out_view_idx, d_out_pixel);
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
 }

@@ -297,6 +297,26 @@ int acez_encoder_output_size(int h, int w, int* out_h, int* out_w);
 int acez_encoder_forward(acez_encoder* enc, const float* d_images, int n_frames, int h, int w, void* d_features,
                          void* stream);
 
+/* Training-buffer sampling for a batch of views whose features were just computed (ace_trainer.py:404-431): per view,
+ * `samples_per_view` rows are drawn uniformly with replacement among the pixels whose mask byte is non-zero
+ * (torch.multinomial(mask, n, replacement=True), ace_trainer.py:419-422) and written, view after view, to the output
+ * arrays -- which are slices of acez_train_buffer's d_features / d_target_px / d_view_idx at the current fill offset.
+ *   d_view_features  bfloat16 [n_views * map_h * map_w][channels]   (acez_encoder_forward's output)
+ *   d_masks          uint8 [n_views][map_h][map_w] validity at feature resolution (the nearest-neighbour resize of
+ *                    ace_trainer.py:373-374), or NULL = every pixel valid. Every view must have a valid pixel
+ *                    (the reference skips empty views, ace_trainer.py:377-378; so must the caller).
+ *   seed, first_view_id   the draw of sample s of view v is a counter-based stream keyed by (seed, first_view_id + v, s)
+ *   view_index_base  value written to d_out_view_idx for view 0 (index into the caller's per-view tables)
+ *   d_out_features   bfloat16 [n_views * samples_per_view][channels]
+ *   d_out_target_px  float32  [n_views * samples_per_view][2] = 8 * (x + 0.5, y + 0.5)   (ace_util.py:7-13)
+ *   d_out_view_idx   int32    [n_views * samples_per_view]
+ *   d_out_pixel      int32    [n_views * samples_per_view] chosen feature-map pixel y * map_w + x, or NULL (diagnostics)
+ * Asynchronous on `stream`. */
+int acez_buffer_sample_views(const void* d_view_features, const uint8_t* d_masks, int n_views, int map_h, int map_w,
+                             int channels, int samples_per_view, uint64_t seed, uint64_t first_view_id,
+                             int32_t view_index_base, void* d_out_features, float* d_out_target_px,
+                             int32_t* d_out_view_idx, int32_t* d_out_pixel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
