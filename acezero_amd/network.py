@@ -74,7 +74,29 @@ class Regressor:
 
     __call__ = forward
 
-    def register(self, inputs, intrinsics, params, seed, frame_ids=None, want_masks=False):
-        """images -> (poses [B,4,4] cam->world, inlier counts [B], masks): register_mapping.py:201-242 for a batch, all on device."""
-        sc = self.forward(inputs)
-        return dsacstar.register_batch(sc, intrinsics, params, seed, frame_ids, want_masks=want_masks)
+    def register(self, inputs, intrinsics, params, seed, frame_ids=None, want_masks=False, ransac_group=512):
+        """images -> (poses [B,4,4] cam->world, inlier counts [B], masks): register_mapping.py:201-242 for a batch, all on device.
+
+        Frames go through encoder + head in chunks of the context's max_frames; RANSAC is launched once per `ransac_group`
+        frames (one 256-thread workgroup per frame: a launch wants hundreds of frames) on a side stream, so that the
+        latency-bound RANSAC of one group overlaps the MFMA-bound encoder of the next."""
+        b = int(inputs.shape[0])
+        ids = list(range(b)) if frame_ids is None else list(frame_ids)
+        main = torch.cuda.current_stream(self.device)
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(self.device)
+        poses, inl, masks, keep = [], [], [], []
+        for g0 in range(0, b, ransac_group):
+            g1 = min(b, g0 + ransac_group)
+            sc = self.forward(inputs[g0:g1])
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                p, i, m = dsacstar.register_batch(sc, intrinsics[g0:g1], params, seed, ids[g0:g1], want_masks=want_masks)
+            keep.append(sc)   # alive until the side stream has consumed it
+            poses.append(p); inl.append(i); masks.append(m)
+        main.wait_stream(self._side)
+        for t in keep + poses + inl + [m for m in masks if m is not None]:
+            t.record_stream(main)
+        return torch.cat(poses), torch.cat(inl), (torch.cat(masks) if want_masks else None)

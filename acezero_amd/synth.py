@@ -92,6 +92,56 @@ def expand_per_patch(prob, idx):
     }
 
 
+ENCODER_LAYERS = [  # (name, c_in, c_out, kernel) in Encoder.__init__ order, ace_network.py:26-40
+    ("conv1", 1, 32, 3), ("conv2", 32, 64, 3), ("conv3", 64, 128, 3), ("conv4", 128, 256, 3), ("res1_conv1", 256, 256, 3),
+    ("res1_conv2", 256, 256, 1), ("res1_conv3", 256, 256, 3), ("res2_conv1", 256, 512, 3), ("res2_conv2", 512, 512, 1),
+    ("res2_conv3", 512, 512, 3), ("res2_skip", 256, 512, 1)]
+
+
+def init_encoder_weights(seed=4099, out_channels=512):
+    """Seeded numpy stand-in for the pretrained encoder blob (not available offline): the reference's state_dict keys with
+    nn.Conv2d's default init bounds U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias. Returns {key: float32 array}."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, ci, co, k in ENCODER_LAYERS:
+        if name in ("res2_conv3", "res2_skip"):
+            co = out_channels
+        bound = 1.0 / np.sqrt(ci * k * k)
+        sd[name + ".weight"] = rng.uniform(-bound, bound, size=(co, ci, k, k)).astype(np.float32)
+        sd[name + ".bias"] = rng.uniform(-bound, bound, size=(co,)).astype(np.float32)
+    return sd
+
+
+def head_num_params(num_head_blocks=1, use_homogeneous=True):
+    return (3 + 3 * num_head_blocks + 2) * (512 * 512 + 512) + (4 if use_homogeneous else 3) * 513
+
+
+def init_head_params(seed, num_head_blocks=1, use_homogeneous=True, scale=1.0):
+    """Deterministic (numpy PCG64) stand-in for nn.Conv2d's default init of the head: flat float32 vector in the order of
+    Head.named_parameters() (the layout of acez_param_buffers.d_params)."""
+    rng = np.random.default_rng(seed)
+    bound = scale / math.sqrt(512.0)
+    return rng.uniform(-bound, bound, size=head_num_params(num_head_blocks, use_homogeneous)).astype(np.float32)
+
+
+def head_state_dict(flat, num_head_blocks=1, use_homogeneous=True, mean=(0.0, 0.0, 0.0)):
+    """Head.state_dict()-shaped dict (numpy views) of a flat parameter vector (ace_network.py:85-118 key names)."""
+    names = ["res3_conv1", "res3_conv2", "res3_conv3"]
+    for b in range(num_head_blocks):
+        names += [f"{b}c0", f"{b}c1", f"{b}c2"]
+    names += ["fc1", "fc2"]
+    flat = np.asarray(flat, np.float32)
+    sd, o = {}, 0
+    for name in names:
+        sd[name + ".weight"] = flat[o:o + 262144].reshape(512, 512, 1, 1); o += 262144
+        sd[name + ".bias"] = flat[o:o + 512]; o += 512
+    no = 4 if use_homogeneous else 3
+    sd["fc3.weight"] = flat[o:o + no * 512].reshape(no, 512, 1, 1); o += no * 512
+    sd["fc3.bias"] = flat[o:o + no]
+    sd["mean"] = np.asarray(mean, np.float32).reshape(1, 3, 1, 1)
+    return sd
+
+
 def make_gray_images(seed=77, n=2, h=480, w=640):
     """Normalised grayscale frames [n,1,h,w] float32 as the dataset hands them to the network: smooth random texture,
     (x/255 - 0.4) / 0.25 (dataset.py:150-153)."""

@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--buffer-patches", type=int, default=8_000_000)   # train_ace.py:122
     ap.add_argument("--reg-frames", type=int, default=2048)
+    ap.add_argument("--e2e-frames", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -64,15 +65,15 @@ def make_buffer(n_patches, device, seed):
 
 
 def bench_training(args, rank, world, device):
+    from acezero_amd import synth
     from acezero_amd.head import HeadTrainer
-    from oracle import head_oracle
     per_rank = args.buffer_patches // world
     prob, feats, target_px, view_idx = make_buffer(per_rank, device, 2089 + rank)
     total_iters = args.steps + args.warmup + 64
     tr = HeadTrainer(prob["mean"], max_batch=BATCH, global_batch=BATCH * world, loss_type="tanh", schedule="1cyclepoly",
                      iterations=max(total_iters, 25000), lr_min=0.0005, lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005,
                      cooldown_iterations=5000)                                  # ace_zero.py:105-123 mapping settings
-    tr.load_flat(head_oracle.init_params(1))
+    tr.load_flat(torch.from_numpy(synth.init_head_params(1)))
     tr.set_buffer(feats, target_px, view_idx, prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"], prob["view_image"],
                   prob["image_pose_inv"])
     g = torch.Generator(device=device).manual_seed(8191 + rank)
@@ -143,6 +144,61 @@ def bench_registration(args, rank, world, device):
     return n, dt, ok
 
 
+ENC_FLOP_PER_FRAME = 58.37e9    # 480x640: sum over the 11 convolutions of 2*Ho*Wo*Cin*Cout*k*k (ace_network.py:26-40)
+HEAD_FLOP_PER_FRAME = 4800 * (8 * 2 * 512 * 512 + 2 * 512 * 4)
+
+
+def bench_pipeline(args, rank, world, device):
+    """(a) images -> encoder -> head -> RANSAC with nothing leaving HBM, (b) training-buffer creation
+    (encoder + mask-weighted sampling). 480x640 synthetic grey frames, random-init encoder/head weights (no checkpoints here)."""
+    import numpy as np
+    from acezero_amd import synth
+    from acezero_amd.buffer import BufferBuilder
+    from acezero_amd.network import Regressor
+    chunk, total = 32, args.e2e_frames // world
+    esd = {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights(seed=4099).items()}
+    hsd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(synth.init_head_params(3)).items()}
+    net = Regressor.create_from_split_state_dict(esd, hsd, max_frames=chunk, max_h=480, max_w=640)
+    img = torch.from_numpy(synth.make_gray_images(seed=1 + rank, n=4, h=480, w=640)).to(device).repeat(chunk // 4, 1, 1, 1).contiguous()
+    prm = dict(hyps=32, thr=10.0, alpha=100.0, max_reproj=100.0, sub=8, max_tries=16)
+    intr = [(525.0, 320.0, 240.0)] * chunk
+    net.register(img, intr, prm, 1305, list(range(chunk)))
+    torch.cuda.synchronize()
+    # (1) the encoder alone, for its roofline line
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    rows = net.encoder.features_rows(img)
+    e0.record()
+    for c in range(4):
+        net.encoder.features_rows(img, out=rows)
+    e1.record()
+    torch.cuda.synchronize()
+    enc_ms_per_frame = e0.elapsed_time(e1) / (4 * chunk)
+    # (2) the whole pipeline on `total` frames (the same 32 views repeated: content does not change the work)
+    nfr = (total // chunk) * chunk
+    big = img.repeat(nfr // chunk, 1, 1, 1)
+    intr_all = intr * (nfr // chunk)
+    net.register(big[:2 * chunk], intr_all[:2 * chunk], prm, 1305)   # warm-up of the grouped path
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    poses, inl, _ = net.register(big, intr_all, prm, 1305)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    enc_ms = enc_ms_per_frame * nfr
+    del big
+    # buffer creation: 1024 samples per view (train_ace.py:128)
+    bld = BufferBuilder(net.encoder, capacity=nfr * 1024, samples_per_image=1024, seed=2089)
+    eye = torch.eye(4).repeat(chunk, 1, 1)
+    K = torch.tensor([[525.0, 0, 320.0], [0, 525.0, 240.0], [0, 0, 1.0]]).repeat(chunk, 1, 1)
+    Ki = torch.linalg.inv(K)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for c in range(total // chunk):
+        bld.add_views(img, None, eye, eye, K, Ki, list(range(chunk)))
+    torch.cuda.synchronize()
+    dtb = time.perf_counter() - t1
+    return {"frames": nfr, "e2e_s": dt, "encoder_ms": enc_ms, "buffer_s": dtb, "buffer_rows": bld.n}
+
+
 def cpu_baseline():
     """Oracle timed on the host cores (kind "port": the reference itself is not on the GPU box)."""
     from acezero_amd import synth
@@ -199,6 +255,7 @@ def main():
 
     dt, st, prof = bench_training(args, rank, world, device)
     nreg, dt_reg, reg_ok = bench_registration(args, rank, world, device)
+    pipe = bench_pipeline(args, rank, world, device)
     if world > 1:
         t = torch.tensor([dt, dt_reg], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -227,6 +284,16 @@ def main():
             "registration": {"metric": "DSAC* images-registered/sec", "value": nreg * world / dt_reg, "unit": "images/s",
                              "frames": nreg * world, "hypotheses": 32, "max_tries": 16, "frac_frames_registered": reg_ok,
                              "note": "RANSAC only, 60x80 scene coordinates resident in HBM"},
+            "registration_e2e": {"metric": "images registered/sec, grey 480x640 frame -> encoder -> head -> RANSAC, device resident",
+                                 "value": pipe["frames"] * world / pipe["e2e_s"], "unit": "images/s", "frames": pipe["frames"] * world,
+                                 "encoder_ms_per_frame": pipe["encoder_ms"] / pipe["frames"],
+                                 "encoder_tflops": ENC_FLOP_PER_FRAME * pipe["frames"] / (pipe["encoder_ms"] * 1e-3) / 1e12,
+                                 "encoder_frac_of_mfma_peak": ENC_FLOP_PER_FRAME * pipe["frames"] / (pipe["encoder_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                                 "whole_pipeline_tflops": (ENC_FLOP_PER_FRAME + HEAD_FLOP_PER_FRAME) * pipe["frames"] / pipe["e2e_s"] / 1e12,
+                                 "note": "rank 0's numbers x world; random-init weights, synthetic frames; encoder = convgemm_kernel (implicit GEMM, bf16 MFMA)"},
+            "buffer_creation": {"metric": "training-buffer rows/sec (encoder + 1024 mask-weighted samples per 480x640 view)",
+                                "value": pipe["buffer_rows"] * world / pipe["buffer_s"], "unit": "patches/s",
+                                "views_per_s": pipe["frames"] * world / pipe["buffer_s"]},
             "roofline": {"bound": "mfma", "kernel": "rowgemm80_kernel (5120x512x512 bf16, fwd + dgrad launches)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": gemm_n,

@@ -30,17 +30,9 @@ def bf16_round(x):
 
 
 def init_weights(seed=4099, out_channels=512):
-    """Seeded state_dict with the reference's key names and nn.Conv2d's default init bounds (kaiming-uniform a=sqrt(5)
-    == U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias).  numpy streams so fixtures regenerate anywhere."""
-    rng = np.random.default_rng(seed)
-    sd = {}
-    for name, ci, co, k, _ in LAYERS:
-        if name in ("res2_conv3", "res2_skip"):
-            co = out_channels
-        bound = 1.0 / np.sqrt(ci * k * k)
-        sd[name + ".weight"] = torch.from_numpy(rng.uniform(-bound, bound, size=(co, ci, k, k)).astype(np.float32))
-        sd[name + ".bias"] = torch.from_numpy(rng.uniform(-bound, bound, size=(co,)).astype(np.float32))
-    return sd
+    """Seeded state_dict with the reference's key names (generator: acezero_amd.synth.init_encoder_weights)."""
+    from acezero_amd import synth
+    return {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights(seed, out_channels).items()}
 
 
 class EncoderOracle:

@@ -67,11 +67,10 @@ class HeadParams:
 
 
 def init_params(seed, num_head_blocks=1, use_homogeneous=True, scale=1.0):
-    """Deterministic (numpy PCG64) stand-in for nn.Conv2d's default init: U(-1/sqrt(512), 1/sqrt(512))."""
-    n = num_params(num_head_blocks, use_homogeneous)
-    rng = np.random.default_rng(seed)
-    bound = scale / math.sqrt(512.0)
-    return torch.from_numpy(rng.uniform(-bound, bound, size=n).astype(np.float32))
+    """Deterministic (numpy PCG64) stand-in for nn.Conv2d's default init: U(-1/sqrt(512), 1/sqrt(512)).
+    The generator lives with the other synthetic inputs (acezero_amd/synth.py) so that bench.py's timed legs need no oracle."""
+    from acezero_amd import synth
+    return torch.from_numpy(synth.init_head_params(seed, num_head_blocks, use_homogeneous, scale))
 
 
 class HeadOracle:
