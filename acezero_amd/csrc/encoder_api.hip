@@ -16,6 +16,7 @@
 //                           padding border / K padding / rows past the end.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -34,6 +35,7 @@ struct ConvGemmArgs {
   uint16_t* out;          // [M][Co]
   const uint16_t* zeros;  // >= 128 bytes of zeros: DMA source of every padded chunk
   int Hi, Wi, Ci, ci_shift, Ho, Wo, Co, ksize, stride, pad, K, Kp, M;
+  int dbg;   // ablation (ACEZ_CONV_DBG, convgemm256 only; 0 in production): 2 = no MFMA, 4 = no loads
 };
 
 // 1 -> 32 channels, 3x3, stride 1, pad 1, ReLU. image fp32 [F][H][W] (rounded to bf16 on the fly), out NHWC bf16.
@@ -232,7 +234,360 @@ __global__ __launch_bounds__(512) void convgemm_kernel(ConvGemmArgs a) {
   }
 }
 
-static void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------------
+// convgemm256: the large-M variant (encoder layers with >= 128 output channels, i.e. 97 % of its FLOPs). 256 rows x 128
+// columns per workgroup halves the L2->LDS bytes per FLOP of the 80-row tile (the measured bound of that kernel at
+// ~50-70 GB/s of LDS-DMA fill per CU). 16 waves: 8 multipliers (4 x 2 grid of 64 x 64 sub-tiles, 2 x 2
+// v_mfma_f32_32x32x16_bf16 fragments: 4 ds_read_b128 feed 4 MFMAs) and 8 loaders (6 DMA instructions each per 64-wide
+// K stage: 2 for the W tile, 4 for the In tile). 3-slot ring of 48 KiB stages; the slot rotation is chosen so that the
+// LAST stage sits in slot 2, which leaves slots 0-1 free for the [256][128] epilogue tile one stage early: the loaders
+// fetch the residual / skip tile into it while the multipliers work on the last stage.
+// ---------------------------------------------------------------------------------------------------
+template <bool RELU, bool HAS_ADD>
+__global__ __launch_bounds__(1024) void convgemm256_kernel(ConvGemmArgs a) {
+  constexpr int STAGE = (128 + 256) * 64;     // elements per ring slot
+  __shared__ __attribute__((aligned(16))) uint16_t smem[3 * STAGE];
+  uint16_t* const stO = smem;                 // epilogue tile [256][128] (slots 0-1)
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int M = a.M, Co = a.Co, Kp = a.Kp;
+  const int ntiles = Co >> 7;
+  const int mtiles = (M + 255) >> 8;
+  const int per_xcd = (mtiles + 7) >> 3;
+  const int jx = blockIdx.x >> 3;
+  const int mt = (blockIdx.x & 7) * per_xcd + jx / ntiles;
+  if (mt >= mtiles) return;
+  const int n0 = (jx % ntiles) << 7, m0 = mt << 8;
+  const int KT = Kp >> 6;
+  const int rot = (3 - (KT % 3)) % 3;         // slot(kt) = (kt + rot) % 3 with slot(KT - 1) == 2
+
+  if (w >= 8) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = w - 8;
+    const uint16_t* gW[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (lw * 2 + j) * 8 + (l >> 3);
+      gW[j] = a.W + (size_t)(n0 + row) * Kp + ((l & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+    const uint16_t* ibase[4];
+    int iy0[4], ix0[4], kc[4];
+    bool pv[4];
+    const int hw = a.Ho * a.Wo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (lw * 4 + j) * 8 + (l >> 3);
+      const int p = m0 + row;
+      pv[j] = p < M;
+      const int pp = pv[j] ? p : 0;
+      const int f = pp / hw, r = pp - f * hw;
+      const int y = r / a.Wo, x = r - y * a.Wo;
+      iy0[j] = y * a.stride - a.pad;
+      ix0[j] = x * a.stride - a.pad;
+      ibase[j] = a.In + (size_t)f * a.Hi * a.Wi * a.Ci;
+      kc[j] = ((l & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+    const uint16_t* zp = a.zeros + (l & 7) * 8;
+    auto issue = [&](int kt) {
+      uint16_t* slot = smem + ((kt + rot) % 3) * STAGE;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + kt * 64), (lvoid_t*)(slot + (lw * 2 + j) * 8 * 64), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k0 = kt * 64 + kc[j];
+        const int tap = k0 >> a.ci_shift, ci = k0 & (a.Ci - 1);
+        const int ky = (a.ksize == 3) ? (tap * 11) >> 5 : 0;
+        const int kx = tap - 3 * ky;
+        const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+        const bool ok = pv[j] && k0 < a.K && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+        const uint16_t* g = ok ? ibase[j] + (((size_t)iy * a.Wi + ix) << a.ci_shift) + ci : zp;
+        __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(slot + 128 * 64 + (lw * 4 + j) * 8 * 64), 16, 0, 0);
+      }
+    };
+    const bool do_loads = !(a.dbg & 4);
+    if (do_loads) for (int kt = 0; kt < 3 && kt < KT; ++kt) issue(kt);
+    for (int kt = 0; kt < KT; ++kt) {
+      // issued so far: 0..2 at kt = 0, 0..kt+1 afterwards; 6 DMA instructions per stage, in-order completion
+      const int later = (kt == 0) ? min(2, KT - 1) : min(1, KT - 1 - kt);
+      if (later >= 2) ACEZ_VMCNT(12);
+      else if (later == 1) ACEZ_VMCNT(6);
+      else ACEZ_VMCNT(0);
+      __builtin_amdgcn_s_barrier();   // stage kt has landed; the multipliers are done with stage kt - 1
+      if (do_loads && kt >= 1 && kt + 2 < KT) issue(kt + 2);
+      if (HAS_ADD && kt == KT - 1) {
+        // slots 0-1 are free from here on (KT >= 3 for every layer that has a residual input): residual tile -> stO
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int row = (lw * 8 + j) * 4 + (l >> 4);
+          const uint16_t* g = a.add + (size_t)min(m0 + row, M - 1) * Co + n0 + (((l & 15) ^ (row & 15)) << 3);
+          __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(stO + (lw * 8 + j) * 4 * 128), 16, 0, 0);
+        }
+      }
+    }
+    ACEZ_VMCNT(0);
+    __builtin_amdgcn_s_barrier();     // K loop finished, residual tile landed
+    __builtin_amdgcn_s_barrier();     // output tile written
+  } else {
+    // ------------------------------------------------------------------ multiplier waves
+    const int wm = w >> 1, wn = w & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fr = l & 31, fh = l >> 5;
+    for (int kt = 0; kt < KT; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      if (a.dbg & 2) continue;
+      const uint16_t* sW = smem + ((kt + rot) % 3) * STAGE;
+      const uint16_t* sI = sW + 128 * 64;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int c = kk * 2 + fh;
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz(wn * 64 + i * 32 + fr, c)]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz(wm * 64 + j * 32 + fr, c)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ml = wm * 64 + j * 32 + fr;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nl = wn * 64 + i * 32 + 8 * q + 4 * fh;
+          const float4 b = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+          float v[4] = {acc[i][j][4 * q + 0] + b.x, acc[i][j][4 * q + 1] + b.y, acc[i][j][4 * q + 2] + b.z, acc[i][j][4 * q + 3] + b.w};
+          if (RELU) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+          }
+          uint16_t* po = &stO[st_off(ml, nl)];
+          if (HAS_ADD) {
+            float ad[4];
+            unpack4(*reinterpret_cast<const uint2*>(po), ad);
+            v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
+          }
+          *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // ------------------------------------------------------------------ all sixteen waves: copy the tile out, full rows
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = t + 1024 * it, row = q >> 4, ch = q & 15, m = m0 + row;
+    if (m < M)
+      *reinterpret_cast<uint4*>(a.out + (size_t)m * Co + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&stO[row * 128 + ((ch ^ (row & 15)) << 3)]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// convgemm512: 256 rows x 256 columns per workgroup for the layers with >= 256 output channels when there are enough
+// tiles to fill the chip several times. Why: every GEMM kernel of this package ends up with ~96 KiB of LDS-DMA in flight per
+// CU (the ring is bounded by the 160 KiB LDS) and measures ~70-77 GB/s of fill per CU, i.e. ~1.3 us of latency under load
+// (Little's law) -- loads-only and MFMA-only ablations of convgemm256 take the same time and ADD. The only lever left is
+// FLOP per byte: 256 x 256 needs 1.5x fewer bytes per FLOP than 256 x 128 (131 FLOP/B: 75 GB/s per CU then feeds the full
+// MFMA rate) and its 128 x 64 wave tiles need 0.75 KiB of fragment reads per MFMA instead of 1 KiB.
+// 12 waves: 8 multipliers (2 x 4 grid of 128-row x 64-column sub-tiles = 2 x 4 fragments of v_mfma_f32_32x32x16_bf16,
+// 128 accumulator registers) and 4 loaders (8 DMA instructions each per stage). K stages are 32 wide (32 KiB), 4-slot ring.
+// The [256][256] bf16 epilogue tile needs the whole ring, so a residual input is fetched after the K loop.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz32(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3); }
+// [256][256] bf16 epilogue tile: chunk index (0..31) XOR row & 31
+__device__ __forceinline__ int st_off256(int row, int col) { return row * 256 + ((((col >> 3) ^ (row & 31)) << 3) | (col & 7)); }
+
+template <bool RELU, bool HAS_ADD>
+__global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
+  constexpr int STAGE = 512 * 32;             // elements per ring slot: [W 256 x 32 | In 256 x 32]
+  __shared__ __attribute__((aligned(16))) uint16_t smem[4 * STAGE];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int M = a.M, Co = a.Co, Kp = a.Kp;
+  const int ntiles = Co >> 8;
+  const int mtiles = (M + 255) >> 8;
+  const int per_xcd = (mtiles + 7) >> 3;
+  const int jx = blockIdx.x >> 3;
+  const int mt = (blockIdx.x & 7) * per_xcd + jx / ntiles;
+  if (mt >= mtiles) return;
+  const int n0 = (jx % ntiles) << 8, m0 = mt << 8;
+  const int KT = Kp >> 5;
+
+  if (w >= 8) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = w - 8;
+    const int lrow = l >> 2, lch = l & 3;     // a DMA instruction covers 16 rows x 64 bytes
+    const uint16_t* gW[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (lw * 4 + j) * 16 + lrow;
+      gW[j] = a.W + (size_t)(n0 + row) * Kp + (lch ^ ((row >> 2) & 3)) * 8;
+    }
+    const uint16_t* ibase[4];
+    int iy0[4], ix0[4], kc[4];
+    bool pv[4];
+    const int hw = a.Ho * a.Wo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (lw * 4 + j) * 16 + lrow;
+      const int p = m0 + row;
+      pv[j] = p < M;
+      const int pp = pv[j] ? p : 0;
+      const int f = pp / hw, r = pp - f * hw;
+      const int y = r / a.Wo, x = r - y * a.Wo;
+      iy0[j] = y * a.stride - a.pad;
+      ix0[j] = x * a.stride - a.pad;
+      ibase[j] = a.In + (size_t)f * a.Hi * a.Wi * a.Ci;
+      kc[j] = (lch ^ ((row >> 2) & 3)) * 8;
+    }
+    const uint16_t* zp = a.zeros + lch * 8;
+    auto issue = [&](int kt) {
+      uint16_t* slot = smem + (kt & 3) * STAGE;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + kt * 32), (lvoid_t*)(slot + (lw * 4 + j) * 16 * 32), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k0 = kt * 32 + kc[j];
+        const int tap = k0 >> a.ci_shift, ci = k0 & (a.Ci - 1);
+        const int ky = (a.ksize == 3) ? (tap * 11) >> 5 : 0;
+        const int kx = tap - 3 * ky;
+        const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+        const bool ok = pv[j] && k0 < a.K && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+        const uint16_t* g = ok ? ibase[j] + (((size_t)iy * a.Wi + ix) << a.ci_shift) + ci : zp;
+        __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(slot + 256 * 32 + (lw * 4 + j) * 16 * 32), 16, 0, 0);
+      }
+    };
+    const bool do_loads = !(a.dbg & 4);
+    if (do_loads) for (int kt = 0; kt < 4 && kt < KT; ++kt) issue(kt);
+    for (int kt = 0; kt < KT; ++kt) {
+      const int later = (kt == 0) ? min(3, KT - 1) : min(2, KT - 1 - kt);
+      if (later >= 3) ACEZ_VMCNT(24);
+      else if (later == 2) ACEZ_VMCNT(16);
+      else if (later == 1) ACEZ_VMCNT(8);
+      else ACEZ_VMCNT(0);
+      __builtin_amdgcn_s_barrier();   // stage kt has landed; the multipliers are done with stage kt - 1
+      if (do_loads && kt >= 1 && kt + 3 < KT) issue(kt + 3);
+    }
+    __builtin_amdgcn_s_barrier();     // the multipliers have left the K loop: the ring is free
+    if (HAS_ADD) {
+      // residual tile [256][256] -> ring space, 128 DMA instructions of 2 rows x 512 bytes (32 per loader)
+      for (int j = 0; j < 32; ++j) {
+        const int row = (lw * 32 + j) * 2 + (l >> 5);
+        const uint16_t* g = a.add + (size_t)min(m0 + row, M - 1) * Co + n0 + (((l & 31) ^ (row & 31)) << 3);
+        __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(smem + (lw * 32 + j) * 2 * 256), 16, 0, 0);
+      }
+      ACEZ_VMCNT(0);
+      __builtin_amdgcn_s_barrier();   // residual tile landed
+    }
+    __builtin_amdgcn_s_barrier();     // output tile written
+  } else {
+    // ------------------------------------------------------------------ multiplier waves
+    const int wm = w >> 2, wn = w & 3;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fr = l & 31, fh = l >> 5;
+    for (int kt = 0; kt < KT; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      if (a.dbg & 2) continue;
+      const uint16_t* sW = smem + (kt & 3) * STAGE;
+      const uint16_t* sI = sW + 256 * 32;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int c = kk * 2 + fh;
+        bf16x8 fa[2], fb[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz32(wn * 64 + i * 32 + fr, c)]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz32(wm * 128 + j * 32 + fr, c)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();     // ring free
+    if (HAS_ADD) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ml = wm * 128 + j * 32 + fr;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nl = wn * 64 + i * 32 + 8 * q + 4 * fh;
+          const float4 b = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+          float v[4] = {acc[i][j][4 * q + 0] + b.x, acc[i][j][4 * q + 1] + b.y, acc[i][j][4 * q + 2] + b.z, acc[i][j][4 * q + 3] + b.w};
+          if (RELU) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+          }
+          uint16_t* po = &smem[st_off256(ml, nl)];
+          if (HAS_ADD) {
+            float ad[4];
+            unpack4(*reinterpret_cast<const uint2*>(po), ad);
+            v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
+          }
+          *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // ------------------------------------------------------------------ all twelve waves: copy the tile out, full 512-byte rows
+  for (int q = t; q < 256 * 32; q += 768) {
+    const int row = q >> 5, ch = q & 31, m = m0 + row;
+    if (m < M)
+      *reinterpret_cast<uint4*>(a.out + (size_t)m * Co + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&smem[row * 256 + ((ch ^ (row & 31)) << 3)]);
+  }
+}
+
+// tile_mode: 0 = choose by size, 80 / 256 = force that row tile where the layer shape allows it (ACEZ_CONV_TILE, tests)
+static void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s, int tile_mode) {
+  const bool huge_ok = g.Co % 256 == 0 && g.Kp >= 256;
+  if (huge_ok && (tile_mode == 512 || (tile_mode == 0 && (int64_t)((g.M + 255) / 256) * (g.Co / 256) >= 4 * 256))) {
+    const int ntiles = g.Co / 256, mtiles = (g.M + 255) / 256;
+    const dim3 grid(8 * ntiles * ((mtiles + 7) / 8)), blk(768);
+    if (g.add) {
+      if (!relu) abort();
+      hipLaunchKernelGGL((convgemm512_kernel<true, true>), grid, blk, 0, s, g);
+    } else if (relu) {
+      hipLaunchKernelGGL((convgemm512_kernel<true, false>), grid, blk, 0, s, g);
+    } else {
+      hipLaunchKernelGGL((convgemm512_kernel<false, false>), grid, blk, 0, s, g);
+    }
+    return;
+  }
+  const bool big_ok = g.Co % 128 == 0 && g.Kp >= 192;
+  if (big_ok && (tile_mode == 256 || (tile_mode == 0 && g.M >= 256 * 128))) {
+    // enough rows to fill the chip with 256-row tiles
+    const int ntiles = g.Co / 128, mtiles = (g.M + 255) / 256;
+    const dim3 grid(8 * ntiles * ((mtiles + 7) / 8)), blk(1024);
+    if (g.add) {
+      if (!relu) abort();
+      hipLaunchKernelGGL((convgemm256_kernel<true, true>), grid, blk, 0, s, g);
+    } else if (relu) {
+      hipLaunchKernelGGL((convgemm256_kernel<true, false>), grid, blk, 0, s, g);
+    } else {
+      hipLaunchKernelGGL((convgemm256_kernel<false, false>), grid, blk, 0, s, g);
+    }
+    return;
+  }
   const int nt = (g.Co % 128 == 0) ? 128 : 64;
   const int ntiles = g.Co / nt;
   const int mtiles = (g.M + 79) / 80;
@@ -249,7 +604,6 @@ static void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s) {
     hipLaunchKernelGGL((convgemm_kernel<128, false, false>), grid, blk, 0, s, g);
   }
 }
-
 
 // ---------------------------------------------------------------------------------------------------
 // Training-buffer sampling (ace_trainer.py:404-431): per view, `samples` feature rows are drawn uniformly WITH replacement
@@ -360,7 +714,7 @@ float host_bf2f(uint16_t h) {
 }  // namespace
 
 struct acez_encoder {
-  int device = 0, out_channels = 512, max_frames = 0, max_h = 0, max_w = 0;
+  int device = 0, out_channels = 512, max_frames = 0, max_h = 0, max_w = 0, tile_mode = 0;
   float* w1 = nullptr;                 // conv1 weights [32][9] (bf16-rounded values in fp32) followed by nothing
   float* bias[ACEZ_ENCODER_LAYERS] = {};
   uint16_t* W[ACEZ_ENCODER_LAYERS] = {};   // bf16 [co][Kp] (layers 1..10)
@@ -388,6 +742,7 @@ extern "C" int acez_encoder_create(acez_encoder** out, const float* const* h_wei
   ACEZ_HIP_CHECK(hipSetDevice(device));
   acez_encoder* e = new acez_encoder();
   e->device = device; e->out_channels = out_channels; e->max_frames = max_frames; e->max_h = max_h; e->max_w = max_w;
+  if (const char* tm = getenv("ACEZ_CONV_TILE")) e->tile_mode = atoi(tm);
   auto A = [&](void** p, size_t bytes) -> hipError_t {
     hipError_t rc = hipMalloc(p, bytes);
     if (rc == hipSuccess) e->allocs.push_back(*p);
@@ -474,7 +829,8 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
       g.In = in; g.W = e->W[li]; g.bias = e->bias[li]; g.add = add; g.out = outp; g.zeros = e->zeros;
       g.Hi = hi; g.Wi = wi; g.Ci = L.ci; g.ci_shift = __builtin_ctz(L.ci); g.Ho = ho; g.Wo = wo; g.Co = e->co[li];
       g.ksize = L.k; g.stride = L.stride; g.pad = L.k / 2; g.K = e->K[li]; g.Kp = e->Kp[li]; g.M = F * ho * wo;
-      launch_convgemm(g, relu, s);
+      if (const char* d = getenv("ACEZ_CONV_DBG")) g.dbg = atoi(d);
+      launch_convgemm(g, relu, s, e->tile_mode);
     };
     conv(1, e->a1, h, w, e->a2, h2, w2, nullptr, true);
     conv(2, e->a2, h2, w2, e->a3, h4, w4, nullptr, true);

@@ -13,9 +13,11 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+@pytest.mark.parametrize("tile", ["0", "80", "256", "512"])
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 120, 200), (3, 41, 77)])
-def test_encoder_matches_bf16_oracle(shape):
+def test_encoder_matches_bf16_oracle(shape, tile, monkeypatch):
     from acezero_amd.encoder import Encoder, output_size
+    monkeypatch.setenv("ACEZ_CONV_TILE", tile)   # 256: the large-M kernel on small inputs (ragged last tiles everywhere)
     n, h, w = shape
     sd = encoder_oracle.init_weights(seed=4099)
     img = torch.from_numpy(synth.make_gray_images(seed=5 + h, n=n, h=h, w=w))
