@@ -105,7 +105,7 @@ __device__ bool inv4x4(const double Ain[16], double out[16]) {
 
 constexpr int MAX_PIX_PER_THREAD = 32;  // N <= 8192
 
-__global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
+__global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = a.N, H = a.H, W = a.W;
   const int Npad = (N + 3) & ~3;
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
   float* sErr = sZ + Npad;
   double* sRed = reinterpret_cast<double*>(sErr + Npad);  // [2][4][28]
   double* sScores = sRed + 2 * 4 * 28;                    // [hyps]
-  int* sInt = reinterpret_cast<int*>(sScores + a.hyps);   // [8]: best, counts[4]
+  double* sHyp = sScores + a.hyps;                        // [hyps][6] sampled poses
+  int* sInt = reinterpret_cast<int*>(sHyp + 6 * a.hyps);  // [8]: best, counts[4]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frame = blockIdx.x;
@@ -136,18 +137,24 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
   // ---- sample + score: hypothesis h on wavefront h % 4
   const float inlierBeta = 5 / a.thr;
   const float score_scale = a.alpha / (float)W / (float)H;
-  for (int h = wave; h < a.hyps; h += 4) {
-    Pose res;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) res.r[i] = res.t[i] = 0;
-    bool found = false;
-    for (int t0 = 0; t0 < a.max_tries && !found; t0 += 64) {
-      const int t = t0 + lane;
+  // Sampling (dsacstar_util.h:135-221): the sequential loop keeps, per hypothesis, the FIRST try whose P3P pose passes the
+  // 4-point check. Tries are independent draws of the counter-based stream, so they are evaluated in parallel and the first
+  // accepted one is picked with a ballot: a wavefront works on 8 of its hypotheses at once, 8 tries each (lane = 8 * slot +
+  // try); almost every hypothesis is settled by the first batch, so the whole workgroup needs ONE P3P latency for 32
+  // hypotheses instead of eight. Hypothesis h lives on wavefront h % 4 (as does its scoring below).
+  for (int pass = 0; wave + 4 * (8 * pass) < a.hyps; ++pass) {
+    const int slot = lane >> 3, tr = lane & 7;
+    const int h = wave + 4 * (8 * pass + slot);
+    const bool hvalid = h < a.hyps;
+    bool settled = !hvalid;   // of this lane's slot
+    for (int t0 = 0; t0 < a.max_tries; t0 += 8) {
+      if (__ballot(!settled) == 0ull) break;
+      const int t = t0 + tr;
       Pose cur;
 #pragma unroll
       for (int i = 0; i < 3; ++i) cur.r[i] = cur.t[i] = 0;
       int status = 0;  // 0: PnP failed (zero pose), 1: solved but rejected by the 4-point check, 2: accepted
-      if (t < a.max_tries) {
+      if (!settled && t < a.max_tries) {
         const uint64_t key = rsm::try_key(a.seed, fp.frame_id, (uint32_t)h, (uint32_t)t);
         float obj[4][3], img[4][2];
 #pragma unroll
@@ -179,20 +186,32 @@ __global__ __launch_bounds__(256) void ransac_kernel(RansacArgs a) {
         }
       }
       const unsigned long long ok = __ballot(status == 2);
-      int src = -1;
-      if (ok) {
-        src = __ffsll((long long)ok) - 1;
-        found = true;
-      } else if (t0 + 64 >= a.max_tries) {
-        src = a.max_tries - 1 - t0;  // every try failed: the last try's pose stays (dsacstar_util.h:157-220)
-      }
-      if (src >= 0) {
+      if (!settled) {
+        const unsigned g = (unsigned)(ok >> (slot * 8)) & 0xffu;
+        int src = -1;
+        if (g) src = __ffs((int)g) - 1;                                  // first accepted try of this batch
+        else if (t0 + 8 >= a.max_tries) src = a.max_tries - 1 - t0;      // every try failed: the last try's pose stays (:157-220)
+        if (src >= 0) {
+          settled = true;
+          if (tr == src) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          res.r[i] = shfl_d(cur.r[i], src);
-          res.t[i] = shfl_d(cur.t[i], src);
+            for (int i = 0; i < 3; ++i) {
+              sHyp[h * 6 + i] = cur.r[i];
+              sHyp[h * 6 + 3 + i] = cur.t[i];
+            }
+          }
         }
       }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();   // the poses of this wave's hypotheses are written by its own lanes
+  for (int h = wave; h < a.hyps; h += 4) {
+    Pose res;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      res.r[i] = sHyp[h * 6 + i];
+      res.t[i] = sHyp[h * 6 + 3 + i];
     }
     // score this hypothesis
     double R[9];
@@ -548,7 +567,7 @@ extern "C" int acez_register_rgb_device(acez_ransac* ctx, const float* d_scene_c
   a.hyp_poses = ctx->d_hyp_poses; a.scores = ctx->d_scores; a.best = ctx->d_best; a.refined = ctx->d_refined;
   a.out_poses = d_out_poses; a.out_inliers = d_out_inliers; a.out_masks = d_out_masks;
   const int Npad = (a.N + 3) & ~3;
-  const size_t lds = (size_t)4 * Npad * sizeof(float) + (size_t)(2 * 4 * 28 + params->hypotheses) * sizeof(double) + 8 * sizeof(int);
+  const size_t lds = (size_t)4 * Npad * sizeof(float) + (size_t)(2 * 4 * 28 + 7 * params->hypotheses) * sizeof(double) + 8 * sizeof(int);
   ACEZ_REQUIRE(lds <= 160 * 1024, "frame + hypotheses do not fit the 160 KB LDS of a CU");
   ACEZ_HIP_CHECK(hipFuncSetAttribute((const void*)ransac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(ransac_kernel, dim3(n_frames), dim3(256), lds, s, a);
