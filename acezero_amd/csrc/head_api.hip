@@ -38,6 +38,7 @@ struct acez_trainer {
   float *log_loss = nullptr, *log_inl = nullptr;
   int log_cap = 0;
   TrainState* st = nullptr;
+  GradReduceArgs last_reduce{};   // partial buffers of the last backward (input of the fused update)
   bool post_pending = false;   // acez_train_update has run; its schedule bookkeeping rides with the next step's gather (flush_post)
   SchedConfig sc;
   std::vector<void*> allocs;
@@ -243,6 +244,7 @@ static void fill_adam_args(acez_trainer* tr, AdamArgs& a) {
   for (int l = 0; l < tr->L; ++l) { a.w_off[l] = (int64_t)l * 262656; a.b_off[l] = a.w_off[l] + 262144; }
   a.fc3_off = tr->fc3_off; a.n_fc3 = (int64_t)tr->no * 513; a.n_params = tr->n_params;
   a.n_layers = tr->L; a.no = tr->no; a.st = tr->st;
+  a.slabs = nullptr; a.nslabs = 0; a.slab_stride = 0;
 }
 
 extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
@@ -392,7 +394,7 @@ static void flush_post(acez_trainer* tr, hipStream_t s) {
   hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap);
 }
 
-extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, int n, void* stream) {
+static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n, void* stream, bool fused) {
   ACEZ_REQUIRE(tr && d_indices, "null pointer");
   ACEZ_REQUIRE(tr->have_buf, "acez_trainer_set_buffer has not been called");
   ACEZ_REQUIRE(n > 0 && n <= tr->max_batch, "n must be in [1, max_batch]");
@@ -501,23 +503,33 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
     a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials; a.n_loss_blocks = nblk; a.grad = tr->pb.d_grad;
     a.n_wide = tr->n_wide; a.n_params = tr->n_params; a.st = st;
     a.bias_partials = tr->bias_partials; a.bias_layer_stride = tr->bias_layer_stride; a.n_layers = tr->L;
+    a.skip_wide = fused ? 1 : 0;
     for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2) ? nblk : (tr->gemm_tile == 80 ? (n + 79) / 80 : 2 * ((n + 127) / 128));
-    const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
-    const int64_t tail_blocks = (((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4) * 64 + 255) / 256;
-    ProfScope ps(tr, s, KC_REDUCE);
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, a);
+    tr->last_reduce = a;   // the fused update reduces the partials itself
+    if (!fused) {
+      const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
+      const int64_t tail_blocks = (((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4) * 64 + 255) / 256;
+      ProfScope ps(tr, s, KC_REDUCE);
+      hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, a);
+    }
   }
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
 }
 
-extern "C" int acez_train_update(acez_trainer* tr, void* stream) {
+extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, int n, void* stream) {
+  return train_backward_impl(tr, d_indices, n, stream, false);
+}
+
+static int train_update_impl(acez_trainer* tr, void* stream, bool fused) {
   ACEZ_REQUIRE(tr, "null trainer");
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   hipStream_t s = (hipStream_t)stream;
   AdamArgs a;
   fill_adam_args(tr, a);
-  const int nsmall = (int)(((int64_t)tr->L * 512 + (int64_t)tr->no * 513 + 255) / 256);
+  if (fused) { a.slabs = tr->slabs; a.nslabs = tr->nslabs; a.slab_stride = tr->n_wide; a.tail = tr->last_reduce; }
+  const int64_t n_small = (int64_t)tr->L * 512 + (int64_t)tr->no * 513;
+  const int nsmall = fused ? (int)(((n_small + 4) * 64 + 255) / 256) : (int)((n_small + 255) / 256);   // fused: a wave per output
   { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3(tr->L * 64 + nsmall), dim3(256), 0, s, a); }
   if (tr->cfg.pose_refinement != 0)
     hipLaunchKernelGGL(adamw_small_kernel, dim3((unsigned)((tr->pb.n_pose_params + 255) / 256)), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,
@@ -528,10 +540,15 @@ extern "C" int acez_train_update(acez_trainer* tr, void* stream) {
   return ACEZ_OK;
 }
 
+extern "C" int acez_train_update(acez_trainer* tr, void* stream) { return train_update_impl(tr, stream, false); }
+
+// Single-GPU step: backward + update with the wide-layer gradients handed from the weight-gradient slabs straight to the
+// optimiser (no flat-gradient round trip through HBM). Bitwise the same parameters as acez_train_backward + acez_train_update;
+// afterwards d_grad holds the bias / fc3 gradients and the statistics, its wide-layer weight part is NOT written.
 extern "C" int acez_train_step(acez_trainer* tr, const int64_t* d_indices, int n, void* stream) {
-  int rc = acez_train_backward(tr, d_indices, n, stream);
+  int rc = train_backward_impl(tr, d_indices, n, stream, true);
   if (rc != ACEZ_OK) return rc;
-  return acez_train_update(tr, stream);
+  return train_update_impl(tr, stream, true);
 }
 
 extern "C" int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out, void* stream) {

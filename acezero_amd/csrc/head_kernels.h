@@ -124,6 +124,7 @@ struct GradReduceArgs {
   float* grad;
   int64_t n_wide, n_params;
   const TrainState* st;
+  int skip_wide;   // fused single-GPU step: the slabs are summed by adamw_kernel itself, only the tail is reduced here
 };
 
 struct AdamArgs {
@@ -138,6 +139,12 @@ struct AdamArgs {
   int64_t fc3_off, n_fc3, n_params;
   int n_layers, no;
   const TrainState* st;
+  // fused single-GPU step (acez_train_step): wide-layer gradients are read as the fixed-order sum of the wgrad slabs
+  // (the same additions grad_reduce_kernel performs) instead of from `grad`; null in the backward / all-reduce / update flow
+  const float* slabs;
+  int nslabs;
+  int64_t slab_stride;
+  GradReduceArgs tail;   // with slabs != null: the partials of the small parameters and statistics (reduced here as well)
 };
 
 }  // namespace acez

@@ -973,32 +973,14 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
 // grad_reduce: flat gradient = fixed-order sum of the wgrad slabs (wide layers) and of the per-workgroup
 // partials of the loss kernel (fc3 + statistics). Deterministic: no atomics anywhere in the step.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
-  if (a.st && !a.st->active) return;
-  const int wide_blocks = (int)((a.n_wide / 4 + 255) / 256);
-  if ((int)blockIdx.x < wide_blocks) {  // weights: 16-byte loads, slabs summed in slab order
-    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i4 >= a.n_wide) return;
-    if ((i4 % 262656) >= 262144) return;  // bias slots are produced by the tail path below
-    float4 acc = *reinterpret_cast<const float4*>(a.slabs + i4);
-    for (int s = 1; s < a.nslabs; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)s * a.slab_stride + i4);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    *reinterpret_cast<float4*>(a.grad + i4) = acc;
-    return;
-  }
-  // tail: one wavefront per output -- the biases of the wide layers (column-sum partials written where each dZ is
-  // produced), fc3 weights/bias, then the 4 statistics. Lane-strided partial sums followed by the fixed butterfly
-  // order: deterministic. (A two-level "32 outputs x 8 groups" variant with coalesced reads measured 2-4x slower: its
-  // 80-deep dependent add chains are latency bound.)
-  const int lane = threadIdx.x & 63;
-  const int64_t k = ((int64_t)(blockIdx.x - wide_blocks) * 256 + threadIdx.x) >> 6;
+// tail outputs, one wavefront per output: the biases of the wide layers (column-sum partials written where each dZ is
+// produced), fc3 weights/bias, then the 4 statistics. Lane-strided partial sums followed by the fixed butterfly order:
+// deterministic; every lane returns the sum. (A two-level "32 outputs x 8 groups" variant with coalesced reads measured
+// 2-4x slower: its 80-deep dependent add chains are latency bound.) Shared by grad_reduce_kernel and the fused adamw_kernel.
+__device__ __forceinline__ float tail_output(const GradReduceArgs& a, int64_t k, int lane, int64_t& dst) {
   const int64_t n_bias = (int64_t)a.n_layers * 512;
   const int64_t n_fc3 = a.n_params - a.n_wide;
-  if (k >= n_bias + n_fc3 + 4) return;
   float acc = 0.f;
-  int64_t dst;
   if (k < n_bias) {
     const int layer = (int)(k >> 9), c = (int)(k & 511);
     const float* p = a.bias_partials + (size_t)layer * a.bias_layer_stride + c;
@@ -1017,6 +999,30 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
+  if (a.st && !a.st->active) return;
+  const int wide_blocks = (int)((a.n_wide / 4 + 255) / 256);
+  const int bx = (int)blockIdx.x + (a.skip_wide ? wide_blocks : 0);
+  if (bx < wide_blocks) {  // weights: 16-byte loads, slabs summed in slab order
+    const int64_t i4 = ((int64_t)bx * 256 + threadIdx.x) * 4;
+    if (i4 >= a.n_wide) return;
+    if ((i4 % 262656) >= 262144) return;  // bias slots are produced by the tail path below
+    float4 acc = *reinterpret_cast<const float4*>(a.slabs + i4);
+    for (int s = 1; s < a.nslabs; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)s * a.slab_stride + i4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(a.grad + i4) = acc;
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t k = ((int64_t)(bx - wide_blocks) * 256 + threadIdx.x) >> 6;
+  if (k >= (int64_t)a.n_layers * 512 + (a.n_params - a.n_wide) + 4) return;
+  int64_t dst;
+  const float acc = tail_output(a, k, lane, dst);
   if (lane == 0) a.grad[dst] = acc;
 }
 
@@ -1026,6 +1032,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
 // fc3 are handled by the trailing workgroups.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float adamw_one(float p, float g, float& m, float& v, const AdamScalars& s) {
+  // no fma contraction here: the function is inlined at several sites (tile path, small-parameter path, fused path) and
+  // every site must round identically -- acez_train_step is bitwise equal to backward + update
+#pragma clang fp contract(off)
   p = p * s.decay;                       // p.mul_(1 - lr * wd)
   m = m + (g - m) * s.one_minus_beta1;   // exp_avg.lerp_(grad, 1 - beta1)
   v = v * s.beta2 + s.one_minus_beta2 * g * g;
@@ -1036,7 +1045,13 @@ __device__ __forceinline__ float adamw_one(float p, float g, float& m, float& v,
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   const TrainState* st = a.st;
   if (!st->active) return;
-  const float lossv = a.grad[a.n_params];
+  float lossv;
+  if (a.slabs) {   // fused step: the statistics are still partials; every wave sums the loss for itself
+    int64_t d;
+    lossv = tail_output(a.tail, (int64_t)a.n_layers * 512 + a.n_fc3, threadIdx.x & 63, d);
+  } else {
+    lossv = a.grad[a.n_params];
+  }
   if (lossv != lossv) return;  // NaN loss: the reference aborts before the optimiser step (ace_trainer.py:615-617)
   const AdamScalars s = st->adam;
   __shared__ uint16_t tileT[64][66];
@@ -1054,7 +1069,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
       const int rr = (t >> 4) + 16 * i;
       const int64_t o = woff + (int64_t)(r0 + rr) * 512 + c0 + cc;
       float4 p = *reinterpret_cast<float4*>(a.params + o);
-      const float4 g = *reinterpret_cast<const float4*>(a.grad + o);
+      float4 g;
+      if (a.slabs) {   // same additions, in the same order, as grad_reduce_kernel's wide part
+        g = *reinterpret_cast<const float4*>(a.slabs + o);
+        for (int sl = 1; sl < a.nslabs; ++sl) {
+          const float4 q = *reinterpret_cast<const float4*>(a.slabs + (size_t)sl * a.slab_stride + o);
+          g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
+        }
+      } else {
+        g = *reinterpret_cast<const float4*>(a.grad + o);
+      }
       float4 m = *reinterpret_cast<float4*>(a.m + o);
       float4 v = *reinterpret_cast<float4*>(a.v + o);
       p.x = adamw_one(p.x, g.x, m.x, v.x, s);
@@ -1083,8 +1107,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   } else {
     // small parameters: biases of the wide layers, fc3 weight + bias
     const int sb = b - a.n_layers * tiles_per_layer;
-    const int64_t k = (int64_t)sb * 256 + t;
     const int64_t n_bias = (int64_t)a.n_layers * 512;
+    if (a.slabs) {
+      // fused step: one wavefront per output reduces the partials (exactly grad_reduce_kernel's tail), stores the
+      // gradient / statistic and applies the optimiser to it
+      const int lane = t & 63;
+      const int64_t k = ((int64_t)sb * 256 + t) >> 6;
+      if (k >= n_bias + a.n_fc3 + 4) return;
+      int64_t o;
+      const float g = tail_output(a.tail, k, lane, o);
+      if (lane != 0) return;
+      a.tail.grad[o] = g;
+      if (k < n_bias + a.n_fc3) {
+        float p = a.params[o], m = a.m[o], v = a.v[o];
+        p = adamw_one(p, g, m, v, s);
+        a.params[o] = p; a.m[o] = m; a.v[o] = v;
+        if (k >= n_bias && (k - n_bias) < (int64_t)a.no * 512) a.W3b[k - n_bias] = f2bf(p);
+      }
+      return;
+    }
+    const int64_t k = (int64_t)sb * 256 + t;
     int64_t o = -1;
     if (k < n_bias) o = a.b_off[k >> 9] + (k & 511);
     else if (k < n_bias + a.n_fc3) o = a.fc3_off + (k - n_bias);

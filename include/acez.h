@@ -236,7 +236,9 @@ int acez_trainer_sync_weights(acez_trainer* tr, void* stream);
  * (iteration >= max_iterations, ace_trainer.py:509-510) is a device-side no-op. */
 int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, int n, void* stream);
 int acez_train_update(acez_trainer* tr, void* stream);
-/* Convenience: backward + update. */
+/* Single-GPU step = backward + update, with the wide-layer weight gradients handed from the split-K slabs straight to the
+ * optimiser: bitwise the same parameters as the two calls above; afterwards d_grad holds the bias / fc3 gradients and the
+ * statistics only (its wide-layer weight part is not written). Use backward / all-reduce / update when ranks exchange d_grad. */
 int acez_train_step(acez_trainer* tr, const int64_t* d_indices, int n, void* stream);
 /* Synchronises `stream` and copies the schedule state. */
 int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out, void* stream);

@@ -87,7 +87,9 @@ def test_training_steps_match_oracle_and_golden(name):
         assert abs(grad[n_params] / cfg["global_batch"] - rec["loss"]) < 2e-3 * abs(rec["loss"])
         assert abs(grad[n_params + 1] / cfg["global_batch"] - rec["inliers"]) <= 2.0 / cfg["global_batch"]
         go = rec["grad"].numpy()
-        assert _rel(grad[:n_params], go) < 5e-3, _rel(grad[:n_params], go)
+        # bf16 roundings of activations / propagated gradients flip by one ulp between the two summation orders: 3-5e-3 on the
+        # full gradient vector, depending on the step
+        assert _rel(grad[:n_params], go) < 8e-3, _rel(grad[:n_params], go)
         if mlp:
             assert _rel(grad[n_params + 4:], rec["pose_grad"].numpy()) < 5e-3, _rel(grad[n_params + 4:], rec["pose_grad"].numpy())
             pose_before = tr.pose_params.cpu().numpy().copy()
@@ -158,3 +160,21 @@ def test_full_batch_gradient_additivity_and_determinism():
     assert abs(float(parts[n] - g_full[n])) < 1e-3 * abs(float(g_full[n]))
     assert float(parts[n + 1]) == float(g_full[n + 1])
     assert torch.isfinite(g_full).all() and float(g_full[:n].abs().sum()) > 0
+
+
+def test_fused_step_equals_backward_plus_update_bitwise():
+    """acez_train_step hands the wgrad slabs straight to AdamW; parameters must match the two-call flow bit for bit."""
+    prob, flat0 = helpers.golden_problem()
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
+    trs = [_trainer(prob, flat0, cfg) for _ in range(2)]
+    batches = helpers.golden_batches(prob, 4)
+    for idx in batches:
+        di = torch.from_numpy(idx.astype(np.int64)).cuda()
+        trs[0].step(di)
+        trs[1].backward(di)
+        trs[1].update()
+    torch.cuda.synchronize()
+    assert torch.equal(trs[0].params, trs[1].params)
+    assert torch.equal(trs[0].adam_m, trs[1].adam_m) and torch.equal(trs[0].adam_v, trs[1].adam_v)
+    a, b = trs[0].state(), trs[1].state()
+    assert a["iteration"] == b["iteration"] == 4 and a["loss"] == b["loss"] and a["lr"] == b["lr"]
