@@ -738,6 +738,12 @@ extern "C" int acez_encoder_create(acez_encoder** out, const float* const* h_wei
   ACEZ_REQUIRE(out_channels > 0 && out_channels % 128 == 0, "out_channels must be a positive multiple of 128");
   ACEZ_REQUIRE(max_frames > 0 && max_h >= 8 && max_w >= 8, "bad capacity");
   for (int i = 0; i < ACEZ_ENCODER_LAYERS; ++i) ACEZ_REQUIRE(h_weights[i] && h_biases[i], "null layer pointer");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    (void)hipGetLastError();
+    acez::set_error("no HIP device visible: the encoder kernels need a gfx950 GPU (there is no CPU fallback)");
+    return ACEZ_ERR_NODEVICE;
+  }
   if (device < 0) ACEZ_HIP_CHECK(hipGetDevice(&device));
   ACEZ_HIP_CHECK(hipSetDevice(device));
   acez_encoder* e = new acez_encoder();
@@ -855,6 +861,14 @@ extern "C" int acez_buffer_sample_views(const void* d_view_features, const uint8
   ACEZ_REQUIRE(n_views > 0 && map_h > 0 && map_w > 0 && samples_per_view > 0, "bad shape");
   ACEZ_REQUIRE(map_h * map_w <= SAMPLE_MAX_HW, "feature map too large for the sampling kernel (24576 pixels)");
   ACEZ_REQUIRE(channels > 0 && channels % 8 == 0, "channels must be a multiple of 8");
+  {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+      (void)hipGetLastError();
+      acez::set_error("no HIP device visible: buffer sampling runs on a gfx950 GPU (there is no CPU fallback)");
+      return ACEZ_ERR_NODEVICE;
+    }
+  }
   const int hw = map_h * map_w;
   int split = (samples_per_view + 255) / 256;   // ~256 samples per workgroup
   if (split > 64) split = 64;

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported():
 def test_library_contains_gfx950_code_objects():
     blob = open(os.path.join(ROOT, "acezero_amd", "libacez.so"), "rb").read()
     assert b"gfx950" in blob
-    for kern in (b"rowgemm_kernel", b"wgrad_kernel", b"loss_kernel", b"adamw_kernel", b"ransac_kernel"):
+    for kern in (b"rowgemm80_kernel", b"wgrad_kernel", b"loss_kernel", b"adamw_kernel", b"ransac_kernel", b"convgemm512_kernel", b"sample_views_kernel"):
         assert kern in blob, kern
 
 
@@ -42,6 +42,22 @@ def test_no_silent_cpu_fallback():
         dsacstar.forward_rgb(torch.zeros(1, 3, 60, 80), torch.zeros(4, 4), 8, 10.0, 525.0, 320.0, 240.0, 100.0, 100.0, 8, 1, 16)
     with pytest.raises(RuntimeError):
         head.HeadTrainer([0, 0, 0])
+    # section E (encoder / buffer sampling): same rule
+    import numpy as np
+    from acezero_amd import synth
+    sd = synth.init_encoder_weights()
+    names = ["conv1", "conv2", "conv3", "conv4", "res1_conv1", "res1_conv2", "res1_conv3", "res2_conv1", "res2_conv2", "res2_conv3", "res2_skip"]
+    wp = (C.c_void_p * 11)(*[sd[n + ".weight"].ctypes.data for n in names])
+    bp = (C.c_void_p * 11)(*[sd[n + ".bias"].ctypes.data for n in names])
+    e = C.c_void_p()
+    assert lib.acez_encoder_create(C.byref(e), wp, bp, 512, 1, 64, 64, -1) == -3
+    assert b"no HIP device" in lib.acez_last_error()
+    dummy = np.zeros(16, np.float32)
+    assert lib.acez_buffer_sample_views(dummy.ctypes.data, None, 1, 2, 2, 8, 4, 1, 0, 0, dummy.ctypes.data, dummy.ctypes.data,
+                                        dummy.ctypes.data, None, None) == -3
+    from acezero_amd import encoder
+    with pytest.raises(RuntimeError):
+        encoder.Encoder({k: torch.from_numpy(v) for k, v in sd.items()})
 
 
 def test_argument_validation_without_device():
@@ -49,5 +65,10 @@ def test_argument_validation_without_device():
     assert lib.acez_ransac_create(None, 1, 60, 80, -1) == -1
     hd = N.HeadDesc(1, 1, (C.c_float * 3)(0, 0, 0), 0.25, 100.0, 0.9)
     assert lib.acez_head_num_params(C.byref(hd)) == 2103300
+    oh, ow = C.c_int(0), C.c_int(0)
+    assert lib.acez_encoder_output_size(480, 640, C.byref(oh), C.byref(ow)) == 0 and (oh.value, ow.value) == (60, 80)
+    assert lib.acez_encoder_output_size(41, 77, C.byref(oh), C.byref(ow)) == 0 and (oh.value, ow.value) == (6, 10)
+    assert lib.acez_encoder_create(None, None, None, 512, 1, 64, 64, -1) == -1
+    assert lib.acez_buffer_sample_views(None, None, 1, 2, 2, 8, 4, 1, 0, 0, None, None, None, None, None) == -1
     hd0 = N.HeadDesc(0, 0, (C.c_float * 3)(0, 0, 0), 0.25, 100.0, 0.9)
     assert lib.acez_head_num_params(C.byref(hd0)) == 5 * 262656 + 3 * 513
