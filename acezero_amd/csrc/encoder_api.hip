@@ -76,6 +76,171 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ im
   for (int i = 0; i < 4; ++i) o[i] = make_uint4(pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// conv12: conv1 (1 -> 32, stride 1) and conv2 (32 -> 64, stride 2) fused, persistent over 8 x 32 output tiles of conv2.
+// As separate kernels these two layers cost 27 % of the encoder's time for 5 % of its FLOPs: conv1's 32-channel map
+// (19.7 MB per 480 x 640 frame) is written and read back, and conv2's 3 x 3 taps re-read it nine times from L2 into a
+// GEMM that is only 64 columns wide. Here a workgroup keeps the conv1 patch of its tile in LDS:
+//   1. image patch 19 x 67 (grey, rounded to bf16) -> LDS; the next tile's patch is already in flight in registers;
+//   2. conv1 on the matrix cores: 35 fragments of 32 patch pixels, B = the 9 taps gathered from the image patch (K = 16),
+//      A = conv1's weights (one register quad), bias + ReLU + bf16 -> conv1 patch [2 column-parity planes][17][33][32 ch]
+//      in LDS (zero outside the image: that is conv2's padding);
+//   3. conv2: wave w owns output row w of the tile (32 pixels x 64 channels); its B fragments are read straight from the
+//      patch (tap (ky, kx) of output x = plane kx & 1, column x + (kx >> 1): unit stride, 16-byte chunk XOR (col >> 2) & 3
+//      -> conflict free), its A fragments (all of conv2's 64 x 288 weights) live in 144 registers for the whole kernel;
+//   4. bias + ReLU + bf16 through a wave-private staging row, 4 KiB contiguous store per output row.
+// ---------------------------------------------------------------------------------------------------
+struct Conv12Args {
+  const float* img;        // [F][H][W] fp32
+  const uint16_t* w1;      // bf16 [32][16]: k = tap (9 used)
+  const float* b1;         // [32]
+  const uint16_t* w2;      // bf16 [64][Kp2], k = tap * 32 + ci
+  const float* b2;         // [64]
+  uint16_t* out;           // NHWC bf16 [F][H2][W2][64]
+  int F, H, W, H2, W2, Kp2, tiles_y, tiles_x, n_tiles;
+};
+
+constexpr int C12_IMG_PITCH = 68, C12_IMG_ROWS = 19, C12_IMG_N = C12_IMG_ROWS * C12_IMG_PITCH;   // 1292
+constexpr int C12_PLANE = 17 * 33 * 32;                                                          // elements per parity plane
+
+__global__ __launch_bounds__(512) void conv12_kernel(Conv12Args a) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_img[C12_IMG_N + 4];
+  __shared__ __attribute__((aligned(16))) uint16_t s_patch[2 * C12_PLANE];
+  __shared__ __attribute__((aligned(16))) uint16_t s_out[8 * 32 * 64];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int fr = l & 31, fh = l >> 5;
+
+  // ---- weights -> registers (once per workgroup)
+  bf16x8 a2[9][2][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a2[tap][kk][i] = *reinterpret_cast<const bf16x8*>(a.w2 + (size_t)(i * 32 + fr) * a.Kp2 + tap * 32 + kk * 16 + 8 * fh);
+  const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a.w1 + fr * 16 + 8 * fh);
+
+  // image patch prefetch: entries t, t + 512, t + 1024 of the [19][68] patch
+  auto load_img = [&](int tile, float v[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = t + 512 * i;
+      v[i] = 0.f;
+      if (tile < a.n_tiles && e < C12_IMG_N) {
+        const int f = tile / (a.tiles_y * a.tiles_x), r = tile - f * (a.tiles_y * a.tiles_x);
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        const int py = e / C12_IMG_PITCH, px = e - py * C12_IMG_PITCH;
+        const int iy = 16 * ty - 2 + py, ix = 64 * tx - 2 + px;
+        if (px < 67 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v[i] = a.img[((size_t)f * a.H + iy) * a.W + ix];
+      }
+    }
+  };
+  float nxt[3];
+  load_img(blockIdx.x, nxt);
+
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int f = tile / (a.tiles_y * a.tiles_x), r = tile - f * (a.tiles_y * a.tiles_x);
+    const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+    const int oy0 = 8 * ty, ox0 = 32 * tx;
+    // ---- 1. image patch -> LDS (bf16), next tile's patch -> registers
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = t + 512 * i;
+      if (e < C12_IMG_N) s_img[e] = f2bf(nxt[i]);
+    }
+    load_img(tile + gridDim.x, nxt);
+    __syncthreads();
+    // ---- 2. conv1 on 32-pixel fragments of the 17 x 65 patch (p = py * 65 + px)
+    for (int fg = w; fg < 35; fg += 8) {
+      const int p = fg * 32 + fr;
+      const int py = min(p / 65, 16), px = p - (p / 65) * 65;
+      const uint16_t* ip = s_img + py * C12_IMG_PITCH + px;   // taps: ip[ky * 68 + kx]
+      uint16_t tp[9];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) tp[ky * 3 + kx] = ip[ky * C12_IMG_PITCH + kx];
+      s16x8 bv;
+      if (fh == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (short)tp[e];
+      } else {
+        bv[0] = (short)tp[8];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) bv[e] = 0;
+      }
+      f32x16 c1;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) c1[q] = 0.f;
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, bv), c1, 0, 0, 0);
+      // conv1 pixel (cy, cx) of this lane; outside the image the map is ZERO (conv2's padding)
+      const int cy = 16 * ty - 1 + py, cx = 64 * tx - 1 + px;
+      const bool inside = p < 17 * 65 && cy >= 0 && cy < a.H && cx >= 0 && cx < a.W;
+      if (p < 17 * 65) {
+        const int q = px >> 1;
+        uint16_t* dst = s_patch + (px & 1) * C12_PLANE + (py * 33 + q) * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {   // channels 8g + 4 fh .. +3 = half of logical chunk g
+          const float4 b = *reinterpret_cast<const float4*>(a.b1 + 8 * g + 4 * fh);
+          float v0 = fmaxf(c1[4 * g + 0] + b.x, 0.f), v1 = fmaxf(c1[4 * g + 1] + b.y, 0.f);
+          float v2 = fmaxf(c1[4 * g + 2] + b.z, 0.f), v3 = fmaxf(c1[4 * g + 3] + b.w, 0.f);
+          if (!inside) v0 = v1 = v2 = v3 = 0.f;
+          *reinterpret_cast<uint2*>(dst + ((g ^ ((q >> 2) & 3)) << 3) + 4 * fh) = pack4(v0, v1, v2, v3);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 3. conv2: output row w of the tile, pixels x = fr, channels 2 x 32
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int q = fr + (kx >> 1);
+        const uint16_t* src = s_patch + (kx & 1) * C12_PLANE + ((2 * w + ky) * 33 + q) * 32;
+        const int sw = (q >> 2) & 3;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(src + (((kk * 2 + fh) ^ sw) << 3));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ky * 3 + kx][kk][i], b, acc[i], 0, 0, 0);
+        }
+      }
+    // ---- 4. bias + ReLU -> wave-private staging row [32 px][64 ch] -> 4 KiB contiguous store
+    uint16_t* so = s_out + w * (32 * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = i * 32 + 8 * g + 4 * fh;
+        const float4 b = *reinterpret_cast<const float4*>(a.b2 + ch);
+        const uint2 y = pack4(fmaxf(acc[i][4 * g + 0] + b.x, 0.f), fmaxf(acc[i][4 * g + 1] + b.y, 0.f), fmaxf(acc[i][4 * g + 2] + b.z, 0.f),
+                              fmaxf(acc[i][4 * g + 3] + b.w, 0.f));
+        // [px][64]: 8 chunks of 8 channels, chunk index XOR px & 7
+        *reinterpret_cast<uint2*>(so + fr * 64 + ((((ch >> 3) ^ (fr & 7)) << 3) | (ch & 7))) = y;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int oy = oy0 + w;
+    if (oy < a.H2) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int pxl = it * 8 + (l >> 3), chk = l & 7;
+        const int ox = ox0 + pxl;
+        if (ox < a.W2)
+          *reinterpret_cast<uint4*>(a.out + (((size_t)f * a.H2 + oy) * a.W2 + ox) * 64 + chk * 8) =
+              *reinterpret_cast<const uint4*>(so + pxl * 64 + ((chk ^ (pxl & 7)) << 3));
+      }
+    }
+  }
+}
+
 // [80][64] staging tile of the 64-column variant: chunk index XOR row & 7
 __device__ __forceinline__ int st_off64(int row, int col) { return row * 64 + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7)); }
 
@@ -715,7 +880,9 @@ float host_bf2f(uint16_t h) {
 
 struct acez_encoder {
   int device = 0, out_channels = 512, max_frames = 0, max_h = 0, max_w = 0, tile_mode = 0;
-  float* w1 = nullptr;                 // conv1 weights [32][9] (bf16-rounded values in fp32) followed by nothing
+  float* w1 = nullptr;                 // conv1 weights [32][9] (bf16-rounded values in fp32)
+  uint16_t* w1b = nullptr;             // conv1 weights bf16 [32][16] (k = tap, zero padded): A operand of conv12_kernel
+  bool fuse12 = true;                  // ACEZ_CONV12=0: separate conv1 / conv2 kernels
   float* bias[ACEZ_ENCODER_LAYERS] = {};
   uint16_t* W[ACEZ_ENCODER_LAYERS] = {};   // bf16 [co][Kp] (layers 1..10)
   int K[ACEZ_ENCODER_LAYERS] = {}, Kp[ACEZ_ENCODER_LAYERS] = {}, co[ACEZ_ENCODER_LAYERS] = {};
@@ -749,6 +916,7 @@ extern "C" int acez_encoder_create(acez_encoder** out, const float* const* h_wei
   acez_encoder* e = new acez_encoder();
   e->device = device; e->out_channels = out_channels; e->max_frames = max_frames; e->max_h = max_h; e->max_w = max_w;
   if (const char* tm = getenv("ACEZ_CONV_TILE")) e->tile_mode = atoi(tm);
+  if (const char* f12 = getenv("ACEZ_CONV12")) e->fuse12 = atoi(f12) != 0;
   auto A = [&](void** p, size_t bytes) -> hipError_t {
     hipError_t rc = hipMalloc(p, bytes);
     if (rc == hipSuccess) e->allocs.push_back(*p);
@@ -778,6 +946,11 @@ extern "C" int acez_encoder_create(acez_encoder** out, const float* const* h_wei
       for (int j = 0; j < 32 * 9; ++j) w[j] = host_bf2f(host_f2bf(h_weights[0][j]));   // [co][1][3][3] is already [co][tap]
       ACEZ_ENC_ALLOC(e->w1, w.size() * sizeof(float));
       ACEZ_HIP_CHECK(hipMemcpy(e->w1, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+      std::vector<uint16_t> wb(32 * 16, 0);
+      for (int o = 0; o < 32; ++o)
+        for (int tp = 0; tp < 9; ++tp) wb[o * 16 + tp] = host_f2bf(h_weights[0][o * 9 + tp]);
+      ACEZ_ENC_ALLOC(e->w1b, wb.size() * sizeof(uint16_t));
+      ACEZ_HIP_CHECK(hipMemcpy(e->w1b, wb.data(), wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     } else {
       // torch layout [co][ci][ky][kx] -> [co][(ky*k + kx) * ci_n + ci], zero padded to Kp
       std::vector<uint16_t> w((size_t)co * e->Kp[i], 0);
@@ -826,9 +999,17 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
     const int F = (n_frames - f0 < e->max_frames) ? n_frames - f0 : e->max_frames;
     const float* img = d_images + (size_t)f0 * h * w;
     uint16_t* feat = (uint16_t*)d_features + (size_t)f0 * h8 * w8 * e->out_channels;
-    const int64_t npix = (int64_t)F * h * w;
-    hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, img, (const float*)e->w1, (const float*)e->bias[0], e->a1, h, w,
-                       npix);
+    if (e->fuse12) {
+      Conv12Args c{};
+      c.img = img; c.w1 = e->w1b; c.b1 = e->bias[0]; c.w2 = e->W[1]; c.b2 = e->bias[1]; c.out = e->a2;
+      c.F = F; c.H = h; c.W = w; c.H2 = h2; c.W2 = w2; c.Kp2 = e->Kp[1];
+      c.tiles_y = (h2 + 7) / 8; c.tiles_x = (w2 + 31) / 32; c.n_tiles = F * c.tiles_y * c.tiles_x;
+      hipLaunchKernelGGL(conv12_kernel, dim3(c.n_tiles < 256 ? c.n_tiles : 256), dim3(512), 0, s, c);
+    } else {
+      const int64_t npix = (int64_t)F * h * w;
+      hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, img, (const float*)e->w1, (const float*)e->bias[0], e->a1, h, w,
+                         npix);
+    }
     auto conv = [&](int li, const uint16_t* in, int hi, int wi, uint16_t* outp, int ho, int wo, const uint16_t* add, bool relu) {
       const LayerDesc& L = kLayers[li];
       ConvGemmArgs g{};
@@ -838,7 +1019,7 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
       if (const char* d = getenv("ACEZ_CONV_DBG")) g.dbg = atoi(d);
       launch_convgemm(g, relu, s, e->tile_mode);
     };
-    conv(1, e->a1, h, w, e->a2, h2, w2, nullptr, true);
+    if (!e->fuse12) conv(1, e->a1, h, w, e->a2, h2, w2, nullptr, true);
     conv(2, e->a2, h2, w2, e->a3, h4, w4, nullptr, true);
     conv(3, e->a3, h4, w4, e->r4, h8, w8, nullptr, true);
     conv(4, e->r4, h8, w8, e->x5, h8, w8, nullptr, true);

@@ -36,6 +36,16 @@ def test_encoder_matches_bf16_oracle(shape, tile, monkeypatch):
     assert _rel(out, ref32) < 2e-2
 
 
+def test_separate_conv1_conv2_path_still_matches(monkeypatch):
+    from acezero_amd.encoder import Encoder
+    monkeypatch.setenv("ACEZ_CONV12", "0")
+    sd = encoder_oracle.init_weights(seed=4099)
+    img = torch.from_numpy(synth.make_gray_images(seed=3, n=2, h=72, w=100))
+    ref = encoder_oracle.EncoderOracle(sd, "bf16").forward(img)
+    out = Encoder(sd, max_frames=2, max_h=72, max_w=100)(img).cpu()
+    assert _rel(out, ref) < 4e-3
+
+
 def test_encoder_golden_reference_features():
     """Against the reference's own Encoder output (tests/golden/encoder_small.npz), at bf16 accuracy."""
     import os
