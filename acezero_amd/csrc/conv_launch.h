@@ -1,0 +1,24 @@
+// conv_launch.h -- the implicit-GEMM convolution launcher (encoder_api.hip), shared with the head's large-batch inference path
+// (a 1x1 convolution over [rows][512] is the head's layer GEMM).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace acez {
+
+struct ConvGemmArgs {
+  const uint16_t* In;     // NHWC bf16 [F][Hi][Wi][Ci]
+  const uint16_t* W;      // bf16 [Co][Kp]
+  const float* bias;      // [Co]
+  const uint16_t* add;    // [M][Co] bf16 or null: added (fp32) after the activation, before the single bf16 store
+  uint16_t* out;          // [M][Co]
+  const uint16_t* zeros;  // >= 128 bytes of zeros: DMA source of every padded chunk
+  int Hi, Wi, Ci, ci_shift, Ho, Wo, Co, ksize, stride, pad, K, Kp, M;
+  int round_before_add;   // 1: the activation is rounded to bf16 BEFORE the residual is added (the head stores it: ace_network.py:126,133)
+  int dbg;   // ablation (ACEZ_CONV_DBG, convgemm256 only; 0 in production): 2 = no MFMA, 4 = no loads
+};
+
+// tile_mode: 0 = choose by size, 80 / 256 / 512 = force that kernel where the layer shape allows it
+void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s, int tile_mode);
+
+}  // namespace acez

@@ -24,19 +24,10 @@
 #include "../../include/acez.h"
 #include "acez_common.h"
 #include "gemm_common.h"
+#include "conv_launch.h"
 
 namespace acez {
 
-struct ConvGemmArgs {
-  const uint16_t* In;     // NHWC bf16 [F][Hi][Wi][Ci]
-  const uint16_t* W;      // bf16 [Co][Kp]
-  const float* bias;      // [Co]
-  const uint16_t* add;    // [M][Co] bf16 or null: added (fp32) after the activation, before the single bf16 store
-  uint16_t* out;          // [M][Co]
-  const uint16_t* zeros;  // >= 128 bytes of zeros: DMA source of every padded chunk
-  int Hi, Wi, Ci, ci_shift, Ho, Wo, Co, ksize, stride, pad, K, Kp, M;
-  int dbg;   // ablation (ACEZ_CONV_DBG, convgemm256 only; 0 in production): 2 = no MFMA, 4 = no loads
-};
 
 // 1 -> 32 channels, 3x3, stride 1, pad 1, ReLU. image fp32 [F][H][W] (rounded to bf16 on the fly), out NHWC bf16.
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ img, const float* __restrict__ w /*[32][9] bf16-rounded*/,
@@ -393,6 +384,7 @@ __global__ __launch_bounds__(512) void convgemm_kernel(ConvGemmArgs a) {
         if (HAS_ADD) {
           float ad[4];
           unpack4(*reinterpret_cast<const uint2*>(po), ad);
+          if (a.round_before_add) unpack4(pack4(v[0], v[1], v[2], v[3]), v);
           v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
         }
         *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
@@ -555,6 +547,7 @@ __global__ __launch_bounds__(1024) void convgemm256_kernel(ConvGemmArgs a) {
           if (HAS_ADD) {
             float ad[4];
             unpack4(*reinterpret_cast<const uint2*>(po), ad);
+            if (a.round_before_add) unpack4(pack4(v[0], v[1], v[2], v[3]), v);
             v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
           }
           *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
@@ -720,6 +713,7 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
           if (HAS_ADD) {
             float ad[4];
             unpack4(*reinterpret_cast<const uint2*>(po), ad);
+            if (a.round_before_add) unpack4(pack4(v[0], v[1], v[2], v[3]), v);
             v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
           }
           *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
@@ -737,7 +731,7 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
 }
 
 // tile_mode: 0 = choose by size, 80 / 256 = force that row tile where the layer shape allows it (ACEZ_CONV_TILE, tests)
-static void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s, int tile_mode) {
+void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s, int tile_mode) {
   const bool huge_ok = g.Co % 256 == 0 && g.Kp >= 256;
   if (huge_ok && (tile_mode == 512 || (tile_mode == 0 && (int64_t)((g.M + 255) / 256) * (g.Co / 256) >= 4 * 256))) {
     const int ntiles = g.Co / 256, mtiles = (g.M + 255) / 256;

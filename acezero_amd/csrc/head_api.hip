@@ -3,6 +3,7 @@
 #include "head_kernels.hip"
 #include "pose_kernels.hip"
 #include "head_fused.hip"
+#include "conv_launch.h"
 #include <stdlib.h>
 #include "acez_common.h"
 #include <vector>
@@ -585,14 +586,39 @@ extern "C" int acez_trainer_last_scene_coords(acez_trainer* tr, float* h_xyz, in
   return ACEZ_OK;
 }
 
+// Inference on many rows (whole frames): the head's layers are 1x1 convolutions over [rows][512], so the large-tile implicit-GEMM
+// kernels of the encoder (256 x 256 tiles) run them; same rounding points as the training forward (round_before_add).
+static uint16_t* launch_forward_conv(acez_trainer* tr, const uint16_t* in0, int n, hipStream_t s) {
+  const float* P = tr->pb.d_params;
+  auto layer = [&](int l, const uint16_t* in, const uint16_t* add, uint16_t* out) {
+    ConvGemmArgs g{};
+    g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144; g.add = add; g.out = out;
+    g.zeros = tr->zeros; g.Hi = 1; g.Wi = 1; g.Ci = 512; g.ci_shift = 9; g.Ho = 1; g.Wo = 1; g.Co = 512; g.ksize = 1; g.stride = 1;
+    g.pad = 0; g.K = 512; g.Kp = 512; g.M = n; g.round_before_add = 1; g.dbg = 0;
+    launch_convgemm(g, true, s, 0);
+  };
+  const uint16_t* r = in0;
+  for (int b = 0; b <= tr->nb; ++b) {
+    layer(3 * b, r, nullptr, tr->out[3 * b]);
+    layer(3 * b + 1, tr->out[3 * b], nullptr, tr->out[3 * b + 1]);
+    layer(3 * b + 2, tr->out[3 * b + 1], r, tr->R[b + 1]);     // R = relu(conv) + R   ace_network.py:126,133
+    r = tr->R[b + 1];
+  }
+  const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
+  layer(f1, r, nullptr, tr->out[f1]);
+  layer(f2, tr->out[f1], nullptr, tr->out[f2]);
+  return tr->out[f2];
+}
+
 static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, float* d_out, int planar_hw, void* stream) {
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   hipStream_t s = (hipStream_t)stream;
   const uint16_t* f = (const uint16_t*)d_features;
   for (int done = 0; done < n; done += tr->max_batch) {
     const int cnt = (n - done < tr->max_batch) ? n - done : tr->max_batch;
-    uint16_t* act = tr->fused_fwd ? launch_forward_fused(tr, f + (size_t)done * 512, nullptr, cnt, false, nullptr, s)
-                                  : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
+    uint16_t* act = tr->fused_fwd      ? launch_forward_fused(tr, f + (size_t)done * 512, nullptr, cnt, false, nullptr, s)
+                    : cnt >= 256 * 128 ? launch_forward_conv(tr, f + (size_t)done * 512, cnt, s)
+                                       : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
     LossArgs a{};
     fill_loss_head(tr, a);
     a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr;

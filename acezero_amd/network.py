@@ -36,8 +36,9 @@ class Regressor:
         self.feature_dim = self.encoder.out_channels
         if self.feature_dim != 512:
             raise ValueError("the head kernels are built for 512 encoder features (ace_network.py:22 default)")
-        # an inference-only context: max_batch rows per internal pass of the head
-        self.heads = HeadTrainer(mean, num_head_blocks=num_head_blocks, use_homogeneous=use_homogeneous, max_batch=4 * oh * ow,
+        # an inference-only context: max_batch rows per internal pass of the head (whole chunks of frames: with >= 32768 rows the
+        # layers run on the encoder's large-tile kernels)
+        self.heads = HeadTrainer(mean, num_head_blocks=num_head_blocks, use_homogeneous=use_homogeneous, max_batch=max(4, max_frames) * oh * ow,
                                  device=device, **kw)
         self.heads.load_state_dict(hs)
         self.device = self.heads.device

@@ -178,3 +178,23 @@ def test_fused_step_equals_backward_plus_update_bitwise():
     assert torch.equal(trs[0].adam_m, trs[1].adam_m) and torch.equal(trs[0].adam_v, trs[1].adam_v)
     a, b = trs[0].state(), trs[1].state()
     assert a["iteration"] == b["iteration"] == 4 and a["loss"] == b["loss"] and a["lr"] == b["lr"]
+
+
+def test_large_batch_inference_runs_on_conv_kernels_and_matches():
+    """>= 32768 rows per pass: the head's layers run on the encoder's large-tile implicit-GEMM kernels (1x1 convolutions)."""
+    from acezero_amd.head import HeadTrainer
+    prob, flat0 = helpers.golden_problem()
+    n = 33000                                     # one pass, ragged last 256-row tile
+    rng = np.random.default_rng(3)
+    feats = torch.from_numpy(prob["features"][rng.integers(0, len(prob["features"]), size=n)])
+    big = HeadTrainer(prob["mean"], max_batch=n)
+    big.load_flat(flat0)
+    small = HeadTrainer(prob["mean"], max_batch=4096)
+    small.load_flat(flat0)
+    Xb = big.get_scene_coordinates(feats.cuda()).cpu().numpy()
+    Xs = small.get_scene_coordinates(feats.cuda()).cpu().numpy()
+    # same rounding points, different accumulation order inside the matrix instructions
+    assert _rel(Xb - prob["mean"], Xs - prob["mean"]) < REL
+    orc = head_oracle.HeadOracle(flat0.clone(), prob["mean"], mode="bf16")
+    Xo = orc.scene_coordinates(feats[:4000]).numpy()
+    assert _rel(Xb[:4000] - prob["mean"], Xo - prob["mean"]) < REL
