@@ -108,14 +108,15 @@ def bench_training(args, rank, world, device):
 
     # roofline leg: per-kernel-class durations from HIP events on the launch stream (outside the timed region:
     # the events themselves perturb the step time)
-    prof = None
-    if rank == 0:
-        tr.set_profiling(True)
-        for i in range(20):
-            step(args.warmup + args.steps + i)
-        torch.cuda.synchronize()
-        prof = tr.get_profile()
-        tr.set_profiling(False)
+    # every rank runs these 20 steps (with N > 1 a step contains an all-reduce: a rank-0-only loop would deadlock)
+    tr.set_profiling(True)
+    for i in range(20):
+        step(args.warmup + args.steps + i)
+    torch.cuda.synchronize()
+    prof = tr.get_profile()
+    tr.set_profiling(False)
+    if dist is not None:
+        dist.barrier()
     return dt, st, prof
 
 
@@ -301,7 +302,7 @@ def main():
                          "note": "HIP events on the launch stream around each chain of dependent rowgemm launches (8 fwd, 7 dgrad per step): average start-to-start cadence incl. the ~1-2 us kernel boundary; rocprofv3 kernel durations are in profiles/"},
             "final_loss": st["loss"],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
