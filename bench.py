@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--reg-frames", type=int, default=2048)
     ap.add_argument("--e2e-frames", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # control-flow smoke of the N > 1 path on a ONE-GPU box: every rank on cuda:0, gloo instead of RCCL (not a measurement)
+    ap.add_argument("--smoke-same-device", action="store_true")
     return ap.parse_args()
 
 
@@ -247,11 +249,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if args.smoke_same_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if args.smoke_same_device:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)
     assert world == args.gpus or world == 1, (world, args.gpus)
 
     dt, st, prof = bench_training(args, rank, world, device)
