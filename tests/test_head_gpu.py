@@ -198,3 +198,24 @@ def test_large_batch_inference_runs_on_conv_kernels_and_matches():
     orc = head_oracle.HeadOracle(flat0.clone(), prob["mean"], mode="bf16")
     Xo = orc.scene_coordinates(feats[:4000]).numpy()
     assert _rel(Xb[:4000] - prob["mean"], Xo - prob["mean"]) < REL
+
+
+@pytest.mark.parametrize("env", [("ACEZ_GEMM_TILE", "128"), ("ACEZ_FUSED_FWD", "1")])
+def test_alternative_kernel_paths_stay_correct(env, monkeypatch):
+    """The 128 x 128 GEMM tiling and the persistent row-tile forward are kept as measured alternatives:
+    same rounding points as the default path, so the same checks must hold."""
+    monkeypatch.setenv(*env)
+    prob, flat0 = helpers.golden_problem()
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
+    tr = _trainer(prob, flat0, cfg)
+    monkeypatch.delenv(env[0])
+    ref = _trainer(prob, flat0, cfg)
+    f = torch.from_numpy(prob["features"][:700]).cuda()
+    Xa, Xr = tr.get_scene_coordinates(f).cpu().numpy(), ref.get_scene_coordinates(f).cpu().numpy()
+    assert _rel(Xa - prob["mean"], Xr - prob["mean"]) < REL
+    idx = torch.from_numpy(helpers.golden_batches(prob, 1)[0].astype(np.int64)).cuda()
+    tr.backward(idx); ref.backward(idx)
+    torch.cuda.synchronize()
+    n = flat0.numel()
+    assert _rel(tr.grad[:n].cpu().numpy(), ref.grad[:n].cpu().numpy()) < 8e-3
+    assert abs(float(tr.grad[n]) - float(ref.grad[n])) < 2e-3 * abs(float(ref.grad[n]))
