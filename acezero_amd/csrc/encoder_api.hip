@@ -730,8 +730,226 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// conv3x3p: the 3 x 3, stride-1 layers (res1_conv1/3, res2_conv1/3 = 85 % of the encoder's FLOPs) with the INPUT kept as an
+// LDS patch. In the implicit-GEMM kernels above every tap's K stages DMA the same input pixels again (nine times per
+// 32-channel chunk); here the loaders bring, per 32-channel chunk, ONE patch of 448 consecutive input pixels (the tile's 256
+// output pixels in (frame, y, x) order plus one image row and one pixel on either side: NHWC frames are back to back, so
+// "pixel p + (ky-1) * W + (kx-1)" is a plain linear offset and padding is a per-lane validity bit), and the nine tap stages
+// of that chunk only stream weights. L2 -> LDS bytes per 32-wide K stage: 16 KiB of weights + 28 KiB / 9 of patch instead
+// of 32 KiB. The multipliers read their B fragments straight from the patch (row q = output row + ky * W + kx, 16-byte chunk
+// XOR (q >> 2) & 3: conflict free for the unit-stride rows of a fragment; invalid taps read a zero row).
+// Tile 256 x 256, 8 multiplier + 4 loader waves, 4-slot weight ring (64 KiB) + 2 patch buffers (56 KiB); the epilogue tile
+// takes the whole 128 KiB. Requires W <= 95 (448-row patch), Ci % 32 == 0, Co % 256 == 0.
+// ---------------------------------------------------------------------------------------------------
+constexpr int P3_ROWS = 448;
+template <bool RELU, bool HAS_ADD>
+__global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
+  constexpr int WSTAGE = 256 * 32;            // elements per weight slot
+  constexpr int PATCH = P3_ROWS * 32;         // elements per patch buffer
+  __shared__ __attribute__((aligned(16))) uint16_t smem[65536 + 32];
+  uint16_t* const sPatch = smem + 4 * WSTAGE;
+  uint16_t* const sZero = smem + 65536;       // 64 bytes of zeros: the target of every padded tap
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int M = a.M, Co = a.Co, Kp = a.Kp, Wi = a.Wi;
+  const int ntiles = Co >> 8;
+  const int mtiles = (M + 255) >> 8;
+  const int per_xcd = (mtiles + 7) >> 3;
+  const int jx = blockIdx.x >> 3;
+  const int mt = (blockIdx.x & 7) * per_xcd + jx / ntiles;
+  if (mt >= mtiles) return;
+  const int n0 = (jx % ntiles) << 8, m0 = mt << 8;
+  const int NC = a.Ci >> 5;                   // 32-channel chunks
+  const int S = NC * 9;                       // stages: chunk-major, tap-minor
+  if (t < 32) {                               // visible after the first barrier of the stage loop
+    sZero[t] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  if (w >= 8) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = w - 8;
+    const int lrow = l >> 2, lch = l & 3;     // a DMA instruction covers 16 rows x 64 bytes
+    const uint16_t* gW[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (lw * 4 + j) * 16 + lrow;
+      gW[j] = a.W + (size_t)(n0 + row) * Kp + (lch ^ ((row >> 2) & 3)) * 8;
+    }
+    // patch rows (lw * 7 + j) * 16 + lrow, j < 7: global pixel m0 - Wi - 1 + row, clamped (clamped rows are never validly read)
+    const uint16_t* gP[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int row = (lw * 7 + j) * 16 + lrow;
+      const int g = min(max(m0 - Wi - 1 + row, 0), M - 1);
+      gP[j] = a.In + ((size_t)g << a.ci_shift) + (lch ^ ((row >> 2) & 3)) * 8;
+    }
+    auto issue_w = [&](int s) {
+      const int cc = s / 9, tap = s - cc * 9;
+      const int koff = tap * a.Ci + cc * 32;
+      uint16_t* slot = smem + (s & 3) * WSTAGE;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + koff), (lvoid_t*)(slot + (lw * 4 + j) * 16 * 32), 16, 0, 0);
+    };
+    auto issue_patch = [&](int cc) {
+      uint16_t* buf = sPatch + (cc & 1) * PATCH;
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(gP[j] + cc * 32), (lvoid_t*)(buf + (lw * 7 + j) * 16 * 32), 16, 0, 0);
+    };
+    issue_patch(0);
+    for (int s = 0; s < 4 && s < S; ++s) issue_w(s);
+    int burst_at = -100;                      // stage after whose barrier the last patch burst was issued
+    for (int s = 0; s < S; ++s) {
+      // weight stages younger than W(s) and already issued: s+1 .. min(s+3 at s = 0, s+2 otherwise); the patch burst issued at
+      // stage b (after W(b+3)) is younger than W(s) for s = b+1 .. b+3. In-order completion: vmcnt(N) with N = their instructions.
+      const int later = (s == 0) ? min(3, S - 1) : min(2, S - 1 - s);
+      const bool burst_young = s >= burst_at + 1 && s <= burst_at + 3;
+      if (burst_young) {
+        if (later >= 2) ACEZ_VMCNT(15);
+        else if (later == 1) ACEZ_VMCNT(11);
+        else ACEZ_VMCNT(7);
+      } else {
+        if (later >= 3) ACEZ_VMCNT(12);
+        else if (later == 2) ACEZ_VMCNT(8);
+        else if (later == 1) ACEZ_VMCNT(4);
+        else ACEZ_VMCNT(0);
+      }
+      __builtin_amdgcn_s_barrier();   // W(s) (and, at a chunk start, its patch) has landed; the multipliers are done with stage s - 1
+      if (s >= 1 && s + 3 < S) issue_w(s + 3);
+      const int cc = s / 9;
+      if (s == cc * 9 && cc + 1 < NC) {   // first stage of chunk cc: the other patch buffer (chunk cc - 1) is free now
+        issue_patch(cc + 1);
+        burst_at = s;
+      }
+    }
+    __builtin_amdgcn_s_barrier();     // the multipliers have left the K loop: all of LDS is free
+    if (HAS_ADD) {
+      for (int j = 0; j < 32; ++j) {
+        const int row = (lw * 32 + j) * 2 + (l >> 5);
+        const uint16_t* g = a.add + (size_t)min(m0 + row, M - 1) * Co + n0 + (((l & 31) ^ (row & 31)) << 3);
+        __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(smem + (lw * 32 + j) * 2 * 256), 16, 0, 0);
+      }
+      ACEZ_VMCNT(0);
+      __builtin_amdgcn_s_barrier();   // residual tile landed
+    }
+    __builtin_amdgcn_s_barrier();     // output tile written
+  } else {
+    // ------------------------------------------------------------------ multiplier waves
+    const int wm = w >> 2, wn = w & 3;
+    const int fr = l & 31, fh = l >> 5;
+    // this lane's four output rows (one per row fragment): patch row of tap (0, 0) and the validity of the nine taps
+    int q0[4];
+    unsigned vmask[4];
+    const int hw = a.Hi * Wi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = wm * 128 + j * 32 + fr;
+      q0[j] = r;                                  // patch origin is pixel m0 - Wi - 1: tap (ky, kx) -> row r + ky * Wi + kx
+      const int p = m0 + r;
+      const int rem = p % hw;
+      const int y = rem / Wi, x = rem - y * Wi;
+      unsigned mk = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iy = y + ky - 1, ix = x + kx - 1;
+          if (p < M && iy >= 0 && iy < a.Hi && ix >= 0 && ix < Wi) mk |= 1u << (ky * 3 + kx);
+        }
+      vmask[j] = mk;
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int cc = 0, tap = 0;
+    for (int s = 0; s < S; ++s) {
+      __builtin_amdgcn_s_barrier();
+      const uint16_t* sW = smem + (s & 3) * WSTAGE;
+      const uint16_t* sP = sPatch + (cc & 1) * PATCH;
+      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+      const int toff = ky * Wi + kx;
+      const uint16_t* bp[4];
+      int bsw[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = q0[j] + toff;
+        const bool ok = (vmask[j] >> tap) & 1u;
+        bp[j] = ok ? sP + q * 32 : sZero;
+        bsw[j] = ok ? (q >> 2) & 3 : 0;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int c = kk * 2 + fh;
+        bf16x8 fa[2], fb[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz32(wn * 64 + i * 32 + fr, c)]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bp[j] + ((c ^ bsw[j]) << 3));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      if (++tap == 9) { tap = 0; ++cc; }
+    }
+    __builtin_amdgcn_s_barrier();     // LDS free
+    if (HAS_ADD) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ml = wm * 128 + j * 32 + fr;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nl = wn * 64 + i * 32 + 8 * q + 4 * fh;
+          const float4 b = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+          float v[4] = {acc[i][j][4 * q + 0] + b.x, acc[i][j][4 * q + 1] + b.y, acc[i][j][4 * q + 2] + b.z, acc[i][j][4 * q + 3] + b.w};
+          if (RELU) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+          }
+          uint16_t* po = &smem[st_off256(ml, nl)];
+          if (HAS_ADD) {
+            float ad[4];
+            unpack4(*reinterpret_cast<const uint2*>(po), ad);
+            if (a.round_before_add) unpack4(pack4(v[0], v[1], v[2], v[3]), v);
+            v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
+          }
+          *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  for (int q = t; q < 256 * 32; q += 768) {
+    const int row = q >> 5, ch = q & 31, m = m0 + row;
+    if (m < M)
+      *reinterpret_cast<uint4*>(a.out + (size_t)m * Co + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&smem[row * 256 + ((ch ^ (row & 31)) << 3)]);
+  }
+}
+
 // tile_mode: 0 = choose by size, 80 / 256 = force that row tile where the layer shape allows it (ACEZ_CONV_TILE, tests)
 void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s, int tile_mode) {
+  const bool patch_ok = g.ksize == 3 && g.stride == 1 && g.pad == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.Wi <= (P3_ROWS - 258) / 2 &&
+                        g.Ci % 32 == 0 && g.Co % 256 == 0 && g.K == g.Kp;
+  if (patch_ok && (tile_mode == 3 || (tile_mode == 0 && (int64_t)((g.M + 255) / 256) * (g.Co / 256) >= 4 * 256))) {
+    const int ntiles = g.Co / 256, mtiles = (g.M + 255) / 256;
+    const dim3 grid(8 * ntiles * ((mtiles + 7) / 8)), blk(768);
+    if (g.add) {
+      if (!relu) abort();
+      hipLaunchKernelGGL((conv3x3p_kernel<true, true>), grid, blk, 0, s, g);
+    } else {
+      if (!relu) abort();
+      hipLaunchKernelGGL((conv3x3p_kernel<true, false>), grid, blk, 0, s, g);
+    }
+    return;
+  }
   const bool huge_ok = g.Co % 256 == 0 && g.Kp >= 256;
   if (huge_ok && (tile_mode == 512 || (tile_mode == 0 && (int64_t)((g.M + 255) / 256) * (g.Co / 256) >= 4 * 256))) {
     const int ntiles = g.Co / 256, mtiles = (g.M + 255) / 256;

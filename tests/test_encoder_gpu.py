@@ -13,7 +13,7 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("tile", ["0", "80", "256", "512"])
+@pytest.mark.parametrize("tile", ["0", "80", "256", "512", "3"])   # 3: the 3x3 patch kernel where the layer allows it
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 120, 200), (3, 41, 77)])
 def test_encoder_matches_bf16_oracle(shape, tile, monkeypatch):
     from acezero_amd.encoder import Encoder, output_size
