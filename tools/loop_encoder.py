@@ -1,3 +1,4 @@
+"""Runs the encoder in a loop for ~9 s (load generator for tools/clock_probe.sh)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
