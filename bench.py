@@ -236,10 +236,21 @@ def cpu_baseline():
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(one, range(nfr)))
     t_reg = time.perf_counter() - t0
+    # encoder (the end-to-end registration leg's dominant cost): torch conv2d fp32 on the host cores, 2 frames of 480 x 640
+    from oracle import encoder_oracle
+    enc = encoder_oracle.EncoderOracle(encoder_oracle.init_weights(seed=4099), "fp32")
+    img = torch.from_numpy(synth.make_gray_images(seed=1, n=2, h=480, w=640))
+    with torch.no_grad():
+        enc.forward(img[:1])
+        t0 = time.perf_counter()
+        enc.forward(img)
+        t_enc = (time.perf_counter() - t0) / 2
     return {"value": BATCH / t_train, "unit": "patches/s", "cores": tcores, "kind": "port",
             "sample": f"{steps} steps of 5120 patches, oracle/head_oracle.py fp32 on torch-CPU with {tcores} of {cores} host threads; "
                       f"registration: {nfr} frames, oracle/dsac_oracle.cpp, {cores} threads",
-            "registration_images_per_s": nfr / t_reg}
+            "registration_images_per_s": nfr / t_reg,
+            "encoder_images_per_s": 1.0 / t_enc,
+            "encoder_sample": f"2 frames of 480x640, oracle/encoder_oracle.py (torch conv2d fp32), {tcores} threads"}
 
 
 def main():
