@@ -776,6 +776,7 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
     for (int j = 0; j < 4; ++j) {
       const int row = (lw * 4 + j) * 16 + lrow;
       gW[j] = a.W + (size_t)(n0 + row) * Kp + (lch ^ ((row >> 2) & 3)) * 8;
+      if (a.dbg & 32) gW[j] = a.W + (size_t)(row & 15) * Kp + lch * 8;   // ablation: same bytes into LDS, but from 16 hot rows
     }
     // patch rows (lw * 7 + j) * 16 + lrow, j < 7: global pixel m0 - Wi - 1 + row, clamped (clamped rows are never validly read)
     const uint16_t* gP[7];
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
     }
     auto issue_w = [&](int s) {
       const int cc = s / 9, tap = s - cc * 9;
-      const int koff = tap * a.Ci + cc * 32;
+      const int koff = (a.dbg & 32) ? 0 : tap * a.Ci + cc * 32;
       uint16_t* slot = smem + (s & 3) * WSTAGE;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
         else ACEZ_VMCNT(0);
       }
       __builtin_amdgcn_s_barrier();   // W(s) (and, at a chunk start, its patch) has landed; the multipliers are done with stage s - 1
-      if (s >= 1 && s + 3 < S) issue_w(s + 3);
+      if (s >= 1 && s + 3 < S && !((a.dbg & 64) && (s & 1))) issue_w(s + 3);   // ablation 64: every other weight stage is not fetched
       const int cc = s / 9;
       if (s == cc * 9 && cc + 1 < NC) {   // first stage of chunk cc: the other patch buffer (chunk cc - 1) is free now
         issue_patch(cc + 1);
