@@ -39,6 +39,9 @@ struct acez_trainer {
   float *log_loss = nullptr, *log_inl = nullptr;
   int log_cap = 0;
   TrainState* st = nullptr;
+  // pose refinement runs on its own stream, beside the head's GEMM chains (it is ~26 tiny launches: serialised they cost +75 us)
+  hipStream_t pose_stream = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_pose_fwd = nullptr, ev_loss = nullptr, ev_pose_bwd = nullptr;
   GradReduceArgs last_reduce{};   // partial buffers of the last backward (input of the fused update)
   bool post_pending = false;   // acez_train_update has run; its schedule bookkeeping rides with the next step's gather (flush_post)
   SchedConfig sc;
@@ -101,6 +104,9 @@ extern "C" void acez_trainer_destroy(acez_trainer* tr) {
   if (!tr) return;
   for (void* p : tr->allocs) (void)hipFree(p);
   for (hipEvent_t e : tr->ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {tr->ev_begin, tr->ev_pose_fwd, tr->ev_loss, tr->ev_pose_bwd})
+    if (e) (void)hipEventDestroy(e);
+  if (tr->pose_stream) (void)hipStreamDestroy(tr->pose_stream);
   delete tr;
 }
 
@@ -128,6 +134,10 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_REQUIRE(tr, "out of host memory");
   ACEZ_HIP_CHECK(hipGetDevice(&tr->device));
   tr->cfg = *cfg;
+  if (cfg->pose_refinement != 0 && !(getenv("ACEZ_POSE_STREAM") && atoi(getenv("ACEZ_POSE_STREAM")) == 0)) {
+    ACEZ_HIP_CHECK(hipStreamCreateWithFlags(&tr->pose_stream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&tr->ev_begin, &tr->ev_pose_fwd, &tr->ev_loss, &tr->ev_pose_bwd}) ACEZ_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
   tr->pb = *params;
   tr->nb = cfg->head.num_head_blocks;
   tr->L = 3 + 3 * tr->nb + 2;
@@ -225,8 +235,8 @@ extern "C" int acez_trainer_set_buffer(acez_trainer* tr, const acez_train_buffer
     A((void**)&tr->pdT, (size_t)I * 12 * sizeof(float));
     A((void**)&tr->pddelta, (size_t)I * 12 * sizeof(float));
     A((void**)&tr->pose_cur, (size_t)I * 16 * sizeof(float));
-    tr->pose_ksplit = (I + 127) / 128;
-    if (tr->pose_ksplit > 32) tr->pose_ksplit = 32;
+    tr->pose_ksplit = (I + 255) / 256;   // image slices of the pose weight-gradient kernel
+    if (tr->pose_ksplit > 8) tr->pose_ksplit = 8;
     if (tr->pose_ksplit < 1) tr->pose_ksplit = 1;
     A((void**)&tr->pose_part, (size_t)tr->pose_ksplit * ACEZ_POSE_MLP_PARAMS * sizeof(float));
     if (!tr->row_dT) {
@@ -326,55 +336,53 @@ static void pose_sgemm(hipStream_t s, const float* A, int64_t sam, int64_t sak, 
 }
 
 // refined poses of all images with the current network: pose_cur [I][16]
-static void pose_forward(acez_trainer* tr, const int* active, hipStream_t s) {
-  const int I = tr->buf.n_images;
-  const float* P = tr->pb.d_pose_params;
-  const float* T0 = tr->buf.d_image_pose_inv;
-  // y = relu(x W^T + b): A = x [I][K], B(k, n) = W[n][k]
-  pose_sgemm(s, T0, 16, 1, P + PO_C1_W, 1, 12, tr->pa1, 128, I, 128, 12, P + PO_C1_B, nullptr, nullptr, 1, active);
-  pose_sgemm(s, tr->pa1, 128, 1, P + PO_C2_W, 1, 128, tr->pa2, 128, I, 128, 128, P + PO_C2_B, nullptr, nullptr, 1, active);
-  pose_sgemm(s, tr->pa2, 128, 1, P + PO_C3_W, 1, 128, tr->pa3, 128, I, 128, 128, P + PO_C3_B, nullptr, nullptr, 1, active);
-  pose_sgemm(s, T0, 16, 1, P + PO_SKIP_W, 1, 12, tr->pr, 128, I, 128, 12, P + PO_SKIP_B, tr->pa3, nullptr, 0, active);  // head_skip(x) + x3
-  pose_sgemm(s, tr->pr, 128, 1, P + PO_F1_W, 1, 128, tr->pf1, 128, I, 128, 128, P + PO_F1_B, nullptr, nullptr, 1, active);
-  pose_sgemm(s, tr->pf1, 128, 1, P + PO_F2_W, 1, 128, tr->pf2, 128, I, 128, 128, P + PO_F2_B, nullptr, nullptr, 1, active);
-  pose_sgemm(s, tr->pf2, 128, 1, P + PO_F3_W, 1, 128, tr->pdlt, 12, I, 12, 128, P + PO_F3_B, nullptr, nullptr, 0, active);
-  hipLaunchKernelGGL(pose_compose_kernel, dim3((I + 255) / 256), dim3(256), 0, s, T0, (const float*)tr->pdlt, tr->cfg.pose_refinement_weight,
-                     tr->pose_cur, I, active);
+static PoseNetArgs pose_net_args(acez_trainer* tr, const int* active) {
+  PoseNetArgs a{};
+  a.P = tr->pb.d_pose_params; a.T0 = tr->buf.d_image_pose_inv; a.I = tr->buf.n_images; a.w = tr->cfg.pose_refinement_weight;
+  a.a1 = tr->pa1; a.a2 = tr->pa2; a.a3 = tr->pa3; a.r = tr->pr; a.f1 = tr->pf1; a.f2 = tr->pf2; a.delta = tr->pdlt; a.pose_cur = tr->pose_cur;
+  a.dT = tr->pdT; a.ddelta = tr->pddelta; a.dz2 = tr->pdz2; a.dz1 = tr->pdz1; a.dr = tr->pdr; a.dzc3 = tr->pdzc3; a.dzc2 = tr->pdzc2;
+  a.dzc1 = tr->pdzc1; a.active = active;
+  return a;
 }
 
-// gradient of the pose network from the per-row pose gradients of the loss kernel -> d_grad tail
+// refined poses of all images (PoseRefiner._predict_pose_updates, refine_poses.py:152-176): one fused launch
+static void pose_forward(acez_trainer* tr, const int* active, hipStream_t s) {
+  const PoseNetArgs a = pose_net_args(tr, active);
+  hipLaunchKernelGGL(pose_mlp_fwd_kernel, dim3((a.I + PN_IMG - 1) / PN_IMG), dim3(256), 0, s, a);
+}
+
+static void launch_pose_grad_reduce(acez_trainer* tr, int n, const int* active, hipStream_t s) {
+  const int I = tr->buf.n_images;
+  int blocks = (I + 3) / 4;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(pose_grad_reduce2_kernel, dim3(blocks), dim3(256), (size_t)n * sizeof(int), s, (const float*)tr->row_dT, (const int*)tr->row_image, n,
+                     tr->pdT, I, active);
+}
+
+// gradient of the pose network from the per-row pose gradients of the loss kernel -> d_grad tail (4 launches)
 static void pose_backward(acez_trainer* tr, int n, const int* active, hipStream_t s) {
   const int I = tr->buf.n_images, Z = tr->pose_ksplit;
-  const float* P = tr->pb.d_pose_params;
-  const float* T0 = tr->buf.d_image_pose_inv;
-  float* part = tr->pose_part;
   const int64_t NP = ACEZ_POSE_MLP_PARAMS;
-  hipLaunchKernelGGL(pose_grad_reduce_kernel, dim3((I * 64 + 255) / 256), dim3(256), 0, s, (const float*)tr->row_dT, (const int*)tr->row_image, n,
-                     tr->pdT, I, active);
-  hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((I + 255) / 256), dim3(256), 0, s, T0, (const float*)tr->pdlt, tr->cfg.pose_refinement_weight,
-                     (const float*)tr->pdT, tr->pddelta, I, active);
-  // weight gradient dW[o][k] = sum_i dY[i][o] X[i][k] (+ bias via the ones column), split over images into Z partials
-  auto wgrad = [&](const float* dY, int O, const float* X, int64_t xpitch, int Kin, int64_t offW, int64_t offB) {
-    pose_sgemm(s, dY, 1, O, X, xpitch, 1, part + offW, Kin, O, Kin + 1, I, nullptr, nullptr, nullptr, 0, active, Z, NP, part + offB);
-  };
-  // input gradient dX = (dY W) (.) mask: A = dY [I][O], B(k = o, n) = W[o][n]
-  auto dgrad = [&](const float* dY, int O, int64_t offW, int Kin, const float* mask, float* out) {
-    pose_sgemm(s, dY, O, 1, P + offW, Kin, 1, out, Kin, I, Kin, O, nullptr, nullptr, mask, 0, active);
-  };
-  wgrad(tr->pddelta, 12, tr->pf2, 128, 128, PO_F3_W, PO_F3_B);
-  dgrad(tr->pddelta, 12, PO_F3_W, 128, tr->pf2, tr->pdz2);
-  wgrad(tr->pdz2, 128, tr->pf1, 128, 128, PO_F2_W, PO_F2_B);
-  dgrad(tr->pdz2, 128, PO_F2_W, 128, tr->pf1, tr->pdz1);
-  wgrad(tr->pdz1, 128, tr->pr, 128, 128, PO_F1_W, PO_F1_B);
-  dgrad(tr->pdz1, 128, PO_F1_W, 128, nullptr, tr->pdr);
-  dgrad(tr->pdz1, 128, PO_F1_W, 128, tr->pa3, tr->pdzc3);
-  wgrad(tr->pdr, 128, T0, 16, 12, PO_SKIP_W, PO_SKIP_B);
-  wgrad(tr->pdzc3, 128, tr->pa2, 128, 128, PO_C3_W, PO_C3_B);
-  dgrad(tr->pdzc3, 128, PO_C3_W, 128, tr->pa2, tr->pdzc2);
-  wgrad(tr->pdzc2, 128, tr->pa1, 128, 128, PO_C2_W, PO_C2_B);
-  dgrad(tr->pdzc2, 128, PO_C2_W, 128, tr->pa1, tr->pdzc1);
-  wgrad(tr->pdzc1, 128, T0, 16, 12, PO_C1_W, PO_C1_B);
-  hipLaunchKernelGGL(small_reduce_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, s, (const float*)part, NP, Z,
+  launch_pose_grad_reduce(tr, n, active, s);
+  const PoseNetArgs a = pose_net_args(tr, active);
+  hipLaunchKernelGGL(pose_mlp_bwd_kernel, dim3((I + PN_IMG - 1) / PN_IMG), dim3(256), 0, s, a);
+  PoseWgradArgs w{};
+  const float* T0 = tr->buf.d_image_pose_inv;
+  const float* dY[7] = {tr->pddelta, tr->pdz2, tr->pdz1, tr->pdr, tr->pdzc3, tr->pdzc2, tr->pdzc1};
+  const float* X[7] = {tr->pf2, tr->pf1, tr->pr, T0, tr->pa2, tr->pa1, T0};
+  const int O[7] = {12, 128, 128, 128, 128, 128, 128}, K[7] = {128, 128, 128, 12, 128, 128, 12}, XP[7] = {128, 128, 128, 16, 128, 128, 16};
+  const int64_t OW[7] = {PN_F3_W, PN_F2_W, PN_F1_W, PN_SKIP_W, PN_C3_W, PN_C2_W, PN_C1_W};
+  const int64_t OB[7] = {PN_F3_B, PN_F2_B, PN_F1_B, PN_SKIP_B, PN_C3_B, PN_C2_B, PN_C1_B};
+  int jobs = 0;
+  for (int l = 0; l < 7; ++l) {
+    w.dY[l] = dY[l]; w.X[l] = X[l]; w.O[l] = O[l]; w.K[l] = K[l]; w.xpitch[l] = XP[l]; w.offW[l] = OW[l]; w.offB[l] = OB[l];
+    w.job_start[l] = jobs;
+    jobs += (O[l] + 15) / 16;
+  }
+  w.job_start[7] = jobs;
+  w.I = I; w.Z = Z; w.part = tr->pose_part; w.part_stride = NP; w.active = active;
+  hipLaunchKernelGGL(pose_mlp_wgrad_kernel, dim3(jobs, Z), dim3(256), 0, s, w);
+  hipLaunchKernelGGL(small_reduce_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, s, (const float*)tr->pose_part, NP, Z,
                      tr->pb.d_grad + tr->n_params + 4, NP, active);
 }
 
@@ -419,14 +427,23 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     hipLaunchKernelGGL(gather_kernel, dim3(gblocks), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n, st);
   }
   delete psg;
-  act = launch_forward(tr, tr->R[0], n, st, s);
   }
   const bool pose_naive = tr->cfg.pose_refinement == 1;
   const bool pose_mlp = tr->cfg.pose_refinement == 2 || pose_naive;   // both need the refined-pose table and per-row pose gradients
-  if (tr->cfg.pose_refinement == 2) pose_forward(tr, &tr->st->active, s);
+  // Pose refinement on its own stream: the refined poses are needed by the loss kernel only, so their ~9 tiny launches run
+  // beside the head's forward chain; the pose-gradient launches (~17) run beside the input-gradient chain and wgrad.
+  hipStream_t ps = (pose_mlp && tr->pose_stream) ? tr->pose_stream : s;
+  if (ps != s) {   // after the schedule bookkeeping of step_begin (the pose kernels read st->active / pose_enable)
+    ACEZ_HIP_CHECK(hipEventRecord(tr->ev_begin, s));
+    ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_begin, 0));
+  }
+  if (tr->cfg.pose_refinement == 2) pose_forward(tr, &tr->st->active, ps);
   if (pose_naive)   // refine_poses.py:224-234: the poses themselves are the parameters; P = 0 + 1 * params, then Gram-Schmidt
-    hipLaunchKernelGGL(pose_compose_kernel, dim3((tr->buf.n_images + 255) / 256), dim3(256), 0, s, (const float*)tr->pa1,
+    hipLaunchKernelGGL(pose_compose_kernel, dim3((tr->buf.n_images + 255) / 256), dim3(256), 0, ps, (const float*)tr->pa1,
                        (const float*)tr->pb.d_pose_params, 1.0f, tr->pose_cur, tr->buf.n_images, (const int*)&tr->st->active);
+  if (ps != s) ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_fwd, ps));
+  if (!tr->fused_fwd) act = launch_forward(tr, tr->R[0], n, st, s);
+  if (ps != s) ACEZ_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_pose_fwd, 0));   // the loss kernel projects with the refined poses
 
   const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
   const int nblk = (n + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS);
@@ -449,14 +466,18 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, s, a);
   }
 
-  if (tr->cfg.pose_refinement == 2) pose_backward(tr, n, &tr->st->active, s);
+  if (ps != s) {   // the pose gradients start from the per-row pose gradients the loss kernel has just written
+    ACEZ_HIP_CHECK(hipEventRecord(tr->ev_loss, s));
+    ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_loss, 0));
+  }
+  if (tr->cfg.pose_refinement == 2) pose_backward(tr, n, &tr->st->active, ps);
   if (pose_naive) {
     const int I = tr->buf.n_images;
-    hipLaunchKernelGGL(pose_grad_reduce_kernel, dim3((I * 64 + 255) / 256), dim3(256), 0, s, (const float*)tr->row_dT, (const int*)tr->row_image, n,
-                       tr->pdT, I, (const int*)&tr->st->active);
-    hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((I + 255) / 256), dim3(256), 0, s, (const float*)tr->pa1, (const float*)tr->pb.d_pose_params, 1.0f,
+    launch_pose_grad_reduce(tr, n, (const int*)&tr->st->active, ps);
+    hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((I + 255) / 256), dim3(256), 0, ps, (const float*)tr->pa1, (const float*)tr->pb.d_pose_params, 1.0f,
                        (const float*)tr->pdT, tr->pb.d_grad + tr->n_params + 4, I, (const int*)&tr->st->active);
   }
+  if (ps != s) ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_bwd, ps));
 
   // input-gradient chain
   auto dgrad = [&](int l, int l_out, const uint16_t* add, const uint16_t* mask, uint16_t* out_main, uint16_t* out_aux) {
@@ -514,6 +535,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
       hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, a);
     }
   }
+  if (ps != s) ACEZ_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_pose_bwd, 0));   // d_grad's pose tail: read by the all-reduce and by the pose AdamW
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
 }

@@ -37,7 +37,7 @@ struct SGemmArgs {
 
 __global__ __launch_bounds__(256) void sgemm_small_kernel(SGemmArgs a) {
   if (a.active && !*a.active) return;
-  __shared__ float sA[16][65], sB[16][65];
+  __shared__ float sA[16][64], sB[16][64];   // 8 KiB: fits beside a resident rowgemm80 workgroup (152 KiB), see pose streams in head_api.hip
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const int kper = (a.K + a.ksplit - 1) / a.ksplit;
@@ -174,6 +174,297 @@ __global__ __launch_bounds__(256) void pose_compose_bwd_kernel(const float* T0, 
     o[r * 4 + 1] = w * gyr[r];
     o[r * 4 + 2] = 0.f;          // the third column of the raw matrix does not reach the output
     o[r * 4 + 3] = w * g[r * 4 + 3];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused pose network (refine_poses.py:15-72 PoseNetwork(0, 128) + :152-176): with one generic GEMM launch per layer the
+// network cost 20 launches of ~23 us at 1000 images (32 workgroups each) -- more than the whole head. The three kernels
+// below run it data-parallel over tiles of 16 images with the layer's weights staged in LDS:
+//   pose_mlp_fwd_kernel    all 7 layers + compose/Gram-Schmidt, keeps the activations the backward needs
+//   pose_mlp_bwd_kernel    compose backward + the chain of input gradients, keeps every layer's output gradient
+//   pose_mlp_wgrad_kernel  dW = dY^T X, db = column sums, for all layers in one launch, images split in Z slices whose
+//                          partials are summed in a fixed order (small_reduce_kernel)
+// fp32 on the vector ALU (the reference keeps this network outside autocast). Parameter order = named_parameters():
+// head_skip, conv1, conv2, conv3, fc1, fc2, fc3 (weight, bias each).
+// ---------------------------------------------------------------------------------------------------
+struct PoseNetArgs {
+  const float* P;          // flat parameters
+  const float* T0;         // [I][16] original world->cam poses
+  int I;
+  float w;                 // update weight (refine_poses.py:165)
+  float *a1, *a2, *a3, *r, *f1, *f2;   // [I][128] activations
+  float* delta;            // [I][12]
+  float* pose_cur;         // [I][16] refined poses (forward) 
+  const float* dT;         // [I][12] gradient wrt the refined pose (backward)
+  float *ddelta, *dz2, *dz1, *dr, *dzc3, *dzc2, *dzc1;   // backward: gradients wrt each layer's pre-activation output
+  const int* active;
+};
+constexpr int64_t PN_SKIP_W = 0, PN_SKIP_B = 1536, PN_C1_W = 1664, PN_C1_B = 3200, PN_C2_W = 3328, PN_C2_B = 19712, PN_C3_W = 19840,
+                  PN_C3_B = 36224, PN_F1_W = 36352, PN_F1_B = 52736, PN_F2_W = 52864, PN_F2_B = 69248, PN_F3_W = 69376, PN_F3_B = 70912;
+constexpr int PN_IMG = 16;     // images per workgroup
+
+// out[img][n] = act( sum_k in[k][img] * W[n][k] + b[n] (+ add) ), n < 128: thread = (image pair t >> 5, 4 channels 4 * (t & 31)).
+// W ([128][K] row-major, K = 12 or 128) is staged transposed in LDS (sWt[k][n]); sIn is [K][16]. Result -> sOut[n][16] and global.
+__device__ __forceinline__ void pn_layer_fwd(const float* __restrict__ W, const float* __restrict__ b, int K, const float* sIn, float* sWt,
+                                             float* sOut, bool relu, const float* sAdd, float* __restrict__ gOut, int i0, int I) {
+  const int t = threadIdx.x;
+  __syncthreads();   // previous users of sWt / sOut are done
+  for (int idx = t; idx < 128 * K; idx += 256) {
+    const int n = idx % 128, k = idx / 128;
+    sWt[k * 128 + n] = W[n * K + k];
+  }
+  __syncthreads();
+  const int p = t >> 5, c = t & 31;
+  float acc[2][4];
+  const float4 bb = *reinterpret_cast<const float4*>(b + 4 * c);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { acc[i][0] = bb.x; acc[i][1] = bb.y; acc[i][2] = bb.z; acc[i][3] = bb.w; }
+  for (int k = 0; k < K; ++k) {
+    const float2 x = *reinterpret_cast<const float2*>(sIn + k * PN_IMG + 2 * p);
+    const float4 wv = *reinterpret_cast<const float4*>(sWt + k * 128 + 4 * c);
+    acc[0][0] = fmaf(x.x, wv.x, acc[0][0]); acc[0][1] = fmaf(x.x, wv.y, acc[0][1]); acc[0][2] = fmaf(x.x, wv.z, acc[0][2]); acc[0][3] = fmaf(x.x, wv.w, acc[0][3]);
+    acc[1][0] = fmaf(x.y, wv.x, acc[1][0]); acc[1][1] = fmaf(x.y, wv.y, acc[1][1]); acc[1][2] = fmaf(x.y, wv.z, acc[1][2]); acc[1][3] = fmaf(x.y, wv.w, acc[1][3]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[i][j];
+      if (sAdd) v += sAdd[(4 * c + j) * PN_IMG + 2 * p + i];
+      if (relu) v = fmaxf(v, 0.f);
+      sOut[(4 * c + j) * PN_IMG + 2 * p + i] = v;
+      const int img = i0 + 2 * p + i;
+      if (img < I) gOut[(size_t)img * 128 + 4 * c + j] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void pose_mlp_fwd_kernel(PoseNetArgs a) {
+  if (a.active && !*a.active) return;
+  __shared__ float sWt[128 * 128];
+  __shared__ float sT[12 * PN_IMG], sX[128 * PN_IMG], sY[128 * PN_IMG], sZ[128 * PN_IMG];
+  const int t = threadIdx.x, i0 = blockIdx.x * PN_IMG;
+  if (t < 12 * PN_IMG) {
+    const int k = t / PN_IMG, i = t % PN_IMG;
+    sT[k * PN_IMG + i] = (i0 + i < a.I) ? a.T0[(size_t)(i0 + i) * 16 + k] : 0.f;
+  }
+  const float* P = a.P;
+  pn_layer_fwd(P + PN_C1_W, P + PN_C1_B, 12, sT, sWt, sX, true, nullptr, a.a1, i0, a.I);           // x1 = relu(conv1(T))
+  pn_layer_fwd(P + PN_C2_W, P + PN_C2_B, 128, sX, sWt, sY, true, nullptr, a.a2, i0, a.I);          // x2
+  pn_layer_fwd(P + PN_C3_W, P + PN_C3_B, 128, sY, sWt, sZ, true, nullptr, a.a3, i0, a.I);          // x3
+  pn_layer_fwd(P + PN_SKIP_W, P + PN_SKIP_B, 12, sT, sWt, sX, false, sZ, a.r, i0, a.I);            // res = head_skip(T) + x3
+  pn_layer_fwd(P + PN_F1_W, P + PN_F1_B, 128, sX, sWt, sY, true, nullptr, a.f1, i0, a.I);          // relu(fc1(res))
+  pn_layer_fwd(P + PN_F2_W, P + PN_F2_B, 128, sY, sWt, sZ, true, nullptr, a.f2, i0, a.I);          // relu(fc2(.))
+  __syncthreads();
+  // fc3 (128 -> 12): thread = (image, output); then P = T + w * delta and the Gram-Schmidt step, one thread per image
+  float* sD = sX;   // [12][16]
+  if (t < 12 * PN_IMG) {
+    const int o = t / PN_IMG, i = t % PN_IMG;
+    const float* W3 = P + PN_F3_W + o * 128;
+    float acc = P[PN_F3_B + o];
+    for (int k = 0; k < 128; ++k) acc = fmaf(sZ[k * PN_IMG + i], W3[k], acc);
+    sD[o * PN_IMG + i] = acc;
+    if (i0 + i < a.I) a.delta[(size_t)(i0 + i) * 12 + o] = acc;
+  }
+  __syncthreads();
+  if (t < PN_IMG && i0 + t < a.I) {
+    float Pm[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Pm[k] = sT[k * PN_IMG + t] + a.w * sD[k * PN_IMG + t];
+    float x[3] = {Pm[0], Pm[4], Pm[8]}, y[3] = {Pm[1], Pm[5], Pm[9]};
+    const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    x[0] /= nx; x[1] /= nx; x[2] /= nx;
+    const float d = x[0] * y[0] + x[1] * y[1] + x[2] * y[2];
+    y[0] -= d * x[0]; y[1] -= d * x[1]; y[2] -= d * x[2];
+    const float ny = sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+    y[0] /= ny; y[1] /= ny; y[2] /= ny;
+    const float z[3] = {x[1] * y[2] - x[2] * y[1], x[2] * y[0] - x[0] * y[2], x[0] * y[1] - x[1] * y[0]};
+    float* o = a.pose_cur + (size_t)(i0 + t) * 16;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { o[r * 4 + 0] = x[r]; o[r * 4 + 1] = y[r]; o[r * 4 + 2] = z[r]; o[r * 4 + 3] = Pm[r * 4 + 3]; }
+    o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+  }
+}
+
+// dX[img][k] = (sum_n dY[n][img] * W[n][k]) (.) (act[img][k] > 0), k < 128, N = 12 or 128 rows of W ([N][128] row-major, staged as is)
+__device__ __forceinline__ void pn_layer_bwd(const float* __restrict__ W, int N, const float* sDY, float* sW, float* sDX,
+                                             const float* __restrict__ gAct, float* __restrict__ gOut, int i0, int I) {
+  const int t = threadIdx.x;
+  __syncthreads();
+  for (int idx = t; idx < N * 128; idx += 256) sW[idx] = W[idx];
+  __syncthreads();
+  const int p = t >> 5, c = t & 31;
+  float acc[2][4] = {};
+  for (int n = 0; n < N; ++n) {
+    const float2 dy = *reinterpret_cast<const float2*>(sDY + n * PN_IMG + 2 * p);
+    const float4 wv = *reinterpret_cast<const float4*>(sW + n * 128 + 4 * c);
+    acc[0][0] = fmaf(dy.x, wv.x, acc[0][0]); acc[0][1] = fmaf(dy.x, wv.y, acc[0][1]); acc[0][2] = fmaf(dy.x, wv.z, acc[0][2]); acc[0][3] = fmaf(dy.x, wv.w, acc[0][3]);
+    acc[1][0] = fmaf(dy.y, wv.x, acc[1][0]); acc[1][1] = fmaf(dy.y, wv.y, acc[1][1]); acc[1][2] = fmaf(dy.y, wv.z, acc[1][2]); acc[1][3] = fmaf(dy.y, wv.w, acc[1][3]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int img = i0 + 2 * p + i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[i][j];
+      if (gAct && !(img < I && gAct[(size_t)img * 128 + 4 * c + j] > 0.f)) v = 0.f;
+      if (img >= I) v = 0.f;
+      sDX[(4 * c + j) * PN_IMG + 2 * p + i] = v;
+      if (img < I) gOut[(size_t)img * 128 + 4 * c + j] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pose_mlp_bwd_kernel(PoseNetArgs a) {
+  if (a.active && !*a.active) return;
+  __shared__ float sW[128 * 128];
+  __shared__ float sD[12 * PN_IMG], sX[128 * PN_IMG], sY[128 * PN_IMG];
+  const int t = threadIdx.x, i0 = blockIdx.x * PN_IMG;
+  // compose backward (one thread per image): gradient wrt the refined pose -> gradient wrt the network output
+  if (t < PN_IMG) {
+    float o[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o[k] = 0.f;
+    const int i = i0 + t;
+    if (i < a.I) {
+      float Pm[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) Pm[k] = a.T0[(size_t)i * 16 + k] + a.w * a.delta[(size_t)i * 12 + k];
+      const float xr[3] = {Pm[0], Pm[4], Pm[8]}, yr[3] = {Pm[1], Pm[5], Pm[9]};
+      const float nx = sqrtf(xr[0] * xr[0] + xr[1] * xr[1] + xr[2] * xr[2]);
+      const float x[3] = {xr[0] / nx, xr[1] / nx, xr[2] / nx};
+      const float d = x[0] * yr[0] + x[1] * yr[1] + x[2] * yr[2];
+      const float yp[3] = {yr[0] - d * x[0], yr[1] - d * x[1], yr[2] - d * x[2]};
+      const float ny = sqrtf(yp[0] * yp[0] + yp[1] * yp[1] + yp[2] * yp[2]);
+      const float y[3] = {yp[0] / ny, yp[1] / ny, yp[2] / ny};
+      const float* g = a.dT + (size_t)i * 12;
+      float gx[3] = {g[0], g[4], g[8]}, gy[3] = {g[1], g[5], g[9]};
+      const float gz[3] = {g[2], g[6], g[10]};
+      gx[0] += y[1] * gz[2] - y[2] * gz[1]; gx[1] += y[2] * gz[0] - y[0] * gz[2]; gx[2] += y[0] * gz[1] - y[1] * gz[0];
+      gy[0] += gz[1] * x[2] - gz[2] * x[1]; gy[1] += gz[2] * x[0] - gz[0] * x[2]; gy[2] += gz[0] * x[1] - gz[1] * x[0];
+      const float ydg = y[0] * gy[0] + y[1] * gy[1] + y[2] * gy[2];
+      const float gyp[3] = {(gy[0] - y[0] * ydg) / ny, (gy[1] - y[1] * ydg) / ny, (gy[2] - y[2] * ydg) / ny};
+      const float xdg = x[0] * gyp[0] + x[1] * gyp[1] + x[2] * gyp[2];
+      const float gyr[3] = {gyp[0] - x[0] * xdg, gyp[1] - x[1] * xdg, gyp[2] - x[2] * xdg};
+      gx[0] -= d * gyp[0] + xdg * yr[0]; gx[1] -= d * gyp[1] + xdg * yr[1]; gx[2] -= d * gyp[2] + xdg * yr[2];
+      const float xdgx = x[0] * gx[0] + x[1] * gx[1] + x[2] * gx[2];
+      const float gxr[3] = {(gx[0] - x[0] * xdgx) / nx, (gx[1] - x[1] * xdgx) / nx, (gx[2] - x[2] * xdgx) / nx};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        o[r * 4 + 0] = a.w * gxr[r];
+        o[r * 4 + 1] = a.w * gyr[r];
+        o[r * 4 + 2] = 0.f;          // the third column of the raw matrix does not reach the output
+        o[r * 4 + 3] = a.w * g[r * 4 + 3];
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) a.ddelta[(size_t)i * 12 + k] = o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) sD[k * PN_IMG + t] = o[k];
+  }
+  const float* P = a.P;
+  pn_layer_bwd(P + PN_F3_W, 12, sD, sW, sX, a.f2, a.dz2, i0, a.I);      // through fc3, relu'(fc2 out)
+  pn_layer_bwd(P + PN_F2_W, 128, sX, sW, sY, a.f1, a.dz1, i0, a.I);     // through fc2, relu'(fc1 out)
+  pn_layer_bwd(P + PN_F1_W, 128, sY, sW, sX, nullptr, a.dr, i0, a.I);   // through fc1: gradient of res (= of head_skip's output and of x3)
+  // x3 = relu(conv3(x2)): its pre-activation gradient is d(res) masked
+  __syncthreads();
+  for (int idx = t; idx < 128 * PN_IMG; idx += 256) {
+    const int k = idx / PN_IMG, i = idx % PN_IMG, img = i0 + i;
+    float v = sX[idx];
+    if (!(img < a.I && a.a3[(size_t)img * 128 + k] > 0.f)) v = 0.f;
+    sY[idx] = v;
+    if (img < a.I) a.dzc3[(size_t)img * 128 + k] = v;
+  }
+  pn_layer_bwd(P + PN_C3_W, 128, sY, sW, sX, a.a2, a.dzc2, i0, a.I);
+  pn_layer_bwd(P + PN_C2_W, 128, sX, sW, sY, a.a1, a.dzc1, i0, a.I);
+}
+
+// dW[o][k] = sum_i dY[i][o] X[i][k], db[o] = sum_i dY[i][o] for the seven layers; job = (layer, 16 output rows, image slice z).
+struct PoseWgradArgs {
+  const float* dY[7]; const float* X[7];
+  int O[7], K[7], xpitch[7];
+  int64_t offW[7], offB[7];
+  int I, Z;
+  float* part;            // [Z][n_params]
+  int64_t part_stride;
+  const int* active;
+  int job_start[8];       // prefix sums of ceil(O / 16) over the layers
+};
+__global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
+  if (a.active && !*a.active) return;
+  __shared__ float sDY[32][16];
+  __shared__ float sXs[32][128];
+  const int t = threadIdx.x;
+  int layer = 0;
+  while (layer < 6 && (int)blockIdx.x >= a.job_start[layer + 1]) ++layer;
+  const int o0 = ((int)blockIdx.x - a.job_start[layer]) * 16;
+  const int z = blockIdx.y;
+  const int O = a.O[layer], K = a.K[layer], xp = a.xpitch[layer];
+  const float* dY = a.dY[layer];
+  const float* X = a.X[layer];
+  const int per = (a.I + a.Z - 1) / a.Z;
+  const int ib = z * per, ie = min(a.I, ib + per);
+  const int k = t & 127, h = t >> 7;   // thread: column k, output rows o0 + 8h .. +7
+  float acc[8], accb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[j] = 0.f; accb[j] = 0.f; }
+  for (int c0 = ib; c0 < ie; c0 += 32) {
+    __syncthreads();
+    for (int idx = t; idx < 32 * 16; idx += 256) {
+      const int i = idx >> 4, o = idx & 15;
+      sDY[i][o] = (c0 + i < ie && o0 + o < O) ? dY[(size_t)(c0 + i) * O + o0 + o] : 0.f;
+    }
+    for (int idx = t; idx < 32 * 128; idx += 256) {
+      const int i = idx >> 7, kk = idx & 127;
+      sXs[i][kk] = (c0 + i < ie && kk < K) ? X[(size_t)(c0 + i) * xp + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+      const float x = sXs[i][k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dy = sDY[i][8 * h + j];
+        acc[j] = fmaf(dy, x, acc[j]);
+        accb[j] += dy;
+      }
+    }
+  }
+  float* part = a.part + (size_t)z * a.part_stride;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int o = o0 + 8 * h + j;
+    if (o < O) {
+      if (k < K) part[a.offW[layer] + (size_t)o * K + k] = acc[j];
+      if (k == 0) part[a.offB[layer] + o] = accb[j];
+    }
+  }
+}
+
+// dT[i][:] = sum over the batch rows whose image is i of row_dT[row][:], rows visited in increasing order (fixed order, no
+// atomics): a workgroup stages the row -> image table in LDS once; each of its wavefronts then owns images and scans the table 64
+// rows at a time (ballot).
+__global__ __launch_bounds__(256) void pose_grad_reduce2_kernel(const float* row_dT /*[n][12]*/, const int* row_image /*[n]*/, int n,
+                                                                float* dT /*[I][12]*/, int n_images, const int* active) {
+  if (active && !*active) return;
+  extern __shared__ int s_img[];
+  for (int r = threadIdx.x; r < n; r += 256) s_img[r] = row_image[r];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+  for (int img = wave_global; img < n_images; img += nwaves) {
+    float acc = 0.f;  // lane k < 12 accumulates component k
+    for (int r0 = 0; r0 < n; r0 += 64) {
+      const int r = r0 + lane;
+      const bool hit = (r < n) && (s_img[r] == img);
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if (lane < 12) acc += row_dT[(size_t)(r0 + b) * 12 + lane];
+      }
+    }
+    if (lane < 12) dT[(size_t)img * 12 + lane] = acc;
   }
 }
 

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--buffer-patches", type=int, default=8_000_000)   # train_ace.py:122
     ap.add_argument("--reg-frames", type=int, default=2048)
     ap.add_argument("--e2e-frames", type=int, default=1024)
+    ap.add_argument("--pose-refinement", default="none", choices=["none", "mlp"])   # ace_zero.py:86 maps every non-seed iteration with mlp
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # control-flow smoke of the N > 1 path on a ONE-GPU box: every rank on cuda:0, gloo instead of RCCL (not a measurement)
     ap.add_argument("--smoke-same-device", action="store_true")
@@ -74,7 +75,8 @@ def bench_training(args, rank, world, device):
     total_iters = args.steps + args.warmup + 64
     tr = HeadTrainer(prob["mean"], max_batch=BATCH, global_batch=BATCH * world, loss_type="tanh", schedule="1cyclepoly",
                      iterations=max(total_iters, 25000), lr_min=0.0005, lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005,
-                     cooldown_iterations=5000)                                  # ace_zero.py:105-123 mapping settings
+                     cooldown_iterations=5000, pose_refinement=args.pose_refinement,
+                     refine_calibration=args.pose_refinement != "none", focal_init=float(prob["focal"]))   # ace_zero.py:105-123 mapping settings
     tr.load_flat(torch.from_numpy(synth.init_head_params(1)))
     tr.set_buffer(feats, target_px, view_idx, prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"], prob["view_image"],
                   prob["image_pose_inv"])
@@ -296,7 +298,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "7-Scenes-chess-like ace_zero mapping step: 8M-patch bf16 feature buffer in HBM, batch 5120 per GPU, "
-                                   "default head (1 block, 2 103 300 params), tanh loss, 1cyclepoly AdamW, pose_refinement none",
+                                   "default head (1 block, 2 103 300 params), tanh loss, 1cyclepoly AdamW, pose_refinement " + args.pose_refinement,
                        "buffer_patches": args.buffer_patches, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "parallelism": f"dp{world}"},
             "whole_step_flop_frac_of_mfma_peak": patches_per_s / world * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS * 1e12),
