@@ -51,6 +51,7 @@ struct acez_trainer {
   float *pa1 = nullptr, *pa2 = nullptr, *pa3 = nullptr, *pr = nullptr, *pf1 = nullptr, *pf2 = nullptr, *pdlt = nullptr, *pose_cur = nullptr;
   float *pdT = nullptr, *pddelta = nullptr, *pdz2 = nullptr, *pdz1 = nullptr, *pdr = nullptr, *pdzc3 = nullptr, *pdzc2 = nullptr, *pdzc1 = nullptr;
   float* pose_part = nullptr;
+  float* pose_wt = nullptr;     // [4][128][128] transposed pose-network weights (forward)
   float* row_dT = nullptr;
   int* row_image = nullptr;
   // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
@@ -239,6 +240,7 @@ extern "C" int acez_trainer_set_buffer(acez_trainer* tr, const acez_train_buffer
     if (tr->pose_ksplit > 8) tr->pose_ksplit = 8;
     if (tr->pose_ksplit < 1) tr->pose_ksplit = 1;
     A((void**)&tr->pose_part, (size_t)tr->pose_ksplit * ACEZ_POSE_MLP_PARAMS * sizeof(float));
+    A((void**)&tr->pose_wt, (size_t)4 * 128 * 128 * sizeof(float));
     if (!tr->row_dT) {
       A((void**)&tr->row_dT, (size_t)tr->max_batch * 12 * sizeof(float));
       A((void**)&tr->row_image, (size_t)tr->max_batch * sizeof(int));
@@ -341,13 +343,14 @@ static PoseNetArgs pose_net_args(acez_trainer* tr, const int* active) {
   a.P = tr->pb.d_pose_params; a.T0 = tr->buf.d_image_pose_inv; a.I = tr->buf.n_images; a.w = tr->cfg.pose_refinement_weight;
   a.a1 = tr->pa1; a.a2 = tr->pa2; a.a3 = tr->pa3; a.r = tr->pr; a.f1 = tr->pf1; a.f2 = tr->pf2; a.delta = tr->pdlt; a.pose_cur = tr->pose_cur;
   a.dT = tr->pdT; a.ddelta = tr->pddelta; a.dz2 = tr->pdz2; a.dz1 = tr->pdz1; a.dr = tr->pdr; a.dzc3 = tr->pdzc3; a.dzc2 = tr->pdzc2;
-  a.dzc1 = tr->pdzc1; a.active = active;
+  a.dzc1 = tr->pdzc1; a.active = active; a.Wt = tr->pose_wt;
   return a;
 }
 
 // refined poses of all images (PoseRefiner._predict_pose_updates, refine_poses.py:152-176): one fused launch
 static void pose_forward(acez_trainer* tr, const int* active, hipStream_t s) {
   const PoseNetArgs a = pose_net_args(tr, active);
+  hipLaunchKernelGGL(pose_transpose_kernel, dim3(4, 4, 4), dim3(256), 0, s, a.P, tr->pose_wt, active);
   hipLaunchKernelGGL(pose_mlp_fwd_kernel, dim3((a.I + PN_IMG - 1) / PN_IMG), dim3(256), 0, s, a);
 }
 

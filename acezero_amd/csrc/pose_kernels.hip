@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void pose_compose_bwd_kernel(const float* T0, 
 // ---------------------------------------------------------------------------------------------------
 struct PoseNetArgs {
   const float* P;          // flat parameters
+  const float* Wt;         // [4][128][128] transposed copies of conv2, conv3, fc1, fc2 (pose_transpose_kernel), forward only
   const float* T0;         // [I][16] original world->cam poses
   int I;
   float w;                 // update weight (refine_poses.py:165)
@@ -206,13 +207,18 @@ constexpr int PN_IMG = 16;     // images per workgroup
 
 // out[img][n] = act( sum_k in[k][img] * W[n][k] + b[n] (+ add) ), n < 128: thread = (image pair t >> 5, 4 channels 4 * (t & 31)).
 // W ([128][K] row-major, K = 12 or 128) is staged transposed in LDS (sWt[k][n]); sIn is [K][16]. Result -> sOut[n][16] and global.
-__device__ __forceinline__ void pn_layer_fwd(const float* __restrict__ W, const float* __restrict__ b, int K, const float* sIn, float* sWt,
-                                             float* sOut, bool relu, const float* sAdd, float* __restrict__ gOut, int i0, int I) {
+__device__ __forceinline__ void pn_layer_fwd(const float* __restrict__ W, const float* __restrict__ Wt, const float* __restrict__ b, int K,
+                                             const float* sIn, float* sWt, float* sOut, bool relu, const float* sAdd,
+                                             float* __restrict__ gOut, int i0, int I) {
   const int t = threadIdx.x;
   __syncthreads();   // previous users of sWt / sOut are done
-  for (int idx = t; idx < 128 * K; idx += 256) {
-    const int n = idx % 128, k = idx / 128;
-    sWt[k * 128 + n] = W[n * K + k];
+  if (Wt) {          // [K = 128][128] already transposed in global memory: coalesced 16-byte copies
+    for (int idx = t; idx < 128 * 128 / 4; idx += 256) reinterpret_cast<float4*>(sWt)[idx] = reinterpret_cast<const float4*>(Wt)[idx];
+  } else {
+    for (int idx = t; idx < 128 * K; idx += 256) {
+      const int n = idx % 128, k = idx / 128;
+      sWt[k * 128 + n] = W[n * K + k];
+    }
   }
   __syncthreads();
   const int p = t >> 5, c = t & 31;
@@ -220,6 +226,7 @@ __device__ __forceinline__ void pn_layer_fwd(const float* __restrict__ W, const 
   const float4 bb = *reinterpret_cast<const float4*>(b + 4 * c);
 #pragma unroll
   for (int i = 0; i < 2; ++i) { acc[i][0] = bb.x; acc[i][1] = bb.y; acc[i][2] = bb.z; acc[i][3] = bb.w; }
+#pragma unroll 4
   for (int k = 0; k < K; ++k) {
     const float2 x = *reinterpret_cast<const float2*>(sIn + k * PN_IMG + 2 * p);
     const float4 wv = *reinterpret_cast<const float4*>(sWt + k * 128 + 4 * c);
@@ -239,6 +246,21 @@ __device__ __forceinline__ void pn_layer_fwd(const float* __restrict__ W, const 
     }
 }
 
+// Wt[l][k][n] = W_l[n][k] for the four 128 x 128 layers (conv2, conv3, fc1, fc2): 64 K elements, once per step
+__global__ __launch_bounds__(256) void pose_transpose_kernel(const float* P, float* Wt, const int* active) {
+  if (active && !*active) return;
+  __shared__ float tile[32][33];
+  const int64_t off[4] = {PN_C2_W, PN_C3_W, PN_F1_W, PN_F2_W};
+  const int l = blockIdx.z, bx = blockIdx.x * 32, by = blockIdx.y * 32;   // W tile rows n = by.., cols k = bx..
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* W = P + off[l];
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) tile[ty + j][tx] = W[(by + ty + j) * 128 + bx + tx];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) Wt[(size_t)l * 16384 + (bx + ty + j) * 128 + by + tx] = tile[tx][ty + j];
+}
+
 __global__ __launch_bounds__(256) void pose_mlp_fwd_kernel(PoseNetArgs a) {
   if (a.active && !*a.active) return;
   __shared__ float sWt[128 * 128];
@@ -249,12 +271,12 @@ __global__ __launch_bounds__(256) void pose_mlp_fwd_kernel(PoseNetArgs a) {
     sT[k * PN_IMG + i] = (i0 + i < a.I) ? a.T0[(size_t)(i0 + i) * 16 + k] : 0.f;
   }
   const float* P = a.P;
-  pn_layer_fwd(P + PN_C1_W, P + PN_C1_B, 12, sT, sWt, sX, true, nullptr, a.a1, i0, a.I);           // x1 = relu(conv1(T))
-  pn_layer_fwd(P + PN_C2_W, P + PN_C2_B, 128, sX, sWt, sY, true, nullptr, a.a2, i0, a.I);          // x2
-  pn_layer_fwd(P + PN_C3_W, P + PN_C3_B, 128, sY, sWt, sZ, true, nullptr, a.a3, i0, a.I);          // x3
-  pn_layer_fwd(P + PN_SKIP_W, P + PN_SKIP_B, 12, sT, sWt, sX, false, sZ, a.r, i0, a.I);            // res = head_skip(T) + x3
-  pn_layer_fwd(P + PN_F1_W, P + PN_F1_B, 128, sX, sWt, sY, true, nullptr, a.f1, i0, a.I);          // relu(fc1(res))
-  pn_layer_fwd(P + PN_F2_W, P + PN_F2_B, 128, sY, sWt, sZ, true, nullptr, a.f2, i0, a.I);          // relu(fc2(.))
+  pn_layer_fwd(P + PN_C1_W, nullptr, P + PN_C1_B, 12, sT, sWt, sX, true, nullptr, a.a1, i0, a.I);            // x1 = relu(conv1(T))
+  pn_layer_fwd(nullptr, a.Wt + 0 * 16384, P + PN_C2_B, 128, sX, sWt, sY, true, nullptr, a.a2, i0, a.I);     // x2
+  pn_layer_fwd(nullptr, a.Wt + 1 * 16384, P + PN_C3_B, 128, sY, sWt, sZ, true, nullptr, a.a3, i0, a.I);     // x3
+  pn_layer_fwd(P + PN_SKIP_W, nullptr, P + PN_SKIP_B, 12, sT, sWt, sX, false, sZ, a.r, i0, a.I);             // res = head_skip(T) + x3
+  pn_layer_fwd(nullptr, a.Wt + 2 * 16384, P + PN_F1_B, 128, sX, sWt, sY, true, nullptr, a.f1, i0, a.I);     // relu(fc1(res))
+  pn_layer_fwd(nullptr, a.Wt + 3 * 16384, P + PN_F2_B, 128, sY, sWt, sZ, true, nullptr, a.f2, i0, a.I);     // relu(fc2(.))
   __syncthreads();
   // fc3 (128 -> 12): thread = (image, output); then P = T + w * delta and the Gram-Schmidt step, one thread per image
   float* sD = sX;   // [12][16]
@@ -392,7 +414,7 @@ struct PoseWgradArgs {
 };
 __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
   if (a.active && !*a.active) return;
-  __shared__ float sDY[32][16];
+  __shared__ __attribute__((aligned(16))) float sDY[32][16];
   __shared__ float sXs[32][128];
   const int t = threadIdx.x;
   int layer = 0;
@@ -422,11 +444,12 @@ __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
 #pragma unroll 4
     for (int i = 0; i < 32; ++i) {
       const float x = sXs[i][k];
+      const float4 d0 = *reinterpret_cast<const float4*>(&sDY[i][8 * h]), d1 = *reinterpret_cast<const float4*>(&sDY[i][8 * h + 4]);
+      const float dy[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float dy = sDY[i][8 * h + j];
-        acc[j] = fmaf(dy, x, acc[j]);
-        accb[j] += dy;
+        acc[j] = fmaf(dy[j], x, acc[j]);
+        accb[j] += dy[j];
       }
     }
   }
