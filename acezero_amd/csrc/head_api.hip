@@ -364,8 +364,7 @@ static void launch_pose_grad_reduce(acez_trainer* tr, int n, const int* active, 
 
 // gradient of the pose network from the per-row pose gradients of the loss kernel -> d_grad tail (4 launches)
 static void pose_backward(acez_trainer* tr, int n, const int* active, hipStream_t s) {
-  const int I = tr->buf.n_images, Z = tr->pose_ksplit;
-  const int64_t NP = ACEZ_POSE_MLP_PARAMS;
+  const int I = tr->buf.n_images;
   launch_pose_grad_reduce(tr, n, active, s);
   const PoseNetArgs a = pose_net_args(tr, active);
   hipLaunchKernelGGL(pose_mlp_bwd_kernel, dim3((I + PN_IMG - 1) / PN_IMG), dim3(256), 0, s, a);
@@ -380,13 +379,11 @@ static void pose_backward(acez_trainer* tr, int n, const int* active, hipStream_
   for (int l = 0; l < 7; ++l) {
     w.dY[l] = dY[l]; w.X[l] = X[l]; w.O[l] = O[l]; w.K[l] = K[l]; w.xpitch[l] = XP[l]; w.offW[l] = OW[l]; w.offB[l] = OB[l];
     w.job_start[l] = jobs;
-    jobs += (O[l] + 15) / 16;
+    jobs += ((O[l] + 15) / 16) * ((K[l] + 15) / 16);
   }
   w.job_start[7] = jobs;
-  w.I = I; w.Z = Z; w.part = tr->pose_part; w.part_stride = NP; w.active = active;
-  hipLaunchKernelGGL(pose_mlp_wgrad_kernel, dim3(jobs, Z), dim3(256), 0, s, w);
-  hipLaunchKernelGGL(small_reduce_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, s, (const float*)tr->pose_part, NP, Z,
-                     tr->pb.d_grad + tr->n_params + 4, NP, active);
+  w.I = I; w.grad = tr->pb.d_grad + tr->n_params + 4; w.active = active;
+  hipLaunchKernelGGL(pose_mlp_wgrad_kernel, dim3(jobs), dim3(256), 0, s, w);
 }
 
 static PostArgs post_args(acez_trainer* tr) {

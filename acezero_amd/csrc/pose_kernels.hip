@@ -205,65 +205,62 @@ constexpr int64_t PN_SKIP_W = 0, PN_SKIP_B = 1536, PN_C1_W = 1664, PN_C1_B = 320
                   PN_C3_B = 36224, PN_F1_W = 36352, PN_F1_B = 52736, PN_F2_W = 52864, PN_F2_B = 69248, PN_F3_W = 69376, PN_F3_B = 70912;
 constexpr int PN_IMG = 16;     // images per workgroup
 
-// out[img][n] = act( sum_k in[k][img] * W[n][k] + b[n] (+ add) ), n < 128: thread = (image pair t >> 5, 4 channels 4 * (t & 31)).
-// W ([128][K] row-major, K = 12 or 128) is staged transposed in LDS (sWt[k][n]); sIn is [K][16]. Result -> sOut[n][16] and global.
-__device__ __forceinline__ void pn_layer_fwd(const float* __restrict__ W, const float* __restrict__ Wt, const float* __restrict__ b, int K,
-                                             const float* sIn, float* sWt, float* sOut, bool relu, const float* sAdd,
-                                             float* __restrict__ gOut, int i0, int I) {
-  const int t = threadIdx.x;
-  __syncthreads();   // previous users of sWt / sOut are done
-  if (Wt) {          // [K = 128][128] already transposed in global memory: coalesced 16-byte copies
-    for (int idx = t; idx < 128 * 128 / 4; idx += 256) reinterpret_cast<float4*>(sWt)[idx] = reinterpret_cast<const float4*>(Wt)[idx];
-  } else {
-    for (int idx = t; idx < 128 * K; idx += 256) {
-      const int n = idx % 128, k = idx / 128;
-      sWt[k * 128 + n] = W[n * K + k];
-    }
-  }
-  __syncthreads();
-  const int p = t >> 5, c = t & 31;
-  float acc[2][4];
-  const float4 bb = *reinterpret_cast<const float4*>(b + 4 * c);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { acc[i][0] = bb.x; acc[i][1] = bb.y; acc[i][2] = bb.z; acc[i][3] = bb.w; }
-#pragma unroll 4
-  for (int k = 0; k < K; ++k) {
-    const float2 x = *reinterpret_cast<const float2*>(sIn + k * PN_IMG + 2 * p);
-    const float4 wv = *reinterpret_cast<const float4*>(sWt + k * 128 + 4 * c);
-    acc[0][0] = fmaf(x.x, wv.x, acc[0][0]); acc[0][1] = fmaf(x.x, wv.y, acc[0][1]); acc[0][2] = fmaf(x.x, wv.z, acc[0][2]); acc[0][3] = fmaf(x.x, wv.w, acc[0][3]);
-    acc[1][0] = fmaf(x.y, wv.x, acc[1][0]); acc[1][1] = fmaf(x.y, wv.y, acc[1][1]); acc[1][2] = fmaf(x.y, wv.z, acc[1][2]); acc[1][3] = fmaf(x.y, wv.w, acc[1][3]);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v = acc[i][j];
-      if (sAdd) v += sAdd[(4 * c + j) * PN_IMG + 2 * p + i];
-      if (relu) v = fmaxf(v, 0.f);
-      sOut[(4 * c + j) * PN_IMG + 2 * p + i] = v;
-      const int img = i0 + 2 * p + i;
-      if (img < I) gOut[(size_t)img * 128 + 4 * c + j] = v;
-    }
-}
+typedef __attribute__((ext_vector_type(4))) float pn_f4;
 
-// Wt[l][k][n] = W_l[n][k] for the four 128 x 128 layers (conv2, conv3, fc1, fc2): 64 K elements, once per step
-__global__ __launch_bounds__(256) void pose_transpose_kernel(const float* P, float* Wt, const int* active) {
-  if (active && !*active) return;
-  __shared__ float tile[32][33];
-  const int64_t off[4] = {PN_C2_W, PN_C3_W, PN_F1_W, PN_F2_W};
-  const int l = blockIdx.z, bx = blockIdx.x * 32, by = blockIdx.y * 32;   // W tile rows n = by.., cols k = bx..
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const float* W = P + off[l];
+// One layer for a tile of 16 images on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate):
+//   out[n][img] = epi( sum_k A(n, k) * in[k][img] ),  A(n, k) = Wa[n * si + k * sk]   (n < N, k < K, K % 4 == 0)
+// The A operand is read straight from global memory (L2-resident, 284 KiB for the whole network): no weight staging, so a
+// layer is ~32 dependent MFMA steps instead of a 128-iteration LDS-latency-bound loop. Wave w owns the 16-row blocks 2w and
+// 2w + 1 of the output (lane: column = image l & 15, rows 4 * (l >> 4) + r). in: LDS [K][16]; out: LDS [N][16] + global [I][N].
+//   forward : A = W (si = K, sk = 1) or its transposed copy, epi = (+ bias, + add, relu)
+//   backward: A = W^T (si = 1, sk = row pitch of W), epi = (mask by the stored activation)
+__device__ __forceinline__ void pn_mfma_layer(const float* __restrict__ Wa, int si, int sk, int N, int K, const float* __restrict__ bias,
+                                              const float* sIn, bool relu, const float* sAdd, const float* __restrict__ gMask,
+                                              float* sOut, float* __restrict__ gOut, int i0, int I) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = l & 15, lk = l >> 4;
+  __syncthreads();   // sIn complete, previous readers of sOut done
+  const int n0 = w * 32;
+  if (n0 < N) {
+    const bool two = n0 + 16 < N;
+    const int r0 = min(n0 + li, N - 1), r1 = min(n0 + 16 + li, N - 1);
+    const float* p0 = Wa + (size_t)r0 * si + (size_t)lk * sk;
+    const float* p1 = Wa + (size_t)r1 * si + (size_t)lk * sk;
+    const bool v0 = n0 + li < N, v1 = n0 + 16 + li < N;
+    pn_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      const float bq = sIn[(k0 + lk) * PN_IMG + li];
+      float a0 = p0[(size_t)k0 * sk], a1 = p1[(size_t)k0 * sk];
+      if (!v0) a0 = 0.f;
+      if (!v1) a1 = 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq, acc0, 0, 0, 0);
+      if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bq, acc1, 0, 0, 0);
+    }
+    const int img = i0 + li;
 #pragma unroll
-  for (int j = 0; j < 32; j += 8) tile[ty + j][tx] = W[(by + ty + j) * 128 + bx + tx];
-  __syncthreads();
+    for (int blk = 0; blk < 2; ++blk) {
+      const int nb = n0 + 16 * blk + 4 * lk;   // rows nb .. nb+3 of this lane
+      if (nb >= N) continue;
+      const pn_f4 acc = blk ? acc1 : acc0;
+      float v[4] = {acc[0], acc[1], acc[2], acc[3]};
 #pragma unroll
-  for (int j = 0; j < 32; j += 8) Wt[(size_t)l * 16384 + (bx + ty + j) * 128 + by + tx] = tile[tx][ty + j];
+      for (int r = 0; r < 4; ++r) {
+        const int n = nb + r;
+        if (bias) v[r] += bias[n];
+        if (sAdd) v[r] += sAdd[n * PN_IMG + li];
+        if (relu) v[r] = fmaxf(v[r], 0.f);
+        if (gMask && !(img < I && gMask[(size_t)img * N + n] > 0.f)) v[r] = 0.f;
+        if (img >= I) v[r] = 0.f;
+        sOut[n * PN_IMG + li] = v[r];
+      }
+      if (img < I) *reinterpret_cast<float4*>(gOut + (size_t)img * N + nb) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void pose_mlp_fwd_kernel(PoseNetArgs a) {
   if (a.active && !*a.active) return;
-  __shared__ float sWt[128 * 128];
   __shared__ float sT[12 * PN_IMG], sX[128 * PN_IMG], sY[128 * PN_IMG], sZ[128 * PN_IMG];
   const int t = threadIdx.x, i0 = blockIdx.x * PN_IMG;
   if (t < 12 * PN_IMG) {
@@ -271,24 +268,17 @@ __global__ __launch_bounds__(256) void pose_mlp_fwd_kernel(PoseNetArgs a) {
     sT[k * PN_IMG + i] = (i0 + i < a.I) ? a.T0[(size_t)(i0 + i) * 16 + k] : 0.f;
   }
   const float* P = a.P;
-  pn_layer_fwd(P + PN_C1_W, nullptr, P + PN_C1_B, 12, sT, sWt, sX, true, nullptr, a.a1, i0, a.I);            // x1 = relu(conv1(T))
-  pn_layer_fwd(nullptr, a.Wt + 0 * 16384, P + PN_C2_B, 128, sX, sWt, sY, true, nullptr, a.a2, i0, a.I);     // x2
-  pn_layer_fwd(nullptr, a.Wt + 1 * 16384, P + PN_C3_B, 128, sY, sWt, sZ, true, nullptr, a.a3, i0, a.I);     // x3
-  pn_layer_fwd(P + PN_SKIP_W, nullptr, P + PN_SKIP_B, 12, sT, sWt, sX, false, sZ, a.r, i0, a.I);             // res = head_skip(T) + x3
-  pn_layer_fwd(nullptr, a.Wt + 2 * 16384, P + PN_F1_B, 128, sX, sWt, sY, true, nullptr, a.f1, i0, a.I);     // relu(fc1(res))
-  pn_layer_fwd(nullptr, a.Wt + 3 * 16384, P + PN_F2_B, 128, sY, sWt, sZ, true, nullptr, a.f2, i0, a.I);     // relu(fc2(.))
-  __syncthreads();
-  // fc3 (128 -> 12): thread = (image, output); then P = T + w * delta and the Gram-Schmidt step, one thread per image
+  const float* Wt = a.Wt;   // [4][k][n] transposed copies of conv2, conv3, fc1, fc2: consecutive lanes read consecutive floats
+  pn_mfma_layer(P + PN_C1_W, 12, 1, 128, 12, P + PN_C1_B, sT, true, nullptr, nullptr, sX, a.a1, i0, a.I);              // x1 = relu(conv1(T))
+  pn_mfma_layer(Wt + 0 * 16384, 1, 128, 128, 128, P + PN_C2_B, sX, true, nullptr, nullptr, sY, a.a2, i0, a.I);         // x2
+  pn_mfma_layer(Wt + 1 * 16384, 1, 128, 128, 128, P + PN_C3_B, sY, true, nullptr, nullptr, sZ, a.a3, i0, a.I);         // x3
+  pn_mfma_layer(P + PN_SKIP_W, 12, 1, 128, 12, P + PN_SKIP_B, sT, false, sZ, nullptr, sX, a.r, i0, a.I);               // res = head_skip(T) + x3
+  pn_mfma_layer(Wt + 2 * 16384, 1, 128, 128, 128, P + PN_F1_B, sX, true, nullptr, nullptr, sY, a.f1, i0, a.I);         // relu(fc1(res))
+  pn_mfma_layer(Wt + 3 * 16384, 1, 128, 128, 128, P + PN_F2_B, sY, true, nullptr, nullptr, sZ, a.f2, i0, a.I);         // relu(fc2(.))
   float* sD = sX;   // [12][16]
-  if (t < 12 * PN_IMG) {
-    const int o = t / PN_IMG, i = t % PN_IMG;
-    const float* W3 = P + PN_F3_W + o * 128;
-    float acc = P[PN_F3_B + o];
-    for (int k = 0; k < 128; ++k) acc = fmaf(sZ[k * PN_IMG + i], W3[k], acc);
-    sD[o * PN_IMG + i] = acc;
-    if (i0 + i < a.I) a.delta[(size_t)(i0 + i) * 12 + o] = acc;
-  }
+  pn_mfma_layer(P + PN_F3_W, 128, 1, 12, 128, P + PN_F3_B, sZ, false, nullptr, nullptr, sD, a.delta, i0, a.I);         // fc3: the pose update
   __syncthreads();
+  // P = T + w * delta and the Gram-Schmidt step, one thread per image
   if (t < PN_IMG && i0 + t < a.I) {
     float Pm[12];
 #pragma unroll
@@ -308,38 +298,23 @@ __global__ __launch_bounds__(256) void pose_mlp_fwd_kernel(PoseNetArgs a) {
   }
 }
 
-// dX[img][k] = (sum_n dY[n][img] * W[n][k]) (.) (act[img][k] > 0), k < 128, N = 12 or 128 rows of W ([N][128] row-major, staged as is)
-__device__ __forceinline__ void pn_layer_bwd(const float* __restrict__ W, int N, const float* sDY, float* sW, float* sDX,
-                                             const float* __restrict__ gAct, float* __restrict__ gOut, int i0, int I) {
-  const int t = threadIdx.x;
-  __syncthreads();
-  for (int idx = t; idx < N * 128; idx += 256) sW[idx] = W[idx];
-  __syncthreads();
-  const int p = t >> 5, c = t & 31;
-  float acc[2][4] = {};
-  for (int n = 0; n < N; ++n) {
-    const float2 dy = *reinterpret_cast<const float2*>(sDY + n * PN_IMG + 2 * p);
-    const float4 wv = *reinterpret_cast<const float4*>(sW + n * 128 + 4 * c);
-    acc[0][0] = fmaf(dy.x, wv.x, acc[0][0]); acc[0][1] = fmaf(dy.x, wv.y, acc[0][1]); acc[0][2] = fmaf(dy.x, wv.z, acc[0][2]); acc[0][3] = fmaf(dy.x, wv.w, acc[0][3]);
-    acc[1][0] = fmaf(dy.y, wv.x, acc[1][0]); acc[1][1] = fmaf(dy.y, wv.y, acc[1][1]); acc[1][2] = fmaf(dy.y, wv.z, acc[1][2]); acc[1][3] = fmaf(dy.y, wv.w, acc[1][3]);
-  }
+// Wt[l][k][n] = W_l[n][k] for the four 128 x 128 layers (conv2, conv3, fc1, fc2): 64 K elements, once per step
+__global__ __launch_bounds__(256) void pose_transpose_kernel(const float* P, float* Wt, const int* active) {
+  if (active && !*active) return;
+  __shared__ float tile[32][33];
+  const int64_t off[4] = {PN_C2_W, PN_C3_W, PN_F1_W, PN_F2_W};
+  const int l = blockIdx.z, bx = blockIdx.x * 32, by = blockIdx.y * 32;   // W tile rows n = by.., cols k = bx..
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* W = P + off[l];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int img = i0 + 2 * p + i;
+  for (int j = 0; j < 32; j += 8) tile[ty + j][tx] = W[(by + ty + j) * 128 + bx + tx];
+  __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v = acc[i][j];
-      if (gAct && !(img < I && gAct[(size_t)img * 128 + 4 * c + j] > 0.f)) v = 0.f;
-      if (img >= I) v = 0.f;
-      sDX[(4 * c + j) * PN_IMG + 2 * p + i] = v;
-      if (img < I) gOut[(size_t)img * 128 + 4 * c + j] = v;
-    }
-  }
+  for (int j = 0; j < 32; j += 8) Wt[(size_t)l * 16384 + (bx + ty + j) * 128 + by + tx] = tile[tx][ty + j];
 }
 
 __global__ __launch_bounds__(256) void pose_mlp_bwd_kernel(PoseNetArgs a) {
   if (a.active && !*a.active) return;
-  __shared__ float sW[128 * 128];
   __shared__ float sD[12 * PN_IMG], sX[128 * PN_IMG], sY[128 * PN_IMG];
   const int t = threadIdx.x, i0 = blockIdx.x * PN_IMG;
   // compose backward (one thread per image): gradient wrt the refined pose -> gradient wrt the network output
@@ -385,9 +360,10 @@ __global__ __launch_bounds__(256) void pose_mlp_bwd_kernel(PoseNetArgs a) {
     for (int k = 0; k < 12; ++k) sD[k * PN_IMG + t] = o[k];
   }
   const float* P = a.P;
-  pn_layer_bwd(P + PN_F3_W, 12, sD, sW, sX, a.f2, a.dz2, i0, a.I);      // through fc3, relu'(fc2 out)
-  pn_layer_bwd(P + PN_F2_W, 128, sX, sW, sY, a.f1, a.dz1, i0, a.I);     // through fc2, relu'(fc1 out)
-  pn_layer_bwd(P + PN_F1_W, 128, sY, sW, sX, nullptr, a.dr, i0, a.I);   // through fc1: gradient of res (= of head_skip's output and of x3)
+  // dX[k][img] = sum_n W[n][k] dY[n][img]: A(k, n) = W[n * 128 + k] -> si = 1, sk = 128
+  pn_mfma_layer(P + PN_F3_W, 1, 128, 128, 12, nullptr, sD, false, nullptr, a.f2, sX, a.dz2, i0, a.I);     // through fc3, relu'(fc2 out)
+  pn_mfma_layer(P + PN_F2_W, 1, 128, 128, 128, nullptr, sX, false, nullptr, a.f1, sY, a.dz1, i0, a.I);    // through fc2, relu'(fc1 out)
+  pn_mfma_layer(P + PN_F1_W, 1, 128, 128, 128, nullptr, sY, false, nullptr, nullptr, sX, a.dr, i0, a.I);  // through fc1: gradient of res
   // x3 = relu(conv3(x2)): its pre-activation gradient is d(res) masked
   __syncthreads();
   for (int idx = t; idx < 128 * PN_IMG; idx += 256) {
@@ -397,69 +373,68 @@ __global__ __launch_bounds__(256) void pose_mlp_bwd_kernel(PoseNetArgs a) {
     sY[idx] = v;
     if (img < a.I) a.dzc3[(size_t)img * 128 + k] = v;
   }
-  pn_layer_bwd(P + PN_C3_W, 128, sY, sW, sX, a.a2, a.dzc2, i0, a.I);
-  pn_layer_bwd(P + PN_C2_W, 128, sX, sW, sY, a.a1, a.dzc1, i0, a.I);
+  pn_mfma_layer(P + PN_C3_W, 1, 128, 128, 128, nullptr, sY, false, nullptr, a.a2, sX, a.dzc2, i0, a.I);
+  pn_mfma_layer(P + PN_C2_W, 1, 128, 128, 128, nullptr, sX, false, nullptr, a.a1, sY, a.dzc1, i0, a.I);
 }
 
-// dW[o][k] = sum_i dY[i][o] X[i][k], db[o] = sum_i dY[i][o] for the seven layers; job = (layer, 16 output rows, image slice z).
+// dW[o][k] = sum_i dY[i][o] X[i][k], db[o] = sum_i dY[i][o] for the seven layers, on the fp32 matrix cores straight from global
+// memory: a workgroup owns one 16 x 16 tile of one layer's dW; its four waves take a quarter of the images each
+// (A(o, img) = dY[img][o], B(img, k) = X[img][k], 4 images per MFMA step) and are combined in wave order -> the FINAL gradient,
+// no partial buffers. Tiles with k-block 0 also produce the bias gradient (B = 1).
 struct PoseWgradArgs {
   const float* dY[7]; const float* X[7];
   int O[7], K[7], xpitch[7];
   int64_t offW[7], offB[7];
-  int I, Z;
-  float* part;            // [Z][n_params]
-  int64_t part_stride;
+  int I;
+  float* grad;            // pose gradient vector (d_grad + n_params + 4)
   const int* active;
-  int job_start[8];       // prefix sums of ceil(O / 16) over the layers
+  int job_start[8];       // prefix sums of ceil(O / 16) * ceil(K / 16) over the layers
 };
 __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
   if (a.active && !*a.active) return;
-  __shared__ __attribute__((aligned(16))) float sDY[32][16];
-  __shared__ float sXs[32][128];
-  const int t = threadIdx.x;
+  __shared__ float sAcc[4][2][16][17];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = l & 15, lk = l >> 4;
   int layer = 0;
   while (layer < 6 && (int)blockIdx.x >= a.job_start[layer + 1]) ++layer;
-  const int o0 = ((int)blockIdx.x - a.job_start[layer]) * 16;
-  const int z = blockIdx.y;
   const int O = a.O[layer], K = a.K[layer], xp = a.xpitch[layer];
+  const int kb = (K + 15) / 16;
+  const int job = (int)blockIdx.x - a.job_start[layer];
+  const int o0 = (job / kb) * 16, k0 = (job % kb) * 16;
   const float* dY = a.dY[layer];
   const float* X = a.X[layer];
-  const int per = (a.I + a.Z - 1) / a.Z;
-  const int ib = z * per, ie = min(a.I, ib + per);
-  const int k = t & 127, h = t >> 7;   // thread: column k, output rows o0 + 8h .. +7
-  float acc[8], accb[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { acc[j] = 0.f; accb[j] = 0.f; }
-  for (int c0 = ib; c0 < ie; c0 += 32) {
-    __syncthreads();
-    for (int idx = t; idx < 32 * 16; idx += 256) {
-      const int i = idx >> 4, o = idx & 15;
-      sDY[i][o] = (c0 + i < ie && o0 + o < O) ? dY[(size_t)(c0 + i) * O + o0 + o] : 0.f;
-    }
-    for (int idx = t; idx < 32 * 128; idx += 256) {
-      const int i = idx >> 7, kk = idx & 127;
-      sXs[i][kk] = (c0 + i < ie && kk < K) ? X[(size_t)(c0 + i) * xp + kk] : 0.f;
-    }
-    __syncthreads();
+  const int per = ((a.I + 3) / 4 + 3) / 4 * 4;   // images per wave, multiple of 4
+  const int ib = w * per, ie = min(a.I, ib + per);
+  const bool vo = o0 + li < O, vk = k0 + li < K;
+  const int oc = min(o0 + li, O - 1), kc = min(k0 + li, K - 1);
+  pn_f4 acc = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = k0 == 0;
 #pragma unroll 4
-    for (int i = 0; i < 32; ++i) {
-      const float x = sXs[i][k];
-      const float4 d0 = *reinterpret_cast<const float4*>(&sDY[i][8 * h]), d1 = *reinterpret_cast<const float4*>(&sDY[i][8 * h + 4]);
-      const float dy[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        acc[j] = fmaf(dy[j], x, acc[j]);
-        accb[j] += dy[j];
-      }
-    }
+  for (int i = ib; i < ie; i += 4) {
+    const int img = i + lk;
+    const bool vi = img < ie;
+    const int ic = min(img, a.I - 1);
+    float av = dY[(size_t)ic * O + oc], bv = X[(size_t)ic * xp + kc];
+    if (!(vi && vo)) av = 0.f;
+    if (!(vi && vk)) bv = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    if (want_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av, vi ? 1.f : 0.f, accb, 0, 0, 0);
   }
-  float* part = a.part + (size_t)z * a.part_stride;
+  // lane: column li (k), rows 4 * lk + r (o)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int o = o0 + 8 * h + j;
-    if (o < O) {
-      if (k < K) part[a.offW[layer] + (size_t)o * K + k] = acc[j];
-      if (k == 0) part[a.offB[layer] + o] = accb[j];
+  for (int r = 0; r < 4; ++r) {
+    sAcc[w][0][4 * lk + r][li] = acc[r];
+    sAcc[w][1][4 * lk + r][li] = accb[r];
+  }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int oo = 4 * lk + r, o = o0 + oo, kk = k0 + li;
+      const float g = ((sAcc[0][0][oo][li] + sAcc[1][0][oo][li]) + sAcc[2][0][oo][li]) + sAcc[3][0][oo][li];
+      if (o < O && kk < K) a.grad[a.offW[layer] + (size_t)o * K + kk] = g;
+      if (want_bias && li == 0 && o < O)
+        a.grad[a.offB[layer] + o] = ((sAcc[0][1][oo][0] + sAcc[1][1][oo][0]) + sAcc[2][1][oo][0]) + sAcc[3][1][oo][0];
     }
   }
 }
