@@ -356,9 +356,7 @@ static void pose_forward(acez_trainer* tr, const int* active, hipStream_t s) {
 
 static void launch_pose_grad_reduce(acez_trainer* tr, int n, const int* active, hipStream_t s) {
   const int I = tr->buf.n_images;
-  int blocks = (I + 3) / 4;
-  if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(pose_grad_reduce2_kernel, dim3(blocks), dim3(256), (size_t)n * sizeof(int), s, (const float*)tr->row_dT, (const int*)tr->row_image, n,
+  hipLaunchKernelGGL(pose_grad_reduce2_kernel, dim3((I + 15) / 16), dim3(256), 0, s, (const float*)tr->row_dT, (const int*)tr->row_image, n,
                      tr->pdT, I, active);
 }
 

@@ -214,30 +214,54 @@ typedef __attribute__((ext_vector_type(4))) float pn_f4;
 // 2w + 1 of the output (lane: column = image l & 15, rows 4 * (l >> 4) + r). in: LDS [K][16]; out: LDS [N][16] + global [I][N].
 //   forward : A = W (si = K, sk = 1) or its transposed copy, epi = (+ bias, + add, relu)
 //   backward: A = W^T (si = 1, sk = row pitch of W), epi = (mask by the stored activation)
-__device__ __forceinline__ void pn_mfma_layer(const float* __restrict__ Wa, int si, int sk, int N, int K, const float* __restrict__ bias,
-                                              const float* sIn, bool relu, const float* sAdd, const float* __restrict__ gMask,
-                                              float* sOut, float* __restrict__ gOut, int i0, int I) {
+// The A operands of a layer do not depend on the previous layer's result, only the B operand (activations in LDS) does: they
+// are fetched one layer AHEAD (pn_fetch) so that a layer costs its MFMA chain, not an L2 round trip (~1 us) plus the chain.
+template <int K>
+struct PnA {
+  float a0[K / 4], a1[K / 4];
+};
+template <int K>
+__device__ __forceinline__ void pn_fetch(PnA<K>& A, const float* __restrict__ Wa, int si, int sk, int N) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = l & 15, lk = l >> 4, n0 = w * 32;
+  const int r0 = min(n0 + li, N - 1), r1 = min(n0 + 16 + li, N - 1);
+  const float* p0 = Wa + (size_t)r0 * si + (size_t)lk * sk;
+  const float* p1 = Wa + (size_t)r1 * si + (size_t)lk * sk;
+  const bool v0 = n0 + li < N, v1 = n0 + 16 + li < N;
+#pragma unroll
+  for (int q = 0; q < K / 4; ++q) {
+    const float x0 = p0[(size_t)(4 * q) * sk], x1 = p1[(size_t)(4 * q) * sk];
+    A.a0[q] = v0 ? x0 : 0.f;
+    A.a1[q] = v1 ? x1 : 0.f;
+  }
+}
+template <int K>
+__device__ __forceinline__ void pn_mfma_layer(const PnA<K>& A, int N, const float* __restrict__ bias, const float* sIn, bool relu,
+                                              const float* sAdd, const float* __restrict__ gMask, float* sOut, float* __restrict__ gOut,
+                                              int i0, int I) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = l & 15, lk = l >> 4;
+  const int n0 = w * 32, img = i0 + li;
+  // bias / relu-mask values of this lane's 8 output rows: independent of the MFMA chain, requested before it
+  float bv[2][4], mv[2][4];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = min(n0 + 16 * blk + 4 * lk + r, N - 1);
+      bv[blk][r] = bias ? bias[n] : 0.f;
+      mv[blk][r] = gMask ? gMask[(size_t)min(img, I - 1) * N + n] : 1.f;
+    }
   __syncthreads();   // sIn complete, previous readers of sOut done
-  const int n0 = w * 32;
   if (n0 < N) {
     const bool two = n0 + 16 < N;
-    const int r0 = min(n0 + li, N - 1), r1 = min(n0 + 16 + li, N - 1);
-    const float* p0 = Wa + (size_t)r0 * si + (size_t)lk * sk;
-    const float* p1 = Wa + (size_t)r1 * si + (size_t)lk * sk;
-    const bool v0 = n0 + li < N, v1 = n0 + 16 + li < N;
     pn_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int k0 = 0; k0 < K; k0 += 4) {
-      const float bq = sIn[(k0 + lk) * PN_IMG + li];
-      float a0 = p0[(size_t)k0 * sk], a1 = p1[(size_t)k0 * sk];
-      if (!v0) a0 = 0.f;
-      if (!v1) a1 = 0.f;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq, acc0, 0, 0, 0);
-      if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bq, acc1, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < K / 4; ++q) {
+      const float bq = sIn[(4 * q + lk) * PN_IMG + li];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A.a0[q], bq, acc0, 0, 0, 0);
+      if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A.a1[q], bq, acc1, 0, 0, 0);
     }
-    const int img = i0 + li;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       const int nb = n0 + 16 * blk + 4 * lk;   // rows nb .. nb+3 of this lane
@@ -247,11 +271,10 @@ __device__ __forceinline__ void pn_mfma_layer(const float* __restrict__ Wa, int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = nb + r;
-        if (bias) v[r] += bias[n];
+        v[r] += bv[blk][r];
         if (sAdd) v[r] += sAdd[n * PN_IMG + li];
         if (relu) v[r] = fmaxf(v[r], 0.f);
-        if (gMask && !(img < I && gMask[(size_t)img * N + n] > 0.f)) v[r] = 0.f;
-        if (img >= I) v[r] = 0.f;
+        if (!(mv[blk][r] > 0.f) || img >= I) v[r] = 0.f;
         sOut[n * PN_IMG + li] = v[r];
       }
       if (img < I) *reinterpret_cast<float4*>(gOut + (size_t)img * N + nb) = make_float4(v[0], v[1], v[2], v[3]);
@@ -269,14 +292,23 @@ __global__ __launch_bounds__(256) void pose_mlp_fwd_kernel(PoseNetArgs a) {
   }
   const float* P = a.P;
   const float* Wt = a.Wt;   // [4][k][n] transposed copies of conv2, conv3, fc1, fc2: consecutive lanes read consecutive floats
-  pn_mfma_layer(P + PN_C1_W, 12, 1, 128, 12, P + PN_C1_B, sT, true, nullptr, nullptr, sX, a.a1, i0, a.I);              // x1 = relu(conv1(T))
-  pn_mfma_layer(Wt + 0 * 16384, 1, 128, 128, 128, P + PN_C2_B, sX, true, nullptr, nullptr, sY, a.a2, i0, a.I);         // x2
-  pn_mfma_layer(Wt + 1 * 16384, 1, 128, 128, 128, P + PN_C3_B, sY, true, nullptr, nullptr, sZ, a.a3, i0, a.I);         // x3
-  pn_mfma_layer(P + PN_SKIP_W, 12, 1, 128, 12, P + PN_SKIP_B, sT, false, sZ, nullptr, sX, a.r, i0, a.I);               // res = head_skip(T) + x3
-  pn_mfma_layer(Wt + 2 * 16384, 1, 128, 128, 128, P + PN_F1_B, sX, true, nullptr, nullptr, sY, a.f1, i0, a.I);         // relu(fc1(res))
-  pn_mfma_layer(Wt + 3 * 16384, 1, 128, 128, 128, P + PN_F2_B, sY, true, nullptr, nullptr, sZ, a.f2, i0, a.I);         // relu(fc2(.))
+  PnA<12> A12;
+  PnA<128> Aa, Ab;
+  pn_fetch<12>(A12, P + PN_C1_W, 12, 1, 128);
+  pn_fetch<128>(Aa, Wt + 0 * 16384, 1, 128, 128);
+  pn_mfma_layer<12>(A12, 128, P + PN_C1_B, sT, true, nullptr, nullptr, sX, a.a1, i0, a.I);              // x1 = relu(conv1(T))
+  pn_fetch<128>(Ab, Wt + 1 * 16384, 1, 128, 128);
+  pn_mfma_layer<128>(Aa, 128, P + PN_C2_B, sX, true, nullptr, nullptr, sY, a.a2, i0, a.I);              // x2
+  pn_fetch<12>(A12, P + PN_SKIP_W, 12, 1, 128);
+  pn_mfma_layer<128>(Ab, 128, P + PN_C3_B, sY, true, nullptr, nullptr, sZ, a.a3, i0, a.I);              // x3
+  pn_fetch<128>(Aa, Wt + 2 * 16384, 1, 128, 128);
+  pn_mfma_layer<12>(A12, 128, P + PN_SKIP_B, sT, false, sZ, nullptr, sX, a.r, i0, a.I);                 // res = head_skip(T) + x3
+  pn_fetch<128>(Ab, Wt + 3 * 16384, 1, 128, 128);
+  pn_mfma_layer<128>(Aa, 128, P + PN_F1_B, sX, true, nullptr, nullptr, sY, a.f1, i0, a.I);              // relu(fc1(res))
+  pn_fetch<128>(Aa, P + PN_F3_W, 128, 1, 12);
+  pn_mfma_layer<128>(Ab, 128, P + PN_F2_B, sY, true, nullptr, nullptr, sZ, a.f2, i0, a.I);              // relu(fc2(.))
   float* sD = sX;   // [12][16]
-  pn_mfma_layer(P + PN_F3_W, 128, 1, 12, 128, P + PN_F3_B, sZ, false, nullptr, nullptr, sD, a.delta, i0, a.I);         // fc3: the pose update
+  pn_mfma_layer<128>(Aa, 12, P + PN_F3_B, sZ, false, nullptr, nullptr, sD, a.delta, i0, a.I);           // fc3: the pose update
   __syncthreads();
   // P = T + w * delta and the Gram-Schmidt step, one thread per image
   if (t < PN_IMG && i0 + t < a.I) {
@@ -361,9 +393,16 @@ __global__ __launch_bounds__(256) void pose_mlp_bwd_kernel(PoseNetArgs a) {
   }
   const float* P = a.P;
   // dX[k][img] = sum_n W[n][k] dY[n][img]: A(k, n) = W[n * 128 + k] -> si = 1, sk = 128
-  pn_mfma_layer(P + PN_F3_W, 1, 128, 128, 12, nullptr, sD, false, nullptr, a.f2, sX, a.dz2, i0, a.I);     // through fc3, relu'(fc2 out)
-  pn_mfma_layer(P + PN_F2_W, 1, 128, 128, 128, nullptr, sX, false, nullptr, a.f1, sY, a.dz1, i0, a.I);    // through fc2, relu'(fc1 out)
-  pn_mfma_layer(P + PN_F1_W, 1, 128, 128, 128, nullptr, sY, false, nullptr, nullptr, sX, a.dr, i0, a.I);  // through fc1: gradient of res
+  PnA<12> A12;
+  PnA<128> Aa, Ab;
+  pn_fetch<12>(A12, P + PN_F3_W, 1, 128, 128);
+  pn_fetch<128>(Aa, P + PN_F2_W, 1, 128, 128);
+  pn_mfma_layer<12>(A12, 128, nullptr, sD, false, nullptr, a.f2, sX, a.dz2, i0, a.I);     // through fc3, relu'(fc2 out)
+  pn_fetch<128>(Ab, P + PN_F1_W, 1, 128, 128);
+  pn_mfma_layer<128>(Aa, 128, nullptr, sX, false, nullptr, a.f1, sY, a.dz1, i0, a.I);     // through fc2, relu'(fc1 out)
+  pn_fetch<128>(Aa, P + PN_C3_W, 1, 128, 128);
+  pn_mfma_layer<128>(Ab, 128, nullptr, sY, false, nullptr, nullptr, sX, a.dr, i0, a.I);   // through fc1: gradient of res
+  pn_fetch<128>(Ab, P + PN_C2_W, 1, 128, 128);
   // x3 = relu(conv3(x2)): its pre-activation gradient is d(res) masked
   __syncthreads();
   for (int idx = t; idx < 128 * PN_IMG; idx += 256) {
@@ -373,8 +412,8 @@ __global__ __launch_bounds__(256) void pose_mlp_bwd_kernel(PoseNetArgs a) {
     sY[idx] = v;
     if (img < a.I) a.dzc3[(size_t)img * 128 + k] = v;
   }
-  pn_mfma_layer(P + PN_C3_W, 1, 128, 128, 128, nullptr, sY, false, nullptr, a.a2, sX, a.dzc2, i0, a.I);
-  pn_mfma_layer(P + PN_C2_W, 1, 128, 128, 128, nullptr, sX, false, nullptr, a.a1, sY, a.dzc1, i0, a.I);
+  pn_mfma_layer<128>(Aa, 128, nullptr, sY, false, nullptr, a.a2, sX, a.dzc2, i0, a.I);
+  pn_mfma_layer<128>(Ab, 128, nullptr, sX, false, nullptr, a.a1, sY, a.dzc1, i0, a.I);
 }
 
 // dW[o][k] = sum_i dY[i][o] X[i][k], db[o] = sum_i dY[i][o] for the seven layers, on the fp32 matrix cores straight from global
@@ -409,9 +448,31 @@ __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
   const int oc = min(o0 + li, O - 1), kc = min(k0 + li, K - 1);
   pn_f4 acc = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
   const bool want_bias = k0 == 0;
-#pragma unroll 4
-  for (int i = ib; i < ie; i += 4) {
-    const int img = i + lk;
+  // full groups of 4 images: plain pointer walks (the address arithmetic, not the MFMA, was the cost of this loop)
+  const int nfull = (ie > ib) ? (ie - ib) / 4 : 0;
+  const float* pa = dY + (size_t)(ib + lk) * O + oc;
+  const float* pb = X + (size_t)(ib + lk) * xp + kc;
+  const size_t sa = (size_t)4 * O, sb = (size_t)4 * xp;
+  if (want_bias) {
+#pragma unroll 16
+    for (int g = 0; g < nfull; ++g) {
+      float av = pa[g * sa], bv = pb[g * sb];
+      if (!vo) av = 0.f;
+      if (!vk) bv = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av, 1.f, accb, 0, 0, 0);
+    }
+  } else {
+#pragma unroll 16
+    for (int g = 0; g < nfull; ++g) {
+      float av = pa[g * sa], bv = pb[g * sb];
+      if (!vo) av = 0.f;
+      if (!vk) bv = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  if (ie > ib && ib + 4 * nfull < ie) {   // ragged last group
+    const int img = ib + 4 * nfull + lk;
     const bool vi = img < ie;
     const int ic = min(img, a.I - 1);
     float av = dY[(size_t)ic * O + oc], bv = X[(size_t)ic * xp + kc];
@@ -439,53 +500,74 @@ __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
   }
 }
 
-// dT[i][:] = sum over the batch rows whose image is i of row_dT[row][:], rows visited in increasing order (fixed order, no
-// atomics): a workgroup stages the row -> image table in LDS once; each of its wavefronts then owns images and scans the table 64
-// rows at a time (ballot).
+// dT[i][:] = sum over the batch rows whose image is i of row_dT[row][:], rows in increasing order (fixed order, no atomics).
+// A workgroup owns 16 images. Every dependent global access costs an L2 round trip (~1 us), so the kernel is three phases with ONE
+// round trip each: (1) each wave loads its quarter of the row -> image table into registers and appends the hits of its images, in row
+// order, to an LDS list (ballot + popcount); (2) all hit rows are fetched together into LDS; (3) thread (image, component) walks the
+// lists in order and adds from LDS.
+constexpr int PGR_MAX_HITS = 1024;   // per workgroup (16 images) and pass
 __global__ __launch_bounds__(256) void pose_grad_reduce2_kernel(const float* row_dT /*[n][12]*/, const int* row_image /*[n]*/, int n,
                                                                 float* dT /*[I][12]*/, int n_images, const int* active) {
   if (active && !*active) return;
-  extern __shared__ int s_img[];
-  for (int r = threadIdx.x; r < n; r += 256) s_img[r] = row_image[r];
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
-  for (int img = wave_global; img < n_images; img += nwaves) {
-    float acc = 0.f;  // lane k < 12 accumulates component k
-    for (int r0 = 0; r0 < n; r0 += 64) {
-      const int r = r0 + lane;
-      const bool hit = (r < n) && (s_img[r] == img);
-      unsigned long long m = __ballot(hit);
-      while (m) {
-        const int b = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        if (lane < 12) acc += row_dT[(size_t)(r0 + b) * 12 + lane];
+  __shared__ int sRow[PGR_MAX_HITS];
+  __shared__ unsigned char sRel[PGR_MAX_HITS];
+  __shared__ float sVal[PGR_MAX_HITS][12];
+  __shared__ int sCnt[4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, i0 = blockIdx.x * 16;
+  constexpr int cap = PGR_MAX_HITS / 4;            // list capacity per wave
+  // One pass over all rows when the lists fit (many images: ~5 rows per image); otherwise (few images) passes of 1024 rows, which
+  // cannot overflow. Row order is preserved either way.
+  int chunk = n;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    float acc = 0.f;                               // thread (image t / 12, component t % 12)
+    bool overflow = false;
+    for (int cb = 0; cb < n; cb += chunk) {
+      const int ce = min(n, cb + chunk);
+      const int q = ((ce - cb + 3) / 4 + 63) / 64 * 64;      // rows per wave in this pass
+      const int rb = cb + w * q, re = min(ce, rb + q);
+      int cnt = 0;
+      for (int c0 = rb; c0 < re; c0 += 64 * 16) {            // 16 table entries per lane in flight
+        int rel[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int r = c0 + 64 * j + lane;
+          rel[j] = (r < re) ? row_image[r] - i0 : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const bool hit = rel[j] >= 0 && rel[j] < 16;
+          const unsigned long long m = __ballot(hit);
+          if (hit) {
+            const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < cap) { sRow[w * cap + pos] = c0 + 64 * j + lane; sRel[w * cap + pos] = (unsigned char)rel[j]; }
+          }
+          cnt += __popcll(m);
+        }
+      }
+      __syncthreads();                             // previous pass' readers of the lists are done
+      if (lane == 0) sCnt[w] = cnt;
+      __syncthreads();
+      if (sCnt[0] > cap || sCnt[1] > cap || sCnt[2] > cap || sCnt[3] > cap) { overflow = true; break; }
+      for (int wv = 0; wv < 4; ++wv)
+        for (int idx = t; idx < sCnt[wv] * 12; idx += 256) {
+          const int h = wv * cap + idx / 12, c = idx % 12;
+          sVal[h][c] = row_dT[(size_t)sRow[h] * 12 + c];
+        }
+      __syncthreads();
+      if (t < 16 * 12) {
+        const int im = t / 12, c = t % 12;
+        for (int wv = 0; wv < 4; ++wv)
+          for (int h = 0; h < sCnt[wv]; ++h)
+            if (sRel[wv * cap + h] == im) acc += sVal[wv * cap + h][c];
       }
     }
-    if (lane < 12) dT[(size_t)img * 12 + lane] = acc;
-  }
-}
-
-// dT[i][:] = sum over the batch rows whose image is i of row_dT[row][:], rows visited in increasing order: one wave per
-// image scans the row->image table 64 rows at a time (ballot), so the sum order is fixed (no atomics)
-__global__ __launch_bounds__(256) void pose_grad_reduce_kernel(const float* row_dT /*[n][12]*/, const int* row_image /*[n]*/, int n,
-                                                               float* dT /*[I][12]*/, int n_images, const int* active) {
-  if (active && !*active) return;
-  const int lane = threadIdx.x & 63;
-  const int img = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  if (img >= n_images) return;
-  float acc = 0.f;  // lane k < 12 accumulates component k
-  for (int r0 = 0; r0 < n; r0 += 64) {
-    const int r = r0 + lane;
-    const bool hit = (r < n) && (row_image[r] == img);
-    unsigned long long m = __ballot(hit);
-    while (m) {
-      const int b = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      if (lane < 12) acc += row_dT[(size_t)(r0 + b) * 12 + lane];
+    if (!overflow) {
+      if (t < 16 * 12 && i0 + t / 12 < n_images) dT[(size_t)(i0 + t / 12) * 12 + t % 12] = acc;
+      return;
     }
+    chunk = 1024;                                  // 256 rows per wave: the lists cannot overflow
+    __syncthreads();
   }
-  if (lane < 12) dT[(size_t)img * 12 + lane] = acc;
 }
 
 // torch.optim.AdamW on a small flat parameter vector with its own step counter; the gradient is the fixed-order
