@@ -453,22 +453,23 @@ __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
   const float* pa = dY + (size_t)(ib + lk) * O + oc;
   const float* pb = X + (size_t)(ib + lk) * xp + kc;
   const size_t sa = (size_t)4 * O, sb = (size_t)4 * xp;
-  if (want_bias) {
-#pragma unroll 16
-    for (int g = 0; g < nfull; ++g) {
-      float av = pa[g * sa], bv = pb[g * sb];
-      if (!vo) av = 0.f;
-      if (!vk) bv = 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-      accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av, 1.f, accb, 0, 0, 0);
+  // 16 steps of operands are requested together (the compiler keeps a runtime-trip-count loop at one step per L2 round trip)
+  for (int g0 = 0; g0 < nfull; g0 += 16) {
+    float av[16], bv[16], on[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const bool ok = g0 + j < nfull;
+      const int g = min(g0 + j, nfull - 1);
+      const float x = pa[g * sa], y = pb[g * sb];
+      av[j] = (ok && vo) ? x : 0.f;
+      bv[j] = (ok && vk) ? y : 0.f;
+      on[j] = ok ? 1.f : 0.f;
     }
-  } else {
-#pragma unroll 16
-    for (int g = 0; g < nfull; ++g) {
-      float av = pa[g * sa], bv = pb[g * sb];
-      if (!vo) av = 0.f;
-      if (!vk) bv = 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+    if (want_bias) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], on[j], accb, 0, 0, 0);
     }
   }
   if (ie > ib && ib + 4 * nfull < ie) {   // ragged last group
@@ -531,7 +532,8 @@ __global__ __launch_bounds__(256) void pose_grad_reduce2_kernel(const float* row
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const int r = c0 + 64 * j + lane;
-          rel[j] = (r < re) ? row_image[r] - i0 : -1;
+          const int v = row_image[min(r, n - 1)];   // unconditional load (a load under a branch is waited for on the spot)
+          rel[j] = (r < re) ? v - i0 : -1;
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -548,11 +550,25 @@ __global__ __launch_bounds__(256) void pose_grad_reduce2_kernel(const float* row
       if (lane == 0) sCnt[w] = cnt;
       __syncthreads();
       if (sCnt[0] > cap || sCnt[1] > cap || sCnt[2] > cap || sCnt[3] > cap) { overflow = true; break; }
-      for (int wv = 0; wv < 4; ++wv)
-        for (int idx = t; idx < sCnt[wv] * 12; idx += 256) {
-          const int h = wv * cap + idx / 12, c = idx % 12;
-          sVal[h][c] = row_dT[(size_t)sRow[h] * 12 + c];
+      {   // fetch all hit rows: 8 independent loads per thread and round trip
+        const int b1 = sCnt[0], b2 = b1 + sCnt[1], b3 = b2 + sCnt[2], H = b3 + sCnt[3];
+        for (int f0 = 0; f0 < H * 12; f0 += 256 * 8) {
+          float tmp[8];
+          int slot[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int f = f0 + t + 256 * u;
+            const int hh = min(f / 12, H - 1), c = f % 12;
+            const int wv = (hh >= b3) ? 3 : (hh >= b2) ? 2 : (hh >= b1) ? 1 : 0;
+            const int base = (wv == 3) ? b3 : (wv == 2) ? b2 : (wv == 1) ? b1 : 0;
+            slot[u] = (f < H * 12) ? wv * cap + (hh - base) : -1;
+            tmp[u] = row_dT[(size_t)sRow[wv * cap + (hh - base)] * 12 + c];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (slot[u] >= 0) sVal[slot[u]][(f0 + t + 256 * u) % 12] = tmp[u];
         }
+      }
       __syncthreads();
       if (t < 16 * 12) {
         const int im = t / 12, c = t % 12;
