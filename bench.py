@@ -67,16 +67,21 @@ def make_buffer(n_patches, device, seed):
     return prob, feats, target_px, view_idx
 
 
-def bench_training(args, rank, world, device):
+def bench_training(args, rank, world, device, pose_refinement=None, steps=None, buffer_patches=None):
+    """pose_refinement None -> args.pose_refinement (the headline leg); 'mlp' -> ace_zero's non-seed mapping iterations
+    (--pose_refinement mlp --refine_calibration True, ace_zero.py:86,97,262-264)."""
+    pose_refinement = pose_refinement or args.pose_refinement
+    steps = steps or args.steps
+    buffer_patches = buffer_patches or args.buffer_patches
     from acezero_amd import synth
     from acezero_amd.head import HeadTrainer
-    per_rank = args.buffer_patches // world
+    per_rank = buffer_patches // world
     prob, feats, target_px, view_idx = make_buffer(per_rank, device, 2089 + rank)
-    total_iters = args.steps + args.warmup + 64
+    total_iters = steps + args.warmup + 64
     tr = HeadTrainer(prob["mean"], max_batch=BATCH, global_batch=BATCH * world, loss_type="tanh", schedule="1cyclepoly",
                      iterations=max(total_iters, 25000), lr_min=0.0005, lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005,
-                     cooldown_iterations=5000, pose_refinement=args.pose_refinement,
-                     refine_calibration=args.pose_refinement != "none", focal_init=float(prob["focal"]))   # ace_zero.py:105-123 mapping settings
+                     cooldown_iterations=5000, pose_refinement=pose_refinement,
+                     refine_calibration=pose_refinement != "none", focal_init=float(prob["focal"]))   # ace_zero.py:105-123 mapping settings
     tr.load_flat(torch.from_numpy(synth.init_head_params(1)))
     tr.set_buffer(feats, target_px, view_idx, prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"], prob["view_image"],
                   prob["image_pose_inv"])
@@ -101,21 +106,21 @@ def bench_training(args, rank, world, device):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(args.warmup + i)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = tr.state()
-    assert st["iteration"] == args.warmup + args.steps and not st["nan"], st
+    assert st["iteration"] == args.warmup + steps and not st["nan"], st
 
     # roofline leg: per-kernel-class durations from HIP events on the launch stream (outside the timed region:
     # the events themselves perturb the step time)
     # every rank runs these 20 steps (with N > 1 a step contains an all-reduce: a rank-0-only loop would deadlock)
     tr.set_profiling(True)
     for i in range(20):
-        step(args.warmup + args.steps + i)
+        step(args.warmup + steps + i)
     torch.cuda.synchronize()
     prof = tr.get_profile()
     tr.set_profiling(False)
@@ -275,12 +280,13 @@ def main():
     assert world == args.gpus or world == 1, (world, args.gpus)
 
     dt, st, prof = bench_training(args, rank, world, device)
+    dt_ref, st_ref, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000))
     nreg, dt_reg, reg_ok = bench_registration(args, rank, world, device)
     pipe = bench_pipeline(args, rank, world, device)
     if world > 1:
-        t = torch.tensor([dt, dt_reg], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, dt_reg, dt_ref], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt, dt_reg = float(t[0]), float(t[1])
+        dt, dt_reg, dt_ref = float(t[0]), float(t[1]), float(t[2])
     if rank == 0:
         patches_per_s = BATCH * world * args.steps / dt
         gemm_ms, gemm_n = 0.0, 0
@@ -302,6 +308,9 @@ def main():
                        "buffer_patches": args.buffer_patches, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "parallelism": f"dp{world}"},
             "whole_step_flop_frac_of_mfma_peak": patches_per_s / world * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS * 1e12),
+            "refinement_step": {"metric": "ACE patches/sec with --pose_refinement mlp --refine_calibration True (every non-seed mapping iteration of ace_zero.py)",
+                                "value": BATCH * world * 100 / dt_ref, "unit": "patches/s", "ms_per_step": dt_ref / 100 * 1e3, "steps": 100,
+                                "n_images": 1000, "final_loss": st_ref["loss"]},
             "registration": {"metric": "DSAC* images-registered/sec", "value": nreg * world / dt_reg, "unit": "images/s",
                              "frames": nreg * world, "hypotheses": 32, "max_tries": 16, "frac_frames_registered": reg_ok,
                              "note": "RANSAC only, 60x80 scene coordinates resident in HBM"},
