@@ -47,10 +47,9 @@ struct acez_trainer {
   SchedConfig sc;
   std::vector<void*> allocs;
   // pose refinement (mlp): per-image activations and gradients, allocated by set_buffer (needs n_images)
-  int pose_images = 0, pose_ksplit = 1;
+  int pose_images = 0;
   float *pa1 = nullptr, *pa2 = nullptr, *pa3 = nullptr, *pr = nullptr, *pf1 = nullptr, *pf2 = nullptr, *pdlt = nullptr, *pose_cur = nullptr;
   float *pdT = nullptr, *pddelta = nullptr, *pdz2 = nullptr, *pdz1 = nullptr, *pdr = nullptr, *pdzc3 = nullptr, *pdzc2 = nullptr, *pdzc1 = nullptr;
-  float* pose_part = nullptr;
   float* pose_wt = nullptr;     // [4][128][128] transposed pose-network weights (forward)
   float* row_dT = nullptr;
   int* row_image = nullptr;
@@ -236,10 +235,6 @@ extern "C" int acez_trainer_set_buffer(acez_trainer* tr, const acez_train_buffer
     A((void**)&tr->pdT, (size_t)I * 12 * sizeof(float));
     A((void**)&tr->pddelta, (size_t)I * 12 * sizeof(float));
     A((void**)&tr->pose_cur, (size_t)I * 16 * sizeof(float));
-    tr->pose_ksplit = (I + 255) / 256;   // image slices of the pose weight-gradient kernel
-    if (tr->pose_ksplit > 8) tr->pose_ksplit = 8;
-    if (tr->pose_ksplit < 1) tr->pose_ksplit = 1;
-    A((void**)&tr->pose_part, (size_t)tr->pose_ksplit * ACEZ_POSE_MLP_PARAMS * sizeof(float));
     A((void**)&tr->pose_wt, (size_t)4 * 128 * 128 * sizeof(float));
     if (!tr->row_dT) {
       A((void**)&tr->row_dT, (size_t)tr->max_batch * 12 * sizeof(float));
@@ -322,22 +317,7 @@ static void fill_loss_head(acez_trainer* tr, LossArgs& a) {
   a.max_inv_scale = tr->cfg.head.max_inv_scale; a.min_inv_scale = tr->cfg.head.min_inv_scale; a.h_beta = tr->cfg.head.h_beta;
 }
 
-// ---- pose refinement (mlp): flat parameter offsets in PoseNetwork.named_parameters() order
-namespace {
-constexpr int64_t PO_SKIP_W = 0, PO_SKIP_B = 1536, PO_C1_W = 1664, PO_C1_B = 3200, PO_C2_W = 3328, PO_C2_B = 19712, PO_C3_W = 19840,
-                  PO_C3_B = 36224, PO_F1_W = 36352, PO_F1_B = 52736, PO_F2_W = 52864, PO_F2_B = 69248, PO_F3_W = 69376, PO_F3_B = 70912;
-}
-
-static void pose_sgemm(hipStream_t s, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t scm,
-                       int M, int N, int K, const float* bias, const float* add, const float* mask, int relu, const int* active,
-                       int ksplit = 1, int64_t csplit = 0, float* lastcol = nullptr) {
-  SGemmArgs g{};
-  g.A = A; g.sa_m = sam; g.sa_k = sak; g.B = B; g.sb_k = sbk; g.sb_n = sbn; g.C = C; g.sc_m = scm; g.sc_n = 1; g.M = M; g.N = N; g.K = K;
-  g.bias = bias; g.add = add; g.mask = mask; g.relu = relu; g.scale = 1.f; g.ksplit = ksplit; g.c_split = csplit; g.active = active; g.c_lastcol = lastcol;
-  hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 63) / 64, (M + 63) / 64, ksplit), dim3(256), 0, s, g);
-}
-
-// refined poses of all images with the current network: pose_cur [I][16]
+// ---- pose refinement (the flat parameter offsets in PoseNetwork.named_parameters() order are PN_* in pose_kernels.hip)
 static PoseNetArgs pose_net_args(acez_trainer* tr, const int* active) {
   PoseNetArgs a{};
   a.P = tr->pb.d_pose_params; a.T0 = tr->buf.d_image_pose_inv; a.I = tr->buf.n_images; a.w = tr->cfg.pose_refinement_weight;

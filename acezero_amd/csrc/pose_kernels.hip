@@ -10,104 +10,13 @@
 // MI355X design: the reference evaluates the network on B = 5120 per-patch copies of the poses; all patches of an
 // image share its pose, so here the network runs once per IMAGE (n_images rows, typically 10^2..10^4) in fp32 on the
 // vector ALU (the reference keeps this part outside autocast too), and the per-patch pose gradients are reduced per
-// image in a fixed order (no atomics). The work is tiny (70 924 parameters) next to the head, so it is expressed
-// with one generic LDS-tiled fp32 GEMM kernel instead of bespoke fused kernels.
+// image in a fixed order (no atomics). First version: one generic LDS-tiled fp32 GEMM launch per layer (26 launches) -- at 1000
+// images that cost more than the whole head step; the fused kernels further down replaced it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "head_kernels.h"
 
 namespace acez {
-
-// C[m][n] = epi( sum_k A(m,k) * B(k,n) ), generic strides, 64x64 tile, 256 threads x (4x4), BK = 16.
-// grid.z splits K; slice z writes its partial to C + z * c_split (reduced by small_reduce_kernel).
-struct SGemmArgs {
-  const float* A; int64_t sa_m, sa_k;
-  const float* B; int64_t sb_k, sb_n;
-  float* C; int64_t sc_m, sc_n;
-  int M, N, K;
-  const float* bias;   // [N] or null
-  const float* add;    // same strides as C, or null (added before relu)
-  const float* mask;   // same strides as C, or null: C is zeroed where mask <= 0 (relu backward)
-  int relu;
-  float scale;         // multiplies the product (before bias/add)
-  int ksplit; int64_t c_split;
-  const int* active;
-  float* c_lastcol;    // if set: column N-1 of B reads as 1.0 and column N-1 of the result goes to c_lastcol[m] (+ z * c_split)
-};
-
-__global__ __launch_bounds__(256) void sgemm_small_kernel(SGemmArgs a) {
-  if (a.active && !*a.active) return;
-  __shared__ float sA[16][64], sB[16][64];   // 8 KiB: fits beside a resident rowgemm80 workgroup (152 KiB), see pose streams in head_api.hip
-  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int kper = (a.K + a.ksplit - 1) / a.ksplit;
-  const int kb = blockIdx.z * kper, ke = min(a.K, kb + kper);
-  float acc[4][4] = {};
-  for (int k0 = kb; k0 < ke; k0 += 16) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int q = t + 256 * p, kk = q >> 6, i = q & 63;
-      const int k = k0 + kk;
-      sA[kk][i] = (k < ke && m0 + i < a.M) ? a.A[(int64_t)(m0 + i) * a.sa_m + (int64_t)k * a.sa_k] : 0.f;
-      const bool ones = a.c_lastcol && (n0 + i == a.N - 1);
-      sB[kk][i] = (k < ke && n0 + i < a.N) ? (ones ? 1.f : a.B[(int64_t)k * a.sb_k + (int64_t)(n0 + i) * a.sb_n]) : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float av[4], bv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { av[i] = sA[kk][ty * 4 + i]; bv[i] = sB[kk][tx * 4 + i]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-    }
-    __syncthreads();
-  }
-  float* C = a.C + (int64_t)blockIdx.z * a.c_split;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
-    if (m >= a.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
-      if (n >= a.N) continue;
-      if (a.c_lastcol && n == a.N - 1) { a.c_lastcol[(int64_t)blockIdx.z * a.c_split + m] = acc[i][j] * a.scale; continue; }
-      const int64_t o = (int64_t)m * a.sc_m + (int64_t)n * a.sc_n;
-      float v = acc[i][j] * a.scale;
-      if (a.bias) v += a.bias[n];
-      if (a.add) v += a.add[o];
-      if (a.relu) v = fmaxf(v, 0.f);
-      if (a.mask && !(a.mask[o] > 0.f)) v = 0.f;
-      C[o] = v;
-    }
-  }
-}
-
-// out[i] = sum_z part[z * stride + i]  (fixed order)
-__global__ __launch_bounds__(256) void small_reduce_kernel(const float* part, int64_t stride, int nz, float* out, int64_t n, const int* active) {
-  if (active && !*active) return;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float acc = 0.f;
-  for (int z = 0; z < nz; ++z) acc += part[(int64_t)z * stride + i];
-  out[i] = acc;
-}
-
-// column sums: out[n] = sum_m X[m][n] for X [M][N] row-major, one wave per column, lane-strided + butterfly
-__global__ __launch_bounds__(256) void colsum_kernel(const float* X, int M, int N, float* out, const int* active) {
-  if (active && !*active) return;
-  const int lane = threadIdx.x & 63;
-  const int n = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  if (n >= N) return;
-  float acc = 0.f;
-  for (int m = lane; m < M; m += 64) acc += X[(int64_t)m * N + n];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if (lane == 0) out[n] = acc;
-}
 
 // refined pose of image i: P = T0[:3] + w * delta (3x4), rotation columns re-orthonormalised (special_gramschmidt),
 // written as a 4x4 (last row 0 0 0 1) for the loss kernel
