@@ -89,12 +89,12 @@ __global__ __launch_bounds__(256) void pose_compose_bwd_kernel(const float* T0, 
 // ---------------------------------------------------------------------------------------------------
 // Fused pose network (refine_poses.py:15-72 PoseNetwork(0, 128) + :152-176): with one generic GEMM launch per layer the
 // network cost 20 launches of ~23 us at 1000 images (32 workgroups each) -- more than the whole head. The three kernels
-// below run it data-parallel over tiles of 16 images with the layer's weights staged in LDS:
+// below run it data-parallel over tiles of 16 images on the fp32 matrix cores, weights read straight from L2:
 //   pose_mlp_fwd_kernel    all 7 layers + compose/Gram-Schmidt, keeps the activations the backward needs
 //   pose_mlp_bwd_kernel    compose backward + the chain of input gradients, keeps every layer's output gradient
 //   pose_mlp_wgrad_kernel  dW = dY^T X, db = column sums, for all layers in one launch: a workgroup owns a 16 x 16 tile, its four
 //                          waves a quarter of the images each, combined in wave order
-// fp32 on the vector ALU (the reference keeps this network outside autocast). Parameter order = named_parameters():
+// fp32 throughout (the reference keeps this network outside autocast). Parameter order = named_parameters():
 // head_skip, conv1, conv2, conv3, fc1, fc2, fc3 (weight, bias each).
 // ---------------------------------------------------------------------------------------------------
 struct PoseNetArgs {
