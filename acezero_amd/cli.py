@@ -175,8 +175,6 @@ def train_main(argv=None):
     if opt.feature_buffer is None:
         raise SystemExit("train_ace.py (MI355X): the image pipeline (dataset.py + encoder) is the reference's; pass the encoder "
                          "features with --feature_buffer buffer.npz (see acezero_amd/cli.py and INTEGRATION.md)")
-    if opt.refinement_ortho != "gram-schmidt":
-        raise SystemExit("procrustes orthonormalisation is not built (DESIGN.md section 8)")
     if opt.batch_size % 512 != 0:
         raise SystemExit("batch_size must be a multiple of 512 (train_ace.py:138)")
     buf = np.load(opt.feature_buffer, allow_pickle=False)
@@ -194,6 +192,7 @@ def train_main(argv=None):
                      refine_calibration=opt.refine_calibration, focal_init=focal, calib_lr=opt.refine_calibration_lr,
                      pose_refinement=opt.pose_refinement, pose_refinement_wait=opt.pose_refinement_wait,
                      pose_refinement_lr=opt.pose_refinement_lr, pose_refinement_weight=opt.pose_refinement_weight,
+                     refinement_ortho=opt.refinement_ortho,
                      pose_seed=opt.base_seed + 511, initial_poses=buf["image_pose_inv"][:, :3] if opt.pose_refinement == "naive" else None)
     if opt.load_weights is not None:
         tr.load_state_dict(torch.load(opt.load_weights, map_location="cpu"))

@@ -120,6 +120,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_REQUIRE(cfg->schedule >= 0 && cfg->schedule <= 2, "unknown schedule");
   ACEZ_REQUIRE(cfg->loss_type >= 0 && cfg->loss_type <= 4, "unknown loss type");
   ACEZ_REQUIRE(cfg->pose_refinement >= 0 && cfg->pose_refinement <= 2, "pose_refinement must be 0 (none), 1 (naive) or 2 (mlp)");
+  ACEZ_REQUIRE(cfg->pose_refinement_ortho == 0 || cfg->pose_refinement_ortho == 1, "pose_refinement_ortho must be 0 (gram-schmidt) or 1 (procrustes)");
   ACEZ_REQUIRE(cfg->pose_refinement == 0 || (params->d_pose_params && params->d_pose_m && params->d_pose_v), "pose refinement needs the pose parameter buffers");
   ACEZ_REQUIRE(cfg->pose_refinement != 2 || params->n_pose_params == ACEZ_POSE_MLP_PARAMS, "mlp: n_pose_params must be ACEZ_POSE_MLP_PARAMS");
   ACEZ_REQUIRE(cfg->pose_refinement != 1 || (params->n_pose_params > 0 && params->n_pose_params % 12 == 0), "naive: n_pose_params must be 12 * n_images");
@@ -323,7 +324,7 @@ static PoseNetArgs pose_net_args(acez_trainer* tr, const int* active) {
   a.P = tr->pb.d_pose_params; a.T0 = tr->buf.d_image_pose_inv; a.I = tr->buf.n_images; a.w = tr->cfg.pose_refinement_weight;
   a.a1 = tr->pa1; a.a2 = tr->pa2; a.a3 = tr->pa3; a.r = tr->pr; a.f1 = tr->pf1; a.f2 = tr->pf2; a.delta = tr->pdlt; a.pose_cur = tr->pose_cur;
   a.dT = tr->pdT; a.ddelta = tr->pddelta; a.dz2 = tr->pdz2; a.dz1 = tr->pdz1; a.dr = tr->pdr; a.dzc3 = tr->pdzc3; a.dzc2 = tr->pdzc2;
-  a.dzc1 = tr->pdzc1; a.active = active; a.Wt = tr->pose_wt;
+  a.dzc1 = tr->pdzc1; a.active = active; a.Wt = tr->pose_wt; a.ortho = tr->cfg.pose_refinement_ortho;
   return a;
 }
 
@@ -418,7 +419,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   if (tr->cfg.pose_refinement == 2) pose_forward(tr, &tr->st->active, ps);
   if (pose_naive)   // refine_poses.py:224-234: the poses themselves are the parameters; P = 0 + 1 * params, then Gram-Schmidt
     hipLaunchKernelGGL(pose_compose_kernel, dim3((tr->buf.n_images + 255) / 256), dim3(256), 0, ps, (const float*)tr->pa1,
-                       (const float*)tr->pb.d_pose_params, 1.0f, tr->pose_cur, tr->buf.n_images, (const int*)&tr->st->active);
+                       (const float*)tr->pb.d_pose_params, 1.0f, tr->pose_cur, tr->buf.n_images, (const int*)&tr->st->active, tr->cfg.pose_refinement_ortho);
   if (ps != s) ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_fwd, ps));
   if (!tr->fused_fwd) act = launch_forward(tr, tr->R[0], n, st, s);
   if (ps != s) ACEZ_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_pose_fwd, 0));   // the loss kernel projects with the refined poses
@@ -453,7 +454,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     const int I = tr->buf.n_images;
     launch_pose_grad_reduce(tr, n, (const int*)&tr->st->active, ps);
     hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((I + 255) / 256), dim3(256), 0, ps, (const float*)tr->pa1, (const float*)tr->pb.d_pose_params, 1.0f,
-                       (const float*)tr->pdT, tr->pb.d_grad + tr->n_params + 4, I, (const int*)&tr->st->active);
+                       (const float*)tr->pdT, tr->pb.d_grad + tr->n_params + 4, I, (const int*)&tr->st->active, tr->cfg.pose_refinement_ortho);
   }
   if (ps != s) ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_bwd, ps));
 
@@ -681,7 +682,7 @@ extern "C" int acez_trainer_get_poses(acez_trainer* tr, float* h_poses34, void* 
     src = tr->pose_cur;
   } else if (tr->cfg.pose_refinement == 1) {
     hipLaunchKernelGGL(pose_compose_kernel, dim3((I + 255) / 256), dim3(256), 0, s, (const float*)tr->pa1, (const float*)tr->pb.d_pose_params, 1.0f,
-                       tr->pose_cur, I, (const int*)nullptr);
+                       tr->pose_cur, I, (const int*)nullptr, tr->cfg.pose_refinement_ortho);
     ACEZ_HIP_CHECK(hipGetLastError());
     src = tr->pose_cur;
   }

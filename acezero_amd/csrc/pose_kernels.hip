@@ -18,65 +18,163 @@
 
 namespace acez {
 
-// refined pose of image i: P = T0[:3] + w * delta (3x4), rotation columns re-orthonormalised (special_gramschmidt),
-// written as a 4x4 (last row 0 0 0 1) for the loss kernel
-__global__ __launch_bounds__(256) void pose_compose_kernel(const float* T0 /*[I][16]*/, const float* delta /*[I][12]*/, float w,
-                                                           float* out /*[I][16]*/, int n_images, const int* active) {
-  if (active && !*active) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_images) return;
-  float P[12];
+// ---------------------------------------------------------------------------------------------------
+// Orthonormalisation of the updated pose's rotation block (refine_poses.py:135-150, --refinement_ortho):
+//   0  roma.special_gramschmidt: Gram-Schmidt on the first two COLUMNS, third = cross product
+//   1  roma.special_procrustes : nearest rotation R = U diag(1, 1, det(U V^T)) V^T of the SVD M = U S V^T
+// (roma 1.4.1 is not vendored in the reference; both are restated from its documentation.) Each comes with its backward.
+// The 3x3 SVD is computed from the Jacobi eigen-decomposition of M^T M (M is close to a rotation: singular values ~1).
+// ---------------------------------------------------------------------------------------------------
+struct Procrustes {
+  float U[9], V[9], sg[3];   // U' = U D (sign fix folded in), V, signed singular values: M = U' diag(sg) V^T, R = U' V^T
+};
+__device__ __forceinline__ void procrustes_decompose(const float m[9], Procrustes& q) {
+  float a[3][3], v[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      a[i][j] = m[0 * 3 + i] * m[0 * 3 + j] + m[1 * 3 + i] * m[1 * 3 + j] + m[2 * 3 + i] * m[2 * 3 + j];   // (M^T M)_ij
+      v[i][j] = (i == j) ? 1.f : 0.f;
+    }
+#pragma unroll
+  for (int sweep = 0; sweep < 6; ++sweep) {
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      constexpr int PP[3] = {0, 0, 1}, QQ[3] = {1, 2, 2}, RR[3] = {2, 1, 0};
+      const int p = PP[pq], qq = QQ[pq], r = RR[pq];
+      const float apq = a[p][qq];
+      if (fabsf(apq) > 1e-30f) {
+        const float tau = (a[qq][qq] - a[p][p]) / (2.f * apq);
+        const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+        const float c = 1.f / sqrtf(1.f + t * t), sn = t * c;
+        a[p][p] -= t * apq;
+        a[qq][qq] += t * apq;
+        a[p][qq] = a[qq][p] = 0.f;
+        const float arp = a[r][p], arq = a[r][qq];
+        a[r][p] = a[p][r] = c * arp - sn * arq;
+        a[r][qq] = a[qq][r] = sn * arp + c * arq;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float vp = v[i][p], vq = v[i][qq];
+          v[i][p] = c * vp - sn * vq;
+          v[i][qq] = sn * vp + c * vq;
+        }
+      }
+    }
+  }
+  float sg[3] = {sqrtf(fmaxf(a[0][0], 1e-30f)), sqrtf(fmaxf(a[1][1], 1e-30f)), sqrtf(fmaxf(a[2][2], 1e-30f))};
+  const float det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+  const int ks = (sg[0] <= sg[1] && sg[0] <= sg[2]) ? 0 : ((sg[1] <= sg[2]) ? 1 : 2);   // the sign fix sits on the smallest singular value
+  const float d = det < 0.f ? -1.f : 1.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float di = (i == ks) ? d : 1.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      q.U[r * 3 + i] = (m[r * 3 + 0] * v[0][i] + m[r * 3 + 1] * v[1][i] + m[r * 3 + 2] * v[2][i]) / sg[i] * di;
+    q.sg[i] = sg[i] * di;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) q.V[r * 3 + i] = v[r][i];
+  }
+}
+__device__ __forceinline__ void procrustes_rotation(const Procrustes& q, float R[9]) {
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) P[r * 4 + c] = T0[(size_t)i * 16 + r * 4 + c] + w * delta[(size_t)i * 12 + r * 4 + c];
-  float x[3] = {P[0], P[4], P[8]}, y[3] = {P[1], P[5], P[9]};
-  const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-  x[0] /= nx; x[1] /= nx; x[2] /= nx;
-  const float d = x[0] * y[0] + x[1] * y[1] + x[2] * y[2];
-  y[0] -= d * x[0]; y[1] -= d * x[1]; y[2] -= d * x[2];
-  const float ny = sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
-  y[0] /= ny; y[1] /= ny; y[2] /= ny;
-  const float z[3] = {x[1] * y[2] - x[2] * y[1], x[2] * y[0] - x[0] * y[2], x[0] * y[1] - x[1] * y[0]};
-  float* o = out + (size_t)i * 16;
+    for (int c = 0; c < 3; ++c) R[r * 3 + c] = q.U[r * 3 + 0] * q.V[c * 3 + 0] + q.U[r * 3 + 1] * q.V[c * 3 + 1] + q.U[r * 3 + 2] * q.V[c * 3 + 2];
+}
+// dL/dM from dL/dR:  Y = U'^T G V,  Z_ij = (Y_ij - Y_ji) / (sg_i + sg_j),  dL/dM = U' Z V^T
+__device__ __forceinline__ void procrustes_backward(const Procrustes& q, const float G[9], float GM[9]) {
+  float Y[3][3], Z[3][3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) { o[r * 4 + 0] = x[r]; o[r * 4 + 1] = y[r]; o[r * 4 + 2] = z[r]; o[r * 4 + 3] = P[r * 4 + 3]; }
-  o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc += q.U[r * 3 + i] * G[r * 3 + c] * q.V[c * 3 + j];
+      Y[i][j] = acc;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float den = q.sg[i] + q.sg[j];
+      Z[i][j] = (i == j || fabsf(den) < 1e-12f) ? 0.f : (Y[i][j] - Y[j][i]) / den;
+    }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc += q.U[r * 3 + i] * Z[i][j] * q.V[c * 3 + j];
+      GM[r * 3 + c] = acc;
+    }
 }
 
-// per-image gradient of the refined pose -> gradient of the network output (delta), through the Gram-Schmidt step
-__global__ __launch_bounds__(256) void pose_compose_bwd_kernel(const float* T0, const float* delta, float w, const float* dT /*[I][12]*/,
-                                                               float* ddelta /*[I][12]*/, int n_images, const int* active) {
-  if (active && !*active) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_images) return;
-  float P[12];
+// refined 4x4 pose from the raw updated 3x4 matrix Pm (row-major [r][4])
+__device__ __forceinline__ void pose_orthonormalise(const float Pm[12], int ortho, float* o /*16*/) {
+  if (ortho == 1) {
+    const float m[9] = {Pm[0], Pm[1], Pm[2], Pm[4], Pm[5], Pm[6], Pm[8], Pm[9], Pm[10]};
+    Procrustes q;
+    procrustes_decompose(m, q);
+    float R[9];
+    procrustes_rotation(q, R);
 #pragma unroll
-  for (int k = 0; k < 12; ++k) P[k] = T0[(size_t)i * 16 + k] + w * delta[(size_t)i * 12 + k];
-  const float xr[3] = {P[0], P[4], P[8]}, yr[3] = {P[1], P[5], P[9]};
+    for (int r = 0; r < 3; ++r) { o[r * 4 + 0] = R[r * 3 + 0]; o[r * 4 + 1] = R[r * 3 + 1]; o[r * 4 + 2] = R[r * 3 + 2]; o[r * 4 + 3] = Pm[r * 4 + 3]; }
+  } else {
+    float x[3] = {Pm[0], Pm[4], Pm[8]}, y[3] = {Pm[1], Pm[5], Pm[9]};
+    const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    x[0] /= nx; x[1] /= nx; x[2] /= nx;
+    const float d = x[0] * y[0] + x[1] * y[1] + x[2] * y[2];
+    y[0] -= d * x[0]; y[1] -= d * x[1]; y[2] -= d * x[2];
+    const float ny = sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+    y[0] /= ny; y[1] /= ny; y[2] /= ny;
+    const float z[3] = {x[1] * y[2] - x[2] * y[1], x[2] * y[0] - x[0] * y[2], x[0] * y[1] - x[1] * y[0]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { o[r * 4 + 0] = x[r]; o[r * 4 + 1] = y[r]; o[r * 4 + 2] = z[r]; o[r * 4 + 3] = Pm[r * 4 + 3]; }
+  }
+  o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+}
+// gradient wrt the raw updated matrix Pm (scaled by w -> gradient wrt the network output / the pose parameters) from the gradient g
+// wrt the refined pose (both 3x4 row-major)
+__device__ __forceinline__ void pose_orthonormalise_bwd(const float Pm[12], const float* g, int ortho, float w, float o[12]) {
+  if (ortho == 1) {
+    const float m[9] = {Pm[0], Pm[1], Pm[2], Pm[4], Pm[5], Pm[6], Pm[8], Pm[9], Pm[10]};
+    Procrustes q;
+    procrustes_decompose(m, q);
+    const float G[9] = {g[0], g[1], g[2], g[4], g[5], g[6], g[8], g[9], g[10]};
+    float GM[9];
+    procrustes_backward(q, G, GM);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { o[r * 4 + 0] = w * GM[r * 3 + 0]; o[r * 4 + 1] = w * GM[r * 3 + 1]; o[r * 4 + 2] = w * GM[r * 3 + 2]; o[r * 4 + 3] = w * g[r * 4 + 3]; }
+    return;
+  }
+  const float xr[3] = {Pm[0], Pm[4], Pm[8]}, yr[3] = {Pm[1], Pm[5], Pm[9]};
   const float nx = sqrtf(xr[0] * xr[0] + xr[1] * xr[1] + xr[2] * xr[2]);
   const float x[3] = {xr[0] / nx, xr[1] / nx, xr[2] / nx};
   const float d = x[0] * yr[0] + x[1] * yr[1] + x[2] * yr[2];
   const float yp[3] = {yr[0] - d * x[0], yr[1] - d * x[1], yr[2] - d * x[2]};
   const float ny = sqrtf(yp[0] * yp[0] + yp[1] * yp[1] + yp[2] * yp[2]);
   const float y[3] = {yp[0] / ny, yp[1] / ny, yp[2] / ny};
-  const float* g = dT + (size_t)i * 12;
   float gx[3] = {g[0], g[4], g[8]}, gy[3] = {g[1], g[5], g[9]};
   const float gz[3] = {g[2], g[6], g[10]};
   // z = x cross y:  dx += y cross gz,  dy += gz cross x
   gx[0] += y[1] * gz[2] - y[2] * gz[1]; gx[1] += y[2] * gz[0] - y[0] * gz[2]; gx[2] += y[0] * gz[1] - y[1] * gz[0];
   gy[0] += gz[1] * x[2] - gz[2] * x[1]; gy[1] += gz[2] * x[0] - gz[0] * x[2]; gy[2] += gz[0] * x[1] - gz[1] * x[0];
-  // y = yp / |yp|
   const float ydg = y[0] * gy[0] + y[1] * gy[1] + y[2] * gy[2];
   const float gyp[3] = {(gy[0] - y[0] * ydg) / ny, (gy[1] - y[1] * ydg) / ny, (gy[2] - y[2] * ydg) / ny};
-  // yp = yr - (x . yr) x
   const float xdg = x[0] * gyp[0] + x[1] * gyp[1] + x[2] * gyp[2];
   const float gyr[3] = {gyp[0] - x[0] * xdg, gyp[1] - x[1] * xdg, gyp[2] - x[2] * xdg};
   gx[0] -= d * gyp[0] + xdg * yr[0]; gx[1] -= d * gyp[1] + xdg * yr[1]; gx[2] -= d * gyp[2] + xdg * yr[2];
-  // x = xr / |xr|
   const float xdgx = x[0] * gx[0] + x[1] * gx[1] + x[2] * gx[2];
   const float gxr[3] = {(gx[0] - x[0] * xdgx) / nx, (gx[1] - x[1] * xdgx) / nx, (gx[2] - x[2] * xdgx) / nx};
-  float* o = ddelta + (size_t)i * 12;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     o[r * 4 + 0] = w * gxr[r];
@@ -84,6 +182,36 @@ __global__ __launch_bounds__(256) void pose_compose_bwd_kernel(const float* T0, 
     o[r * 4 + 2] = 0.f;          // the third column of the raw matrix does not reach the output
     o[r * 4 + 3] = w * g[r * 4 + 3];
   }
+}
+
+// refined pose of image i: P = T0[:3] + w * delta (3x4), rotation columns re-orthonormalised (special_gramschmidt),
+// written as a 4x4 (last row 0 0 0 1) for the loss kernel
+__global__ __launch_bounds__(256) void pose_compose_kernel(const float* T0 /*[I][16]*/, const float* delta /*[I][12]*/, float w,
+                                                           float* out /*[I][16]*/, int n_images, const int* active, int ortho) {
+  if (active && !*active) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_images) return;
+  float P[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) P[k] = T0[(size_t)i * 16 + k] + w * delta[(size_t)i * 12 + k];
+  float o[16];
+  pose_orthonormalise(P, ortho, o);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) out[(size_t)i * 16 + k] = o[k];
+}
+
+// per-image gradient of the refined pose -> gradient of the network output (delta), through the orthonormalisation
+__global__ __launch_bounds__(256) void pose_compose_bwd_kernel(const float* T0, const float* delta, float w, const float* dT /*[I][12]*/,
+                                                               float* ddelta /*[I][12]*/, int n_images, const int* active, int ortho) {
+  if (active && !*active) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_images) return;
+  float P[12], o[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) P[k] = T0[(size_t)i * 16 + k] + w * delta[(size_t)i * 12 + k];
+  pose_orthonormalise_bwd(P, dT + (size_t)i * 12, ortho, w, o);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) ddelta[(size_t)i * 12 + k] = o[k];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -109,6 +237,7 @@ struct PoseNetArgs {
   const float* dT;         // [I][12] gradient wrt the refined pose (backward)
   float *ddelta, *dz2, *dz1, *dr, *dzc3, *dzc2, *dzc1;   // backward: gradients wrt each layer's pre-activation output
   const int* active;
+  int ortho;               // 0 gram-schmidt, 1 procrustes (--refinement_ortho)
 };
 constexpr int64_t PN_SKIP_W = 0, PN_SKIP_B = 1536, PN_C1_W = 1664, PN_C1_B = 3200, PN_C2_W = 3328, PN_C2_B = 19712, PN_C3_W = 19840,
                   PN_C3_B = 36224, PN_F1_W = 36352, PN_F1_B = 52736, PN_F2_W = 52864, PN_F2_B = 69248, PN_F3_W = 69376, PN_F3_B = 70912;
@@ -221,21 +350,13 @@ __global__ __launch_bounds__(256) void pose_mlp_fwd_kernel(PoseNetArgs a) {
   __syncthreads();
   // P = T + w * delta and the Gram-Schmidt step, one thread per image
   if (t < PN_IMG && i0 + t < a.I) {
-    float Pm[12];
+    float Pm[12], o[16];
 #pragma unroll
     for (int k = 0; k < 12; ++k) Pm[k] = sT[k * PN_IMG + t] + a.w * sD[k * PN_IMG + t];
-    float x[3] = {Pm[0], Pm[4], Pm[8]}, y[3] = {Pm[1], Pm[5], Pm[9]};
-    const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    x[0] /= nx; x[1] /= nx; x[2] /= nx;
-    const float d = x[0] * y[0] + x[1] * y[1] + x[2] * y[2];
-    y[0] -= d * x[0]; y[1] -= d * x[1]; y[2] -= d * x[2];
-    const float ny = sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
-    y[0] /= ny; y[1] /= ny; y[2] /= ny;
-    const float z[3] = {x[1] * y[2] - x[2] * y[1], x[2] * y[0] - x[0] * y[2], x[0] * y[1] - x[1] * y[0]};
-    float* o = a.pose_cur + (size_t)(i0 + t) * 16;
+    pose_orthonormalise(Pm, a.ortho, o);
+    float* dst = a.pose_cur + (size_t)(i0 + t) * 16;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) { o[r * 4 + 0] = x[r]; o[r * 4 + 1] = y[r]; o[r * 4 + 2] = z[r]; o[r * 4 + 3] = Pm[r * 4 + 3]; }
-    o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+    for (int k = 0; k < 16; ++k) dst[k] = o[k];
   }
 }
 
@@ -268,32 +389,7 @@ __global__ __launch_bounds__(256) void pose_mlp_bwd_kernel(PoseNetArgs a) {
       float Pm[12];
 #pragma unroll
       for (int k = 0; k < 12; ++k) Pm[k] = a.T0[(size_t)i * 16 + k] + a.w * a.delta[(size_t)i * 12 + k];
-      const float xr[3] = {Pm[0], Pm[4], Pm[8]}, yr[3] = {Pm[1], Pm[5], Pm[9]};
-      const float nx = sqrtf(xr[0] * xr[0] + xr[1] * xr[1] + xr[2] * xr[2]);
-      const float x[3] = {xr[0] / nx, xr[1] / nx, xr[2] / nx};
-      const float d = x[0] * yr[0] + x[1] * yr[1] + x[2] * yr[2];
-      const float yp[3] = {yr[0] - d * x[0], yr[1] - d * x[1], yr[2] - d * x[2]};
-      const float ny = sqrtf(yp[0] * yp[0] + yp[1] * yp[1] + yp[2] * yp[2]);
-      const float y[3] = {yp[0] / ny, yp[1] / ny, yp[2] / ny};
-      const float* g = a.dT + (size_t)i * 12;
-      float gx[3] = {g[0], g[4], g[8]}, gy[3] = {g[1], g[5], g[9]};
-      const float gz[3] = {g[2], g[6], g[10]};
-      gx[0] += y[1] * gz[2] - y[2] * gz[1]; gx[1] += y[2] * gz[0] - y[0] * gz[2]; gx[2] += y[0] * gz[1] - y[1] * gz[0];
-      gy[0] += gz[1] * x[2] - gz[2] * x[1]; gy[1] += gz[2] * x[0] - gz[0] * x[2]; gy[2] += gz[0] * x[1] - gz[1] * x[0];
-      const float ydg = y[0] * gy[0] + y[1] * gy[1] + y[2] * gy[2];
-      const float gyp[3] = {(gy[0] - y[0] * ydg) / ny, (gy[1] - y[1] * ydg) / ny, (gy[2] - y[2] * ydg) / ny};
-      const float xdg = x[0] * gyp[0] + x[1] * gyp[1] + x[2] * gyp[2];
-      const float gyr[3] = {gyp[0] - x[0] * xdg, gyp[1] - x[1] * xdg, gyp[2] - x[2] * xdg};
-      gx[0] -= d * gyp[0] + xdg * yr[0]; gx[1] -= d * gyp[1] + xdg * yr[1]; gx[2] -= d * gyp[2] + xdg * yr[2];
-      const float xdgx = x[0] * gx[0] + x[1] * gx[1] + x[2] * gx[2];
-      const float gxr[3] = {(gx[0] - x[0] * xdgx) / nx, (gx[1] - x[1] * xdgx) / nx, (gx[2] - x[2] * xdgx) / nx};
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        o[r * 4 + 0] = a.w * gxr[r];
-        o[r * 4 + 1] = a.w * gyr[r];
-        o[r * 4 + 2] = 0.f;          // the third column of the raw matrix does not reach the output
-        o[r * 4 + 3] = a.w * g[r * 4 + 3];
-      }
+      pose_orthonormalise_bwd(Pm, a.dT + (size_t)i * 12, a.ortho, a.w, o);
 #pragma unroll
       for (int k = 0; k < 12; ++k) a.ddelta[(size_t)i * 12 + k] = o[k];
     }

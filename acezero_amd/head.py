@@ -58,7 +58,7 @@ class HeadTrainer:
                  iterations=25000, lr_min=0.0005, lr_max=0.005, warmup_iterations=1000, warmup_lr=0.0005,
                  cooldown_iterations=5000, cooldown_trigger_percent=0.7, refine_calibration=False, focal_init=0.0,
                  calib_lr=0.001, pose_refinement="none", pose_refinement_wait=0, pose_refinement_lr=0.001,
-                 pose_refinement_weight=0.1, pose_seed=0, initial_poses=None, homogeneous_min_scale=0.01, homogeneous_max_scale=4.0,
+                 pose_refinement_weight=0.1, refinement_ortho="gram-schmidt", pose_seed=0, initial_poses=None, homogeneous_min_scale=0.01, homogeneous_max_scale=4.0,
                  device=None):
         if not torch.cuda.is_available():
             raise RuntimeError("HeadTrainer needs a GPU: the head kernels are HIP only (no CPU fallback)")
@@ -114,6 +114,9 @@ class HeadTrainer:
         cfg.pose_refinement = 2 if self.pose_mlp else (1 if self.pose_naive else 0)
         cfg.pose_refinement_wait, cfg.pose_refinement_lr = int(pose_refinement_wait), float(pose_refinement_lr)
         cfg.pose_refinement_weight = float(pose_refinement_weight)
+        if refinement_ortho not in ("gram-schmidt", "procrustes"):
+            raise ValueError("refinement_ortho must be 'gram-schmidt' or 'procrustes'")
+        cfg.pose_refinement_ortho = 1 if refinement_ortho == "procrustes" else 0
         pb = N.ParamBuffers(_ptr(self.params), _ptr(self.adam_m), _ptr(self.adam_v), _ptr(self.grad), self.n_params,
                             _ptr(self.pose_params), _ptr(self.pose_m), _ptr(self.pose_v), self.n_pose)
         h = C.c_void_p()

@@ -158,12 +158,12 @@ typedef struct acez_train_config {
   float focal_init;            /* CalibrationRefiner.focal_length_init                                   */
   double calib_lr;
   /* pose refinement (refine_poses.py): 0 = none, 1 = naive (the 3x4 poses are the parameters, :224-234),
-   * 2 = mlp (PoseNetwork(0,128), :152-176); both with Gram-Schmidt orthonormalisation */
+   * 2 = mlp (PoseNetwork(0,128), :152-176) */
   int32_t pose_refinement;
   int32_t pose_refinement_wait;   /* train_ace.py:220                                                     */
   double pose_refinement_lr;      /* train_ace.py:223, 1e-3                                               */
   float pose_refinement_weight;   /* train_ace.py:216, 0.1                                                */
-  int32_t reserved;
+  int32_t pose_refinement_ortho;  /* --refinement_ortho (train_ace.py:226): 0 = gram-schmidt, 1 = procrustes */
 } acez_train_config;
 
 /* Caller-owned parameter storage, so the host side can expose the same state_dict keys as

@@ -277,12 +277,26 @@ def special_gramschmidt(M):
     return torch.stack((x, y, z), dim=-1)
 
 
+def special_procrustes(M):
+    """roma.special_procrustes (roma 1.4.1, not vendored: restated from its documentation -- the rotation closest to M in the
+    Frobenius norm, R = U diag(1, 1, det(U V^T)) V^T for the SVD M = U S V^T)."""
+    U, _, Vh = torch.linalg.svd(M)
+    d = torch.det(U @ Vh)
+    D = torch.diag_embed(torch.stack([torch.ones_like(d), torch.ones_like(d), d], dim=-1))
+    return U @ D @ Vh
+
+
+def orthonormalise(M, ortho):
+    return special_procrustes(M) if ortho == "procrustes" else special_gramschmidt(M)
+
+
 class PoseMLPOracle:
     """refine_poses.py `mlp` strategy evaluated once per image, torch autograd for the backward pass."""
 
-    def __init__(self, flat, update_weight=0.1):
+    def __init__(self, flat, update_weight=0.1, ortho="gram-schmidt"):
         self.flat = flat.clone().requires_grad_(True)
         self.w = update_weight
+        self.ortho = ortho
 
     def _views(self):
         out, o = {}, 0
@@ -300,7 +314,7 @@ class PoseMLPOracle:
         res = lin(x0, "head_skip") + x
         d = lin(torch.relu(lin(torch.relu(lin(res, "fc1")), "fc2")), "fc3")
         upd = (x0 + self.w * d).view(-1, 3, 4)
-        R = special_gramschmidt(upd[:, :3, :3])
+        R = orthonormalise(upd[:, :3, :3], self.ortho)
         out = poses44.clone()
         out = torch.cat([torch.cat([R, upd[:, :3, 3:4]], dim=2), poses44[:, 3:4, :]], dim=1)
         return out
@@ -309,12 +323,13 @@ class PoseMLPOracle:
 class PoseNaiveOracle:
     """refine_poses.py `naive` strategy (:224-234): the [I,3,4] world->cam poses are the parameters."""
 
-    def __init__(self, flat):
+    def __init__(self, flat, ortho="gram-schmidt"):
         self.flat = flat.clone().requires_grad_(True)
+        self.ortho = ortho
 
     def forward(self, poses44):
         cur = self.flat.view(-1, 3, 4)
-        R = special_gramschmidt(cur[:, :3, :3])
+        R = orthonormalise(cur[:, :3, :3], self.ortho)
         return torch.cat([torch.cat([R, cur[:, :3, 3:4]], dim=2), poses44[:, 3:4, :]], dim=1)
 
 
@@ -451,8 +466,9 @@ class TrainerOracle:
         self.log = []
         self.pose = None
         if cfg.get("pose_refinement", "none") in ("mlp", "naive"):
-            self.pose = (PoseMLPOracle(pose_flat, cfg.get("pose_refinement_weight", 0.1)) if cfg["pose_refinement"] == "mlp"
-                         else PoseNaiveOracle(pose_flat))
+            ortho = cfg.get("refinement_ortho", "gram-schmidt")
+            self.pose = (PoseMLPOracle(pose_flat, cfg.get("pose_refinement_weight", 0.1), ortho) if cfg["pose_refinement"] == "mlp"
+                         else PoseNaiveOracle(pose_flat, ortho))
             self.image_pose_inv = torch.as_tensor(image_pose_inv, dtype=torch.float32)
             self.pose_m = torch.zeros_like(pose_flat)
             self.pose_v = torch.zeros_like(pose_flat)

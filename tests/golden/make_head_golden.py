@@ -44,6 +44,7 @@ from acezero_amd import synth  # noqa: E402
 from oracle import head_oracle  # noqa: E402
 import refine_poses  # noqa: E402
 _roma.special_gramschmidt = head_oracle.special_gramschmidt
+_roma.special_procrustes = head_oracle.special_procrustes
 
 CONFIGS = {
     # ace_zero's mapping settings (ace_zero.py:105-123): tanh, 1cyclepoly, lr_max 0.003
@@ -69,6 +70,11 @@ CONFIGS = {
     "head_tanh_depth": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
                             warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
                             refine_calibration=False, steps=6, use_depth=True),
+    # --refinement_ortho procrustes (train_ace.py:226): nearest-rotation orthonormalisation of the updated poses
+    "head_tanh_posemlp_procrustes": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
+                                         warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
+                                         refine_calibration=False, steps=6, pose_refinement="mlp", pose_refinement_wait=2,
+                                         refinement_ortho="procrustes"),
 }
 B = 512
 SEED = 2089
@@ -82,6 +88,7 @@ def full_cfg(c):
     d.setdefault("pose_refinement", "none")
     d.setdefault("pose_refinement_wait", 0)
     d.setdefault("use_depth", False)
+    d.setdefault("refinement_ortho", "gram-schmidt")
     return d
 
 
@@ -90,7 +97,7 @@ def run_reference(cfg, prob, flat0, batches):
         use_half=False, depth_min=cfg["depth_min"], depth_max=cfg["depth_max"], depth_target=cfg["depth_target"],
         repro_loss_hard_clamp=cfg["hard_clamp"], learning_rate_cooldown_trigger_px_threshold=cfg["inlier_px_threshold"],
         pose_refinement_wait=cfg["pose_refinement_wait"], pose_refinement=cfg["pose_refinement"], pose_refinement_lr=0.001,
-        pose_refinement_weight=0.1, refinement_ortho="gram-schmidt", iterations=cfg["iterations"], learning_rate_schedule=cfg["schedule"],
+        pose_refinement_weight=0.1, refinement_ortho=cfg["refinement_ortho"], iterations=cfg["iterations"], learning_rate_schedule=cfg["schedule"],
         learning_rate_min=cfg["lr_min"], learning_rate_max=cfg["lr_max"], learning_rate_warmup_iterations=cfg["warmup_iterations"],
         learning_rate_warmup_learning_rate=cfg["warmup_lr"], learning_rate_cooldown_iterations=cfg["cooldown_iterations"],
         learning_rate_cooldown_trigger_percent_threshold=cfg["cooldown_trigger_percent"])
@@ -198,7 +205,10 @@ def run_reference(cfg, prob, flat0, batches):
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    only = sys.argv[1:]   # optional: names of the configurations to (re)generate
     for name, c in CONFIGS.items():
+        if only and name not in only:
+            continue
         cfg = full_cfg(c)
         prob = synth.make_training_problem(seed=SEED, n_images=6, views_per_image=2, patches_per_view=128)
         # the trainer stores features in half precision; keep them bf16-representable so both modes see the same inputs

@@ -27,6 +27,10 @@ HEAD_CONFIGS = {
     "head_tanh_depth": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
                             warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
                             refine_calibration=False, steps=6, use_depth=True),
+    "head_tanh_posemlp_procrustes": dict(loss_type="tanh", schedule="constant", lr_min=0.0002, lr_max=0.003, warmup_iterations=1000,
+                                         warmup_lr=0.0005, cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20,
+                                         refine_calibration=False, steps=6, pose_refinement="mlp", pose_refinement_wait=2,
+                                         refinement_ortho="procrustes"),
 }
 
 
@@ -38,6 +42,7 @@ def full_cfg(c, prob=None):
     d.setdefault("pose_refinement", "none")
     d.setdefault("pose_refinement_wait", 0)
     d.setdefault("use_depth", False)
+    d.setdefault("refinement_ortho", "gram-schmidt")
     if prob is not None:
         d["focal_init"] = float(prob["focal"])
     return d

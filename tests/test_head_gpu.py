@@ -26,7 +26,7 @@ def _trainer(prob, flat0, cfg, max_batch=helpers.B, global_batch=None):
                      warmup_iterations=cfg["warmup_iterations"], warmup_lr=cfg["warmup_lr"], cooldown_iterations=cfg["cooldown_iterations"],
                      cooldown_trigger_percent=cfg["cooldown_trigger_percent"], refine_calibration=cfg["refine_calibration"],
                      focal_init=float(prob["focal"]), calib_lr=cfg["calib_lr"], pose_refinement=cfg["pose_refinement"],
-                     pose_refinement_wait=cfg["pose_refinement_wait"], pose_seed=helpers.SEED + 3,
+                     pose_refinement_wait=cfg["pose_refinement_wait"], pose_seed=helpers.SEED + 3, refinement_ortho=cfg["refinement_ortho"],
                      initial_poses=prob["image_pose_inv"][:, :3] if cfg["pose_refinement"] == "naive" else None)
     tr.load_flat(flat0)
     tr.set_buffer(prob["features"], prob["target_px"], prob["view_idx"], prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"],
