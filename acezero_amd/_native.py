@@ -4,6 +4,11 @@ and if that fails the import error propagates."""
 import ctypes as C
 import os
 
+# torch FIRST: its wheel bundles its own libamdhip64 / libhsa-runtime64. Loaded first, libacez.so's HIP dependency resolves to
+# that same runtime (one HSA instance per process, shared streams and allocations). Loaded second, the process would hold two
+# HIP runtimes and the one initialised last sees no device.
+import torch  # noqa: F401
+
 from . import build as _build
 
 _lib = None
@@ -94,6 +99,9 @@ SYMBOLS = {
     "acez_encoder_destroy": (None, [C.c_void_p]),
     "acez_encoder_output_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "acez_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "acez_point_cloud_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                          C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
 }
 
 

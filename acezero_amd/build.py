@@ -14,13 +14,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacez.so")
 STAMP = os.path.join(HERE, ".libacez.stamp")
 
-# translation unit -> extra flags.  The RANSAC unit must not contract a*b+c into fma: its fp64 arithmetic is
-# compared bit-for-bit with the CPU oracle (DESIGN.md "Determinism").
+# translation unit -> extra flags.  The RANSAC and point-cloud units must not contract a*b+c into fma: their arithmetic
+# is compared bit-for-bit with the CPU oracle (DESIGN.md "Determinism").
 UNITS = {
     "acez_common.hip": [],
     "head_api.hip": [],
     "encoder_api.hip": [],
     "ransac_api.hip": ["-ffp-contract=off"],
+    "cloud_api.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

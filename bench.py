@@ -206,7 +206,24 @@ def bench_pipeline(args, rank, world, device):
         bld.add_views(img, None, eye, eye, K, Ki, list(range(chunk)))
     torch.cuda.synchronize()
     dtb = time.perf_counter() - t1
-    return {"frames": nfr, "e2e_s": dt, "encoder_ms": enc_ms, "buffer_s": dtb, "buffer_rows": bld.n}
+    # point-cloud extraction filter on scene-coordinate maps resident in HBM: 60 x 80 maps of the synthetic room,
+    # budgets of a 1000-frame mapping sequence (100 .. 1000 points per frame), launched 256 frames at a time
+    from acezero_amd import pointcloud
+    fr = synth.make_registration_frames(seed=9 + rank, n_frames=64, noise_sigma=0.002, outlier_ratio=0.2)
+    maps = torch.from_numpy(fr["scene_coords"]).to(device).repeat(4, 1, 1, 1).contiguous()
+    pinv = torch.from_numpy(np.linalg.inv(fr["poses"]).astype(np.float32)).to(device).repeat(4, 1, 1)
+    Kc = torch.tensor([[fr["focal"], 0, fr["ppx"]], [0, fr["focal"], fr["ppy"]], [0, 0, 1.0]], device=device).repeat(256, 1, 1)
+    pointcloud.filter_scene_coordinates(maps, pinv, Kc, 100.0, False, 1000)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    npts = 0
+    for c in range(8):
+        xyz, _, _, _ = pointcloud.filter_scene_coordinates(maps, pinv, Kc, 100.0, False, 1000, first_frame_id=256 * c)
+        npts += int(xyz.shape[0])
+    torch.cuda.synchronize()
+    dtc = time.perf_counter() - t2
+    return {"frames": nfr, "e2e_s": dt, "encoder_ms": enc_ms, "buffer_s": dtb, "buffer_rows": bld.n, "cloud_frames": 8 * 256, "cloud_s": dtc,
+            "cloud_points": npts}
 
 
 def cpu_baseline():
@@ -252,7 +269,16 @@ def cpu_baseline():
         t0 = time.perf_counter()
         enc.forward(img)
         t_enc = (time.perf_counter() - t0) / 2
+    from oracle import cloud_oracle
+    frc = synth.make_registration_frames(seed=9, n_frames=8, noise_sigma=0.002, outlier_ratio=0.2)
+    pinv = np.linalg.inv(frc["poses"]).astype(np.float32)[:, :3]
+    Kc = np.array([[frc["focal"], 0, frc["ppx"]], [0, frc["focal"], frc["ppy"]], [0, 0, 1]], np.float32)
+    t0 = time.perf_counter()
+    for rep in range(4):
+        cloud_oracle.point_cloud(frc["scene_coords"], pinv, [Kc] * 8, 100.0, False, 1000)
+    t_cloud = (time.perf_counter() - t0) / 32
     return {"value": BATCH / t_train, "unit": "patches/s", "cores": tcores, "kind": "port",
+            "point_cloud_frames_per_s": 1.0 / t_cloud,
             "sample": f"{steps} steps of 5120 patches, oracle/head_oracle.py fp32 on torch-CPU with {tcores} of {cores} host threads; "
                       f"registration: {nfr} frames, oracle/dsac_oracle.cpp, {cores} threads",
             "registration_images_per_s": nfr / t_reg,
@@ -324,6 +350,10 @@ def main():
             "buffer_creation": {"metric": "training-buffer rows/sec (encoder + 1024 mask-weighted samples per 480x640 view)",
                                 "value": pipe["buffer_rows"] * world / pipe["buffer_s"], "unit": "patches/s",
                                 "views_per_s": pipe["frames"] * world / pipe["buffer_s"]},
+            "point_cloud_filter": {"metric": "point-cloud extraction frames/sec (60x80 scene-coordinate maps in HBM -> filtered [N,3] list)",
+                                   "value": pipe["cloud_frames"] * world / pipe["cloud_s"], "unit": "frames/s",
+                                   "points_per_frame": pipe["cloud_points"] / pipe["cloud_frames"],
+                                   "map_bytes_per_s": pipe["cloud_frames"] * world * 57600 / pipe["cloud_s"]},
             "roofline": {"bound": "mfma", "kernel": "rowgemm80_kernel (5120x512x512 bf16, fwd + dgrad launches)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": gemm_n,

@@ -319,6 +319,36 @@ int acez_buffer_sample_views(const void* d_view_features, const uint8_t* d_masks
                              int32_t view_index_base, void* d_out_features, float* d_out_target_px,
                              int32_t* d_out_view_idx, int32_t* d_out_pixel, void* stream);
 
+/* =====================================================================================================
+ * F. Point-cloud extraction
+ * =====================================================================================================
+ * Replaces the per-frame body of ace_vis_util.get_point_cloud_from_network (ace_vis_util.py:430-591; callers
+ * export_point_cloud.py:87-94, ace_zero.py:379-400) from the point where the scene-coordinate maps of a batch of frames
+ * exist on the device (acez_head_forward_maps' output): reprojection error against the pixel grid (:481-499),
+ * scene-coordinate gradient with reflect padding (:501-510), the escalating gradient thresholds 0.1 / 0.5 / 1 / inf
+ * (:443,512-516), depth filter and "keep all if nothing survives" (:518-526), reprojection threshold of 1 px (:451,528-530)
+ * with the relaxed k-th-error branch (:535-544) and the random sub-sampling branch (:545-551), and the merge into one
+ * point list in frame order with the OpenCV -> OpenGL flip (:574-587).  `torch.randperm`'s stream is replaced by a
+ * counter-based draw keyed by (seed, first_frame_id + frame, rank of the surviving point); everything else is bit-exact
+ * against the restatement in oracle/cloud_oracle.py, which is pinned on the reference function's own output.
+ *   d_scene_coords        float32 [n_frames][3][map_h][map_w]
+ *   d_poses_inv           float32 [n_frames][12]: rows of the 3x4 world -> camera transform (gt_inv_pose[:, :3], :479)
+ *   d_intrinsics          float32 [n_frames][9]: row-major K
+ *   filter_depth          metres (export_point_cloud.py:94 passes 100); dense_cloud as ace_vis_util.py:453-456
+ *   points_per_image_min  int(100000 / len(data_loader)), points_per_image_max  int(1000000 / len(data_loader)) (:458-459)
+ *   opengl_convention     non-zero: y and z negated as the reference returns them
+ *   d_keep                uint8 [n_frames][map_h * map_w]   out: 1 = the pixel's point is part of the cloud
+ *   d_counts              int32 [n_frames]                  out: points kept per frame
+ *   d_offsets             int32 [n_frames + 1]              out: exclusive prefix of d_counts; [n_frames] = total N
+ *   d_out_xyz             float32 [n_frames * map_h * map_w][3], first N rows written, frame after frame, pixel order
+ *   d_out_source          int32 [same], frame * map_h * map_w + pixel of every point (colour lookup), or NULL
+ * Asynchronous on `stream`. */
+int acez_point_cloud_filter(const float* d_scene_coords, const float* d_poses_inv, const float* d_intrinsics, int n_frames,
+                            int map_h, int map_w, float filter_depth, int dense_cloud, int points_per_image_min,
+                            int points_per_image_max, uint64_t seed, uint64_t first_frame_id, int opengl_convention,
+                            uint8_t* d_keep, int32_t* d_counts, int32_t* d_offsets, float* d_out_xyz, int32_t* d_out_source,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,3 +64,32 @@ def golden_batches(prob, steps):
 def torch_batch(prob, idx):
     pp = synth.expand_per_patch(prob, idx)
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in pp.items()}
+
+
+# ---- point-cloud extraction cases (tests/golden/cloud_cases.npz holds the reference's output for each) ----
+# name -> (synth seed, frames, map h, w, noise sigma [m], outlier ratio, len(data_loader), filter_depth, dense)
+CLOUD_CASES = {
+    "plain": (11, 3, 24, 32, 0.0004, 0.1, 1000, 100.0, False),
+    "relaxed": (12, 3, 24, 32, 0.02, 0.2, 500, 100.0, False),
+    "subsampled": (13, 3, 24, 32, 0.0004, 0.05, 10000, 100.0, False),
+    "depth_all_out": (14, 2, 24, 32, 0.0004, 0.1, 1000, 0.01, False),
+    "depth_some_out": (15, 3, 24, 32, 0.0004, 0.1, 1000, 2.5, False),
+    "grad_escalation_inf": (16, 3, 24, 32, 0.001, 0.55, 200, 100.0, False),
+    "grad_escalation_mid": (20, 3, 24, 32, 0.06, 0.1, 250, 100.0, False),
+    "dense": (17, 2, 24, 32, 0.02, 0.3, 1000, 3.0, True),
+    "dense_relaxed": (21, 2, 24, 32, 0.02, 0.3, 100, 100.0, True),
+    "dense_subsampled": (18, 2, 24, 32, 0.02, 0.3, 20000, 3.0, True),
+    "wide_map": (19, 2, 15, 93, 0.0004, 0.1, 500, 100.0, False),
+}
+CLOUD_RANDOM_CASES = ("subsampled", "dense_subsampled")   # torch.randperm decides there: only count / subset are comparable
+
+
+def cloud_case_inputs(name):
+    """(scene coords [n,3,h,w], poses_inv [n,4,4] world->camera, K [n,3,3], len(data_loader), filter_depth, dense)."""
+    import numpy as np
+    from acezero_amd import synth
+    seed, n, h, w, sigma, outl, loader_len, depth, dense = CLOUD_CASES[name]
+    fr = synth.make_registration_frames(seed=seed, n_frames=n, h=h, w=w, noise_sigma=sigma, outlier_ratio=outl)
+    poses_inv = np.linalg.inv(fr["poses"]).astype(np.float32)
+    K = np.array([[fr["focal"], 0, fr["ppx"]], [0, fr["focal"], fr["ppy"]], [0, 0, 1]], np.float32)
+    return fr["scene_coords"], poses_inv, np.stack([K] * n), loader_len, depth, dense

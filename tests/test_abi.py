@@ -72,3 +72,15 @@ def test_argument_validation_without_device():
     assert lib.acez_buffer_sample_views(None, None, 1, 2, 2, 8, 4, 1, 0, 0, None, None, None, None, None) == -1
     hd0 = N.HeadDesc(0, 0, (C.c_float * 3)(0, 0, 0), 0.25, 100.0, 0.9)
     assert lib.acez_head_num_params(C.byref(hd0)) == 5 * 262656 + 3 * 513
+
+
+def test_single_hip_runtime_whatever_the_import_order():
+    """libacez.so must bind to the HIP runtime torch ships (one HSA instance per process): build() followed by smoke() in one
+    process loads the library before anything touches torch.cuda."""
+    import subprocess
+    import sys
+    code = ("import __graft_entry__ as g; g.build(); import torch; "
+            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l)); print(len(libs), libs)")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1].startswith("1 "), r.stdout
