@@ -38,7 +38,7 @@ class BufferBuilder:
     def full(self):
         return self.n >= self.capacity
 
-    def add_views(self, image_v1hw, mask_v1hw, aug_pose_inv_v44, pose_inv_v44, K_v33, Kinv_v33, image_index_v):
+    def add_views(self, image_v1hw, mask_v1hw, aug_pose_inv_v44, pose_inv_v44, K_v33, Kinv_v33, image_index_v, want_pixels=False):
         """One dataloader batch (the reference uses batch size 1; any number of same-sized views works here)."""
         if self.full:
             return 0
@@ -53,7 +53,7 @@ class BufferBuilder:
                 if len(sel) == 0:
                     return 0
                 return self.add_views(image_v1hw[sel], mask_v1hw[sel], aug_pose_inv_v44[sel], pose_inv_v44[sel], K_v33[sel],
-                                      Kinv_v33[sel], [image_index_v[int(i)] for i in sel])
+                                      Kinv_v33[sel], [image_index_v[int(i)] for i in sel], want_pixels=want_pixels)
             mask_u8 = m.to(torch.uint8).contiguous()
         else:
             mask_u8 = None
@@ -74,10 +74,12 @@ class BufferBuilder:
         else:
             of, op, ov = self.features[self.n:self.n + n_new], self.target_px[self.n:self.n + n_new], self.view_idx[self.n:self.n + n_new]
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.last_pixels = torch.empty((n_new,), dtype=torch.int32, device=self.dev) if want_pixels else None   # chosen map pixels (y * ow + x)
         N.check(N.lib().acez_buffer_sample_views(C.c_void_p(rows.data_ptr()), C.c_void_p(mask_u8.data_ptr()) if mask_u8 is not None else None,
                                                  v, oh, ow, self.enc.out_channels, self.samples, C.c_uint64(self.seed),
                                                  C.c_uint64(self.n_views), self.n_views, C.c_void_p(of.data_ptr()),
-                                                 C.c_void_p(op.data_ptr()), C.c_void_p(ov.data_ptr()), None, stream))
+                                                 C.c_void_p(op.data_ptr()), C.c_void_p(ov.data_ptr()),
+                                                 C.c_void_p(self.last_pixels.data_ptr()) if want_pixels else None, stream))
         if take < n_new:
             self.features[self.n:self.n + take] = of[:take]
             self.target_px[self.n:self.n + take] = op[:take]

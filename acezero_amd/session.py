@@ -1,0 +1,411 @@
+"""One persistent process per GPU for the whole ACE0 reconstruction loop.
+
+ace_zero.py drives the reconstruction by spawning `train_ace.py` / `register_mapping.py` once per iteration
+(ace_zero_util.py:11-52, ace_zero.py:195-196,235,274,307): every call pays interpreter + torch import, context creation,
+data-loader start-up, and re-encodes every image.  Here the same loop (seed trials -> best seed -> map / register rounds with
+warm start, pose-MLP and focal refinement -> stopping criteria -> final refit) runs in-process on frames that are already in
+memory: HIP context, encoder weights and the ENCODER FEATURES of all frames (4.9 MB per 480x640 frame in bf16: 1000 frames
+= 4.9 GB of the 288 GB) stay resident, so a mapping round is buffer sampling + the training kernels and a registration
+round is head + RANSAC on cached features.
+
+    ses = ReconstructionSession(encoder_state_dict, images_n1hw, depth=seed_depth_nhw)     # opt = default_options(...)
+    result = ses.reconstruct()          # {"poses": cam->world [n,4,4], "confidence": [n], "focal": f, "head": state_dict, ...}
+
+Option names and defaults are ace_zero.py's (:41-177).  What is NOT here is the image pipeline (file decoding, resizing,
+augmentation: dataset.py) and ZoeDepth: frames arrive as normalised grey tensors, views are not augmented (--use_aug False
+semantics) and a seed needs a depth map for its image (ace_zero.py's --depth_files path; the reference falls back to a
+network download otherwise).  There is no CPU fallback.
+"""
+import logging
+import math
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import dsacstar
+from .encoder import Encoder, output_size
+from .head import HeadTrainer, _ptr, _stream
+
+_logger = logging.getLogger("acezero_amd.session")
+
+
+def default_options(**over):
+    """ace_zero.py:41-177 (the flags that reach the hot path) + the train_ace.py / register_mapping.py defaults they rely on."""
+    o = dict(iterations_max=100, registration_threshold=0.99, relative_registration_threshold=0.01, final_refine=True, final_refit=True,
+             final_refit_posewait=5000, refit_iterations=25000, registration_confidence=500, try_seeds=5, seed_iterations=10000,
+             warmstart=True, seed_network=None, export_point_cloud=False, dense_point_cloud=False, refinement="mlp", refinement_ortho="gram-schmidt", pose_refinement_wait=0, pose_refinement_lr=0.001,
+             refine_calibration=True, use_external_focal_length=-1.0, learning_rate_schedule="1cyclepoly", learning_rate_max=0.003,
+             cooldown_iterations=5000, cooldown_threshold=0.7, num_head_blocks=1, max_dataset_passes=10, repro_loss_type="tanh",
+             repro_loss_hard_clamp=1000, repro_loss_soft_clamp=50, ransac_iterations=32, ransac_threshold=10.0, random_seed=1305,
+             # train_ace.py defaults ace_zero.py does not override
+             iterations=25000, learning_rate_min=0.0005, learning_rate_warmup_iterations=1000, learning_rate_warmup_learning_rate=0.0005,
+             max_training_buffer_size=8000000, samples_per_image=1024, batch_size=5120, base_seed=2089, register_seed=1305,
+             max_estimates_seed_scoring=1000,
+             # train_ace.py augmentation flags (:174-182) + dataset.py:38-41; applied on the device to the resident frames
+             use_aug=True, aug_rotation=15, aug_scale=1.5, aug_black_white=0.1)
+    unknown = set(over) - set(o)
+    if unknown:
+        raise TypeError(f"unknown options: {sorted(unknown)}")
+    o.update(over)
+    return SimpleNamespace(**o)
+
+
+def warp_view(image_11hw, scale, angle, jitter=None):
+    """One augmented view of a normalised grey frame as ONE affine warp (dataset.py:283-343): the frame is resized by `scale`
+    (canvas int(H*scale) x int(W*scale)) and rotated by `angle` radians about its centre -- content at offset d from the centre
+    moves to R' d with R' = [[cos, sin], [-sin, cos]] in (x right, y down) pixel coordinates, which is exactly how camera
+    coordinates transform under aug_pose_inv = pose_rot^-1 (dataset.py:337-343,397) -- bilinear, image reflect-padded, mask
+    zero-padded (:327-328). jitter = (brightness, contrast) factors of ColorJitter on the [0,1] grey values (:148), or None.
+    Returns (view [1,1,hs,ws], mask [1,1,hs,ws] bool, grid [1,hs,ws,2] of normalised source coordinates)."""
+    _, _, H, W = image_11hw.shape
+    hs, ws = int(H * scale), int(W * scale)
+    sx, sy = ws / W, hs / H
+    c, s_ = math.cos(angle), math.sin(angle)
+    # output offset p' (pixels, scaled canvas) -> source offset p = R'^T p' / scale; in normalised coordinates x_n = x / (W/2)
+    theta = torch.tensor([[c * (ws / 2) / sx / (W / 2), -s_ * (hs / 2) / sx / (W / 2), 0.0],
+                          [s_ * (ws / 2) / sy / (H / 2), c * (hs / 2) / sy / (H / 2), 0.0]], dtype=torch.float32, device=image_11hw.device)
+    grid = torch.nn.functional.affine_grid(theta.unsqueeze(0), (1, 1, hs, ws), align_corners=False)
+    src = image_11hw
+    if jitter is not None:
+        g = src * 0.25 + 0.4
+        g = (g * jitter[0]).clamp(0, 1)
+        m = g.mean()
+        g = ((g - m) * jitter[1] + m).clamp(0, 1)
+        src = (g - 0.4) / 0.25
+    view = torch.nn.functional.grid_sample(src, grid, mode="bilinear", padding_mode="reflection", align_corners=False)
+    mask = torch.nn.functional.grid_sample(torch.ones_like(image_11hw), grid, mode="bilinear", padding_mode="zeros", align_corners=False) > 0
+    return view, mask, grid
+
+
+def view_depth(depth_11hw, grid, oh, ow):
+    """Depth of an augmented view at its feature-map pixel centres (8x+4, 8y+4): nearest lookup in the frame's depth map through
+    the view's sampling grid (dataset.py:331-334 resizes / rotates the depth with order=0; depth is invariant to both)."""
+    hs, ws = grid.shape[1:3]
+    iy = (torch.arange(oh, device=grid.device) * 8 + 4).clamp(max=hs - 1)
+    ix = (torch.arange(ow, device=grid.device) * 8 + 4).clamp(max=ws - 1)
+    gsub = grid[:, iy][:, :, ix]
+    return torch.nn.functional.grid_sample(depth_11hw, gsub, mode="nearest", padding_mode="zeros", align_corners=False)[0, 0]
+
+
+class ReconstructionSession:
+    def __init__(self, encoder_state_dict, images, opt=None, depth=None, device=None, chunk=32):
+        """images [n,1,H,W] float32 normalised (dataset.py:150-153), any device; depth [n,H/8,W/8] camera z at the feature-map
+        pixel centres (metres, 0 = invalid) or None -- only the seed images' maps are read."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("ReconstructionSession needs a GPU: every stage is a HIP kernel (no CPU fallback)")
+        self.opt = opt or default_options()
+        n, _, H, W = images.shape
+        self.n, self.H, self.W = int(n), int(H), int(W)
+        amax = float(self.opt.aug_scale) if self.opt.use_aug else 1.0
+        self.enc = Encoder.from_state_dict(encoder_state_dict, max_frames=chunk, max_h=int(math.ceil(H * amax)) + 8,
+                                           max_w=int(math.ceil(W * amax)) + 8, device=device)
+        self.dev = self.enc.device
+        self.images = images.to(self.dev, torch.float32).contiguous()    # 1.2 MB per 480x640 frame: resident for the augmented passes
+        self._aug_rng = np.random.default_rng(self.opt.base_seed + 77)
+        self.oh, self.ow = output_size(H, W)
+        self.hw = self.oh * self.ow
+        self.features = torch.empty((self.n, self.hw, self.enc.out_channels), dtype=torch.bfloat16, device=self.dev)
+        t0 = time.time()
+        for c0 in range(0, self.n, chunk):
+            c1 = min(self.n, c0 + chunk)
+            self.enc.features_rows(self.images[c0:c1], out=self.features[c0:c1].view(-1, self.enc.out_channels))
+        torch.cuda.synchronize(self.dev)
+        self.depth = None if depth is None else depth.to(self.dev, torch.float32)
+        f_ext = float(self.opt.use_external_focal_length)
+        self.focal0 = f_ext if f_ext > 0 else math.sqrt(W ** 2 + H ** 2) * 0.7           # dataset.py:269-274
+        self.ppx, self.ppy = W / 2.0, H / 2.0                                            # dataset.py:411-412
+        self.history = []
+        self._views_sampled = 0
+        _logger.info(f"Encoded {self.n} frames in {time.time() - t0:.2f}s; features resident: {self.features.numel() * 2 / 2 ** 30:.2f} GiB")
+
+    # ------------------------------------------------------------------------------------------------ mapping (train_ace.py)
+    def _K(self, focal):
+        return torch.tensor([[focal, 0, self.ppx], [0, focal, self.ppy], [0, 0, 1.0]], dtype=torch.float32)
+
+    def _fill_buffer(self, image_ids, poses_c2w, focal, with_depth):
+        """TrainerACE.create_training_buffer (ace_trainer.py:293-452) on cached features, views not augmented."""
+        o = self.opt
+        ids = torch.as_tensor(list(image_ids), dtype=torch.long, device=self.dev)
+        m = len(ids)
+        total = min(o.max_training_buffer_size, o.max_dataset_passes * m * o.samples_per_image)
+        C = self.enc.out_channels
+        feats = torch.empty((total, C), dtype=torch.bfloat16, device=self.dev)
+        px = torch.empty((total, 2), dtype=torch.float32, device=self.dev)
+        vidx = torch.empty((total,), dtype=torch.int32, device=self.dev)
+        pix = torch.empty((total,), dtype=torch.int32, device=self.dev)
+        src = self.features[ids].reshape(-1, C)                          # one copy of the mapped images' feature maps
+        mask = None
+        if with_depth:                                                  # pixels without a depth are not sampled (dataset.py:384-386 zero them)
+            d = self.depth[ids]
+            mask = ((d > 0) & (d <= 1000)).to(torch.uint8).reshape(m, self.hw).contiguous()
+        filled, n_views = 0, 0
+        while filled < total:
+            v = min(m, (total - filled + o.samples_per_image - 1) // o.samples_per_image)
+            take = min(v * o.samples_per_image, total - filled)
+            if take < v * o.samples_per_image:                           # last, partial view: sample whole views into scratch
+                of = torch.empty((v * o.samples_per_image, C), dtype=torch.bfloat16, device=self.dev)
+                op = torch.empty((v * o.samples_per_image, 2), dtype=torch.float32, device=self.dev)
+                ov = torch.empty((v * o.samples_per_image,), dtype=torch.int32, device=self.dev)
+                ox = torch.empty((v * o.samples_per_image,), dtype=torch.int32, device=self.dev)
+            else:
+                of, op, ov, ox = (t[filled:filled + take] for t in (feats, px, vidx, pix))
+            N.check(N.lib().acez_buffer_sample_views(_ptr(src), _ptr(mask) if mask is not None else None, v, self.oh, self.ow, C,
+                                                     o.samples_per_image, o.base_seed + 4095, self._views_sampled, n_views, _ptr(of), _ptr(op),
+                                                     _ptr(ov), _ptr(ox), _stream()))
+            if take < v * o.samples_per_image:
+                feats[filled:], px[filled:], vidx[filled:], pix[filled:] = of[:take], op[:take], ov[:take], ox[:take]
+            filled += take
+            n_views += v
+            self._views_sampled += v
+        view_image = torch.arange(n_views, dtype=torch.int32) % m        # pass p, view j -> image j
+        poses_c2w = torch.as_tensor(poses_c2w, dtype=torch.float64).reshape(m, 4, 4)
+        pose_inv = torch.linalg.inv(poses_c2w).to(torch.float32)
+        K = self._K(focal)
+        buf = dict(features=feats, target_px=px, view_idx=vidx, view_aug_inv=torch.eye(4)[:3].repeat(n_views, 1, 1),
+                   view_K=K.repeat(n_views, 1, 1), view_Kinv=torch.linalg.inv(K).repeat(n_views, 1, 1), view_image=view_image,
+                   image_pose_inv=pose_inv)
+        if with_depth:
+            # ground-truth scene coordinates from depth (dataset.py:347-388): eye = ((x*8+4 - W/2) / f * d, (y*8+4 - H/2) / f * d, d)
+            img = (vidx.long() % m)
+            d = self.depth[ids].reshape(m, self.hw)[img, pix.long()]
+            eye = torch.stack([(px[:, 0] - self.ppx) / focal * d, (px[:, 1] - self.ppy) / focal * d, d, torch.ones_like(d)], dim=1)
+            buf["target_crds"] = torch.einsum("nij,nj->ni", poses_c2w.to(self.dev, torch.float32)[img][:, :3], eye)
+        return buf
+
+    def _augmented_view(self, img):
+        """dataset.py:283-343,420-427 on the device: random scale (short side 480 * U(1/s, s)), in-plane rotation U(-r, r) degrees,
+        brightness / contrast jitter. Returns (view [1,1,hs,ws], mask bool, scale, angle_rad, sampling grid)."""
+        o, rng = self.opt, self._aug_rng
+        scale = float(rng.uniform(1.0 / o.aug_scale, o.aug_scale))
+        ang = math.radians(float(rng.uniform(-o.aug_rotation, o.aug_rotation)))
+        bw = float(o.aug_black_white)
+        jitter = (float(rng.uniform(1 - bw, 1 + bw)), float(rng.uniform(1 - bw, 1 + bw))) if bw > 0 else None
+        view, mask, grid = warp_view(self.images[img:img + 1], scale, ang, jitter)
+        return view, mask, scale, ang, grid
+
+    def _fill_buffer_augmented(self, image_ids, poses_c2w, focal, with_depth):
+        """create_training_buffer with --use_aug True: every pass re-encodes a freshly augmented view of every mapped image
+        (encoder: ~13 k views/s) and samples it with its validity mask. Views are processed one at a time, as the reference does."""
+        from .buffer import BufferBuilder
+        o = self.opt
+        ids = [int(i) for i in image_ids]
+        m = len(ids)
+        total = min(o.max_training_buffer_size, o.max_dataset_passes * m * o.samples_per_image)
+        bld = BufferBuilder(self.enc, capacity=total, samples_per_image=o.samples_per_image, seed=o.base_seed + 4095 + self._views_sampled)
+        poses_c2w = torch.as_tensor(poses_c2w, dtype=torch.float64).reshape(m, 4, 4)
+        pose_inv = torch.linalg.inv(poses_c2w).to(torch.float32)
+        crds = []
+        while not bld.full:
+            for j, img in enumerate(ids):
+                if bld.full:
+                    break
+                view, mask, scale, ang, grid = self._augmented_view(img)
+                hs, ws = view.shape[2:]
+                f = focal * (int(self.H * scale) / self.H)               # dataset.py:289-290 scales the focal with the short side
+                K = torch.tensor([[f, 0, ws / 2.0], [0, f, hs / 2.0], [0, 0, 1.0]])
+                rot_inv = torch.eye(4)                                   # inverse of pose_rot (dataset.py:337-343)
+                rot_inv[0, 0], rot_inv[0, 1], rot_inv[1, 0], rot_inv[1, 1] = math.cos(ang), math.sin(ang), -math.sin(ang), math.cos(ang)
+                n0 = bld.n
+                if with_depth:
+                    # depth at the view's feature-map pixel centres: nearest lookup through the same warp (dataset.py:331-334, order=0)
+                    oh, ow = output_size(hs, ws)
+                    d = self.depth[img:img + 1].unsqueeze(1)
+                    dv = view_depth(d, grid, oh, ow)
+                    valid = (dv > 0) & (dv <= 1000)
+                    mk = torch.nn.functional.interpolate(mask.float(), size=(oh, ow), mode="nearest")[0, 0] > 0
+                    full_mask = torch.nn.functional.interpolate((mk & valid).float()[None, None], size=(hs, ws), mode="nearest")
+                    took = bld.add_views(view, full_mask, rot_inv.unsqueeze(0), pose_inv[j:j + 1], K.unsqueeze(0), torch.linalg.inv(K).unsqueeze(0), [j],
+                                         want_pixels=True)
+                    if took:
+                        pix = bld.last_pixels[:took].long()
+                        y, x = pix // ow, pix % ow
+                        dd = dv[y, x]
+                        px = bld.target_px[n0:n0 + took]
+                        eye = torch.stack([(px[:, 0] - ws / 2.0) / f * dd, (px[:, 1] - hs / 2.0) / f * dd, dd, torch.ones_like(dd)], dim=1)
+                        T = (poses_c2w[j].to(torch.float32) @ torch.linalg.inv(rot_inv)).to(self.dev)     # pose @ pose_rot (dataset.py:381)
+                        crds.append(eye @ T[:3].T)
+                else:
+                    bld.add_views(view, mask.float(), rot_inv.unsqueeze(0), pose_inv[j:j + 1], K.unsqueeze(0), torch.linalg.inv(K).unsqueeze(0), [j])
+        self._views_sampled += bld.n_views
+        buf = bld.finish()
+        if with_depth:
+            buf["target_crds"] = torch.cat(crds)
+        return buf
+
+    def map(self, image_ids, poses_c2w, focal, *, iterations, loss_type, schedule, lr_max, refinement="none", pose_wait=0,
+            refine_calibration=False, load_weights=None, with_depth=False, tag="map"):
+        """One train_ace.py run (ace_trainer.py:TrainerACE.train): returns {"head": fp16 state_dict, "poses_w2c": [m,3,4] refined,
+        "focal": refined focal, "iterations", "seconds", "patches_per_s", "batch_inliers"}."""
+        o = self.opt
+        t0 = time.time()
+        fill = self._fill_buffer_augmented if self.opt.use_aug else self._fill_buffer
+        buf = fill(image_ids, poses_c2w, focal, with_depth)
+        torch.cuda.synchronize(self.dev)
+        t_fill = time.time() - t0
+        n = int(buf["features"].shape[0])
+        if n < o.batch_size:
+            raise ValueError(f"training buffer of {n} patches is smaller than one batch ({o.batch_size})")
+        poses_c2w = torch.as_tensor(poses_c2w, dtype=torch.float32).reshape(-1, 4, 4)
+        if load_weights is not None:
+            mean = load_weights["mean"].float().view(3)                  # Regressor.create_from_split_state_dict keeps the stored mean
+        else:
+            mean = poses_c2w[:, :3, 3].mean(dim=0)                       # dataset.py:206-225
+        tr = HeadTrainer(mean, num_head_blocks=o.num_head_blocks, use_homogeneous=True, max_batch=o.batch_size, loss_type=loss_type,
+                         soft_clamp=o.repro_loss_soft_clamp, soft_clamp_min=1, circle_schedule=True, hard_clamp=o.repro_loss_hard_clamp,
+                         inlier_px_threshold=10, schedule=schedule, iterations=iterations, lr_min=o.learning_rate_min, lr_max=lr_max,
+                         warmup_iterations=o.learning_rate_warmup_iterations, warmup_lr=o.learning_rate_warmup_learning_rate,
+                         cooldown_iterations=o.cooldown_iterations, cooldown_trigger_percent=o.cooldown_threshold,
+                         refine_calibration=refine_calibration, focal_init=focal, calib_lr=0.001, pose_refinement=refinement,
+                         pose_refinement_wait=pose_wait, pose_refinement_lr=o.pose_refinement_lr, pose_refinement_weight=0.1,
+                         refinement_ortho=o.refinement_ortho, pose_seed=o.base_seed + 511,
+                         initial_poses=buf["image_pose_inv"][:, :3] if refinement == "naive" else None, device=self.dev.index)
+        if load_weights is not None:
+            tr.load_state_dict(load_weights)
+        else:
+            g = torch.Generator().manual_seed(o.base_seed + 1023)        # ace_trainer.py:66-69
+            tr.load_flat((torch.rand(tr.n_params, generator=g) * 2 - 1) / math.sqrt(512.0))
+        tr.set_buffer(**buf)
+        torch.cuda.synchronize(self.dev)
+        t_loop0 = time.time()
+        gen = torch.Generator().manual_seed(o.base_seed + 8191)          # ace_trainer.py:79-80
+        launched, done = 0, False
+        while not done:                                                  # TrainerACE.train / run_epoch (ace_trainer.py:454-497)
+            perm = torch.randperm(n, generator=gen).to(self.dev)
+            for b0 in range(0, n - o.batch_size + 1, o.batch_size):
+                tr.step(perm[b0:b0 + o.batch_size])
+                launched += 1
+                if launched % 64 == 0:                                   # the only host synchronisation of the loop
+                    st = tr.state()
+                    if st["nan"]:
+                        raise RuntimeError("Aborting because of NaN loss")   # ace_trainer.py:615-617
+                    if st["iteration"] >= st["max_iterations"]:
+                        done = True
+                        break
+        st = tr.state()
+        dt = time.time() - t0
+        t_loop = time.time() - t_loop0
+        out = {"head": {k: v.detach().cpu().half() for k, v in tr.state_dict().items()},      # save_model (ace_trainer.py:681-694)
+               "poses_w2c": tr.current_poses(), "focal": float(st["focal_scale"] * focal) if refine_calibration else float(focal),
+               "iterations": int(st["iteration"]), "seconds": dt, "fill_seconds": t_fill, "loop_seconds": t_loop,
+               "patches_per_s": st["iteration"] * o.batch_size / t_loop,
+               "batch_inliers": float(st["batch_inliers"]), "loss": float(st["loss"]), "buffer": n}
+        _logger.info(f"[{tag}] {len(list(image_ids))} images, {n} patches, {out['iterations']} iterations in {dt:.2f}s (buffer {t_fill:.2f}s, loop {t_loop:.2f}s), "
+                     f"batch inliers {out['batch_inliers'] * 100:.1f}%, focal {out['focal']:.1f}")
+        tr.close()
+        return out
+
+    # ---------------------------------------------------------------------------------------- registration (register_mapping.py)
+    def scene_coordinates(self, head_sd, first=0, count=None):
+        """Head.forward on the cached features of frames [first, first+count): float32 [count,3,oh,ow] on the device."""
+        count = self.n - first if count is None else count
+        nb = sum(1 for k in head_sd if k.endswith("c0.weight"))
+        head = HeadTrainer(head_sd["mean"].float().view(3), num_head_blocks=nb, use_homogeneous=head_sd["fc3.weight"].shape[0] == 4,
+                           max_batch=min(count, 64) * self.hw, iterations=1, device=self.dev.index)
+        head.load_state_dict(head_sd)
+        out = torch.empty((count, 3, self.oh, self.ow), dtype=torch.float32, device=self.dev)
+        for c0 in range(0, count, 64):
+            c1 = min(count, c0 + 64)
+            rows = self.features[first + c0:first + c1].view(-1, self.enc.out_channels)
+            N.check(N.lib().acez_head_forward_maps(head._h, _ptr(rows), c1 - c0, self.oh, self.ow, _ptr(out[c0:c1]), _stream()))
+        torch.cuda.synchronize(self.dev)
+        head.close()
+        return out
+
+    def register(self, head_sd, focal, max_estimates=-1, tag="register"):
+        """register_mapping.py:201-276 for every frame: (poses cam->world [k,4,4] float32, inlier counts [k] int32)."""
+        o = self.opt
+        k = self.n if max_estimates <= 0 else min(self.n, max_estimates)
+        t0 = time.time()
+        sc = self.scene_coordinates(head_sd, 0, k)
+        prm = dict(hyps=o.ransac_iterations, thr=o.ransac_threshold, alpha=100.0, max_reproj=100.0, sub=8, max_tries=16)
+        poses, inl, _ = dsacstar.register_batch(sc, [(focal, self.ppx, self.ppy)] * k, prm, o.register_seed, list(range(k)), want_masks=False)
+        poses, inl = poses.cpu().numpy(), inl.cpu().numpy()
+        rate = float((inl > o.registration_confidence).mean())
+        _logger.info(f"[{tag}] {k} frames in {time.time() - t0:.2f}s, {rate * 100:.1f}% above confidence {o.registration_confidence}")
+        return poses, inl
+
+    # --------------------------------------------------------------------------------------------------- the loop (ace_zero.py)
+    def map_seed(self, seed_idx, seed):
+        """ace_zero_util.map_seed: one image, identity pose, depth-supervised, scored on (at most) 1000 frames."""
+        o = self.opt
+        img = int(seed * self.n)                                         # dataset.py:112
+        if self.depth is None:
+            raise RuntimeError("a seed image needs a depth map (ace_zero.py --depth_files); the ZoeDepth fallback is a network download")
+        m = self.map([img], torch.eye(4).unsqueeze(0), self.focal0, iterations=o.seed_iterations, loss_type=o.repro_loss_type,
+                     schedule=o.learning_rate_schedule, lr_max=o.learning_rate_max, with_depth=True, tag=f"iteration0_seed{seed_idx}")
+        _, inl = self.register(m["head"], self.focal0, max_estimates=o.max_estimates_seed_scoring, tag=f"iteration0_seed{seed_idx}_fastcheck")
+        return m, float((inl > o.registration_confidence).mean())
+
+    def reconstruct(self):
+        o = self.opt
+        t_start = time.time()
+        focal = self.focal0
+        if o.seed_network is not None:                                   # ace_zero.py:176-178: a pre-trained head (state_dict) as the seed
+            current, first_id, seed_rates = {"head": o.seed_network}, "seed_network", []
+        else:
+            np.random.seed(o.random_seed)                                # ace_zero.py:181-183
+            seeds = np.random.uniform(size=o.try_seeds)
+            trials = [self.map_seed(i, s) for i, s in enumerate(seeds)]
+            best = int(np.argmax([r for _, r in trials]))
+            current, first_id, seed_rates = trials[best][0], f"iteration0_seed{best}", [r for _, r in trials]
+        poses, conf = self.register(current["head"], focal, tag=first_id)
+        max_rate = float((conf > o.registration_confidence).mean())
+        self.history.append({"id": first_id, "registration_rate": max_rate, "focal": focal, "seed_rates": seed_rates})
+        scheduled_to_stop_early = False
+        iteration = 0
+        for iteration in range(1, o.iterations_max):
+            sel = np.flatnonzero(conf > o.registration_confidence)       # --ace_pose_file_conf_threshold (dataset_io.load_dataset_ace)
+            if len(sel) == 0:
+                raise RuntimeError("no image is registered above the confidence threshold: cannot continue the reconstruction")
+            refit = scheduled_to_stop_early and o.final_refit
+            warm = o.warmstart and (iteration > 1 or o.seed_network is not None) and not refit   # ace_zero.py:266-270
+            if refit:                                                    # ace_zero_util.get_refit_mapping_cmd
+                kw = dict(iterations=o.refit_iterations, loss_type="dyntanh", schedule="circle", lr_max=0.005, pose_wait=o.final_refit_posewait)
+            else:                                                        # ace_zero_util.get_base_mapping_cmd
+                kw = dict(iterations=o.iterations, loss_type=o.repro_loss_type, schedule=o.learning_rate_schedule, lr_max=o.learning_rate_max,
+                          pose_wait=o.pose_refinement_wait)
+            current = self.map(sel, torch.from_numpy(poses[sel]), focal, refinement=o.refinement, refine_calibration=o.refine_calibration,
+                               load_weights=current["head"] if warm else None, tag=f"iteration{iteration}", **kw)
+            focal = current["focal"]                                     # ace_zero.py:297-305: the refined focal goes to the registration
+            poses, conf = self.register(current["head"], focal, tag=f"iteration{iteration}")
+            rate = float((conf > o.registration_confidence).mean())
+            self.history.append({"id": f"iteration{iteration}", "registration_rate": rate, "focal": focal, "mapped_images": int(len(sel)),
+                                 "iterations": current["iterations"], "map_seconds": current["seconds"], "refit": bool(refit)})
+            if scheduled_to_stop_early:
+                break
+            if rate >= o.registration_threshold or (rate - max_rate) < o.relative_registration_threshold:   # ace_zero.py:317-327
+                if o.final_refine:
+                    scheduled_to_stop_early = True
+                else:
+                    break
+            if iteration >= o.iterations_max - 2:
+                scheduled_to_stop_early = True
+            max_rate = max(rate, max_rate)
+        out = {"poses": poses, "confidence": conf, "focal": focal, "head": current["head"], "history": self.history,
+               "iterations": iteration, "seconds": time.time() - t_start}
+        if o.export_point_cloud:                                         # ace_zero.py:379-400
+            out["point_cloud"] = self.point_cloud(current["head"], poses, conf, focal, dense=o.dense_point_cloud)
+        return out
+
+    def point_cloud(self, head_sd, poses_c2w, confidence, focal, dense=False, filter_depth=100, opengl=False):
+        """export_point_cloud.py:66-94 on the cached features of the registered frames (confidence > registration_confidence):
+        (xyz [N,3] float32, source [N] = position in the registered list * hw + map pixel). OpenCV convention by default, as
+        ace_zero.py requests it (--convention opencv, :398)."""
+        from .pointcloud import filter_scene_coordinates
+        sel = np.flatnonzero(np.asarray(confidence) > self.opt.registration_confidence)
+        sc = self.scene_coordinates(head_sd)[torch.from_numpy(sel).to(self.dev)]
+        pinv = torch.linalg.inv(torch.from_numpy(np.asarray(poses_c2w, np.float64)[sel])).to(torch.float32)
+        K = self._K(focal).repeat(len(sel), 1, 1)
+        xyz, src, _, _ = filter_scene_coordinates(sc, pinv, K, filter_depth, dense, len(sel), seed=self.opt.random_seed, opengl=opengl)
+        return xyz.cpu().numpy(), src.cpu().numpy(), sel
+
+
+def write_pose_file(path, image_names, poses_c2w, confidences, focal):
+    """poses_<session>.txt (register_mapping.py:261-276): world->camera quaternion + translation, focal, confidence."""
+    from .cli import write_pose_line
+    with open(path, "w") as f:
+        for name, p, c in zip(image_names, poses_c2w, confidences):
+            write_pose_line(f, name, np.linalg.inv(np.asarray(p, np.float64)), int(c), float(focal))

@@ -112,6 +112,37 @@ def init_encoder_weights(seed=4099, out_channels=512):
     return sd
 
 
+def init_encoder_weights_bandpass(seed=4099, out_channels=512, out_scale=2.0):
+    """A second stand-in for the pretrained encoder, used where the features have to be USABLE (end-to-end mapping /
+    relocalisation tests): He-normal filters with their mean removed and zero biases. Default-initialised filters
+    (init_encoder_weights) leave a dominant common-mode component after eleven ReLU layers (mean pairwise cosine of the
+    pixel features 0.89, effective rank 18); zero-mean filters keep the features decorrelated (cosine 0.1-0.2, rank ~200).
+    The filters of the three stride-2 layers are additionally smoothed with a 3x3 binomial kernel (then re-centred, energy
+    kept): un-smoothed, the stride-8 sampling makes the features of the same scene point differ completely after a 2-pixel
+    image shift (cosine 0.38), smoothed they stay similar (0.80) while unrelated points stay apart (0.23).
+    The last two layers are scaled so that the feature magnitude is O(1)."""
+    rng = np.random.default_rng(seed)
+    k1 = np.array([1.0, 2.0, 1.0]) / 4.0
+    B = np.outer(k1, k1)
+    sd = {}
+    for name, ci, co, k in ENCODER_LAYERS:
+        if name in ("res2_conv3", "res2_skip"):
+            co = out_channels
+        w = rng.normal(0.0, np.sqrt(2.0 / (ci * k * k)), size=(co, ci, k, k))
+        w -= w.mean(axis=(1, 2, 3), keepdims=True)
+        if name in ("conv2", "conv3", "conv4"):
+            e0 = np.sqrt((w ** 2).sum(axis=(1, 2, 3), keepdims=True))
+            wp = np.pad(w, ((0, 0), (0, 0), (1, 1), (1, 1)))
+            w = sum(B[a, b] * wp[:, :, a:a + 3, b:b + 3] for a in range(3) for b in range(3))
+            w -= w.mean(axis=(1, 2, 3), keepdims=True)
+            w *= e0 / np.sqrt((w ** 2).sum(axis=(1, 2, 3), keepdims=True))
+        if name in ("res2_conv3", "res2_skip"):
+            w *= out_scale
+        sd[name + ".weight"] = w.astype(np.float32)
+        sd[name + ".bias"] = np.zeros(co, np.float32)
+    return sd
+
+
 def head_num_params(num_head_blocks=1, use_homogeneous=True):
     return (3 + 3 * num_head_blocks + 2) * (512 * 512 + 512) + (4 if use_homogeneous else 3) * 513
 
@@ -193,3 +224,93 @@ def make_registration_frames(seed=1305, n_frames=8, h=60, w=80, focal=525.0, sub
         pts[:, out] = rng.uniform(0, 1, size=(3, int(out.sum()))) * room[:, None]
         sc[i] = pts.reshape(3, h, w).astype(np.float32)
     return {"scene_coords": sc, "poses": cams, "focal": float(focal), "ppx": float(ppx), "ppy": float(ppy)}
+
+
+def render_room_sequence(seed=2089, n_frames=48, h=480, w=640, focal=525.0, arc_deg=100.0, radius=0.9, device="cpu", pose_override=None):
+    """A view-consistent synthetic mapping sequence (SURVEY.md section 8d "synthetic scene"): a 6 x 4 x 3 m box room whose walls
+    carry a multi-octave value-noise texture defined in WORLD coordinates, seen by a camera that moves on an arc around the
+    room centre looking outwards. Returns a dict of torch tensors on `device`:
+
+      images  [n,1,h,w] float32 normalised as dataset.py:150-153 ((gray - 0.4) / 0.25)
+      poses   [n,4,4] float32 camera -> world      depth [n,h/8,w/8] float32 camera z at the feature-map pixel centres
+      focal, ppx, ppy
+
+    Evaluated with torch ops so that it runs on the GPU box's device in milliseconds; nothing here is part of the product path.
+    """
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    dev = torch.device(device)
+    room = torch.tensor([6.0, 4.0, 3.0])
+    centre = room / 2
+    # camera centres on an arc in the horizontal (x, z) plane at mid height; y axis of the camera = world y
+    ang = torch.deg2rad(torch.linspace(-arc_deg / 2, arc_deg / 2, n_frames)) + 0.3
+    bob = 0.05 * torch.sin(torch.linspace(0, 6.0, n_frames))
+    poses = torch.eye(4).repeat(n_frames, 1, 1)
+    for i in range(n_frames):
+        a = float(ang[i])
+        fwd = torch.tensor([math.sin(a), 0.0, math.cos(a)])          # looking outwards
+        right = torch.tensor([math.cos(a), 0.0, -math.sin(a)])
+        down = torch.tensor([0.0, 1.0, 0.0])
+        R = torch.stack([right, down, fwd], dim=1)                    # columns = camera axes in world
+        pitch = 0.08 * math.sin(0.7 * i)
+        Rx = torch.tensor([[1, 0, 0], [0, math.cos(pitch), -math.sin(pitch)], [0, math.sin(pitch), math.cos(pitch)]], dtype=torch.float32)
+        poses[i, :3, :3] = R @ Rx
+        poses[i, :3, 3] = centre + radius * fwd * 0.6 + torch.tensor([0.0, float(bob[i]), 0.0])
+    if pose_override is not None:                                        # same room and texture, caller-chosen cameras [n,4,4]
+        poses = torch.as_tensor(pose_override, dtype=torch.float32).reshape(-1, 4, 4).cpu()
+        n_frames = poses.shape[0]
+    # value-noise lattices: 6 walls x 4 octaves (cell sizes 0.6 / 0.2 / 0.06 / 0.02 m), bilinear lookups
+    cells = (0.6, 0.2, 0.06, 0.02)
+    amps = (0.30, 0.30, 0.25, 0.15)
+    lat = [[torch.rand((1, 1, int(6.0 / c) + 3, int(6.0 / c) + 3), generator=g).to(dev) for c in cells] for _ in range(6)]
+    poses_d = poses.to(dev)
+    ppx, ppy = w / 2.0, h / 2.0
+
+    def shade(P, wall):
+        """P [...,3] world points, wall [...] in 0..5 -> gray in [0,1]."""
+        out = torch.zeros(P.shape[:-1], device=dev)
+        for wid in range(6):
+            m = wall == wid
+            if not bool(m.any()):
+                continue
+            axis = wid // 2
+            uv = P[m][:, [a for a in range(3) if a != axis]]          # the two in-plane coordinates, metres
+            val = torch.zeros(uv.shape[0], device=dev)
+            for o, c in enumerate(cells):
+                L = lat[wid][o]
+                n = L.shape[-1]
+                gxy = (uv / c + 1.0) / (n - 1) * 2 - 1                # lattice coordinates -> [-1,1]
+                smp = torch.nn.functional.grid_sample(L, gxy.view(1, 1, -1, 2), mode="bilinear", align_corners=True).view(-1)
+                val += amps[o] * smp
+                if o == 1:
+                    blob = torch.sigmoid((smp - 0.62) * 40.0)         # soft-edged "posters" at the 0.2 m scale
+            out[m] = (val - 0.5) * 1.7 + 0.45 + 0.3 * blob
+        return out.clamp(0, 1)
+
+    def cast(pose, xs, ys):
+        gx, gy = torch.meshgrid(xs, ys, indexing="xy")
+        rays = torch.stack([(gx - ppx) / focal, (gy - ppy) / focal, torch.ones_like(gx)], dim=-1).to(dev)   # [H,W,3]
+        d = rays @ pose[:3, :3].T
+        c = pose[:3, 3]
+        roomd = room.to(dev)
+        t1 = (0.0 - c) / d
+        t2 = (roomd - c) / d
+        t = torch.where(d > 0, t2, t1)
+        t = torch.where(d.abs() < 1e-12, torch.full_like(t, float("inf")), t)
+        tmin, axis = t.min(dim=-1)
+        P = c + d * tmin.unsqueeze(-1)
+        side = (torch.gather(d, -1, axis.unsqueeze(-1)).squeeze(-1) > 0).long()
+        return P, axis * 2 + side, tmin * rays[..., 2]                 # camera z = t * ray_z (ray_z = 1)
+
+    images = torch.empty((n_frames, 1, h, w), device=dev)
+    depth = torch.empty((n_frames, h // 8, w // 8), device=dev)
+    px = torch.arange(w, dtype=torch.float32) + 0.5
+    py = torch.arange(h, dtype=torch.float32) + 0.5
+    cx = torch.arange(w // 8, dtype=torch.float32) * 8 + 4
+    cy = torch.arange(h // 8, dtype=torch.float32) * 8 + 4
+    for i in range(n_frames):
+        P, wall, _ = cast(poses_d[i], px, py)
+        images[i, 0] = (shade(P, wall) - 0.4) / 0.25
+        _, _, z = cast(poses_d[i], cx, cy)
+        depth[i] = z
+    return {"images": images, "poses": poses_d, "depth": depth, "focal": float(focal), "ppx": ppx, "ppy": ppy}

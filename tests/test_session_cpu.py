@@ -1,0 +1,91 @@
+"""CPU: host logic of the in-process reconstruction session: option defaults against ace_zero.py's argparse
+(tests/golden/cli_flags.json), the geometry of the on-device augmentation warp against the synthetic renderer, and that the
+session refuses to run without a GPU."""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+from acezero_amd import session, synth
+from acezero_amd.encoder import output_size
+
+
+def _rot_z(th):
+    r = torch.eye(4)
+    r[0, 0], r[0, 1], r[1, 0], r[1, 1] = math.cos(th), -math.sin(th), math.sin(th), math.cos(th)
+    return r                                                         # pose_rot of dataset.py:337-343
+
+
+def test_default_options_are_ace_zero_defaults(golden_dir):
+    flags = json.load(open(os.path.join(golden_dir, "cli_flags.json")))
+    o = vars(session.default_options())
+    shared = [k for k in flags["ace_zero"] if k in o]
+    assert len(shared) >= 28
+    for k in shared:
+        assert o[k] == flags["ace_zero"][k]["default"], k
+    for k in o:                                                      # the train_ace.py flags ace_zero.py leaves at their defaults
+        if k not in flags["ace_zero"] and k in flags["train_ace"]:
+            assert o[k] == flags["train_ace"][k]["default"], k
+    with pytest.raises(TypeError):
+        session.default_options(no_such_flag=1)
+
+
+@pytest.mark.parametrize("deg", [12.0, -9.0])
+def test_warp_rotation_matches_camera_rotated_by_pose_rot(deg):
+    """The warped frame must be what a camera with pose @ pose_rot sees: that is the pairing of image rotation and
+    aug_pose_inv the training step relies on (dataset.py:324-343)."""
+    th = math.radians(deg)
+    seq = synth.render_room_sequence(n_frames=1, h=240, w=320, focal=262.5)
+    ref = synth.render_room_sequence(h=240, w=320, focal=262.5, pose_override=(seq["poses"][0] @ _rot_z(th)).unsqueeze(0))["images"]
+    for sign, lo, hi in ((1, 0.995, 1.0), (-1, -1.0, 0.7)):
+        view, mask, _ = session.warp_view(seq["images"], 1.0, sign * th)
+        a, b = view[0, 0][mask[0, 0]], ref[0, 0][mask[0, 0]]
+        c = float(torch.corrcoef(torch.stack([a, b]))[0, 1])
+        assert lo <= c <= hi, (sign, c)
+    assert 0.8 < float(mask.float().mean()) < 1.0                   # corners fall outside the source frame
+
+
+def test_warp_scale_matches_rendering_at_scaled_focal_and_depth_lookup():
+    seq = synth.render_room_sequence(n_frames=1, h=240, w=320, focal=262.5)
+    sc, th = 1.2, math.radians(11)
+    hs, ws = int(240 * sc), int(320 * sc)
+    ref = synth.render_room_sequence(h=hs, w=ws, focal=262.5 * hs / 240, pose_override=seq["poses"][:1])["images"]
+    view, mask, _ = session.warp_view(seq["images"], sc, 0.0)
+    assert view.shape == ref.shape and bool(mask.all())
+    assert float(torch.corrcoef(torch.stack([view.flatten(), ref.flatten()]))[0, 1]) > 0.995
+    # depth of a rotated + scaled view at its feature-map centres against the renderer's depth for that camera
+    view, mask, grid = session.warp_view(seq["images"], sc, th)
+    oh, ow = output_size(hs, ws)
+    dv = session.view_depth(seq["depth"].unsqueeze(1), grid, oh, ow)
+    gt = synth.render_room_sequence(h=hs - hs % 8, w=ws - ws % 8, focal=262.5 * hs / 240, pose_override=(seq["poses"][0] @ _rot_z(th)).unsqueeze(0))
+    d_gt = gt["depth"][0]
+    h2, w2 = d_gt.shape
+    valid = dv[:h2, :w2] > 0
+    assert float(valid.float().mean()) > 0.85
+    assert float((dv[:h2, :w2] - d_gt)[valid].abs().median()) < 0.02
+
+
+def test_jitter_keeps_range_and_changes_values():
+    seq = synth.render_room_sequence(n_frames=1, h=64, w=96, focal=80.0)
+    v0, _, _ = session.warp_view(seq["images"], 1.0, 0.0)
+    v1, _, _ = session.warp_view(seq["images"], 1.0, 0.0, jitter=(1.1, 0.9))
+    assert torch.allclose(v0, seq["images"], atol=1e-5)              # identity warp
+    assert not torch.allclose(v0, v1) and float(v1.min()) >= (0 - 0.4) / 0.25 - 1e-5 and float(v1.max()) <= (1 - 0.4) / 0.25 + 1e-5
+
+
+def test_bandpass_encoder_standin_has_reference_keys_and_zero_mean_filters():
+    a, b = synth.init_encoder_weights(seed=3), synth.init_encoder_weights_bandpass(seed=3)
+    assert a.keys() == b.keys() and all(a[k].shape == b[k].shape for k in a)
+    for k, w in b.items():
+        if k.endswith(".weight"):
+            assert abs(float(w.mean(axis=(1, 2, 3)).max())) < 1e-6
+        else:
+            assert not w.any()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_session_needs_a_gpu():
+    with pytest.raises(RuntimeError):
+        session.ReconstructionSession({}, torch.zeros(1, 1, 64, 96))

@@ -1,0 +1,103 @@
+"""End-to-end on the GPU (SURVEY 8f N1-N4 together): a view-consistent synthetic room, the stand-in encoder, then
+(1) mapping with known poses + relocalisation of held-out frames, (2) the whole ACE0 loop from a depth-supervised seed in one
+process. These are functional tests of the product (accuracy against ground-truth cameras), not parity tests."""
+import numpy as np
+import pytest
+import torch
+
+from acezero_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pose_err(est, gt):
+    dt = np.linalg.norm(est[:, :3, 3] - gt[:, :3, 3], axis=1)
+    R = np.einsum("nij,nkj->nik", est[:, :3, :3], gt[:, :3, :3])
+    ang = np.degrees(np.arccos(np.clip((np.trace(R, axis1=1, axis2=2) - 1) / 2, -1, 1)))
+    return dt, ang
+
+
+def _align_similarity(est, gt):
+    """Least-squares similarity (Umeyama) of the camera centres, applied to the estimated poses (as eval_poses.py aligns before
+    it measures)."""
+    a, b = est[:, :3, 3], gt[:, :3, 3]
+    ma, mb = a.mean(0), b.mean(0)
+    H = (b - mb).T @ (a - ma) / len(a)
+    U, S, Vt = np.linalg.svd(H)
+    D = np.diag([1, 1, np.sign(np.linalg.det(U) * np.linalg.det(Vt))])
+    R = U @ D @ Vt
+    s = np.trace(np.diag(S) @ D) / ((a - ma) ** 2).sum(1).mean()
+    out = est.copy()
+    out[:, :3, :3] = R @ est[:, :3, :3]
+    out[:, :3, 3] = (s * (R @ (a - ma).T)).T + mb
+    return out, s
+
+
+@pytest.fixture(scope="module")
+def room():
+    seq = synth.render_room_sequence(seed=2089, n_frames=72, arc_deg=36.0, device="cuda")
+    esd = {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights_bandpass(seed=4099).items()}
+    return seq, esd
+
+
+def _opt(seq, **kw):
+    from acezero_amd.session import default_options
+    it = 3000
+    base = dict(use_external_focal_length=seq["focal"], try_seeds=2, seed_iterations=it, iterations=it, refit_iterations=it, iterations_max=8,
+                final_refit_posewait=it // 5, learning_rate_warmup_iterations=it // 5, cooldown_iterations=it // 5, aug_rotation=2,
+                aug_scale=1.06, aug_black_white=0.02)
+    base.update(kw)
+    return default_options(**base)
+
+
+def test_mapping_with_known_poses_relocalises_held_out_frames(room):
+    from acezero_amd.session import ReconstructionSession
+    seq, esd = room
+    n = seq["images"].shape[0]
+    ses = ReconstructionSession(esd, seq["images"], opt=_opt(seq), depth=seq["depth"])
+    even = list(range(0, n, 2))
+    m = ses.map(even, seq["poses"][even].cpu(), seq["focal"], iterations=3000, loss_type="tanh", schedule="1cyclepoly", lr_max=0.003)
+    assert m["iterations"] <= 3000 and m["batch_inliers"] > 0.5 and m["buffer"] == len(even) * 10 * 1024
+    poses, inl = ses.register(m["head"], seq["focal"])
+    dt, ang = _pose_err(poses, seq["poses"].cpu().numpy())
+    odd = np.arange(1, n, 2)
+    assert (inl > 500).mean() >= 0.97
+    assert np.median(dt[odd]) < 0.01 and np.median(ang[odd]) < 0.5, (np.median(dt[odd]), np.median(ang[odd]))     # < 1 cm, < 0.5 deg
+    assert np.median(dt[even]) < 0.01 and np.median(ang[even]) < 0.5
+    # the refined-pose output of a run without refinement is the input (world -> camera)
+    w2c = np.linalg.inv(seq["poses"][even].cpu().numpy().astype(np.float64))[:, :3]
+    assert np.allclose(m["poses_w2c"], w2c, atol=1e-5)
+
+
+def test_ace_zero_loop_reconstructs_the_sequence_in_one_process(room):
+    from acezero_amd.session import ReconstructionSession
+    seq, esd = room
+    n = seq["images"].shape[0]
+    opt = _opt(seq, export_point_cloud=True)
+    ses = ReconstructionSession(esd, seq["images"], opt=opt, depth=seq["depth"])
+    res = ses.reconstruct()
+    hist = res["history"]
+    rates = [h["registration_rate"] for h in hist]
+    assert hist[0]["id"].startswith("iteration0_seed") and len(hist[0]["seed_rates"]) == 2
+    assert 0.0 < rates[0] < 1.0 and rates[-1] >= 0.97 and hist[-1]["refit"]            # grows from a single image to the sequence
+    assert all(h["iterations"] <= opt.iterations for h in hist[1:])
+    ok = res["confidence"] > opt.registration_confidence
+    gt = seq["poses"].cpu().numpy()
+    aligned, scale = _align_similarity(res["poses"][ok].astype(np.float64), gt[ok].astype(np.float64))
+    dt, ang = _pose_err(aligned, gt[ok])
+    assert 0.8 < scale < 1.25                                                              # metric scale comes from the seed's depth
+    assert np.median(dt) < 0.05, np.median(dt)                                             # centres within 5 cm after alignment
+    rel = np.einsum("nij,njk->nik", np.linalg.inv(res["poses"][ok][:-1].astype(np.float64)), res["poses"][ok][1:].astype(np.float64))
+    rel_gt = np.einsum("nij,njk->nik", np.linalg.inv(gt[ok][:-1].astype(np.float64)), gt[ok][1:].astype(np.float64))
+    _, rel_ang = _pose_err(rel, rel_gt)
+    assert np.median(rel_ang) < 0.5                                                        # frame-to-frame rotations
+    xyz, src, sel = res["point_cloud"]
+    assert len(sel) == int(ok.sum()) and xyz.shape[1] == 3 and len(xyz) == len(src) > 1000
+    # the exported points lie on the room's walls (in the reconstruction's frame: map them with the same similarity)
+    from acezero_amd.session import write_pose_file
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        write_pose_file(os.path.join(d, "poses_final.txt"), [f"frame_{i:04d}.png" for i in range(n)], res["poses"], res["confidence"], res["focal"])
+        lines = open(os.path.join(d, "poses_final.txt")).read().splitlines()
+    assert len(lines) == n and len(lines[0].split()) == 10
