@@ -116,6 +116,53 @@ REGISTER_FLAGS = [
 ]
 
 
+# ace_zero.py:41-177
+ACE_ZERO_FLAGS = [
+    (("--depth_files",), str, None, None, "depth maps (16 bit, millimetres) for the seed images; without them the reference downloads ZoeDepth"),
+    (("--iterations_max",), int, 100, None, "maximum number of mapping / relocalisation rounds"),
+    (("--registration_threshold",), float, 0.99, None, "stop when this ratio of images is registered"),
+    (("--relative_registration_threshold",), float, 0.01, None, "stop when fewer new images than this were registered"),
+    (("--final_refine",), _strtobool, True, None, "one more mapping round after the stopping criteria are met"),
+    (("--final_refit",), _strtobool, True, None, "refit a fresh network in the last round"),
+    (("--final_refit_posewait",), int, 5000, None, ""),
+    (("--refit_iterations",), int, 25000, None, ""),
+    (("--registration_confidence",), int, 500, None, "inlier count above which an image counts as registered"),
+    (("--try_seeds",), int, 5, None, "number of seed images to try"),
+    (("--seed_parallel_workers",), int, 3, None, "accepted; seeds run back to back in one process"),
+    (("--seed_iterations",), int, 10000, None, ""),
+    (("--seed_network",), Path, None, None, "pre-trained head to start from"),
+    (("--warmstart",), _strtobool, True, None, ""),
+    (("--export_point_cloud",), _strtobool, False, None, ""),
+    (("--dense_point_cloud",), _strtobool, False, None, ""),
+    (("--refinement",), str, "mlp", ["mlp", "none", "naive"], ""),
+    (("--refinement_ortho",), str, "gram-schmidt", ["gram-schmidt", "procrustes"], ""),
+    (("--pose_refinement_wait",), int, 0, None, ""),
+    (("--pose_refinement_lr",), float, 0.001, None, ""),
+    (("--refine_calibration",), _strtobool, True, None, ""),
+    (("--use_external_focal_length",), float, -1, None, "-1: 70%% of the image diagonal"),
+    (("--learning_rate_schedule",), str, "1cyclepoly", ["circle", "constant", "1cyclepoly"], ""),
+    (("--learning_rate_max",), float, 0.003, None, ""),
+    (("--cooldown_iterations",), int, 5000, None, ""),
+    (("--cooldown_threshold",), float, 0.7, None, ""),
+    (("--image_resolution",), int, 480, None, ""),
+    (("--num_head_blocks",), int, 1, None, ""),
+    (("--max_dataset_passes",), int, 10, None, ""),
+    (("--repro_loss_type",), str, "tanh", ["l1", "l1+sqrt", "l1+log", "tanh", "dyntanh"], ""),
+    (("--repro_loss_hard_clamp",), int, 1000, None, ""),
+    (("--repro_loss_soft_clamp",), int, 50, None, ""),
+    (("--aug_rotation",), int, 15, None, ""),
+    (("--num_data_workers",), int, 12, None, "accepted; frames are decoded once by the main process"),
+    (("--training_buffer_cpu",), _strtobool, False, None, "accepted; the buffer lives in HBM"),
+    (("--ransac_iterations",), int, 32, None, ""),
+    (("--ransac_threshold",), float, 10, None, ""),
+    (("--render_visualization",), _strtobool, False, None, "accepted; rendering is out of scope"),
+    (("--render_flipped_portrait",), _strtobool, False, None, ""),
+    (("--render_marker_size",), float, 0.03, None, ""),
+    (("--iterations_output",), int, 500, None, ""),
+    (("--random_seed",), int, 1305, None, ""),
+]
+
+
 def _add(parser, table):
     for flags, typ, default, choices, hlp in table:
         kw = {"default": default, "help": hlp}
@@ -144,6 +191,17 @@ def register_parser():
     p.add_argument("network", type=Path, help="head weights of the scene")
     _add(p, REGISTER_FLAGS)
     p.add_argument("--feature_file", type=Path, default=None, help="[additive] .npz with per-frame encoder features or scene coordinates")
+    return p
+
+
+def ace_zero_parser():
+    p = argparse.ArgumentParser(description="Run ACE0 for a scene in ONE process on one MI355X (acezero_amd.session).",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("rgb_files", type=str, help="glob of the RGB files, e.g. 'datasets/scene/*.jpg'")
+    p.add_argument("results_folder", type=Path, help="output folder")
+    _add(p, ACE_ZERO_FLAGS)
+    p.add_argument("--encoder_path", type=Path, default=Path(__file__).resolve().parent.parent / "ace_encoder_pretrained.pt",
+                   help="[additive] pre-trained encoder weights (train_ace.py / register_mapping.py take the same flag)")
     return p
 
 
@@ -297,4 +355,84 @@ def register_main(argv=None):
             write_pose_line(f, files[i], np.linalg.inv(poses[i].astype(np.float64)), int(inl[i]), float(focal[i]))   # :261-276
     dt = time.time() - t0
     _logger.info(f"Registered {n} images in {dt:.2f}s ({n / max(dt, 1e-9):.0f} images/s) -> {pose_log_file}")
+    return 0
+
+
+# --------------------------------------------------------------------------------------------------------- ace_zero
+def load_frames(rgb_glob, image_resolution=480):
+    """Minimal stand-in for CamLocDataset's image path without augmentation (dataset.py:189-195,227-237,146-160): decode,
+    resize so that the short side is `image_resolution` (PIL bilinear, as torchvision does for PIL images), grey, normalise.
+    All frames must have one size (the session batches them). Returns (files, float32 [n,1,H,W])."""
+    import glob
+    import torch
+    from PIL import Image
+    files = sorted(glob.glob(rgb_glob))                                 # dataset_io.get_files_from_glob sorts
+    if not files:
+        raise SystemExit(f"no files match {rgb_glob!r}")
+    frames, size = [], None
+    for f in files:
+        im = Image.open(f).convert("RGB")
+        w, h = im.size
+        sc = image_resolution / min(w, h)
+        nw, nh = (image_resolution, int(h * sc)) if w <= h else (int(w * sc), image_resolution)
+        g = np.asarray(im.resize((nw, nh), Image.BILINEAR).convert("L"), np.float32) / 255.0
+        if size is None:
+            size = g.shape
+        elif g.shape != size:
+            raise SystemExit(f"{f}: resized frame is {g.shape}, the first one {size}; the in-process session needs one frame size")
+        frames.append((g - 0.4) / 0.25)
+    return files, torch.from_numpy(np.stack(frames)[:, None])
+
+
+def load_depth_maps(depth_glob, n, frame_hw):
+    """--depth_files (dataset.py:299-304,333,359): 16-bit millimetres -> metres, nearest resize to the frame, value at the
+    feature-map pixel centres (offset 4, stride 8). Returns float32 [n, ceil(H/8), ceil(W/8)]."""
+    import glob
+    import torch
+    from PIL import Image
+    files = sorted(glob.glob(depth_glob))
+    if len(files) != n:
+        raise SystemExit(f"{len(files)} depth files for {n} images")
+    H, W = frame_hw
+    out = np.zeros((n, (H + 7) // 8, (W + 7) // 8), np.float32)
+    for i, f in enumerate(files):
+        d = np.asarray(Image.open(f).resize((W, H), Image.NEAREST), np.float32) / 1000.0
+        sub = d[4::8, 4::8]
+        out[i, :sub.shape[0], :sub.shape[1]] = sub
+    return torch.from_numpy(out)
+
+
+def ace_zero_main(argv=None):
+    import torch
+    from .session import ReconstructionSession, default_options, write_pose_file
+    opt = ace_zero_parser().parse_args(argv)
+    logging.basicConfig(level=logging.INFO)
+    opt.results_folder.mkdir(parents=True, exist_ok=True)
+    files, frames = load_frames(opt.rgb_files, opt.image_resolution)
+    depth = load_depth_maps(opt.depth_files, len(files), frames.shape[2:]) if opt.depth_files is not None else None
+    if depth is None and opt.seed_network is None:
+        raise SystemExit("ace_zero.py (MI355X): seeds need --depth_files (or --seed_network); the reference's ZoeDepth fallback is a "
+                         "network download and not part of this package")
+    known = vars(default_options())
+    over = {k: v for k, v in vars(opt).items() if k in known and k != "seed_network"}
+    if opt.seed_network is not None:
+        over["seed_network"] = torch.load(opt.seed_network, map_location="cpu")
+    ses = ReconstructionSession(torch.load(opt.encoder_path, map_location="cpu"), frames, opt=default_options(**over), depth=depth)
+    res = ses.reconstruct()
+    for h in res["history"]:                                            # the files ace_zero.py leaves behind (SURVEY 8b "process/file contract")
+        write_pose_file(opt.results_folder / f"poses_{h['id']}.txt", files, h["poses"], h["confidence"], h["focal"])
+        torch.save(h["head"], opt.results_folder / f"{h['id']}.pt")
+        _logger.info(f"{h['id']}: registered {h['registration_rate'] * 100:.1f}% of the images")
+    write_pose_file(opt.results_folder / "poses_final.txt", files, res["poses"], res["confidence"], res["focal"])
+    if opt.export_point_cloud:
+        from .pointcloud import write_point_cloud
+        xyz, src, sel = res["point_cloud"]
+        hw = ses.hw
+        f, p = np.divmod(src.astype(np.int64), hw)
+        y, x = np.divmod(p, ses.ow)
+        gray = (frames[sel[f], 0, np.minimum(y * 8 + 4, frames.shape[2] - 1), np.minimum(x * 8 + 4, frames.shape[3] - 1)].numpy() * 0.25 + 0.4) * 255.0
+        write_point_cloud(opt.results_folder / "pc_final.ply", xyz, np.repeat(np.clip(gray, 0, 255)[:, None], 3, axis=1))
+    rates = [float((res["confidence"] > t).mean()) for t in (500, 1000, 2000, 4000)]
+    _logger.info(f"Reconstructed in {res['seconds'] / 60:.1f} minutes, {res['iterations']} iterations; "
+                 "registration rate @500/@1000/@2000/@4000: " + " ".join(f"{r * 100:.1f}%" for r in rates))
     return 0

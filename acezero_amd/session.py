@@ -353,7 +353,8 @@ class ReconstructionSession:
             current, first_id, seed_rates = trials[best][0], f"iteration0_seed{best}", [r for _, r in trials]
         poses, conf = self.register(current["head"], focal, tag=first_id)
         max_rate = float((conf > o.registration_confidence).mean())
-        self.history.append({"id": first_id, "registration_rate": max_rate, "focal": focal, "seed_rates": seed_rates})
+        self.history.append({"id": first_id, "registration_rate": max_rate, "focal": focal, "seed_rates": seed_rates, "poses": poses,
+                             "confidence": conf, "head": current["head"]})
         scheduled_to_stop_early = False
         iteration = 0
         for iteration in range(1, o.iterations_max):
@@ -373,7 +374,8 @@ class ReconstructionSession:
             poses, conf = self.register(current["head"], focal, tag=f"iteration{iteration}")
             rate = float((conf > o.registration_confidence).mean())
             self.history.append({"id": f"iteration{iteration}", "registration_rate": rate, "focal": focal, "mapped_images": int(len(sel)),
-                                 "iterations": current["iterations"], "map_seconds": current["seconds"], "refit": bool(refit)})
+                                 "iterations": current["iterations"], "map_seconds": current["seconds"], "refit": bool(refit), "poses": poses,
+                                 "confidence": conf, "head": current["head"], "poses_w2c_refined": current["poses_w2c"]})
             if scheduled_to_stop_early:
                 break
             if rate >= o.registration_threshold or (rate - max_rate) < o.relative_registration_threshold:   # ace_zero.py:317-327

@@ -29,7 +29,8 @@ def _surface(parser):
 
 
 @pytest.mark.parametrize("name,parser,extra", [("train_ace", cli.train_parser, {"feature_buffer", "num_gpus"}),
-                                               ("register_mapping", cli.register_parser, {"feature_file"})])
+                                               ("register_mapping", cli.register_parser, {"feature_file"}),
+                                               ("ace_zero", cli.ace_zero_parser, {"encoder_path"})])
 def test_flag_surface_matches_reference(name, parser, extra, golden_dir):
     ref = json.load(open(os.path.join(golden_dir, "cli_flags.json")))[name]
     mine = _surface(parser())

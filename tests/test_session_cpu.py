@@ -89,3 +89,26 @@ def test_bandpass_encoder_standin_has_reference_keys_and_zero_mean_filters():
 def test_session_needs_a_gpu():
     with pytest.raises(RuntimeError):
         session.ReconstructionSession({}, torch.zeros(1, 1, 64, 96))
+
+
+def test_frame_and_depth_loaders_roundtrip(tmp_path):
+    import numpy as np
+    from PIL import Image
+    from acezero_amd import cli
+    rng = np.random.default_rng(0)
+    for i in range(2):
+        Image.fromarray(rng.integers(0, 256, size=(240, 320, 3), dtype=np.uint8)).save(tmp_path / f"f{i}.png")
+        d = rng.integers(500, 4000, size=(30, 40)).astype(np.uint16)
+        Image.fromarray(np.kron(d, np.ones((8, 8), np.uint16))).save(tmp_path / f"d{i}.png")
+        if i == 1:
+            last = d
+    files, frames = cli.load_frames(str(tmp_path / "f*.png"), image_resolution=120)
+    assert [os.path.basename(f) for f in files] == ["f0.png", "f1.png"] and frames.shape == (2, 1, 120, 160)
+    assert float(frames.min()) >= (0 - 0.4) / 0.25 - 1e-6 and float(frames.max()) <= (1 - 0.4) / 0.25 + 1e-6     # dataset.py:150-153
+    depth = cli.load_depth_maps(str(tmp_path / "d*.png"), 2, (240, 320))
+    assert depth.shape == (2, 30, 40) and np.allclose(depth[1].numpy(), last / 1000.0)                           # mm -> m at (8x+4, 8y+4)
+    with pytest.raises(SystemExit):
+        cli.load_depth_maps(str(tmp_path / "d0*.png"), 2, (240, 320))
+    Image.fromarray(np.zeros((100, 320, 3), np.uint8)).save(tmp_path / "f2.png")
+    with pytest.raises(SystemExit):
+        cli.load_frames(str(tmp_path / "f*.png"), image_resolution=120)

@@ -101,3 +101,33 @@ def test_ace_zero_loop_reconstructs_the_sequence_in_one_process(room):
         write_pose_file(os.path.join(d, "poses_final.txt"), [f"frame_{i:04d}.png" for i in range(n)], res["poses"], res["confidence"], res["focal"])
         lines = open(os.path.join(d, "poses_final.txt")).read().splitlines()
     assert len(lines) == n and len(lines[0].split()) == 10
+
+
+def test_ace_zero_script_from_image_files(tmp_path):
+    """ace_zero.py's command line on files: PNG frames + 16-bit depth maps + an encoder checkpoint in, the reference's output
+    files out (poses_<id>.txt / <id>.pt per round, poses_final.txt, pc_final.ply)."""
+    from PIL import Image
+    from acezero_amd import cli
+    seq = synth.render_room_sequence(seed=7, n_frames=48, arc_deg=24.0, device="cuda")
+    img = ((seq["images"][:, 0] * 0.25 + 0.4).clamp(0, 1) * 255).round().to(torch.uint8).cpu().numpy()
+    dep = (seq["depth"].cpu().numpy() * 1000).round().astype(np.uint16)
+    for i in range(len(img)):
+        Image.fromarray(np.stack([img[i]] * 3, -1)).save(tmp_path / f"rgb_{i:04d}.png")
+        Image.fromarray(np.kron(dep[i], np.ones((8, 8), np.uint16))).save(tmp_path / f"depth_{i:04d}.png")
+    torch.save({k: torch.from_numpy(v) for k, v in synth.init_encoder_weights_bandpass(seed=4099).items()}, tmp_path / "encoder.pt")
+    out = tmp_path / "result"
+    it = "2500"
+    rc = cli.ace_zero_main([str(tmp_path / "rgb_*.png"), str(out), "--depth_files", str(tmp_path / "depth_*.png"), "--encoder_path",
+                            str(tmp_path / "encoder.pt"), "--use_external_focal_length", str(seq["focal"]), "--try_seeds", "1",
+                            "--seed_iterations", it, "--refit_iterations", it, "--final_refit_posewait", "500", "--cooldown_iterations", "500",
+                            "--iterations_max", "6", "--aug_rotation", "2", "--export_point_cloud", "True"])
+    assert rc == 0
+    final = open(out / "poses_final.txt").read().splitlines()
+    assert len(final) == 48 and all(len(line.split()) == 10 for line in final)
+    conf = np.array([float(line.split()[-1]) for line in final])
+    assert (conf > 500).mean() >= 0.9
+    assert (out / "poses_iteration0_seed0.txt").exists() and (out / "iteration0_seed0.pt").exists() and (out / "iteration1.pt").exists()
+    head = torch.load(out / "iteration1.pt")
+    assert head["fc3.weight"].dtype == torch.float16 and head["fc3.weight"].shape == (4, 512, 1, 1)               # save_model: half, Head keys
+    ply = open(out / "pc_final.ply", "rb").read(200)
+    assert ply.startswith(b"ply\nformat binary_little_endian")
