@@ -230,11 +230,10 @@ def train_main(argv=None):
     from .head import HeadTrainer
     opt = train_parser().parse_args(argv)
     logging.basicConfig(level=logging.INFO)
-    if opt.feature_buffer is None:
-        raise SystemExit("train_ace.py (MI355X): the image pipeline (dataset.py + encoder) is the reference's; pass the encoder "
-                         "features with --feature_buffer buffer.npz (see acezero_amd/cli.py and INTEGRATION.md)")
     if opt.batch_size % 512 != 0:
         raise SystemExit("batch_size must be a multiple of 512 (train_ace.py:138)")
+    if opt.feature_buffer is None:
+        return _train_from_images(opt)
     buf = np.load(opt.feature_buffer, allow_pickle=False)
     n = min(int(buf["features"].shape[0]), opt.max_training_buffer_size)
     focal = float(opt.use_external_focal_length) if opt.use_external_focal_length is not None else float(buf["focal"])
@@ -313,6 +312,95 @@ def train_main(argv=None):
     return 0
 
 
+def read_ace_pose_file(path, confidence_threshold):
+    """dataset_io.load_dataset_ace (:96-156): (files, cam->world 4x4 float64 [k,4,4], focal lengths) of the entries whose confidence
+    is not below the threshold."""
+    from scipy.spatial.transform import Rotation
+    files, poses, focals = [], [], []
+    for line in open(path).read().splitlines():
+        tok = line.split()
+        assert len(tok) == 10, f"Expected 10 tokens per line in pose file, got {len(tok)}"
+        if float(tok[-1]) < confidence_threshold:
+            continue
+        q = [float(t) for t in tok[1:5]]
+        T = np.eye(4)
+        T[:3, :3] = Rotation.from_quat(q[1:] + [q[0]]).as_matrix()
+        T[:3, 3] = [float(t) for t in tok[5:8]]
+        files.append(tok[0]); poses.append(np.linalg.inv(T)); focals.append(float(tok[-2]))
+    return files, np.stack(poses) if poses else np.zeros((0, 4, 4)), focals
+
+
+def _session_options(opt, **extra):
+    from .session import default_options
+    known = vars(default_options())
+    over = {k: v for k, v in vars(opt).items() if k in known and v is not None}
+    over.update(extra)
+    return default_options(**over)
+
+
+def _train_from_images(opt):
+    """train_ace.py on image files: poses from --use_ace_pose_file / --pose_files / --use_pose_seed, one mapping run of the session."""
+    import glob
+    import torch
+    from .session import ReconstructionSession
+    if opt.use_ace_pose_file is not None:
+        files, poses, focals = read_ace_pose_file(opt.use_ace_pose_file, opt.ace_pose_file_conf_threshold)
+        files, frames, fscale = load_frames(None, opt.image_resolution, files=files)
+    else:
+        files, frames, fscale = load_frames(opt.rgb_files, opt.image_resolution)
+        focals = []
+        poses = np.stack([np.loadtxt(f) for f in sorted(glob.glob(opt.pose_files))]) if opt.pose_files is not None else None   # dataset_io.load_pose
+    depth = load_depth_maps(opt.depth_files, len(files), frames.shape[2:]) if opt.depth_files is not None else None
+    ids = list(range(len(files)))
+    if opt.use_pose_seed >= 0:                                           # dataset.py:110-124
+        ids, poses = [int(opt.use_pose_seed * len(files))], np.eye(4)[None]
+        if depth is None:
+            raise SystemExit("--use_pose_seed needs --depth_files here (the reference's ZoeDepth fallback is a network download)")
+    elif poses is None or len(poses) != len(files):
+        raise SystemExit("need one pose per image: --use_ace_pose_file, --pose_files or --use_pose_seed")
+    H, W = frames.shape[2:]
+    if opt.use_external_focal_length is not None:
+        focal = opt.use_external_focal_length * fscale
+    elif opt.use_heuristic_focal_length or not focals:
+        focal = math.sqrt(W ** 2 + H ** 2) * 0.7
+    else:
+        assert np.allclose(focals, focals[0]), "a single focal length is supported"
+        focal = focals[0] * fscale
+    so = _session_options(opt, cooldown_iterations=opt.learning_rate_cooldown_iterations, use_external_focal_length=focal,
+                          cooldown_threshold=opt.learning_rate_cooldown_trigger_percent_threshold)
+    ses = ReconstructionSession(torch.load(opt.encoder_path, map_location="cpu"), frames, opt=so, depth=depth)
+    m = ses.map(ids, torch.from_numpy(np.asarray(poses, np.float64)), focal, iterations=opt.iterations, loss_type=opt.repro_loss_type,
+                schedule=opt.learning_rate_schedule, lr_max=opt.learning_rate_max, refinement=opt.pose_refinement,
+                pose_wait=opt.pose_refinement_wait, refine_calibration=opt.refine_calibration,
+                load_weights=torch.load(opt.load_weights, map_location="cpu") if opt.load_weights is not None else None,
+                with_depth=opt.use_pose_seed >= 0 or opt.depth_files is not None, tag=opt.output_map_file.stem)
+    opt.output_map_file.parent.mkdir(parents=True, exist_ok=True)
+    torch.save(m["head"], opt.output_map_file)                           # save_model (ace_trainer.py:681-694)
+    pose_file = opt.output_map_file.parent / f"poses_{opt.output_map_file.stem}_preliminary.txt"
+    with open(pose_file, "w") as f:                                      # save_poses (ace_trainer.py:696-728)
+        for j, i in enumerate(ids):
+            write_pose_line(f, files[i], np.vstack([m["poses_w2c"][j], [0, 0, 0, 1.0]]), float("inf"), m["focal"] / fscale)
+    _logger.info(f"Done without errors. {m['iterations']} iterations in {m['seconds']:.1f}s ({m['patches_per_s']:.0f} patches/s). "
+                 f"Saved trained head weights to: {opt.output_map_file}; refined poses to: {pose_file}")
+    return 0
+
+
+def _register_from_images(opt):
+    """register_mapping.py on image files: encoder -> head -> RANSAC for every frame (register_mapping.py:201-276)."""
+    import torch
+    from .session import ReconstructionSession, write_pose_file
+    files, frames, fscale = load_frames(opt.rgb_files, opt.image_resolution)
+    so = _session_options(opt, use_external_focal_length=opt.use_external_focal_length * fscale if opt.use_external_focal_length > 0 else -1.0,
+                          ransac_iterations=opt.hypotheses, ransac_threshold=opt.threshold, register_seed=opt.base_seed, use_aug=False,
+                          registration_confidence=opt.confidence_threshold)
+    ses = ReconstructionSession(torch.load(opt.encoder_path, map_location="cpu"), frames, opt=so)
+    poses, inl = ses.register(torch.load(opt.network, map_location="cpu"), ses.focal0, max_estimates=opt.max_estimates, max_tries=opt.hypotheses_max_tries)
+    out = Path(opt.network).parent / f"poses_{opt.session}.txt"
+    write_pose_file(out, files[:len(poses)], poses, inl, ses.focal0 / fscale)
+    _logger.info(f"Registered {len(poses)} images -> {out}")
+    return 0
+
+
 # --------------------------------------------------------------------------------------------------------- register
 def register_main(argv=None):
     import torch
@@ -321,8 +409,7 @@ def register_main(argv=None):
     opt = register_parser().parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     if opt.feature_file is None:
-        raise SystemExit("register_mapping.py (MI355X): pass the encoder output with --feature_file frames.npz "
-                         "(features [n,H*W,512] + h,w or scene_coordinates [n,3,H,W], focal, ppx, ppy, image_files)")
+        return _register_from_images(opt)
     torch.manual_seed(opt.base_seed)
     data = np.load(opt.feature_file, allow_pickle=False)
     files = [str(x) for x in data["image_files"]]
@@ -359,17 +446,19 @@ def register_main(argv=None):
 
 
 # --------------------------------------------------------------------------------------------------------- ace_zero
-def load_frames(rgb_glob, image_resolution=480):
+def load_frames(rgb_glob, image_resolution=480, files=None):
     """Minimal stand-in for CamLocDataset's image path without augmentation (dataset.py:189-195,227-237,146-160): decode,
     resize so that the short side is `image_resolution` (PIL bilinear, as torchvision does for PIL images), grey, normalise.
-    All frames must have one size (the session batches them). Returns (files, float32 [n,1,H,W])."""
+    All frames must have one size (the session batches them). Returns (files, float32 [n,1,H,W], resize factor): focal lengths
+    on the command line and in pose files refer to the ORIGINAL image size and are multiplied by that factor (dataset.py:289-290)."""
     import glob
     import torch
     from PIL import Image
-    files = sorted(glob.glob(rgb_glob))                                 # dataset_io.get_files_from_glob sorts
+    if files is None:
+        files = sorted(glob.glob(rgb_glob))                             # dataset_io.get_files_from_glob sorts
     if not files:
         raise SystemExit(f"no files match {rgb_glob!r}")
-    frames, size = [], None
+    frames, size, factor = [], None, 1.0
     for f in files:
         im = Image.open(f).convert("RGB")
         w, h = im.size
@@ -381,7 +470,8 @@ def load_frames(rgb_glob, image_resolution=480):
         elif g.shape != size:
             raise SystemExit(f"{f}: resized frame is {g.shape}, the first one {size}; the in-process session needs one frame size")
         frames.append((g - 0.4) / 0.25)
-    return files, torch.from_numpy(np.stack(frames)[:, None])
+        factor = sc
+    return files, torch.from_numpy(np.stack(frames)[:, None]), factor
 
 
 def load_depth_maps(depth_glob, n, frame_hw):
@@ -408,22 +498,24 @@ def ace_zero_main(argv=None):
     opt = ace_zero_parser().parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     opt.results_folder.mkdir(parents=True, exist_ok=True)
-    files, frames = load_frames(opt.rgb_files, opt.image_resolution)
+    files, frames, fscale = load_frames(opt.rgb_files, opt.image_resolution)
     depth = load_depth_maps(opt.depth_files, len(files), frames.shape[2:]) if opt.depth_files is not None else None
     if depth is None and opt.seed_network is None:
         raise SystemExit("ace_zero.py (MI355X): seeds need --depth_files (or --seed_network); the reference's ZoeDepth fallback is a "
                          "network download and not part of this package")
     known = vars(default_options())
     over = {k: v for k, v in vars(opt).items() if k in known and k != "seed_network"}
+    if opt.use_external_focal_length > 0:
+        over["use_external_focal_length"] = opt.use_external_focal_length * fscale
     if opt.seed_network is not None:
         over["seed_network"] = torch.load(opt.seed_network, map_location="cpu")
     ses = ReconstructionSession(torch.load(opt.encoder_path, map_location="cpu"), frames, opt=default_options(**over), depth=depth)
     res = ses.reconstruct()
     for h in res["history"]:                                            # the files ace_zero.py leaves behind (SURVEY 8b "process/file contract")
-        write_pose_file(opt.results_folder / f"poses_{h['id']}.txt", files, h["poses"], h["confidence"], h["focal"])
+        write_pose_file(opt.results_folder / f"poses_{h['id']}.txt", files, h["poses"], h["confidence"], h["focal"] / fscale)
         torch.save(h["head"], opt.results_folder / f"{h['id']}.pt")
         _logger.info(f"{h['id']}: registered {h['registration_rate'] * 100:.1f}% of the images")
-    write_pose_file(opt.results_folder / "poses_final.txt", files, res["poses"], res["confidence"], res["focal"])
+    write_pose_file(opt.results_folder / "poses_final.txt", files, res["poses"], res["confidence"], res["focal"] / fscale)
     if opt.export_point_cloud:
         from .pointcloud import write_point_cloud
         xyz, src, sel = res["point_cloud"]

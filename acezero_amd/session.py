@@ -45,7 +45,12 @@ def default_options(**over):
              max_training_buffer_size=8000000, samples_per_image=1024, batch_size=5120, base_seed=2089, register_seed=1305,
              max_estimates_seed_scoring=1000,
              # train_ace.py augmentation flags (:174-182) + dataset.py:38-41; applied on the device to the resident frames
-             use_aug=True, aug_rotation=15, aug_scale=1.5, aug_black_white=0.1)
+             use_aug=True, aug_rotation=15, aug_scale=1.5, aug_black_white=0.1,
+             # train_ace.py flags only its own command line changes
+             use_homogeneous=True, repro_loss_soft_clamp_min=1, repro_loss_schedule="circle", refine_calibration_lr=0.001,
+             pose_refinement_weight=0.1, learning_rate_cooldown_trigger_px_threshold=10, depth_min=0.1, depth_target=10, depth_max=1000,
+             # register_mapping.py flags (:63-72)
+             inlieralpha=100.0, maxpixelerror=100.0)
     unknown = set(over) - set(o)
     if unknown:
         raise TypeError(f"unknown options: {sorted(unknown)}")
@@ -253,13 +258,16 @@ class ReconstructionSession:
             mean = load_weights["mean"].float().view(3)                  # Regressor.create_from_split_state_dict keeps the stored mean
         else:
             mean = poses_c2w[:, :3, 3].mean(dim=0)                       # dataset.py:206-225
-        tr = HeadTrainer(mean, num_head_blocks=o.num_head_blocks, use_homogeneous=True, max_batch=o.batch_size, loss_type=loss_type,
-                         soft_clamp=o.repro_loss_soft_clamp, soft_clamp_min=1, circle_schedule=True, hard_clamp=o.repro_loss_hard_clamp,
-                         inlier_px_threshold=10, schedule=schedule, iterations=iterations, lr_min=o.learning_rate_min, lr_max=lr_max,
+        tr = HeadTrainer(mean, num_head_blocks=o.num_head_blocks, use_homogeneous=o.use_homogeneous, max_batch=o.batch_size, loss_type=loss_type,
+                         soft_clamp=o.repro_loss_soft_clamp, soft_clamp_min=o.repro_loss_soft_clamp_min,
+                         circle_schedule=o.repro_loss_schedule == "circle", hard_clamp=o.repro_loss_hard_clamp, depth_min=o.depth_min,
+                         depth_max=o.depth_max, depth_target=o.depth_target,
+                         inlier_px_threshold=o.learning_rate_cooldown_trigger_px_threshold, schedule=schedule, iterations=iterations,
+                         lr_min=o.learning_rate_min, lr_max=lr_max,
                          warmup_iterations=o.learning_rate_warmup_iterations, warmup_lr=o.learning_rate_warmup_learning_rate,
                          cooldown_iterations=o.cooldown_iterations, cooldown_trigger_percent=o.cooldown_threshold,
-                         refine_calibration=refine_calibration, focal_init=focal, calib_lr=0.001, pose_refinement=refinement,
-                         pose_refinement_wait=pose_wait, pose_refinement_lr=o.pose_refinement_lr, pose_refinement_weight=0.1,
+                         refine_calibration=refine_calibration, focal_init=focal, calib_lr=o.refine_calibration_lr, pose_refinement=refinement,
+                         pose_refinement_wait=pose_wait, pose_refinement_lr=o.pose_refinement_lr, pose_refinement_weight=o.pose_refinement_weight,
                          refinement_ortho=o.refinement_ortho, pose_seed=o.base_seed + 511,
                          initial_poses=buf["image_pose_inv"][:, :3] if refinement == "naive" else None, device=self.dev.index)
         if load_weights is not None:
@@ -314,13 +322,13 @@ class ReconstructionSession:
         head.close()
         return out
 
-    def register(self, head_sd, focal, max_estimates=-1, tag="register"):
+    def register(self, head_sd, focal, max_estimates=-1, tag="register", max_tries=16):
         """register_mapping.py:201-276 for every frame: (poses cam->world [k,4,4] float32, inlier counts [k] int32)."""
         o = self.opt
         k = self.n if max_estimates <= 0 else min(self.n, max_estimates)
         t0 = time.time()
         sc = self.scene_coordinates(head_sd, 0, k)
-        prm = dict(hyps=o.ransac_iterations, thr=o.ransac_threshold, alpha=100.0, max_reproj=100.0, sub=8, max_tries=16)
+        prm = dict(hyps=o.ransac_iterations, thr=o.ransac_threshold, alpha=float(o.inlieralpha), max_reproj=float(o.maxpixelerror), sub=8, max_tries=max_tries)
         poses, inl, _ = dsacstar.register_batch(sc, [(focal, self.ppx, self.ppy)] * k, prm, o.register_seed, list(range(k)), want_masks=False)
         poses, inl = poses.cpu().numpy(), inl.cpu().numpy()
         rate = float((inl > o.registration_confidence).mean())

@@ -60,7 +60,7 @@ def test_pose_line_format_roundtrip(tmp_path):
 
 def test_missing_feature_file_is_a_clear_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_ace.py"), "x/*.png", "/tmp/out.pt"], capture_output=True, text=True, cwd=ROOT)
-    assert r.returncode != 0 and "--feature_buffer" in (r.stderr + r.stdout)
+    assert r.returncode != 0 and "no files match" in (r.stderr + r.stdout)
 
 
 @pytest.mark.gpu

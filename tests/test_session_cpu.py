@@ -102,8 +102,8 @@ def test_frame_and_depth_loaders_roundtrip(tmp_path):
         Image.fromarray(np.kron(d, np.ones((8, 8), np.uint16))).save(tmp_path / f"d{i}.png")
         if i == 1:
             last = d
-    files, frames = cli.load_frames(str(tmp_path / "f*.png"), image_resolution=120)
-    assert [os.path.basename(f) for f in files] == ["f0.png", "f1.png"] and frames.shape == (2, 1, 120, 160)
+    files, frames, factor = cli.load_frames(str(tmp_path / "f*.png"), image_resolution=120)
+    assert [os.path.basename(f) for f in files] == ["f0.png", "f1.png"] and frames.shape == (2, 1, 120, 160) and factor == 0.5
     assert float(frames.min()) >= (0 - 0.4) / 0.25 - 1e-6 and float(frames.max()) <= (1 - 0.4) / 0.25 + 1e-6     # dataset.py:150-153
     depth = cli.load_depth_maps(str(tmp_path / "d*.png"), 2, (240, 320))
     assert depth.shape == (2, 30, 40) and np.allclose(depth[1].numpy(), last / 1000.0)                           # mm -> m at (8x+4, 8y+4)

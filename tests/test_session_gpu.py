@@ -131,3 +131,35 @@ def test_ace_zero_script_from_image_files(tmp_path):
     assert head["fc3.weight"].dtype == torch.float16 and head["fc3.weight"].shape == (4, 512, 1, 1)               # save_model: half, Head keys
     ply = open(out / "pc_final.ply", "rb").read(200)
     assert ply.startswith(b"ply\nformat binary_little_endian")
+
+
+def test_train_ace_and_register_mapping_scripts_on_image_files(tmp_path):
+    """train_ace.py with an ACE pose file, then register_mapping.py, both on PNG frames (the reference's two-step workflow)."""
+    from PIL import Image
+    from acezero_amd import cli
+    seq = synth.render_room_sequence(seed=11, n_frames=40, arc_deg=20.0, device="cuda")
+    img = ((seq["images"][:, 0] * 0.25 + 0.4).clamp(0, 1) * 255).round().to(torch.uint8).cpu().numpy()
+    files = []
+    for i in range(len(img)):
+        files.append(str(tmp_path / f"rgb_{i:04d}.png"))
+        Image.fromarray(np.stack([img[i]] * 3, -1)).save(files[-1])
+    torch.save({k: torch.from_numpy(v) for k, v in synth.init_encoder_weights_bandpass(seed=4099).items()}, tmp_path / "encoder.pt")
+    gt = seq["poses"].cpu().numpy().astype(np.float64)
+    with open(tmp_path / "poses_in.txt", "w") as f:                     # every second frame is a mapping frame (confidence 2000), the rest is below the threshold
+        for i in range(len(img)):
+            cli.write_pose_line(f, files[i], np.linalg.inv(gt[i]), 2000 if i % 2 == 0 else 10, seq["focal"])
+    out = tmp_path / "map" / "scene.pt"
+    rc = cli.train_main([str(tmp_path / "rgb_*.png"), str(out), "--use_ace_pose_file", str(tmp_path / "poses_in.txt"), "--encoder_path",
+                         str(tmp_path / "encoder.pt"), "--iterations", "2500", "--learning_rate_schedule", "1cyclepoly", "--learning_rate_max", "0.003",
+                         "--repro_loss_type", "tanh", "--learning_rate_cooldown_iterations", "500", "--aug_rotation", "2", "--aug_scale", "1.06"])
+    assert rc == 0 and out.exists()
+    prelim = open(tmp_path / "map" / "poses_scene_preliminary.txt").read().splitlines()
+    assert len(prelim) == 20 and prelim[0].split()[-1] == "inf"                                                   # ace_trainer.py:714
+    rc = cli.register_main([str(tmp_path / "rgb_*.png"), str(out), "--encoder_path", str(tmp_path / "encoder.pt"), "--session", "query",
+                            "--use_external_focal_length", str(seq["focal"]), "--hypotheses", "32", "--hypotheses_max_tries", "16"])
+    assert rc == 0
+    fl, poses, focals = cli.read_ace_pose_file(tmp_path / "map" / "poses_query.txt", 500)
+    assert len(fl) >= 38 and np.allclose(focals, seq["focal"])
+    idx = [files.index(f) for f in fl]
+    dt, ang = _pose_err(poses, gt[idx])
+    assert np.median(dt) < 0.01 and np.median(ang) < 0.5
