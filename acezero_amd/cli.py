@@ -263,14 +263,15 @@ def train_main(argv=None):
                   target_crds=buf["target_crds"][:n] if "target_crds" in buf.files else None)   # present = use_depth (ace_trainer.py:86-92)
     _logger.info(f"Training buffer: {n} patches, {buf['image_pose_inv'].shape[0]} images.")
 
-    gen = torch.Generator().manual_seed(opt.base_seed + 8191)       # ace_trainer.py:79-80 training generator
     log_path = opt.output_map_file.with_suffix(".txt")
     start = time.time()
     epoch, launched, done = 0, 0, False
     orig_poses = np.linalg.inv(buf["image_pose_inv"].astype(np.float64))[:, :3, 3]
     with open(log_path, "w", 1) as log:
+        from .head import epoch_permutations
+        perms = epoch_permutations(n, opt.base_seed + 8191, tr.device)   # ace_trainer.py:79-80,466 (drawn on the device)
         while not done:
-            perm = torch.randperm(n, generator=gen).cuda()           # ace_trainer.py:466
+            perm = next(perms)
             for b0 in range(0, n - opt.batch_size + 1, opt.batch_size):
                 tr.step(perm[b0:b0 + opt.batch_size])
                 launched += 1

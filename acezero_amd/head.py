@@ -49,6 +49,18 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def epoch_permutations(n, seed, device):
+    """Endless stream of per-epoch permutations of the buffer rows (TrainerACE.run_epoch, ace_trainer.py:466) as int64 device
+    tensors. The reference draws them with torch.randperm on the CPU; measured here that costs 100 us per training step
+    (12 ms per 600 k rows, 55 % on top of an 8 M-row epoch) because the host cannot run ahead of the GPU across the draw, so
+    the draw is a device-side torch.randperm from a device generator seeded like the reference's (seed = base_seed + 8191):
+    same law (a uniform permutation per epoch), different stream."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    while True:
+        yield torch.randperm(n, generator=gen, device=device)
+
+
 class HeadTrainer:
     """One head + its optimiser/schedule state on one GPU, driven through libacez.so."""
 

@@ -27,7 +27,7 @@ import torch
 from . import _native as N
 from . import dsacstar
 from .encoder import Encoder, output_size
-from .head import HeadTrainer, _ptr, _stream
+from .head import HeadTrainer, _ptr, _stream, epoch_permutations
 
 _logger = logging.getLogger("acezero_amd.session")
 
@@ -233,7 +233,8 @@ class ReconstructionSession:
                         T = (poses_c2w[j].to(torch.float32) @ torch.linalg.inv(rot_inv)).to(self.dev)     # pose @ pose_rot (dataset.py:381)
                         crds.append(eye @ T[:3].T)
                 else:
-                    bld.add_views(view, mask.float(), rot_inv.unsqueeze(0), pose_inv[j:j + 1], K.unsqueeze(0), torch.linalg.inv(K).unsqueeze(0), [j])
+                    bld.add_views(view, mask.float(), rot_inv.unsqueeze(0), pose_inv[j:j + 1], K.unsqueeze(0), torch.linalg.inv(K).unsqueeze(0), [j],
+                                  check_empty=False)     # a rotation of at most aug_rotation degrees never empties the mask
         self._views_sampled += bld.n_views
         buf = bld.finish()
         if with_depth:
@@ -278,10 +279,10 @@ class ReconstructionSession:
         tr.set_buffer(**buf)
         torch.cuda.synchronize(self.dev)
         t_loop0 = time.time()
-        gen = torch.Generator().manual_seed(o.base_seed + 8191)          # ace_trainer.py:79-80
         launched, done = 0, False
+        perms = epoch_permutations(n, o.base_seed + 8191, self.dev)       # ace_trainer.py:79-80 seed of the training generator
         while not done:                                                  # TrainerACE.train / run_epoch (ace_trainer.py:454-497)
-            perm = torch.randperm(n, generator=gen).to(self.dev)
+            perm = next(perms)
             for b0 in range(0, n - o.batch_size + 1, o.batch_size):
                 tr.step(perm[b0:b0 + o.batch_size])
                 launched += 1
