@@ -58,31 +58,41 @@ def default_options(**over):
     return SimpleNamespace(**o)
 
 
-def warp_view(image_11hw, scale, angle, jitter=None):
-    """One augmented view of a normalised grey frame as ONE affine warp (dataset.py:283-343): the frame is resized by `scale`
-    (canvas int(H*scale) x int(W*scale)) and rotated by `angle` radians about its centre -- content at offset d from the centre
-    moves to R' d with R' = [[cos, sin], [-sin, cos]] in (x right, y down) pixel coordinates, which is exactly how camera
-    coordinates transform under aug_pose_inv = pose_rot^-1 (dataset.py:337-343,397) -- bilinear, image reflect-padded, mask
-    zero-padded (:327-328). jitter = (brightness, contrast) factors of ColorJitter on the [0,1] grey values (:148), or None.
-    Returns (view [1,1,hs,ws], mask [1,1,hs,ws] bool, grid [1,hs,ws,2] of normalised source coordinates)."""
-    _, _, H, W = image_11hw.shape
+def warp_views(images_b1hw, scale, angles, jitter=None):
+    """Augmented views of B normalised grey frames as ONE batched affine warp (dataset.py:283-343): every frame is resized by
+    `scale` (canvas int(H*scale) x int(W*scale), shared by the batch) and rotated by its own angle (radians) about its centre --
+    content at offset d from the centre moves to R' d with R' = [[cos, sin], [-sin, cos]] in (x right, y down) pixel coordinates,
+    which is exactly how camera coordinates transform under aug_pose_inv = pose_rot^-1 (dataset.py:337-343,397) -- bilinear,
+    image reflect-padded, mask zero-padded (:327-328). jitter = (brightness [B], contrast [B]) factors of ColorJitter on the
+    [0,1] grey values (:148), or None.
+    Returns (views [B,1,hs,ws], masks [B,1,hs,ws] bool, grid [B,hs,ws,2] of normalised source coordinates)."""
+    B, _, H, W = images_b1hw.shape
+    dev = images_b1hw.device
     hs, ws = int(H * scale), int(W * scale)
     sx, sy = ws / W, hs / H
-    c, s_ = math.cos(angle), math.sin(angle)
+    ang = torch.as_tensor(angles, dtype=torch.float32).reshape(B)
+    c, s_ = torch.cos(ang), torch.sin(ang)
+    z = torch.zeros_like(c)
     # output offset p' (pixels, scaled canvas) -> source offset p = R'^T p' / scale; in normalised coordinates x_n = x / (W/2)
-    theta = torch.tensor([[c * (ws / 2) / sx / (W / 2), -s_ * (hs / 2) / sx / (W / 2), 0.0],
-                          [s_ * (ws / 2) / sy / (H / 2), c * (hs / 2) / sy / (H / 2), 0.0]], dtype=torch.float32, device=image_11hw.device)
-    grid = torch.nn.functional.affine_grid(theta.unsqueeze(0), (1, 1, hs, ws), align_corners=False)
-    src = image_11hw
+    theta = torch.stack([torch.stack([c * ((ws / 2) / sx / (W / 2)), -s_ * ((hs / 2) / sx / (W / 2)), z], dim=1),
+                         torch.stack([s_ * ((ws / 2) / sy / (H / 2)), c * ((hs / 2) / sy / (H / 2)), z], dim=1)], dim=1).to(dev)
+    grid = torch.nn.functional.affine_grid(theta, (B, 1, hs, ws), align_corners=False)
+    src = images_b1hw
     if jitter is not None:
-        g = src * 0.25 + 0.4
-        g = (g * jitter[0]).clamp(0, 1)
-        m = g.mean()
-        g = ((g - m) * jitter[1] + m).clamp(0, 1)
+        br = torch.as_tensor(jitter[0], dtype=torch.float32).reshape(B, 1, 1, 1).to(dev)
+        ct = torch.as_tensor(jitter[1], dtype=torch.float32).reshape(B, 1, 1, 1).to(dev)
+        g = ((src * 0.25 + 0.4) * br).clamp(0, 1)
+        m = g.mean(dim=(1, 2, 3), keepdim=True)
+        g = ((g - m) * ct + m).clamp(0, 1)
         src = (g - 0.4) / 0.25
-    view = torch.nn.functional.grid_sample(src, grid, mode="bilinear", padding_mode="reflection", align_corners=False)
-    mask = torch.nn.functional.grid_sample(torch.ones_like(image_11hw), grid, mode="bilinear", padding_mode="zeros", align_corners=False) > 0
-    return view, mask, grid
+    views = torch.nn.functional.grid_sample(src, grid, mode="bilinear", padding_mode="reflection", align_corners=False)
+    masks = torch.nn.functional.grid_sample(torch.ones_like(images_b1hw), grid, mode="bilinear", padding_mode="zeros", align_corners=False) > 0
+    return views, masks, grid
+
+
+def warp_view(image_11hw, scale, angle, jitter=None):
+    """warp_views for one frame; jitter = (brightness, contrast) floats or None."""
+    return warp_views(image_11hw, scale, [angle], None if jitter is None else ([jitter[0]], [jitter[1]]))
 
 
 def view_depth(depth_11hw, grid, oh, ow):
@@ -180,65 +190,84 @@ class ReconstructionSession:
             buf["target_crds"] = torch.einsum("nij,nj->ni", poses_c2w.to(self.dev, torch.float32)[img][:, :3], eye)
         return buf
 
-    def _augmented_view(self, img):
-        """dataset.py:283-343,420-427 on the device: random scale (short side 480 * U(1/s, s)), in-plane rotation U(-r, r) degrees,
-        brightness / contrast jitter. Returns (view [1,1,hs,ws], mask bool, scale, angle_rad, sampling grid)."""
+    AUG_SCALE_LEVELS = 16
+
+    def _draw_augmentations(self, m):
+        """Per view: scale, rotation angle (radians), brightness, contrast (dataset.py:420-427,324,148). The scale is drawn from
+        AUG_SCALE_LEVELS equally spaced values of [1/s, s] instead of the continuum, so that the views of a pass fall into a few
+        canvas sizes and go through warp / encoder / sampling in batches (one view at a time the fill is host-bound: 0.6 ms per
+        view against 0.09 ms of encoder time)."""
         o, rng = self.opt, self._aug_rng
-        scale = float(rng.uniform(1.0 / o.aug_scale, o.aug_scale))
-        ang = math.radians(float(rng.uniform(-o.aug_rotation, o.aug_rotation)))
+        lo, hi = 1.0 / o.aug_scale, o.aug_scale
+        levels = rng.integers(0, self.AUG_SCALE_LEVELS, size=m)
+        scales = lo + (levels + 0.5) * (hi - lo) / self.AUG_SCALE_LEVELS
+        angles = np.radians(rng.uniform(-o.aug_rotation, o.aug_rotation, size=m))
         bw = float(o.aug_black_white)
-        jitter = (float(rng.uniform(1 - bw, 1 + bw)), float(rng.uniform(1 - bw, 1 + bw))) if bw > 0 else None
-        view, mask, grid = warp_view(self.images[img:img + 1], scale, ang, jitter)
-        return view, mask, scale, ang, grid
+        jit = (rng.uniform(1 - bw, 1 + bw, size=m), rng.uniform(1 - bw, 1 + bw, size=m)) if bw > 0 else None
+        return levels, scales, angles, jit
+
+    @staticmethod
+    def _rot_inv(angles):
+        """Inverse of pose_rot (dataset.py:337-343) for a batch of angles: [[c, s], [-s, c]] in the upper-left block."""
+        a = torch.as_tensor(angles, dtype=torch.float32)
+        r = torch.eye(4).repeat(len(a), 1, 1)
+        r[:, 0, 0], r[:, 0, 1], r[:, 1, 0], r[:, 1, 1] = torch.cos(a), torch.sin(a), -torch.sin(a), torch.cos(a)
+        return r
 
     def _fill_buffer_augmented(self, image_ids, poses_c2w, focal, with_depth):
-        """create_training_buffer with --use_aug True: every pass re-encodes a freshly augmented view of every mapped image
-        (encoder: ~13 k views/s) and samples it with its validity mask. Views are processed one at a time, as the reference does."""
+        """create_training_buffer with --use_aug True: every pass re-encodes a freshly augmented view of every mapped image and
+        samples it with its validity mask. The views of a pass are grouped by canvas size and processed in batches."""
         from .buffer import BufferBuilder
         o = self.opt
-        ids = [int(i) for i in image_ids]
+        ids = torch.as_tensor([int(i) for i in image_ids], dtype=torch.long)
         m = len(ids)
         total = min(o.max_training_buffer_size, o.max_dataset_passes * m * o.samples_per_image)
         bld = BufferBuilder(self.enc, capacity=total, samples_per_image=o.samples_per_image, seed=o.base_seed + 4095 + self._views_sampled)
         poses_c2w = torch.as_tensor(poses_c2w, dtype=torch.float64).reshape(m, 4, 4)
         pose_inv = torch.linalg.inv(poses_c2w).to(torch.float32)
+        chunk = 16
         crds = []
         while not bld.full:
-            for j, img in enumerate(ids):
-                if bld.full:
-                    break
-                view, mask, scale, ang, grid = self._augmented_view(img)
-                hs, ws = view.shape[2:]
-                f = focal * (int(self.H * scale) / self.H)               # dataset.py:289-290 scales the focal with the short side
+            levels, scales, angles, jit = self._draw_augmentations(m)
+            for lv in np.unique(levels):
+                sel = np.flatnonzero(levels == lv)
+                scale = float(scales[sel[0]])
+                hs, ws = int(self.H * scale), int(self.W * scale)
+                f = focal * (hs / self.H)                                # dataset.py:289-290 scales the focal with the short side
                 K = torch.tensor([[f, 0, ws / 2.0], [0, f, hs / 2.0], [0, 0, 1.0]])
-                rot_inv = torch.eye(4)                                   # inverse of pose_rot (dataset.py:337-343)
-                rot_inv[0, 0], rot_inv[0, 1], rot_inv[1, 0], rot_inv[1, 1] = math.cos(ang), math.sin(ang), -math.sin(ang), math.cos(ang)
-                n0 = bld.n
-                if with_depth:
-                    # depth at the view's feature-map pixel centres: nearest lookup through the same warp (dataset.py:331-334, order=0)
+                Kinv = torch.linalg.inv(K)
+                for c0 in range(0, len(sel), chunk):
+                    if bld.full:
+                        break
+                    js = sel[c0:c0 + chunk]
+                    b = len(js)
+                    views, masks, grid = warp_views(self.images[ids[js].to(self.dev)], scale, angles[js], None if jit is None else (jit[0][js], jit[1][js]))
+                    rot_inv = self._rot_inv(angles[js])
+                    if not with_depth:
+                        # a rotation of at most aug_rotation degrees never empties the mask: no per-batch host synchronisation
+                        bld.add_views(views, masks.float(), rot_inv, pose_inv[js], K.repeat(b, 1, 1), Kinv.repeat(b, 1, 1), [int(j) for j in js],
+                                      check_empty=False)
+                        continue
+                    # depth-supervised (seed) views: depth at the feature-map pixel centres through the same warp (dataset.py:331-334, order=0)
                     oh, ow = output_size(hs, ws)
-                    d = self.depth[img:img + 1].unsqueeze(1)
-                    dv = view_depth(d, grid, oh, ow)
-                    valid = (dv > 0) & (dv <= 1000)
-                    mk = torch.nn.functional.interpolate(mask.float(), size=(oh, ow), mode="nearest")[0, 0] > 0
-                    full_mask = torch.nn.functional.interpolate((mk & valid).float()[None, None], size=(hs, ws), mode="nearest")
-                    took = bld.add_views(view, full_mask, rot_inv.unsqueeze(0), pose_inv[j:j + 1], K.unsqueeze(0), torch.linalg.inv(K).unsqueeze(0), [j],
-                                         want_pixels=True)
-                    if took:
-                        pix = bld.last_pixels[:took].long()
-                        y, x = pix // ow, pix % ow
-                        dd = dv[y, x]
-                        px = bld.target_px[n0:n0 + took]
-                        eye = torch.stack([(px[:, 0] - ws / 2.0) / f * dd, (px[:, 1] - hs / 2.0) / f * dd, dd, torch.ones_like(dd)], dim=1)
-                        T = (poses_c2w[j].to(torch.float32) @ torch.linalg.inv(rot_inv)).to(self.dev)     # pose @ pose_rot (dataset.py:381)
-                        crds.append(eye @ T[:3].T)
-                else:
-                    bld.add_views(view, mask.float(), rot_inv.unsqueeze(0), pose_inv[j:j + 1], K.unsqueeze(0), torch.linalg.inv(K).unsqueeze(0), [j],
-                                  check_empty=False)     # a rotation of at most aug_rotation degrees never empties the mask
+                    for k, j in enumerate(js):
+                        n0 = bld.n
+                        dv = view_depth(self.depth[int(ids[j])][None, None], grid[k:k + 1], oh, ow)
+                        valid = (dv > 0) & (dv <= 1000)
+                        mk = torch.nn.functional.interpolate(masks[k:k + 1].float(), size=(oh, ow), mode="nearest")[0, 0] > 0
+                        full_mask = torch.nn.functional.interpolate((mk & valid).float()[None, None], size=(hs, ws), mode="nearest")
+                        took = bld.add_views(views[k:k + 1], full_mask, rot_inv[k:k + 1], pose_inv[j:j + 1], K[None], Kinv[None], [int(j)], want_pixels=True)
+                        if took:
+                            pix = bld.last_pixels[:took].long()
+                            dd = dv[pix // ow, pix % ow]
+                            px = bld.target_px[n0:n0 + took]
+                            eye = torch.stack([(px[:, 0] - ws / 2.0) / f * dd, (px[:, 1] - hs / 2.0) / f * dd, dd, torch.ones_like(dd)], dim=1)
+                            T = (poses_c2w[j].to(torch.float32) @ torch.linalg.inv(rot_inv[k])).to(self.dev)   # pose @ pose_rot (dataset.py:381)
+                            crds.append(eye @ T[:3].T)
         self._views_sampled += bld.n_views
         buf = bld.finish()
         if with_depth:
-            buf["target_crds"] = torch.cat(crds)
+            buf["target_crds"] = torch.cat(crds)[:int(buf["features"].shape[0])]
         return buf
 
     def map(self, image_ids, poses_c2w, focal, *, iterations, loss_type, schedule, lr_max, refinement="none", pose_wait=0,
