@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--reg-frames", type=int, default=2048)
     ap.add_argument("--e2e-frames", type=int, default=1024)
     ap.add_argument("--pose-refinement", default="none", choices=["none", "mlp"])   # ace_zero.py:86 maps every non-seed iteration with mlp
+    ap.add_argument("--session-frames", type=int, default=120, help="frames of the in-process ACE0 reconstruction leg (N = 1 only; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # control-flow smoke of the N > 1 path on a ONE-GPU box: every rank on cuda:0, gloo instead of RCCL (not a measurement)
     ap.add_argument("--smoke-same-device", action="store_true")
@@ -226,6 +227,30 @@ def bench_pipeline(args, rank, world, device):
             "cloud_points": npts}
 
 
+def bench_session(args, device):
+    """the whole ace_zero.py loop in one process on a synthetic, view-consistent sequence (480x640 frames of
+    a textured room, 0.5 degrees apart; stand-in encoder weights; reduced iteration counts and augmentation range -- see DESIGN 4c)."""
+    from acezero_amd import synth
+    from acezero_amd.session import ReconstructionSession, default_options
+    n, it = args.session_frames, 4000
+    seq = synth.render_room_sequence(seed=2089, n_frames=n, arc_deg=0.5 * n, device=str(device))
+    esd = {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights_bandpass(seed=4099).items()}
+    opt = default_options(use_external_focal_length=seq["focal"], try_seeds=2, seed_iterations=it, iterations=it, refit_iterations=it,
+                          iterations_max=8, final_refit_posewait=it // 5, learning_rate_warmup_iterations=it // 5, cooldown_iterations=it // 5,
+                          aug_rotation=2, aug_scale=1.06, aug_black_white=0.02)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ses = ReconstructionSession(esd, seq["images"], opt=opt, depth=seq["depth"])
+    res = ses.reconstruct()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    hist = res["history"]
+    return {"metric": "in-process ACE0 reconstruction (seed trials + map/register rounds + final refit), wall-clock seconds", "value": dt,
+            "unit": "s", "higher_is_better": False, "frames": n, "rounds": len(hist), "registration_rates": [round(h["registration_rate"], 3) for h in hist],
+            "training_iterations": int(sum(h.get("iterations", 0) for h in hist) + 2 * it), "max_iterations_per_round": it,
+            "note": "synthetic textured room, stand-in encoder (zero-mean smoothed random filters), augmentation +-2 deg / x1.06, 2 seed trials"}
+
+
 def cpu_baseline():
     """Oracle timed on the host cores (kind "port": the reference itself is not on the GPU box)."""
     from acezero_amd import synth
@@ -309,6 +334,7 @@ def main():
     dt_ref, st_ref, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000))
     nreg, dt_reg, reg_ok = bench_registration(args, rank, world, device)
     pipe = bench_pipeline(args, rank, world, device)
+    sess = bench_session(args, device) if world == 1 and args.session_frames > 0 else None
     if world > 1:
         t = torch.tensor([dt, dt_reg, dt_ref], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -350,6 +376,7 @@ def main():
             "buffer_creation": {"metric": "training-buffer rows/sec (encoder + 1024 mask-weighted samples per 480x640 view)",
                                 "value": pipe["buffer_rows"] * world / pipe["buffer_s"], "unit": "patches/s",
                                 "views_per_s": pipe["frames"] * world / pipe["buffer_s"]},
+            "ace_zero_session": sess,
             "point_cloud_filter": {"metric": "point-cloud extraction frames/sec (60x80 scene-coordinate maps in HBM -> filtered [N,3] list)",
                                    "value": pipe["cloud_frames"] * world / pipe["cloud_s"], "unit": "frames/s",
                                    "points_per_frame": pipe["cloud_points"] / pipe["cloud_frames"],

@@ -5,7 +5,7 @@
 # Summaries land in gpurun_out/prof_keep/ (copied to profiles/ by hand and committed).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-CMD="timeout 300 python $R/bench.py --steps 100 --warmup 20 --buffer-patches 2000000 --reg-frames 1024 --e2e-frames 256 --no-cpu-baseline"
+CMD="timeout 300 python $R/bench.py --steps 100 --warmup 20 --buffer-patches 2000000 --reg-frames 1024 --e2e-frames 256 --session-frames 0 --no-cpu-baseline"
 if [ "$1" = "quick" ]; then QUICK=1; fi
 OUT=$R/gpurun_out/prof
 KEEP=$R/gpurun_out/prof_keep
