@@ -45,8 +45,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "full":
     res = ses.reconstruct()
     for h in res["history"]:
         print(h)
-    seed_img = int(np.random.RandomState(0).uniform())  # placeholder
-    # align: est poses live in the seed camera's frame
+    # the estimated poses live in the seed camera's frame: compose with the seed's ground-truth pose
     np.random.seed(opt.random_seed)
     seeds = np.random.uniform(size=opt.try_seeds)
     best = int(res["history"][0]["id"].split("seed")[1])
