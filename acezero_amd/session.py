@@ -396,7 +396,7 @@ class ReconstructionSession:
         scheduled_to_stop_early = False
         iteration = 0
         for iteration in range(1, o.iterations_max):
-            sel = np.flatnonzero(conf > o.registration_confidence)       # --ace_pose_file_conf_threshold (dataset_io.load_dataset_ace)
+            sel = np.flatnonzero(conf >= o.registration_confidence)      # --ace_pose_file_conf_threshold: load_dataset_ace drops `confidence < threshold`
             if len(sel) == 0:
                 raise RuntimeError("no image is registered above the confidence threshold: cannot continue the reconstruction")
             refit = scheduled_to_stop_early and o.final_refit
