@@ -372,6 +372,9 @@ class ReconstructionSession:
         img = int(seed * self.n)                                         # dataset.py:112
         if self.depth is None:
             raise RuntimeError("a seed image needs a depth map (ace_zero.py --depth_files); the ZoeDepth fallback is a network download")
+        rows = self.opt.max_dataset_passes * self.opt.samples_per_image
+        if rows < self.opt.batch_size:                                   # one image gives passes x samples rows (10 240 by default = two batches)
+            raise ValueError(f"a seed image yields {rows} buffer rows, fewer than one batch of {self.opt.batch_size}: raise --max_dataset_passes")
         m = self.map([img], torch.eye(4).unsqueeze(0), self.focal0, iterations=o.seed_iterations, loss_type=o.repro_loss_type,
                      schedule=o.learning_rate_schedule, lr_max=o.learning_rate_max, with_depth=True, tag=f"iteration0_seed{seed_idx}")
         _, inl = self.register(m["head"], self.focal0, max_estimates=o.max_estimates_seed_scoring, tag=f"iteration0_seed{seed_idx}_fastcheck")
