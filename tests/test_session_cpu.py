@@ -112,3 +112,76 @@ def test_frame_and_depth_loaders_roundtrip(tmp_path):
     Image.fromarray(np.zeros((100, 320, 3), np.uint8)).save(tmp_path / "f2.png")
     with pytest.raises(SystemExit):
         cli.load_frames(str(tmp_path / "f*.png"), image_resolution=120)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the reconstruction loop's decisions against the reference's own ace_zero.py (tests/golden/make_ace_zero_loop_golden.py)
+class _ScriptedSession(session.ReconstructionSession):
+    """map / register replaced by scripted outcomes; everything else (seed trials, selection of the best seed, warm start,
+    refit settings, stopping criteria, focal hand-over) is the product's reconstruct()."""
+
+    def __init__(self, opt, rates, n=200):
+        import numpy as np
+        self.opt, self.n, self.H, self.W = opt, n, 480, 640
+        self.depth = torch.zeros(1)
+        f_ext = float(opt.use_external_focal_length)
+        self.focal0 = f_ext if f_ext > 0 else -1.0          # "-1" = the heuristic, as ace_zero.py passes it on
+        self.history, self.calls, self._rates, self._maps = [], [], list(rates), 0
+        self._np = np
+
+    def map(self, image_ids, poses_c2w, focal, *, iterations, loss_type, schedule, lr_max, refinement="none", pose_wait=0,
+            refine_calibration=False, load_weights=None, with_depth=False, tag="map"):
+        if not with_depth:
+            self._maps += 1
+        self.calls.append({"cmd": "train", "id": tag, "seed": with_depth, "iterations": iterations, "loss": loss_type, "schedule": schedule,
+                           "lr_max": lr_max, "pose_wait": pose_wait, "refinement": refinement, "refine_calibration": bool(refine_calibration),
+                           "load_weights": None if load_weights is None else load_weights["id"], "images": len(list(image_ids))})
+        return {"head": {"id": tag}, "poses_w2c": None, "focal": 500.0 + self._maps if not with_depth else focal, "iterations": iterations,
+                "seconds": 0.0}
+
+    def register(self, head_sd, focal, max_estimates=-1, tag="register", max_tries=16):
+        np = self._np
+        rate = self._rates.pop(0)
+        conf = np.zeros(self.n, np.int32)
+        conf[:round(rate * self.n)] = 1000
+        self.calls.append({"cmd": "register", "network": head_sd["id"], "session": tag, "focal": focal, "max_estimates": max_estimates})
+        return np.tile(np.eye(4, dtype=np.float32), (self.n, 1, 1)), conf
+
+
+def _reference_decisions(calls):
+    out = []
+    for c in calls:
+        f = c["flags"]
+        if c["cmd"] == "train":
+            out.append({"cmd": "train", "id": c["id"], "seed": "use_pose_seed" in f, "iterations": int(f.get("iterations", 25000)),
+                        "loss": f["repro_loss_type"], "schedule": f["learning_rate_schedule"], "lr_max": float(f["learning_rate_max"]),
+                        "pose_wait": int(f["pose_refinement_wait"]), "refinement": f.get("pose_refinement", "none"),
+                        "refine_calibration": f.get("refine_calibration", "False") == "True",
+                        "load_weights": os.path.splitext(os.path.basename(f["load_weights"]))[0] if "load_weights" in f else None})
+        else:
+            out.append({"cmd": "register", "network": c["network"], "session": f["session"], "focal": float(f["use_external_focal_length"]),
+                        "max_estimates": int(f.get("max_estimates", -1))})
+    return out
+
+
+@pytest.mark.parametrize("name", ["reaches_threshold", "relative_threshold", "no_final_refine", "no_final_refit", "iterations_max",
+                                  "no_warmstart", "naive_refinement_no_calibration", "slow_growth"])
+def test_reconstruction_loop_makes_the_reference_decisions(golden_dir, name):
+    g = json.load(open(os.path.join(golden_dir, "ace_zero_loop.json")))[name]
+    argv = g["argv"]
+    over = {argv[i].lstrip("-"): argv[i + 1] for i in range(0, len(argv), 2)}
+    conv = {"final_refine": lambda v: v == "True", "final_refit": lambda v: v == "True", "warmstart": lambda v: v == "True",
+            "refine_calibration": lambda v: v == "True", "iterations_max": int, "refinement": str}
+    opt = session.default_options(try_seeds=2, **{k: conv[k](v) for k, v in over.items()})
+    ses = _ScriptedSession(opt, g["rates"])
+    res = ses.reconstruct()
+    ref = _reference_decisions(g["calls"])
+    mine = [{k: v for k, v in c.items() if k != "images"} for c in ses.calls]
+    assert len(mine) == len(ref), ([c.get("id") or c.get("session") for c in mine], [c.get("id") or c.get("session") for c in ref])
+    for a, b in zip(mine, ref):
+        assert a == b, (a, b)
+    assert len(g["rates"]) - len(ses._rates) == g["registers_used"]
+    # mapping rounds use the frames registered above the confidence threshold in the previous round
+    trains = [c for c in ses.calls if c["cmd"] == "train" and not c["seed"]]
+    assert [c["images"] for c in trains] == [round(r * 200) for r in g["rates"][2:2 + len(trains)]]
+    assert res["iterations"] == len(trains)
