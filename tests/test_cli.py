@@ -99,3 +99,24 @@ def test_train_then_register_end_to_end(tmp_path):
         T[:3, 3] = [float(x) for x in t[5:8]]
         np.testing.assert_allclose(np.linalg.inv(T)[:3, 3], fr["poses"][i][:3, 3], atol=0.03)   # file stores world->cam
         assert float(t[9]) > 1000
+
+
+def test_pose_files_are_the_reference_format_both_ways(golden_dir, tmp_path):
+    """tests/golden/pose_file_ref.txt was written by the reference's write_pose_to_pose_file and parsed by its load_dataset_ace
+    (make_pose_file_golden.py): our writer must produce the same bytes, our reader the same entries."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(golden_dir, "make_pose_file_golden.py"))
+    src = open(os.path.join(golden_dir, "make_pose_file_golden.py")).read()
+    ns = {}
+    exec(src[src.index("def poses("):src.index('if __name__ == "__main__":')], {"np": np, "Rotation": __import__("scipy.spatial.transform", fromlist=["Rotation"]).Rotation}, ns)
+    P, conf = ns["poses"]()
+    out = tmp_path / "mine.txt"
+    with open(out, "w") as f:
+        for i in range(len(P)):
+            cli.write_pose_line(f, f"scene/frame_{i:03d}.png", P[i], int(conf[i]) if i else float("inf"), 525.0 + i)
+    assert open(out).read() == open(os.path.join(golden_dir, "pose_file_ref.txt")).read()
+    ref = np.load(os.path.join(golden_dir, "pose_file_ref.npz"))
+    files, c2w, focals = cli.read_ace_pose_file(os.path.join(golden_dir, "pose_file_ref.txt"), 500)
+    assert files == [str(x) for x in ref["files"]] and np.allclose(focals, ref["focals"])
+    assert np.allclose(c2w, ref["c2w"], atol=1e-6)          # the reference returns float32 matrices
+    assert "scene/frame_001.png" not in files and "scene/frame_000.png" in files and "scene/frame_002.png" in files   # 499 dropped; inf, 500 kept
