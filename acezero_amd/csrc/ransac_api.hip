@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
     out->errsq = acc[27];
   };
   auto lm_step = [&](const LMAccum& acc, const double* prevParam, int lambdaLg10, double* prm) {
-    // The 6x6 eigen-solve is ~55 us of serial fp64 work with identical inputs on every lane: only wavefront 0 runs it and
+    // The 6x6 solve is serial fp64 work with identical inputs on every lane (Cholesky: ~2 us; its eigen fallback ~55 us): only wavefront 0 runs it and
     // hands the step over through LDS, which leaves the other three SIMDs to the second workgroup of this CU
     // (every lm_step is followed by an lm_accumulate, whose block reduction orders the next overwrite of sStep).
     double* sStep = sHyp;   // the sampled poses are dead after the selection
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
       double A[36], x[6];
       for (int i = 0; i < 36; ++i) A[i] = acc.JtJ[i];
       for (int i = 0; i < 6; ++i) A[i * 6 + i] *= 1. + lambda;
-      rsm::solve_sym6(A, acc.JtErr, x);
+      rsm::solve_normal6(A, acc.JtErr, x);
       if (lane == 0)
         for (int i = 0; i < 6; ++i) sStep[i] = x[i];
     }

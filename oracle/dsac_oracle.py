@@ -95,6 +95,12 @@ def solve_sym6(A, b):
     return x
 
 
+def solve_normal6(A, b):
+    x = np.zeros(6)
+    lib().oracle_solve_normal6(_p(np.ascontiguousarray(A, np.float64)), _p(np.ascontiguousarray(b, np.float64)), _p(x))
+    return x
+
+
 def inv4x4(A):
     out = np.zeros(16)
     lib().oracle_inv4x4.restype = C.c_int

@@ -28,6 +28,7 @@ void probe_project(const double* pose6, float focal, float ppx, float ppy, const
                  J12n ? J12n + 12 * i : nullptr, J12n ? J12n + 12 * i + 6 : nullptr);
 }
 void probe_solve_sym6(const double* A36, const double* b6, double* x6) { rsm::solve_sym6(A36, b6, x6); }
+void probe_solve_normal6(const double* A36, const double* b6, double* x6) { rsm::solve_normal6(A36, b6, x6); }
 void probe_det_math(const double* x, int n, double* s, double* c, double* ac, double* ex, double* cb) {
   for (int i = 0; i < n; ++i) {
     detm::sincos(x[i], &s[i], &c[i]);

@@ -147,3 +147,25 @@ def test_lm_refinement_converges_from_perturbed_pose():
     flags = np.ones((60, 80), np.uint8); flags[::3, ::2] = 0
     out = O.pnp_iterative(sc, 8, fr["focal"], fr["ppx"], fr["ppy"], flags, start)
     np.testing.assert_allclose(out, gt, atol=1e-5)
+
+
+def test_normal_equation_solver_cholesky_and_fallback():
+    """D4 of oracle/dsac_oracle.cpp: Cholesky on the damped normal equations, eigen pseudo-inverse when a pivot is not safely positive."""
+    rng = np.random.default_rng(12)
+    for trial in range(20):
+        J = rng.normal(size=(40, 6)) * np.array([300.0, 300.0, 300.0, 50.0, 50.0, 80.0])     # rotation / translation columns of a PnP Jacobian
+        A = J.T @ J
+        A[np.diag_indices(6)] *= 1 + 10.0 ** rng.integers(-16, 3)
+        b = J.T @ rng.normal(size=40)
+        x = O.solve_normal6(A, b)
+        ref = np.linalg.solve(A, b)
+        assert np.allclose(x, ref, rtol=1e-8, atol=1e-12 * np.abs(ref).max())
+        assert np.allclose(x, O.solve_sym6(A, b), rtol=1e-7, atol=1e-11 * np.abs(ref).max())  # the two solvers agree on SPD systems
+    # rank-deficient: the fallback is the pseudo-inverse solution, bit for bit
+    J = rng.normal(size=(40, 6))
+    J[:, 5] = J[:, 4]
+    A = J.T @ J
+    b = J.T @ rng.normal(size=40)
+    x = O.solve_normal6(A, b)
+    assert np.array_equal(x.view(np.uint64), O.solve_sym6(A, b).view(np.uint64))
+    assert np.allclose(x, np.linalg.pinv(A) @ b, rtol=1e-6, atol=1e-9)

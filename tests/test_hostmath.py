@@ -90,3 +90,7 @@ def test_rodrigues_project_solve_bitexact(probe):
         x = np.zeros(6)
         probe.probe_solve_sym6(_p(np.ascontiguousarray(A)), _p(b), _p(x))
         assert np.array_equal(x.view(np.uint64), O.solve_sym6(A, b).view(np.uint64))
+        Ad = A.copy()
+        Ad[np.diag_indices(6)] *= 1 + 10.0 ** rng.integers(-16, 3)        # the damped system of an LM step
+        probe.probe_solve_normal6(_p(np.ascontiguousarray(Ad)), _p(b), _p(x))
+        assert np.array_equal(x.view(np.uint64), O.solve_normal6(Ad, b).view(np.uint64))
