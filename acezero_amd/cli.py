@@ -205,6 +205,26 @@ def ace_zero_parser():
     return p
 
 
+def export_point_cloud_parser():
+    """export_point_cloud.py:26-58."""
+    p = argparse.ArgumentParser(description="Extract point cloud from network or visualization buffer file; .txt and .ply are supported.",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("output_file", type=Path)
+    p.add_argument("--network", type=Path, help="network to extract point cloud from.")
+    p.add_argument("--pose_file", type=Path, help="pose file of images that trained the network")
+    p.add_argument("--visualization_buffer", type=Path, help="vis buffer file that contains a pre-calculated point cloud.")
+    p.add_argument("--encoder_path", type=Path, default="<path>", help="file containing pre-trained encoder weights")
+    p.add_argument("--image_resolution", type=int, default=480, help="base image resolution")
+    p.add_argument("--confidence_threshold", type=int, default=500)
+    p.add_argument("--convention", type=str, default="opengl", choices=["opengl", "opencv"], help="coordinate convention of the point cloud")
+    p.add_argument("--dense_point_cloud", type=_strtobool, default=False, help="do not filter points based on reprojection error")
+    return p
+
+
+def _default_encoder_path(path):
+    return Path(__file__).resolve().parent.parent / "ace_encoder_pretrained.pt" if str(path) == "<path>" else Path(path)
+
+
 # ------------------------------------------------------------------------------------------------------- file formats
 def write_pose_line(f, rgb_file, pose_w2c, confidence, focal_length):
     """dataset_io.py:159-186: `file qw qx qy qz tx ty tz focal confidence`, world->cam."""
@@ -369,7 +389,7 @@ def _train_from_images(opt):
         focal = focals[0] * fscale
     so = _session_options(opt, cooldown_iterations=opt.learning_rate_cooldown_iterations, use_external_focal_length=focal,
                           cooldown_threshold=opt.learning_rate_cooldown_trigger_percent_threshold)
-    ses = ReconstructionSession(torch.load(opt.encoder_path, map_location="cpu"), frames, opt=so, depth=depth)
+    ses = ReconstructionSession(torch.load(_default_encoder_path(opt.encoder_path), map_location="cpu"), frames, opt=so, depth=depth)
     m = ses.map(ids, torch.from_numpy(np.asarray(poses, np.float64)), focal, iterations=opt.iterations, loss_type=opt.repro_loss_type,
                 schedule=opt.learning_rate_schedule, lr_max=opt.learning_rate_max, refinement=opt.pose_refinement,
                 pose_wait=opt.pose_refinement_wait, refine_calibration=opt.refine_calibration,
@@ -394,7 +414,7 @@ def _register_from_images(opt):
     so = _session_options(opt, use_external_focal_length=opt.use_external_focal_length * fscale if opt.use_external_focal_length > 0 else -1.0,
                           ransac_iterations=opt.hypotheses, ransac_threshold=opt.threshold, register_seed=opt.base_seed, use_aug=False,
                           registration_confidence=opt.confidence_threshold)
-    ses = ReconstructionSession(torch.load(opt.encoder_path, map_location="cpu"), frames, opt=so)
+    ses = ReconstructionSession(torch.load(_default_encoder_path(opt.encoder_path), map_location="cpu"), frames, opt=so)
     poses, inl = ses.register(torch.load(opt.network, map_location="cpu"), ses.focal0, max_estimates=opt.max_estimates, max_tries=opt.hypotheses_max_tries)
     out = Path(opt.network).parent / f"poses_{opt.session}.txt"
     write_pose_file(out, files[:len(poses)], poses, inl, ses.focal0 / fscale)
@@ -447,7 +467,7 @@ def register_main(argv=None):
 
 
 # --------------------------------------------------------------------------------------------------------- ace_zero
-def load_frames(rgb_glob, image_resolution=480, files=None):
+def load_frames(rgb_glob, image_resolution=480, files=None, return_rgb=False):
     """Minimal stand-in for CamLocDataset's image path without augmentation (dataset.py:189-195,227-237,146-160): decode,
     resize so that the short side is `image_resolution` (PIL bilinear, as torchvision does for PIL images), grey, normalise.
     All frames must have one size (the session batches them). Returns (files, float32 [n,1,H,W], resize factor): focal lengths
@@ -459,19 +479,24 @@ def load_frames(rgb_glob, image_resolution=480, files=None):
         files = sorted(glob.glob(rgb_glob))                             # dataset_io.get_files_from_glob sorts
     if not files:
         raise SystemExit(f"no files match {rgb_glob!r}")
-    frames, size, factor = [], None, 1.0
+    frames, size, factor, rgbs = [], None, 1.0, []
     for f in files:
         im = Image.open(f).convert("RGB")
         w, h = im.size
         sc = image_resolution / min(w, h)
         nw, nh = (image_resolution, int(h * sc)) if w <= h else (int(w * sc), image_resolution)
-        g = np.asarray(im.resize((nw, nh), Image.BILINEAR).convert("L"), np.float32) / 255.0
+        small = im.resize((nw, nh), Image.BILINEAR)
+        g = np.asarray(small.convert("L"), np.float32) / 255.0
+        if return_rgb:
+            rgbs.append(np.asarray(small, np.uint8))
         if size is None:
             size = g.shape
         elif g.shape != size:
             raise SystemExit(f"{f}: resized frame is {g.shape}, the first one {size}; the in-process session needs one frame size")
         frames.append((g - 0.4) / 0.25)
         factor = sc
+    if return_rgb:
+        return files, torch.from_numpy(np.stack(frames)[:, None]), factor, np.stack(rgbs)
     return files, torch.from_numpy(np.stack(frames)[:, None]), factor
 
 
@@ -499,7 +524,7 @@ def ace_zero_main(argv=None):
     opt = ace_zero_parser().parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     opt.results_folder.mkdir(parents=True, exist_ok=True)
-    files, frames, fscale = load_frames(opt.rgb_files, opt.image_resolution)
+    files, frames, fscale, rgb = load_frames(opt.rgb_files, opt.image_resolution, return_rgb=True)
     depth = load_depth_maps(opt.depth_files, len(files), frames.shape[2:]) if opt.depth_files is not None else None
     if depth is None and opt.seed_network is None:
         raise SystemExit("ace_zero.py (MI355X): seeds need --depth_files (or --seed_network); the reference's ZoeDepth fallback is a "
@@ -510,7 +535,7 @@ def ace_zero_main(argv=None):
         over["use_external_focal_length"] = opt.use_external_focal_length * fscale
     if opt.seed_network is not None:
         over["seed_network"] = torch.load(opt.seed_network, map_location="cpu")
-    ses = ReconstructionSession(torch.load(opt.encoder_path, map_location="cpu"), frames, opt=default_options(**over), depth=depth)
+    ses = ReconstructionSession(torch.load(_default_encoder_path(opt.encoder_path), map_location="cpu"), frames, opt=default_options(**over), depth=depth)
     res = ses.reconstruct()
     for h in res["history"]:                                            # the files ace_zero.py leaves behind (SURVEY 8b "process/file contract")
         write_pose_file(opt.results_folder / f"poses_{h['id']}.txt", files, h["poses"], h["confidence"], h["focal"] / fscale)
@@ -520,12 +545,57 @@ def ace_zero_main(argv=None):
     if opt.export_point_cloud:
         from .pointcloud import write_point_cloud
         xyz, src, sel = res["point_cloud"]
-        hw = ses.hw
-        f, p = np.divmod(src.astype(np.int64), hw)
-        y, x = np.divmod(p, ses.ow)
-        gray = (frames[sel[f], 0, np.minimum(y * 8 + 4, frames.shape[2] - 1), np.minimum(x * 8 + 4, frames.shape[3] - 1)].numpy() * 0.25 + 0.4) * 255.0
-        write_point_cloud(opt.results_folder / "pc_final.ply", xyz, np.repeat(np.clip(gray, 0, 255)[:, None], 3, axis=1))
+        f, p = np.divmod(src.astype(np.int64), ses.hw)
+        write_point_cloud(opt.results_folder / "pc_final.ply", xyz, source_colours(rgb, sel[f], p, ses.ow))
     rates = [float((res["confidence"] > t).mean()) for t in (500, 1000, 2000, 4000)]
     _logger.info(f"Reconstructed in {res['seconds'] / 60:.1f} minutes, {res['iterations']} iterations; "
                  "registration rate @500/@1000/@2000/@4000: " + " ".join(f"{r * 100:.1f}%" for r in rates))
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ export_point_cloud
+def source_colours(rgb_nhw3, frame_of_point, pixel_of_point, map_w):
+    """Colour of every kept map pixel: the image value at its centre (nearest-neighbour sub-sampling with offset 4, stride 8,
+    ace_vis_util.py:566-570), as 0..255 floats."""
+    y, x = np.divmod(pixel_of_point.astype(np.int64), map_w)
+    yy = np.minimum(y * 8 + 4, rgb_nhw3.shape[1] - 1)
+    xx = np.minimum(x * 8 + 4, rgb_nhw3.shape[2] - 1)
+    return rgb_nhw3[frame_of_point, yy, xx].astype(np.float64)
+
+
+def export_point_cloud_main(argv=None):
+    """export_point_cloud.py: from a visualisation buffer (host only) or from network + pose file (encoder -> head -> filter on
+    the device)."""
+    import pickle
+    import torch
+    from .pointcloud import write_point_cloud
+    parser = export_point_cloud_parser()
+    opt = parser.parse_args(argv)
+    logging.basicConfig(level=logging.INFO)
+    if opt.visualization_buffer is None and (opt.network is None or opt.pose_file is None):
+        parser.error("You must provide either a visualization buffer or network and pose file.")
+    if opt.dense_point_cloud and opt.visualization_buffer is not None:
+        parser.error("A dense cloud cannot be extracted from a visualization buffer. Please provide network and pose file.")
+    if opt.visualization_buffer is not None:
+        with open(opt.visualization_buffer, "rb") as f:
+            state = pickle.load(f)
+        xyz, clr = np.asarray(state["map_xyz"]).copy(), np.asarray(state["map_clr"])
+        if opt.convention == "opencv":                                   # the buffer holds OpenGL coordinates (:104-107)
+            xyz[:, 1], xyz[:, 2] = -xyz[:, 1], -xyz[:, 2]
+    else:
+        from .session import ReconstructionSession, default_options
+        files, c2w, focals = read_ace_pose_file(opt.pose_file, opt.confidence_threshold)
+        if not files:
+            raise SystemExit("no pose above the confidence threshold")
+        assert np.allclose(focals, focals[0]), "a single focal length is supported"
+        files, frames, fscale, rgb = load_frames(None, opt.image_resolution, files=files, return_rgb=True)
+        so = default_options(use_external_focal_length=focals[0] * fscale, use_aug=False, registration_confidence=opt.confidence_threshold)
+        ses = ReconstructionSession(torch.load(_default_encoder_path(opt.encoder_path), map_location="cpu"), frames, opt=so)
+        conf = np.full(len(files), np.inf)
+        xyz, src, sel = ses.point_cloud(torch.load(opt.network, map_location="cpu"), c2w, conf, ses.focal0, dense=opt.dense_point_cloud,
+                                        filter_depth=100, opengl=opt.convention == "opengl")
+        f, p = np.divmod(src.astype(np.int64), ses.hw)
+        clr = source_colours(rgb, sel[f], p, ses.ow)
+    write_point_cloud(opt.output_file, xyz, clr)
+    _logger.info(f"Done. Wrote point cloud to: {opt.output_file}")
     return 0

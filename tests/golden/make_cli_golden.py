@@ -1,4 +1,4 @@
-"""Dump the reference's argparse surface (flag names, defaults, choices) of train_ace.py, register_mapping.py and ace_zero.py
+"""Dump the reference's argparse surface (flag names, defaults, choices) of train_ace.py, register_mapping.py, ace_zero.py and export_point_cloud.py
 to tests/golden/cli_flags.json. Build container only (needs /root/reference). The parsers are captured by running
 the scripts with argparse.ArgumentParser.parse_args patched to raise after construction."""
 import argparse
@@ -49,7 +49,8 @@ def capture(script):
 if __name__ == "__main__":
     for name in ["joblib", "dataset_io"]:
         sys.modules.setdefault(name, MagicMock())
-    res = {"train_ace": capture("train_ace.py"), "register_mapping": capture("register_mapping.py"), "ace_zero": capture("ace_zero.py")}
+    res = {"train_ace": capture("train_ace.py"), "register_mapping": capture("register_mapping.py"), "ace_zero": capture("ace_zero.py"),
+           "export_point_cloud": capture("export_point_cloud.py")}
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "cli_flags.json"), "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
     print({k: len(v) for k, v in res.items()})

@@ -30,7 +30,8 @@ def _surface(parser):
 
 @pytest.mark.parametrize("name,parser,extra", [("train_ace", cli.train_parser, {"feature_buffer", "num_gpus"}),
                                                ("register_mapping", cli.register_parser, {"feature_file"}),
-                                               ("ace_zero", cli.ace_zero_parser, {"encoder_path"})])
+                                               ("ace_zero", cli.ace_zero_parser, {"encoder_path"}),
+                                               ("export_point_cloud", cli.export_point_cloud_parser, set())])
 def test_flag_surface_matches_reference(name, parser, extra, golden_dir):
     ref = json.load(open(os.path.join(golden_dir, "cli_flags.json")))[name]
     mine = _surface(parser())
@@ -120,3 +121,21 @@ def test_pose_files_are_the_reference_format_both_ways(golden_dir, tmp_path):
     assert files == [str(x) for x in ref["files"]] and np.allclose(focals, ref["focals"])
     assert np.allclose(c2w, ref["c2w"], atol=1e-6)          # the reference returns float32 matrices
     assert "scene/frame_001.png" not in files and "scene/frame_000.png" in files and "scene/frame_002.png" in files   # 499 dropped; inf, 500 kept
+
+
+def test_export_point_cloud_from_visualization_buffer(tmp_path):
+    """The host-only branch of export_point_cloud.py (:95-107): a pickled {'map_xyz', 'map_clr'} buffer in OpenGL coordinates."""
+    import pickle
+    xyz = np.array([[1.0, 2.0, 3.0], [-0.5, 0.25, 4.0]], np.float32)
+    clr = np.array([[10.0, 20.0, 30.0], [200.0, 100.0, 0.0]])
+    with open(tmp_path / "buf.pkl", "wb") as f:
+        pickle.dump({"map_xyz": xyz, "map_clr": clr}, f)
+    assert cli.export_point_cloud_main([str(tmp_path / "pc.txt"), "--visualization_buffer", str(tmp_path / "buf.pkl"), "--convention", "opencv"]) == 0
+    rows = [line.split() for line in open(tmp_path / "pc.txt").read().splitlines()]
+    assert [float(v) for v in rows[0][:3]] == [1.0, -2.0, -3.0] and rows[1][3:] == ["200", "100", "0"]
+    with pytest.raises(SystemExit):
+        cli.export_point_cloud_main([str(tmp_path / "pc.txt")])                                    # neither buffer nor network + pose file
+    with pytest.raises(SystemExit):
+        cli.export_point_cloud_main([str(tmp_path / "pc.txt"), "--visualization_buffer", str(tmp_path / "buf.pkl"), "--dense_point_cloud", "True"])
+    c = cli.source_colours(np.arange(2 * 16 * 24 * 3, dtype=np.uint8).reshape(2, 16, 24, 3), np.array([1, 0]), np.array([4, 0]), 3)
+    assert c.shape == (2, 3) and np.array_equal(c[1], np.arange(2 * 16 * 24 * 3, dtype=np.uint8).reshape(2, 16, 24, 3)[0, 4, 4])

@@ -1,6 +1,8 @@
 """End-to-end on the GPU (SURVEY 8f N1-N4 together): a view-consistent synthetic room, the stand-in encoder, then
 (1) mapping with known poses + relocalisation of held-out frames, (2) the whole ACE0 loop from a depth-supervised seed in one
 process. These are functional tests of the product (accuracy against ground-truth cameras), not parity tests."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -131,6 +133,22 @@ def test_ace_zero_script_from_image_files(tmp_path):
     assert head["fc3.weight"].dtype == torch.float16 and head["fc3.weight"].shape == (4, 512, 1, 1)               # save_model: half, Head keys
     ply = open(out / "pc_final.ply", "rb").read(200)
     assert ply.startswith(b"ply\nformat binary_little_endian")
+    # export_point_cloud.py on the final network + pose file (the reference's stand-alone export)
+    rc = cli.export_point_cloud_main([str(out / "pc.txt"), "--network", str(out / hist_last(out)), "--pose_file", str(out / "poses_final.txt"),
+                                      "--encoder_path", str(tmp_path / "encoder.pt"), "--convention", "opencv"])
+    assert rc == 0
+    pts = np.loadtxt(out / "pc.txt")
+    assert pts.shape[1] == 6 and len(pts) > 1000 and pts[:, 3:].min() >= 0 and pts[:, 3:].max() <= 255
+    assert np.allclose(pts[:, 3], pts[:, 4]) and np.allclose(pts[:, 4], pts[:, 5])                 # grey frames -> grey points
+    # the points lie on the room's walls in the reconstruction's frame: all within the room's diagonal of its centre
+    assert np.percentile(np.linalg.norm(pts[:, :3] - np.median(pts[:, :3], axis=0), axis=1), 95) < 8.0
+
+
+def hist_last(out):
+    """The last round's head checkpoint written by ace_zero.py (iteration<k>.pt with the largest k)."""
+    import re
+    ks = [int(m.group(1)) for m in (re.match(r"iteration(\d+)\.pt$", f) for f in os.listdir(out)) if m]
+    return f"iteration{max(ks)}.pt"
 
 
 def test_train_ace_and_register_mapping_scripts_on_image_files(tmp_path):
