@@ -16,7 +16,7 @@ import torch
 from . import _native as N
 from . import dsacstar
 from .encoder import Encoder, output_size
-from .head import HeadTrainer, _ptr, _stream
+from .head import HeadTrainer, _ptr, _stream, layer_names
 
 
 class Regressor:
@@ -33,6 +33,7 @@ class Regressor:
             kw = {"homogeneous_max_scale": float(hs["max_scale"]), "homogeneous_min_scale": float(hs["min_scale"])}
         oh, ow = output_size(max_h, max_w)
         self.encoder = Encoder.from_state_dict(encoder_state_dict, max_frames=max_frames, max_h=max_h, max_w=max_w, device=device)
+        self._enc_args = (max_frames, max_h, max_w)
         self.feature_dim = self.encoder.out_channels
         if self.feature_dim != 512:
             raise ValueError("the head kernels are built for 512 encoder features (ace_network.py:22 default)")
@@ -46,6 +47,33 @@ class Regressor:
     @classmethod
     def create_from_split_state_dict(cls, encoder_state_dict, head_state_dict, **kw):
         return cls(encoder_state_dict, head_state_dict, **kw)
+
+    @classmethod
+    def create_from_encoder(cls, encoder_state_dict, mean, num_head_blocks, use_homogeneous, seed=None, **kw):
+        """ace_network.py:177-199: pre-trained encoder + a freshly initialised head (nn.Conv2d's default init: uniform in
+        +-1/sqrt(fan_in) for weights and biases; `seed` makes it reproducible, the reference draws from the global generator)."""
+        import math
+        g = torch.Generator()
+        if seed is not None:
+            g.manual_seed(int(seed))
+        no = 4 if use_homogeneous else 3
+        bound = 1.0 / math.sqrt(512.0)
+        hs = {}
+        for name in layer_names(int(num_head_blocks)):
+            hs[name + ".weight"] = (torch.rand((512, 512, 1, 1), generator=g) * 2 - 1) * bound
+            hs[name + ".bias"] = (torch.rand((512,), generator=g) * 2 - 1) * bound
+        hs["fc3.weight"] = (torch.rand((no, 512, 1, 1), generator=g) * 2 - 1) * bound
+        hs["fc3.bias"] = (torch.rand((no,), generator=g) * 2 - 1) * bound
+        hs["mean"] = torch.as_tensor(mean, dtype=torch.float32).view(1, 3, 1, 1).clone()
+        return cls(encoder_state_dict, hs, **kw)
+
+    def load_encoder(self, encoder_dict_file):
+        """ace_network.py:253-257: replace the encoder weights from a checkpoint file."""
+        sd = torch.load(encoder_dict_file, map_location="cpu")
+        old = self.encoder
+        self.encoder = Encoder.from_state_dict(sd, max_frames=self._enc_args[0], max_h=self._enc_args[1], max_w=self._enc_args[2],
+                                               device=self.device.index)
+        old.close()
 
     @classmethod
     def create_from_state_dict(cls, state_dict, **kw):

@@ -56,3 +56,24 @@ def test_register_images_equals_stagewise_composition():
     poses2, inl2, _ = dsacstar.register_batch(sc, intr, params, 11, [5, 6], want_masks=False)
     assert torch.equal(poses, poses2) and torch.equal(inl, inl2)
     assert poses.shape == (2, 4, 4) and bool(torch.isfinite(poses).all())
+
+
+def test_create_from_encoder_and_load_encoder(tmp_path):
+    """Regressor.create_from_encoder (ace_network.py:177-199) and load_encoder (:253-257)."""
+    from acezero_amd.network import Regressor
+    esd = {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights(seed=4099).items()}
+    net = Regressor.create_from_encoder(esd, mean=torch.tensor([1.0, 2.0, 3.0]), num_head_blocks=2, use_homogeneous=False, seed=3, max_frames=2,
+                                        max_h=64, max_w=96)
+    sd = net.heads.state_dict()
+    assert "1c2.weight" in sd and "2c0.weight" not in sd and sd["fc3.weight"].shape == (3, 512, 1, 1)
+    assert float(sd["fc1.weight"].abs().max()) <= 1.0 / 512 ** 0.5 + 1e-7 and torch.equal(sd["mean"].view(3).cpu(), torch.tensor([1.0, 2.0, 3.0]))
+    img = torch.from_numpy(synth.make_gray_images(seed=2, n=2, h=64, w=96))
+    a = net(img).clone()
+    assert a.shape == (2, 3, 8, 12) and bool(torch.isfinite(a).all())
+    esd2 = {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights(seed=5).items()}
+    torch.save(esd2, tmp_path / "enc.pt")
+    net.load_encoder(tmp_path / "enc.pt")
+    b = net(img)
+    assert not torch.allclose(a, b)
+    ref = Regressor.create_from_split_state_dict(esd2, {k: v.cpu() for k, v in sd.items()}, max_frames=2, max_h=64, max_w=96)(img)
+    assert torch.equal(b, ref)
