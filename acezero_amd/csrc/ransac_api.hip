@@ -113,10 +113,16 @@ __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
   float* sY = sX + Npad;
   float* sZ = sY + Npad;
   float* sErr = sZ + Npad;
-  double* sRed = reinterpret_cast<double*>(sErr + Npad);  // [2][4][28]
-  double* sScores = sRed + 2 * 4 * 28;                    // [hyps]
+  // one fp64 region of max(7 * hyps, 232) doubles, used twice: during sampling / scoring / selection it holds the scores [hyps] and
+  // the sampled poses [hyps][6]; both are dead once the best hypothesis is chosen, and the refinement reuses the region for the LM
+  // step hand-over (6 doubles, padded to 8) and the double-buffered block-reduction scratch [2][4][28]. Keeping the two apart cost
+  // 1.8 KB more: 64 hypotheses then exceeded half of the 160 KiB LDS by 576 bytes and ran ONE workgroup per CU (20 ms vs 12 ms).
+  double* sRegion = reinterpret_cast<double*>(sErr + Npad);
+  double* sScores = sRegion;                              // [hyps]
   double* sHyp = sScores + a.hyps;                        // [hyps][6] sampled poses
-  int* sInt = reinterpret_cast<int*>(sHyp + 6 * a.hyps);  // [8]: best, counts[4]
+  double* sRed = sRegion + 8;                             // [2][4][28] (refinement only)
+  const int region = (7 * a.hyps > 232) ? 7 * a.hyps : 232;
+  int* sInt = reinterpret_cast<int*>(sRegion + region);   // [8]: best, counts[4]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frame = blockIdx.x;
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
     // The 6x6 solve is serial fp64 work with identical inputs on every lane (Cholesky: ~2 us; its eigen fallback ~55 us): only wavefront 0 runs it and
     // hands the step over through LDS, which leaves the other three SIMDs to the second workgroup of this CU
     // (every lm_step is followed by an lm_accumulate, whose block reduction orders the next overwrite of sStep).
-    double* sStep = sHyp;   // the sampled poses are dead after the selection
+    double* sStep = sRegion;   // the scores / sampled poses are dead after the selection
     if (wave == 0) {
       const double lambda = detm::pow10i(lambdaLg10);
       double A[36], x[6];
@@ -576,7 +582,8 @@ extern "C" int acez_register_rgb_device(acez_ransac* ctx, const float* d_scene_c
   a.hyp_poses = ctx->d_hyp_poses; a.scores = ctx->d_scores; a.best = ctx->d_best; a.refined = ctx->d_refined;
   a.out_poses = d_out_poses; a.out_inliers = d_out_inliers; a.out_masks = d_out_masks;
   const int Npad = (a.N + 3) & ~3;
-  const size_t lds = (size_t)4 * Npad * sizeof(float) + (size_t)(2 * 4 * 28 + 7 * params->hypotheses) * sizeof(double) + 8 * sizeof(int);
+  const int region = 7 * params->hypotheses > 232 ? 7 * params->hypotheses : 232;   // see the layout comment in ransac_kernel
+  const size_t lds = (size_t)4 * Npad * sizeof(float) + (size_t)region * sizeof(double) + 8 * sizeof(int);
   ACEZ_REQUIRE(lds <= 160 * 1024, "frame + hypotheses do not fit the 160 KB LDS of a CU");
   ACEZ_HIP_CHECK(hipFuncSetAttribute((const void*)ransac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(ransac_kernel, dim3(n_frames), dim3(256), lds, s, a);

@@ -12,11 +12,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 sc = torch.from_numpy(fr["scene_coords"]).cuda().repeat(n // 64, 1, 1, 1).contiguous()
 intr = [(fr["focal"], fr["ppx"], fr["ppy"])] * n
 ids = list(range(n))
-for name, hyps, tries, ref in (("full (32 hyps, 16 tries, refinement)", 32, 16, 100), ("no refinement", 32, 16, 0), ("one refinement round", 32, 16, 1),
-                               ("no refinement, 1 try", 32, 1, 0), ("1 hypothesis, 1 try, no refinement", 1, 1, 0),
+for name, hyps, tries, ref in (("full (32 hyps, 16 tries, refinement to convergence)", 32, 16, 100), ("one refinement round", 32, 16, 1),
+                               ("two refinement rounds", 32, 16, 2), ("8 hypotheses, one round", 8, 16, 1), ("32 hypotheses, 1 try, one round", 32, 1, 1),
                                ("64 hypotheses, refinement", 64, 16, 100)):
     prm = N.RansacParams(hyps, tries, 10.0, 100.0, 100.0, 8, ref, 0)
-    dsacstar.register_batch(sc, intr, prm, 1305, ids, want_masks=False)
+    for _ in range(4):                                   # the first launches after a context (re)allocation are slow
+        dsacstar.register_batch(sc, intr, prm, 1305, ids, want_masks=False)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
