@@ -880,7 +880,7 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
       int bsw[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int q = q0[j] + toff;
+        const int q = q0[0] + j * 32 + toff;      // q0[j] = q0[0] + 32 j: one live register instead of four
         const bool ok = (vmask[j] >> tap) & 1u;
         bp[j] = ok ? sP + q * 32 : sZero;
         bsw[j] = ok ? (q >> 2) & 3 : 0;
@@ -888,15 +888,20 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int c = kk * 2 + fh;
-        bf16x8 fa[2], fb[4];
+        bf16x8 fa[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz32(wn * 64 + i * 32 + fr, c)]);
+        // the four row fragments in two halves: two B fragments live at a time (the 128 accumulator registers leave ~40 for everything else)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bp[j] + ((c ^ bsw[j]) << 3));
+        for (int jh = 0; jh < 2; ++jh) {
+          bf16x8 fb[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bp[jh * 2 + j] + ((c ^ bsw[jh * 2 + j]) << 3));
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][jh * 2 + j], 0, 0, 0);
+        }
       }
       if (++tap == 9) { tap = 0; ++cc; }
     }
