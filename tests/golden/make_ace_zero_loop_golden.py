@@ -33,6 +33,8 @@ SCENARIOS = {
     "no_warmstart": (["--warmstart", "False"], [0.05, 0.10, 0.10, 0.40, 0.80, 0.995, 1.0, 1.0]),
     "naive_refinement_no_calibration": (["--refinement", "naive", "--refine_calibration", "False"], [0.2, 0.1, 0.2, 0.995, 1.0, 1.0]),
     "slow_growth": ([], [0.02, 0.01, 0.02, 0.10, 0.25, 0.45, 0.60, 0.605, 0.61, 0.61]),
+    # a pre-trained network instead of seed trials: the first register command uses it, mapping round 1 warm-starts from it
+    "seed_network": (["--seed_network", "SEEDDIR/seed_network.pt"], [0.30, 0.60, 0.995, 1.0, 1.0]),
 }
 
 
@@ -78,7 +80,7 @@ def run_scenario(name):
     dio.load_dataset_ace = load_dataset_ace
     sys.modules["dataset_io"] = dio
     argv = sys.argv
-    sys.argv = ["ace_zero.py", "scene/*.png", str(tmp), "--seed_parallel_workers", "1", "--try_seeds", "2"] + extra
+    sys.argv = ["ace_zero.py", "scene/*.png", str(tmp), "--seed_parallel_workers", "1", "--try_seeds", "2"] + [e.replace("SEEDDIR", str(tmp)) for e in extra]
     try:
         runpy.run_path(os.path.join(REF, "ace_zero.py"), run_name="__main__")
     finally:

@@ -165,13 +165,14 @@ def _reference_decisions(calls):
 
 
 @pytest.mark.parametrize("name", ["reaches_threshold", "relative_threshold", "no_final_refine", "no_final_refit", "iterations_max",
-                                  "no_warmstart", "naive_refinement_no_calibration", "slow_growth"])
+                                  "no_warmstart", "naive_refinement_no_calibration", "slow_growth", "seed_network"])
 def test_reconstruction_loop_makes_the_reference_decisions(golden_dir, name):
     g = json.load(open(os.path.join(golden_dir, "ace_zero_loop.json")))[name]
     argv = g["argv"]
     over = {argv[i].lstrip("-"): argv[i + 1] for i in range(0, len(argv), 2)}
     conv = {"final_refine": lambda v: v == "True", "final_refit": lambda v: v == "True", "warmstart": lambda v: v == "True",
-            "refine_calibration": lambda v: v == "True", "iterations_max": int, "refinement": str}
+            "refine_calibration": lambda v: v == "True", "iterations_max": int, "refinement": str,
+            "seed_network": lambda v: {"id": "seed_network"}}       # the session takes the loaded state_dict; ace_zero.py the file
     opt = session.default_options(try_seeds=2, **{k: conv[k](v) for k, v in over.items()})
     ses = _ScriptedSession(opt, g["rates"])
     res = ses.reconstruct()
@@ -183,5 +184,6 @@ def test_reconstruction_loop_makes_the_reference_decisions(golden_dir, name):
     assert len(g["rates"]) - len(ses._rates) == g["registers_used"]
     # mapping rounds use the frames registered above the confidence threshold in the previous round
     trains = [c for c in ses.calls if c["cmd"] == "train" and not c["seed"]]
-    assert [c["images"] for c in trains] == [round(r * 200) for r in g["rates"][2:2 + len(trains)]]
+    first = 0 if name == "seed_network" else 2          # rates consumed before the first mapping round: none / the two seed checks
+    assert [c["images"] for c in trains] == [round(r * 200) for r in g["rates"][first:first + len(trains)]]
     assert res["iterations"] == len(trains)
