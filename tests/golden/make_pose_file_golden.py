@@ -16,15 +16,8 @@ import dataset_io  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def poses(n=12, seed=5):
-    """world -> camera matrices (float64) and confidences, seeded."""
-    rng = np.random.default_rng(seed)
-    out = np.tile(np.eye(4), (n, 1, 1))
-    out[:, :3, :3] = Rotation.from_rotvec(rng.normal(0, 1.0, size=(n, 3))).as_matrix()
-    out[:, :3, 3] = rng.normal(0, 3.0, size=(n, 3))
-    conf = rng.integers(0, 3000, size=n)
-    conf[1], conf[2] = 499, 500          # the threshold itself is kept (confidence < threshold is dropped), 499 is not
-    return out, conf
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from tests.helpers import pose_file_cases as poses  # noqa: E402
 
 
 if __name__ == "__main__":

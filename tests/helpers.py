@@ -93,3 +93,17 @@ def cloud_case_inputs(name):
     poses_inv = np.linalg.inv(fr["poses"]).astype(np.float32)
     K = np.array([[fr["focal"], 0, fr["ppx"]], [0, fr["focal"], fr["ppy"]], [0, 0, 1]], np.float32)
     return fr["scene_coords"], poses_inv, np.stack([K] * n), loader_len, depth, dense
+
+
+# ---- pose-file cases (tests/golden/pose_file_ref.txt / .npz hold what the reference's writer / reader make of them) ----
+def pose_file_cases(n=12, seed=5):
+    """world -> camera matrices (float64) and confidences, seeded."""
+    import numpy as np
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    out = np.tile(np.eye(4), (n, 1, 1))
+    out[:, :3, :3] = Rotation.from_rotvec(rng.normal(0, 1.0, size=(n, 3))).as_matrix()
+    out[:, :3, 3] = rng.normal(0, 3.0, size=(n, 3))
+    conf = rng.integers(0, 3000, size=n)
+    conf[1], conf[2] = 499, 500          # the threshold itself is kept (confidence < threshold is dropped), 499 is not
+    return out, conf

@@ -105,12 +105,8 @@ def test_train_then_register_end_to_end(tmp_path):
 def test_pose_files_are_the_reference_format_both_ways(golden_dir, tmp_path):
     """tests/golden/pose_file_ref.txt was written by the reference's write_pose_to_pose_file and parsed by its load_dataset_ace
     (make_pose_file_golden.py): our writer must produce the same bytes, our reader the same entries."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("mk", os.path.join(golden_dir, "make_pose_file_golden.py"))
-    src = open(os.path.join(golden_dir, "make_pose_file_golden.py")).read()
-    ns = {}
-    exec(src[src.index("def poses("):src.index('if __name__ == "__main__":')], {"np": np, "Rotation": __import__("scipy.spatial.transform", fromlist=["Rotation"]).Rotation}, ns)
-    P, conf = ns["poses"]()
+    from tests.helpers import pose_file_cases
+    P, conf = pose_file_cases()
     out = tmp_path / "mine.txt"
     with open(out, "w") as f:
         for i in range(len(P)):
