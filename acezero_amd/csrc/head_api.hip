@@ -3,6 +3,7 @@
 #include "head_kernels.hip"
 #include "pose_kernels.hip"
 #include "head_fused.hip"
+#include "head_chain.hip"
 #include "conv_launch.h"
 #include <stdlib.h>
 #include "acez_common.h"
@@ -64,6 +65,10 @@ struct acez_trainer {
   // launches -> off by default; ACEZ_FUSED_FWD=1 selects it.
   bool fused_fwd = false;
   int gemm_tile = 80;  // rows per rowgemm workgroup: 80 (256 workgroups at batch 5120) or 128; ACEZ_GEMM_TILE overrides
+  // Row-persistent chain kernel (head_chain.hip): gather + forward + loss + input gradients in one launch. Default;
+  // ACEZ_CHAIN=0 selects the per-layer launches (rowgemm80 / loss_kernel), kept as the tested reference path.
+  bool chain = true;
+  uint2* maskbits = nullptr;   // [L][max_blocks][256] ReLU mask bits of the chain kernel
 };
 
 enum { KC_SCHED = 0, KC_GATHER, KC_GEMM_FWD, KC_LOSS, KC_GEMM_DGRAD, KC_WGRAD, KC_REDUCE, KC_ADAMW, KC_COUNT };
@@ -150,6 +155,8 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->max_batch = cfg->max_batch;
   if (const char* e = getenv("ACEZ_FUSED_FWD")) tr->fused_fwd = atoi(e) != 0;
   if (const char* e = getenv("ACEZ_GEMM_TILE")) tr->gemm_tile = atoi(e) == 128 ? 128 : 80;
+  if (const char* e = getenv("ACEZ_CHAIN")) tr->chain = atoi(e) != 0;
+  if (tr->fused_fwd) tr->chain = false;
   tr->nslabs = 256 / (16 * tr->L);
   if (tr->nslabs < 1) tr->nslabs = 1;
 
@@ -173,6 +180,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->bias_layer_stride = (int64_t)max_blocks * 512;
   A((void**)&tr->bias_partials, (size_t)tr->L * tr->bias_layer_stride * sizeof(float));
   A((void**)&tr->xyz, (size_t)tr->max_batch * 3 * sizeof(float));
+  A((void**)&tr->maskbits, (size_t)tr->L * max_blocks * 256 * sizeof(uint2));
   A((void**)&tr->zeros, 1024);
   tr->log_cap = cfg->iterations + 8;
   A((void**)&tr->log_loss, (size_t)tr->log_cap * sizeof(float));
@@ -318,6 +326,66 @@ static void fill_loss_head(acez_trainer* tr, LossArgs& a) {
   a.max_inv_scale = tr->cfg.head.max_inv_scale; a.min_inv_scale = tr->cfg.head.min_inv_scale; a.h_beta = tr->cfg.head.h_beta;
 }
 
+
+// training-mode arguments of the loss phases (loss_kernel / the chain kernel's loss phase)
+static void fill_loss_train(acez_trainer* tr, LossArgs& a, const uint16_t* act, const int64_t* d_indices, int n, bool pose_tables) {
+  const int f2 = 3 * (tr->nb + 1) + 1;
+  fill_loss_head(tr, a);
+  a.act = act; a.n = n;
+  a.idx = d_indices; a.target_px = tr->buf.d_target_px; a.target_crds = tr->buf.d_target_crds; a.view_idx = tr->buf.d_view_idx;
+  a.view_aug_inv = tr->buf.d_view_aug_inv; a.view_K = tr->buf.d_view_K; a.view_Kinv = tr->buf.d_view_Kinv;
+  a.view_image = tr->buf.d_view_image; a.image_pose_inv = pose_tables ? tr->pose_cur : tr->buf.d_image_pose_inv;
+  a.row_dT = pose_tables ? tr->row_dT : nullptr; a.row_image = pose_tables ? tr->row_image : nullptr;
+  a.loss_type = tr->cfg.loss_type; a.refine_calibration = tr->cfg.refine_calibration;
+  a.hard_clamp = tr->cfg.hard_clamp; a.depth_min = tr->cfg.depth_min; a.depth_max = tr->cfg.depth_max;
+  a.depth_target = tr->cfg.depth_target; a.inlier_px = tr->cfg.inlier_px_threshold;
+  a.inv_batch = 1.0f / (float)tr->cfg.global_batch; a.focal_init = tr->cfg.focal_init;
+  a.st = tr->st; a.out_xyz = tr->xyz; a.dZ = tr->dZ[f2];
+  a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
+  a.bias_partials = tr->bias_partials + (size_t)f2 * tr->bias_layer_stride; a.dbg = 0;
+}
+
+// The dependent chain of a step as one launch of chain_kernel (head_chain.hip). phases: 1 = gather + forward (the fc2 output
+// is stored for a later phase-2 launch), 2 = loss + input gradients (from the stored fc2 output), 3 = everything.
+static void launch_chain(acez_trainer* tr, const int64_t* d_indices, int n, int phases, bool pose_tables, hipStream_t s) {
+  const int nb = tr->nb, f1 = 3 * (nb + 1), f2 = f1 + 1;
+  ChainArgs c{};
+  c.src = (phases & 1) ? (const uint16_t*)tr->buf.d_features : tr->out[f2];
+  c.idx = d_indices; c.g_in = tr->R[0]; c.maskbits = tr->maskbits;
+  c.bias_partials = tr->bias_partials; c.bias_layer_stride = tr->bias_layer_stride;
+  c.n = n; c.phases = phases; c.st = tr->st;
+  const float* P = tr->pb.d_params;
+  int k = 0;
+  auto fwd = [&](int l, uint16_t* g_out, int residual, int mask_layer) {
+    ChainStep& S = c.step[k++];
+    S.W = tr->Wb + (size_t)l * 262144; S.bias = P + (int64_t)l * 262656 + 262144; S.g_out = g_out;
+    S.residual = residual; S.add = 0; S.aux = 0; S.mask_layer = mask_layer; S.bias_slot = 0;
+  };
+  for (int b = 0; b <= nb; ++b) {
+    fwd(3 * b, tr->out[3 * b], 0, 3 * b);
+    fwd(3 * b + 1, tr->out[3 * b + 1], 0, 3 * b + 1);
+    fwd(3 * b + 2, tr->R[b + 1], 1, 3 * b + 2);   // the relu output itself is only needed as a mask (bits); R[b+1] feeds wgrad
+  }
+  fwd(f1, tr->out[f1], 0, f1);
+  fwd(f2, phases == 1 ? tr->out[f2] : nullptr, 0, -1);   // fc2's mask is applied by the loss phase from the tile itself
+  c.n_fwd = k;
+  auto bwd = [&](int l, int l_out, int add, int aux) {
+    ChainStep& S = c.step[k++];
+    S.W = tr->WbT + (size_t)l * 262144; S.bias = nullptr; S.g_out = tr->dZ[l_out];
+    S.residual = 0; S.add = add; S.aux = aux; S.mask_layer = l_out; S.bias_slot = l_out;
+  };
+  bwd(f2, f1, 0, 0);
+  bwd(f1, 3 * nb + 2, 0, 1);
+  for (int b = nb; b >= 0; --b) {
+    bwd(3 * b + 2, 3 * b + 1, 0, 0);
+    bwd(3 * b + 1, 3 * b, 0, 0);
+    if (b > 0) bwd(3 * b, 3 * (b - 1) + 2, 1, 1);
+  }
+  c.n_bwd = k - c.n_fwd;
+  fill_loss_train(tr, c.loss, nullptr, d_indices, n, pose_tables);
+  hipLaunchKernelGGL(chain_kernel, dim3((n + CHAIN_ROWS - 1) / CHAIN_ROWS), dim3(CHAIN_THREADS), 0, s, c);
+}
+
 // ---- pose refinement (the flat parameter offsets in PoseNetwork.named_parameters() order are PN_* in pose_kernels.hip)
 static PoseNetArgs pose_net_args(acez_trainer* tr, const int* active) {
   PoseNetArgs a{};
@@ -391,6 +459,51 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   const TrainState* st = tr->st;
   tr->last_n = n;
 
+  const bool pose_naive = tr->cfg.pose_refinement == 1;
+  const bool pose_mlp = tr->cfg.pose_refinement == 2 || pose_naive;   // both need the refined-pose table and per-row pose gradients
+  // Pose refinement on its own stream: the refined poses are needed by the loss phase only, so their launches run beside the
+  // head's forward chain; the pose-gradient launches run beside the input-gradient chain and wgrad.
+  hipStream_t ps = (pose_mlp && tr->pose_stream) ? tr->pose_stream : s;
+  const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
+  const int nblk = (n + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS);
+  auto pose_fwd_launches = [&](hipStream_t q) {
+    if (tr->cfg.pose_refinement == 2) pose_forward(tr, &tr->st->active, q);
+    if (pose_naive)   // refine_poses.py:224-234: the poses themselves are the parameters; P = 0 + 1 * params, then Gram-Schmidt
+      hipLaunchKernelGGL(pose_compose_kernel, dim3((tr->buf.n_images + 255) / 256), dim3(256), 0, q, (const float*)tr->pa1,
+                         (const float*)tr->pb.d_pose_params, 1.0f, tr->pose_cur, tr->buf.n_images, (const int*)&tr->st->active, tr->cfg.pose_refinement_ortho);
+  };
+  auto pose_bwd_launches = [&](hipStream_t q) {
+    if (tr->cfg.pose_refinement == 2) pose_backward(tr, n, &tr->st->active, q);
+    if (pose_naive) {
+      const int I = tr->buf.n_images;
+      launch_pose_grad_reduce(tr, n, (const int*)&tr->st->active, q);
+      hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((I + 255) / 256), dim3(256), 0, q, (const float*)tr->pa1, (const float*)tr->pb.d_pose_params, 1.0f,
+                         (const float*)tr->pdT, tr->pb.d_grad + tr->n_params + 4, I, (const int*)&tr->st->active, tr->cfg.pose_refinement_ortho);
+    }
+  };
+
+  if (tr->chain) {
+    // ---- one launch for gather + forward + loss + input gradients (head_chain.hip). The schedule bookkeeping that closes the
+    // previous step must be complete before it starts (its workgroups read the state), so it is its own small launch here.
+    flush_post(tr, s);
+    if (ps != s) {
+      ACEZ_HIP_CHECK(hipEventRecord(tr->ev_begin, s));
+      ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_begin, 0));
+      pose_fwd_launches(ps);                                       // beside the forward half of the chain
+      ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_fwd, ps));
+      { ProfScope sc(tr, s, KC_GEMM_FWD); launch_chain(tr, d_indices, n, 1, pose_mlp, s); tr->prof_launches += tr->L; }
+      ACEZ_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_pose_fwd, 0));   // the loss phase projects with the refined poses
+      { ProfScope sc(tr, s, KC_GEMM_DGRAD); launch_chain(tr, d_indices, n, 2, pose_mlp, s); tr->prof_launches += tr->L - 1; }
+      ACEZ_HIP_CHECK(hipEventRecord(tr->ev_loss, s));
+      ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_loss, 0));
+      pose_bwd_launches(ps);                                       // beside wgrad
+      ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_bwd, ps));
+    } else {
+      pose_fwd_launches(s);
+      { ProfScope sc(tr, s, KC_GEMM_FWD); launch_chain(tr, d_indices, n, 3, pose_mlp, s); tr->prof_launches += 2 * tr->L - 1; }
+      pose_bwd_launches(s);
+    }
+  } else {
   uint16_t* act = nullptr;
   if (tr->fused_fwd) {
     flush_post(tr, s);
@@ -407,40 +520,18 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   }
   delete psg;
   }
-  const bool pose_naive = tr->cfg.pose_refinement == 1;
-  const bool pose_mlp = tr->cfg.pose_refinement == 2 || pose_naive;   // both need the refined-pose table and per-row pose gradients
-  // Pose refinement on its own stream: the refined poses are needed by the loss kernel only, so their ~9 tiny launches run
-  // beside the head's forward chain; the pose-gradient launches (~17) run beside the input-gradient chain and wgrad.
-  hipStream_t ps = (pose_mlp && tr->pose_stream) ? tr->pose_stream : s;
   if (ps != s) {   // after the schedule bookkeeping of step_begin (the pose kernels read st->active / pose_enable)
     ACEZ_HIP_CHECK(hipEventRecord(tr->ev_begin, s));
     ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_begin, 0));
   }
-  if (tr->cfg.pose_refinement == 2) pose_forward(tr, &tr->st->active, ps);
-  if (pose_naive)   // refine_poses.py:224-234: the poses themselves are the parameters; P = 0 + 1 * params, then Gram-Schmidt
-    hipLaunchKernelGGL(pose_compose_kernel, dim3((tr->buf.n_images + 255) / 256), dim3(256), 0, ps, (const float*)tr->pa1,
-                       (const float*)tr->pb.d_pose_params, 1.0f, tr->pose_cur, tr->buf.n_images, (const int*)&tr->st->active, tr->cfg.pose_refinement_ortho);
+  pose_fwd_launches(ps);
   if (ps != s) ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_fwd, ps));
   if (!tr->fused_fwd) act = launch_forward(tr, tr->R[0], n, st, s);
   if (ps != s) ACEZ_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_pose_fwd, 0));   // the loss kernel projects with the refined poses
 
-  const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
-  const int nblk = (n + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS);
   {
     LossArgs a{};
-    fill_loss_head(tr, a);
-    a.act = act; a.n = n;
-    a.idx = d_indices; a.target_px = tr->buf.d_target_px; a.target_crds = tr->buf.d_target_crds; a.view_idx = tr->buf.d_view_idx;
-    a.view_aug_inv = tr->buf.d_view_aug_inv; a.view_K = tr->buf.d_view_K; a.view_Kinv = tr->buf.d_view_Kinv;
-    a.view_image = tr->buf.d_view_image; a.image_pose_inv = pose_mlp ? tr->pose_cur : tr->buf.d_image_pose_inv;
-    a.row_dT = pose_mlp ? tr->row_dT : nullptr; a.row_image = pose_mlp ? tr->row_image : nullptr;
-    a.loss_type = tr->cfg.loss_type; a.refine_calibration = tr->cfg.refine_calibration;
-    a.hard_clamp = tr->cfg.hard_clamp; a.depth_min = tr->cfg.depth_min; a.depth_max = tr->cfg.depth_max;
-    a.depth_target = tr->cfg.depth_target; a.inlier_px = tr->cfg.inlier_px_threshold;
-    a.inv_batch = 1.0f / (float)tr->cfg.global_batch; a.focal_init = tr->cfg.focal_init;
-    a.st = st; a.out_xyz = tr->xyz; a.dZ = tr->dZ[f2];
-    a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
-    a.bias_partials = tr->bias_partials + (size_t)f2 * tr->bias_layer_stride; a.dbg = 0;
+    fill_loss_train(tr, a, act, d_indices, n, pose_mlp);
     ProfScope ps(tr, s, KC_LOSS);
     hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, s, a);
   }
@@ -449,13 +540,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     ACEZ_HIP_CHECK(hipEventRecord(tr->ev_loss, s));
     ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_loss, 0));
   }
-  if (tr->cfg.pose_refinement == 2) pose_backward(tr, n, &tr->st->active, ps);
-  if (pose_naive) {
-    const int I = tr->buf.n_images;
-    launch_pose_grad_reduce(tr, n, (const int*)&tr->st->active, ps);
-    hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((I + 255) / 256), dim3(256), 0, ps, (const float*)tr->pa1, (const float*)tr->pb.d_pose_params, 1.0f,
-                       (const float*)tr->pdT, tr->pb.d_grad + tr->n_params + 4, I, (const int*)&tr->st->active, tr->cfg.pose_refinement_ortho);
-  }
+  pose_bwd_launches(ps);
   if (ps != s) ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_bwd, ps));
 
   // input-gradient chain
@@ -482,6 +567,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   }
 
   delete dchain;
+  }
   // weight gradients of all wide layers in one launch
   {
     WgradArgs a{};
@@ -505,7 +591,8 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     a.n_wide = tr->n_wide; a.n_params = tr->n_params; a.st = st;
     a.bias_partials = tr->bias_partials; a.bias_layer_stride = tr->bias_layer_stride; a.n_layers = tr->L;
     a.skip_wide = fused ? 1 : 0;
-    for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2) ? nblk : (tr->gemm_tile == 80 ? (n + 79) / 80 : 2 * ((n + 127) / 128));
+    // partial rows per layer: one per 32-row workgroup from the chain kernel / the loss kernel, one per row tile from rowgemm
+    for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2 || tr->chain) ? nblk : (tr->gemm_tile == 80 ? (n + 79) / 80 : 2 * ((n + 127) / 128));
     tr->last_reduce = a;   // the fused update reduces the partials itself
     if (!fused) {
       const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
@@ -666,6 +753,26 @@ extern "C" int acez_trainer_get_profile(acez_trainer* tr, float* h_ms8, int32_t*
   }
   tr->ev_used.clear();
   tr->ev_next = 0;
+  return ACEZ_OK;
+}
+
+// Diagnostics for the tests: copy one of the trainer's intermediate device buffers to the host. kind 0: post-ReLU output of wide
+// layer `index` [n][512] bf16; 1: dZ of layer `index` [n][512] bf16; 2: residual stream `index` [n][512] bf16 (0 = the gathered
+// batch); 3: weight-gradient slab `index` [n_wide] fp32; 4: bias-gradient partial rows of layer `index` [max_blocks][512] fp32.
+extern "C" int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, void* h_out, int64_t bytes, void* stream) {
+  ACEZ_REQUIRE(tr && h_out && bytes > 0, "null pointer");
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  const void* src = nullptr;
+  int64_t cap = 0;
+  const int64_t act_bytes = (int64_t)tr->max_batch * 512 * 2;
+  if (kind == 0 && index >= 0 && index < tr->L) { src = tr->out[index]; cap = act_bytes; }
+  else if (kind == 1 && index >= 0 && index < tr->L) { src = tr->dZ[index]; cap = act_bytes; }
+  else if (kind == 2 && index >= 0 && index < tr->nb + 2) { src = tr->R[index]; cap = act_bytes; }
+  else if (kind == 3 && index >= 0 && index < tr->nslabs) { src = tr->slabs + (size_t)index * tr->n_wide; cap = tr->n_wide * 4; }
+  else if (kind == 4 && index >= 0 && index < tr->L) { src = tr->bias_partials + (size_t)index * tr->bias_layer_stride; cap = tr->bias_layer_stride * 4; }
+  ACEZ_REQUIRE(src && bytes <= cap, "unknown buffer or size out of range");
+  ACEZ_HIP_CHECK(hipMemcpyAsync(h_out, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return ACEZ_OK;
 }
 

@@ -39,9 +39,7 @@ struct HeadFwdArgs {
   const TrainState* st;
 };
 
-// activation tile addressing: [32][512] bf16, 16-byte chunk index XOR (row & 15): the 16 rows a ds_read_b128
-// lane group touches land on 16 different slots of the 256-byte bank row
-__device__ __forceinline__ int act_off(int row, int ch) { return row * 512 + ((((ch >> 3) ^ (row & 15)) << 3) | (ch & 7)); }
+// activation tile addressing: act_off() of head_kernels.hip
 
 __global__ __launch_bounds__(256, 1) void headfwd_kernel(HeadFwdArgs a) {
   if (a.st && !a.st->active) return;

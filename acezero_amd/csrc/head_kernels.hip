@@ -618,34 +618,51 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
 constexpr int LOSS_ROWS = 8;
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
-__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
-  if (a.st && !a.st->active) return;
-  // four independent wavefronts of LOSS_ROWS = 8 rows each; only the gradient partials are combined across them (in
-  // wave order) so that a workgroup emits ONE partial per 32 rows
-  __shared__ float s_s_all[4][LOSS_ROWS][4];
-  __shared__ float s_ds_all[4][LOSS_ROWS][4];
-  __shared__ float s_red_all[4][LOSS_ROWS][4];
-  __shared__ float s_comb[3][40][64];   // waves 1..3 -> wave 0
-  const int wv = threadIdx.x >> 6;
-  float (*s_s)[4] = s_s_all[wv];
-  float (*s_ds)[4] = s_ds_all[wv];
-  float (*s_red)[4] = s_red_all[wv];
-  const int t = threadIdx.x & 63, l = t;
-  const int m0 = (blockIdx.x * 4 + wv) * LOSS_ROWS;
-  const int n = a.n, no = a.no;
+// [32][512] bf16 activation tile of the row-persistent kernels (head_fused.hip, head_chain.hip): 16-byte chunk index XOR
+// (row & 15), so that the 16 rows a ds_read_b128 lane group touches land on 16 different slots of a 256-byte bank row
+__device__ __forceinline__ int act_off(int row, int ch) { return row * 512 + ((((ch >> 3) ^ (row & 15)) << 3) | (ch & 7)); }
 
-  // phase B's per-row inputs sit behind a chain of dependent loads (idx -> view -> image): start it now so that its
-  // latency hides under phase A
-  int64_t pre_p = 0;
-  int pre_view = 0, pre_img = 0;
-  float pre_tu = 0.f, pre_tv = 0.f;
-  if (a.idx && t < LOSS_ROWS && m0 + t < n) {
-    pre_p = a.idx[m0 + t];
-    pre_view = a.view_idx[pre_p];
-    pre_img = a.view_image[pre_view];
-    pre_tu = a.target_px[pre_p * 2 + 0];
-    pre_tv = a.target_px[pre_p * 2 + 1];
+// phase B's per-row inputs sit behind a chain of dependent loads (idx -> view -> image): they are fetched early (at kernel
+// entry) so that the latency hides under phase A / under the forward GEMMs of the chain kernel
+struct LossPre {
+  int64_t p;
+  int view, img;
+  float tu, tv;
+};
+__device__ __forceinline__ LossPre loss_prefetch(const LossArgs& a, int m0, int t) {
+  LossPre q{0, 0, 0, 0.f, 0.f};
+  if (a.idx && t < LOSS_ROWS && m0 + t < a.n) {
+    q.p = a.idx[m0 + t];
+    q.view = a.view_idx[q.p];
+    q.img = a.view_image[q.view];
+    q.tu = a.target_px[q.p * 2 + 0];
+    q.tv = a.target_px[q.p * 2 + 1];
   }
+  return q;
+}
+
+// LDS scratch of the loss phases, in floats: s_s / s_ds / s_red [4 waves][LOSS_ROWS][4], s_comb [3][40][64] (waves 1..3 ->
+// wave 0), s_small [3][8]
+constexpr int LOSS_SCRATCH_FLOATS = 3 * 4 * LOSS_ROWS * 4 + 3 * 40 * 64 + 3 * 8;
+
+// The three phases for the 32 rows of workgroup `block` (four wavefronts wv = 0..3 of 64 lanes t). LDSACT = false: the fc2
+// output is read from a.act and dZ goes to a.dZ (loss_kernel). LDSACT = true: both live in the swizzled LDS tile `Xt`
+// (act_off) of the chain kernel, dZ overwrites the activations in place and is ALSO written to a.dZ. The four waves meet
+// once (__syncthreads: every wave of the workgroup must arrive, also waves that do not run this function).
+template <bool LDSACT>
+__device__ __forceinline__ void loss_body(const LossArgs& a, const int block, const int wv, const int t, uint16_t* Xt, float* scratch,
+                                          const LossPre pre) {
+  float (*s_s)[4] = reinterpret_cast<float (*)[4]>(scratch + wv * LOSS_ROWS * 4);
+  float (*s_ds)[4] = reinterpret_cast<float (*)[4]>(scratch + (4 + wv) * LOSS_ROWS * 4);
+  float (*s_red)[4] = reinterpret_cast<float (*)[4]>(scratch + (8 + wv) * LOSS_ROWS * 4);
+  float (*s_comb)[40][64] = reinterpret_cast<float (*)[40][64]>(scratch + 12 * LOSS_ROWS * 4);
+  float (*s_small)[8] = reinterpret_cast<float (*)[8]>(scratch + 12 * LOSS_ROWS * 4 + 3 * 40 * 64);
+  const int l = t;
+  const int m0 = (block * 4 + wv) * LOSS_ROWS;
+  const int n = a.n, no = a.no;
+  const int64_t pre_p = pre.p;
+  const int pre_view = pre.view, pre_img = pre.img;
+  const float pre_tu = pre.tu, pre_tv = pre.tv;
 
   // ---- phase A
   {
@@ -666,7 +683,8 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
       const int r = rr, m = m0 + r;
       float x[8];
       if (m < n) {
-        const uint4 v = *reinterpret_cast<const uint4*>(a.act + (size_t)m * 512 + l * 8);
+        const uint4 v = LDSACT ? *reinterpret_cast<const uint4*>(&Xt[act_off(wv * LOSS_ROWS + r, l * 8)])
+                               : *reinterpret_cast<const uint4*>(a.act + (size_t)m * 512 + l * 8);
         unpack4(make_uint2(v.x, v.y), &x[0]);
         unpack4(make_uint2(v.z, v.w), &x[4]);
       } else {
@@ -897,7 +915,8 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
 #pragma unroll
     for (int r = 0; r < LOSS_ROWS; ++r) {
       const int m = min(m0 + r, n - 1);  // rows past the end carry ds == 0 and are not stored
-      const uint4 v = *reinterpret_cast<const uint4*>(a.act + (size_t)m * 512 + 8 * t);
+      const uint4 v = LDSACT ? *reinterpret_cast<const uint4*>(&Xt[act_off(wv * LOSS_ROWS + r, 8 * t)])
+                             : *reinterpret_cast<const uint4*>(a.act + (size_t)m * 512 + 8 * t);
       float x[8], d[8];
       unpack4(make_uint2(v.x, v.y), &x[0]);
       unpack4(make_uint2(v.z, v.w), &x[4]);
@@ -916,6 +935,8 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
       for (int e = 0; e < 8; ++e)
         if (!(x[e] > 0.f)) d[e] = 0.f;  // relu mask of the fc2 output
       const uint2 lo = pack4(d[0], d[1], d[2], d[3]), hi = pack4(d[4], d[5], d[6], d[7]);
+      // chain kernel: the gradient replaces the activations of this row in the LDS tile (rows past the end become zero rows)
+      if (LDSACT) *reinterpret_cast<uint4*>(&Xt[act_off(wv * LOSS_ROWS + r, 8 * t)]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
       if (m0 + r < n) {
         *reinterpret_cast<uint4*>(a.dZ + (size_t)m * 512 + 8 * t) = make_uint4(lo.x, lo.y, hi.x, hi.y);
         float q[8];
@@ -937,7 +958,6 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) s_comb[wv - 1][32 + e][t] = bsum[e];
     }
-    __shared__ float s_small[3][8];
     if (wv > 0 && t < 4) s_small[wv - 1][t] = stat;
     if (wv > 0 && t < no) s_small[wv - 1][4 + t] = fb3;
     __syncthreads();
@@ -953,10 +973,10 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
         if (t < 3) stat += s_small[u][t];
         if (t < no) fb3 += s_small[u][4 + t];
       }
-      float* bp = a.bias_partials + (size_t)blockIdx.x * 512 + 8 * t;
+      float* bp = a.bias_partials + (size_t)block * 512 + 8 * t;
       *reinterpret_cast<float4*>(bp) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
       *reinterpret_cast<float4*>(bp + 4) = make_float4(bsum[4], bsum[5], bsum[6], bsum[7]);
-      float* gp = a.fc3_partials + (size_t)blockIdx.x * a.fc3_stride;
+      float* gp = a.fc3_partials + (size_t)block * a.fc3_stride;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (j < no) {
@@ -964,9 +984,17 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
           *reinterpret_cast<float4*>(gp + (size_t)j * 512 + 8 * t + 4) = make_float4(gw[j][4], gw[j][5], gw[j][6], gw[j][7]);
         }
       if (t < no) gp[(size_t)no * 512 + t] = fb3;
-      if (t < 3) a.stat_partials[(size_t)blockIdx.x * 4 + t] = stat;
+      if (t < 3) a.stat_partials[(size_t)block * 4 + t] = stat;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
+  if (a.st && !a.st->active) return;
+  __shared__ float scratch[LOSS_SCRATCH_FLOATS];
+  const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
+  const LossPre pre = loss_prefetch(a, (blockIdx.x * 4 + wv) * LOSS_ROWS, t);
+  loss_body<false>(a, blockIdx.x, wv, t, nullptr, scratch, pre);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -251,6 +251,21 @@ class HeadTrainer:
         N.check(self.lib.acez_trainer_get_profile(self._h, ms.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
 
+    DEBUG_KINDS = {"out": 0, "dZ": 1, "R": 2, "slab": 3, "bias_partials": 4}
+
+    def debug_read(self, kind, index, rows):
+        """Intermediate buffer of the last backward call (tests): 'out' / 'dZ' / 'R' -> uint16 [rows,512] (bf16 bit patterns),
+        'slab' -> float32 [n_wide], 'bias_partials' -> float32 [rows,512]."""
+        if kind in ("out", "dZ", "R"):
+            out = np.zeros((rows, 512), np.uint16)
+        elif kind == "slab":
+            out = np.zeros(self.L * 262656, np.float32)
+        else:
+            out = np.zeros((rows, 512), np.float32)
+        N.check(self.lib.acez_trainer_debug_read(self._h, self.DEBUG_KINDS[kind], int(index), out.ctypes.data_as(C.c_void_p),
+                                                 out.nbytes, _stream()))
+        return out
+
     def current_poses(self):
         """Refined world->cam poses [n_images,3,4] (PoseRefiner.get_all_current_poses, refine_poses.py:184-210)."""
         n = int(self._buf["image_pose_inv"].shape[0])

@@ -253,6 +253,12 @@ int acez_trainer_last_scene_coords(acez_trainer* tr, float* h_xyz, int n, void* 
 int acez_trainer_set_profiling(acez_trainer* tr, int enable);
 int acez_trainer_get_profile(acez_trainer* tr, float* h_ms8, int32_t* h_counts8);
 
+/* Diagnostics for the tests: copy one intermediate device buffer of the last backward call to the host (synchronous).
+ * kind 0: post-ReLU output of wide layer `index`, bf16 [n][512];  1: dZ of layer `index`, bf16 [n][512];
+ * 2: residual stream `index` (0 = the gathered batch), bf16 [n][512];  3: weight-gradient slab `index`, f32 [n_wide];
+ * 4: bias-gradient partial rows of layer `index`, f32 [max_batch/32][512].  No reference counterpart (autograd internals). */
+int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, void* h_out, int64_t bytes, void* stream);
+
 /* Current refined world->cam poses of all images, f32 [n_images][3][4] (PoseRefiner.get_all_current_poses,
  * refine_poses.py:184-210); the original poses when pose refinement is off. Synchronous. */
 int acez_trainer_get_poses(acez_trainer* tr, float* h_poses34, void* stream);
