@@ -51,6 +51,24 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chu
 // the row-wise copy)
 __device__ __forceinline__ int st_off(int row, int col) { return row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7)); }
 
+// Cross-lane sums with DPP (no LDS traffic, unlike __shfl_xor = ds_bpermute). row16_sum: sum over the 16 lanes of a DPP row (the
+// lanes that share l >> 4), every lane of the row gets it. wave_sum63: sum over the wavefront, valid in lanes 48..63. Fixed
+// orders -> deterministic.
+#define ACEZ_DPP_ADD(v, ctrl, rowmask) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rowmask), 0xF, false)))
+__device__ __forceinline__ float row16_sum(float v) {
+  v = ACEZ_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+  v = ACEZ_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+  v = ACEZ_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror
+  v = ACEZ_DPP_ADD(v, 0x140, 0xF);   // row_mirror
+  return v;
+}
+__device__ __forceinline__ float wave_sum63(float v) {
+  v = row16_sum(v);
+  v = ACEZ_DPP_ADD(v, 0x142, 0xA);   // row_bcast:15 -> rows 1 and 3 add the sum of the row before
+  v = ACEZ_DPP_ADD(v, 0x143, 0xC);   // row_bcast:31 -> rows 2 and 3 add the sum of rows 0..1
+  return v;
+}
+
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 #define ACEZ_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")

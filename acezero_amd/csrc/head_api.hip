@@ -65,10 +65,14 @@ struct acez_trainer {
   // launches -> off by default; ACEZ_FUSED_FWD=1 selects it.
   bool fused_fwd = false;
   int gemm_tile = 80;  // rows per rowgemm workgroup: 80 (256 workgroups at batch 5120) or 128; ACEZ_GEMM_TILE overrides
-  // Row-persistent chain kernel (head_chain.hip): gather + forward + loss + input gradients in one launch. Default;
-  // ACEZ_CHAIN=0 selects the per-layer launches (rowgemm80 / loss_kernel), kept as the tested reference path.
-  bool chain = true;
-  uint2* maskbits = nullptr;   // [L][max_blocks][256] ReLU mask bits of the chain kernel
+  // Row-persistent chain kernel (head_chain.hip): gather + forward + loss + input gradients in one launch, bit-exact with the
+  // per-layer launches (tests/test_chain_gpu.py). Measured on MI355X at batch 5120: 141-148 us for the chain against 147 us for
+  // the 17 launches it replaces, plus a separate schedule launch -> NOT faster; opt-in with ACEZ_CHAIN=1.
+  bool chain = false;
+  uint32_t* maskbits = nullptr;   // [L][max_blocks][512] ReLU mask bits of the chain kernel
+  unsigned long long* chain_trace = nullptr;   // [2][256] s_memtime stamps (ACEZ_CHAIN_TRACE=1; acez_trainer_debug_read kind 5)
+  int* chain_err = nullptr;       // sticky error word of the chain kernel (a bounded spin expired)
+  std::vector<uint16_t*> dRc;     // residual-gradient buffers of the chain kernel, one per fan-in (never re-read after a rewrite)
 };
 
 enum { KC_SCHED = 0, KC_GATHER, KC_GEMM_FWD, KC_LOSS, KC_GEMM_DGRAD, KC_WGRAD, KC_REDUCE, KC_ADAMW, KC_COUNT };
@@ -180,7 +184,14 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->bias_layer_stride = (int64_t)max_blocks * 512;
   A((void**)&tr->bias_partials, (size_t)tr->L * tr->bias_layer_stride * sizeof(float));
   A((void**)&tr->xyz, (size_t)tr->max_batch * 3 * sizeof(float));
-  A((void**)&tr->maskbits, (size_t)tr->L * max_blocks * 256 * sizeof(uint2));
+  A((void**)&tr->maskbits, (size_t)tr->L * max_blocks * 512 * sizeof(uint32_t));
+  A((void**)&tr->chain_err, sizeof(int));
+  if (getenv("ACEZ_CHAIN_TRACE")) {
+    A((void**)&tr->chain_trace, 512 * sizeof(unsigned long long));
+    if (rc == ACEZ_OK) (void)hipMemset(tr->chain_trace, 0, 512 * sizeof(unsigned long long));
+  }
+  tr->dRc.resize(tr->nb + 1, nullptr);
+  for (int b = 0; b <= tr->nb; ++b) A((void**)&tr->dRc[b], act_bytes);
   A((void**)&tr->zeros, 1024);
   tr->log_cap = cfg->iterations + 8;
   A((void**)&tr->log_loss, (size_t)tr->log_cap * sizeof(float));
@@ -201,6 +212,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   hipLaunchKernelGGL(sched_init_kernel, dim3(1), dim3(64), 0, 0, tr->st, sc);
   ACEZ_HIP_CHECK(hipGetLastError());
   ACEZ_HIP_CHECK(hipMemset(tr->zeros, 0, 1024));
+  ACEZ_HIP_CHECK(hipMemset(tr->chain_err, 0, sizeof(int)));
   ACEZ_HIP_CHECK(hipMemset(tr->log_loss, 0, (size_t)tr->log_cap * sizeof(float)));
   ACEZ_HIP_CHECK(hipMemset(tr->log_inl, 0, (size_t)tr->log_cap * sizeof(float)));
   ACEZ_HIP_CHECK(hipDeviceSynchronize());
@@ -343,6 +355,7 @@ static void fill_loss_train(acez_trainer* tr, LossArgs& a, const uint16_t* act, 
   a.st = tr->st; a.out_xyz = tr->xyz; a.dZ = tr->dZ[f2];
   a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
   a.bias_partials = tr->bias_partials + (size_t)f2 * tr->bias_layer_stride; a.dbg = 0;
+  if (const char* e = getenv("ACEZ_LOSS_DBG")) a.dbg = atoi(e);   // ablation: 1 = stop after phase A, 2 = after phase B (timing only)
 }
 
 // The dependent chain of a step as one launch of chain_kernel (head_chain.hip). phases: 1 = gather + forward (the fc2 output
@@ -351,39 +364,45 @@ static void launch_chain(acez_trainer* tr, const int64_t* d_indices, int n, int 
   const int nb = tr->nb, f1 = 3 * (nb + 1), f2 = f1 + 1;
   ChainArgs c{};
   c.src = (phases & 1) ? (const uint16_t*)tr->buf.d_features : tr->out[f2];
-  c.idx = d_indices; c.g_in = tr->R[0]; c.maskbits = tr->maskbits;
+  c.idx = d_indices; c.g_in = tr->R[0]; c.g_dz_last = tr->dZ[f2]; c.maskbits = tr->maskbits;
   c.bias_partials = tr->bias_partials; c.bias_layer_stride = tr->bias_layer_stride;
-  c.n = n; c.phases = phases; c.st = tr->st;
+  c.n = n; c.phases = phases; c.st = tr->st; c.err = tr->chain_err; c.trace = tr->chain_trace;
+  if (const char* e = getenv("ACEZ_CHAIN_DBG")) c.dbg = atoi(e);
   const float* P = tr->pb.d_params;
   int k = 0;
-  auto fwd = [&](int l, uint16_t* g_out, int residual, int mask_layer) {
+  auto fwd = [&](int l, uint16_t* g_out, const uint16_t* r_in, int mask_layer) {
     ChainStep& S = c.step[k++];
     S.W = tr->Wb + (size_t)l * 262144; S.bias = P + (int64_t)l * 262656 + 262144; S.g_out = g_out;
-    S.residual = residual; S.add = 0; S.aux = 0; S.mask_layer = mask_layer; S.bias_slot = 0;
+    S.r_in = r_in; S.r_out = nullptr; S.mask_layer = mask_layer; S.bias_slot = 0;
   };
   for (int b = 0; b <= nb; ++b) {
-    fwd(3 * b, tr->out[3 * b], 0, 3 * b);
-    fwd(3 * b + 1, tr->out[3 * b + 1], 0, 3 * b + 1);
-    fwd(3 * b + 2, tr->R[b + 1], 1, 3 * b + 2);   // the relu output itself is only needed as a mask (bits); R[b+1] feeds wgrad
+    fwd(3 * b, tr->out[3 * b], nullptr, 3 * b);
+    fwd(3 * b + 1, tr->out[3 * b + 1], nullptr, 3 * b + 1);
+    fwd(3 * b + 2, tr->R[b + 1], tr->R[b], 3 * b + 2);   // the relu output itself is only needed as a mask (bits); R[b+1] feeds wgrad
   }
-  fwd(f1, tr->out[f1], 0, f1);
-  fwd(f2, phases == 1 ? tr->out[f2] : nullptr, 0, -1);   // fc2's mask is applied by the loss phase from the tile itself
+  fwd(f1, tr->out[f1], nullptr, f1);
+  fwd(f2, phases == 1 ? tr->out[f2] : nullptr, nullptr, -1);   // fc2's mask is applied by the loss phase from the tile itself
   c.n_fwd = k;
-  auto bwd = [&](int l, int l_out, int add, int aux) {
+  auto bwd = [&](int l, int l_out, const uint16_t* r_in, uint16_t* r_out) {
     ChainStep& S = c.step[k++];
     S.W = tr->WbT + (size_t)l * 262144; S.bias = nullptr; S.g_out = tr->dZ[l_out];
-    S.residual = 0; S.add = add; S.aux = aux; S.mask_layer = l_out; S.bias_slot = l_out;
+    S.r_in = r_in; S.r_out = r_out; S.mask_layer = l_out; S.bias_slot = l_out;
   };
-  bwd(f2, f1, 0, 0);
-  bwd(f1, 3 * nb + 2, 0, 1);
+  bwd(f2, f1, nullptr, nullptr);
+  int cur = 0;
+  bwd(f1, 3 * nb + 2, nullptr, tr->dRc[cur]);
   for (int b = nb; b >= 0; --b) {
-    bwd(3 * b + 2, 3 * b + 1, 0, 0);
-    bwd(3 * b + 1, 3 * b, 0, 0);
-    if (b > 0) bwd(3 * b, 3 * (b - 1) + 2, 1, 1);
+    bwd(3 * b + 2, 3 * b + 1, nullptr, nullptr);
+    bwd(3 * b + 1, 3 * b, nullptr, nullptr);
+    if (b > 0) {
+      bwd(3 * b, 3 * (b - 1) + 2, tr->dRc[cur], tr->dRc[cur + 1]);
+      ++cur;
+    }
   }
   c.n_bwd = k - c.n_fwd;
   fill_loss_train(tr, c.loss, nullptr, d_indices, n, pose_tables);
-  hipLaunchKernelGGL(chain_kernel, dim3((n + CHAIN_ROWS - 1) / CHAIN_ROWS), dim3(CHAIN_THREADS), 0, s, c);
+  if (c.dbg) hipLaunchKernelGGL(chain_kernel<true>, dim3((n + CHAIN_ROWS - 1) / CHAIN_ROWS), dim3(CHAIN_THREADS), 0, s, c);
+  else hipLaunchKernelGGL(chain_kernel<false>, dim3((n + CHAIN_ROWS - 1) / CHAIN_ROWS), dim3(CHAIN_THREADS), 0, s, c);
 }
 
 // ---- pose refinement (the flat parameter offsets in PoseNetwork.named_parameters() order are PN_* in pose_kernels.hip)
@@ -645,8 +664,14 @@ extern "C" int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out,
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   flush_post(tr, (hipStream_t)stream);
   TrainState hs;
+  int chain_err = 0;
   ACEZ_HIP_CHECK(hipMemcpyAsync(&hs, tr->st, sizeof(TrainState), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  ACEZ_HIP_CHECK(hipMemcpyAsync(&chain_err, tr->chain_err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  if (chain_err) {
+    set_error("chain kernel: a bounded spin expired (internal protocol error); results of this trainer are invalid");
+    return ACEZ_ERR_HIP;
+  }
   h_out->iteration = hs.iteration; h_out->max_iterations = hs.max_iterations; h_out->in_cooldown = hs.in_cooldown;
   h_out->nan_flag = hs.nan_flag; h_out->lr = hs.lr; h_out->last_loss = hs.last_loss;
   h_out->last_batch_inliers = hs.last_inliers; h_out->focal_scale = 1.0 + hs.calib_g;
@@ -770,6 +795,7 @@ extern "C" int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, vo
   else if (kind == 2 && index >= 0 && index < tr->nb + 2) { src = tr->R[index]; cap = act_bytes; }
   else if (kind == 3 && index >= 0 && index < tr->nslabs) { src = tr->slabs + (size_t)index * tr->n_wide; cap = tr->n_wide * 4; }
   else if (kind == 4 && index >= 0 && index < tr->L) { src = tr->bias_partials + (size_t)index * tr->bias_layer_stride; cap = tr->bias_layer_stride * 4; }
+  else if (kind == 5 && tr->chain_trace) { src = tr->chain_trace; cap = 512 * 8; }
   ACEZ_REQUIRE(src && bytes <= cap, "unknown buffer or size out of range");
   ACEZ_HIP_CHECK(hipMemcpyAsync(h_out, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));

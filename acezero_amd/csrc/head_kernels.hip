@@ -610,10 +610,11 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// loss kernel (32 rows per workgroup = four independent wavefronts of LOSS_ROWS = 8 rows):
-//   A  fc3 forward, one wave per row, fp32 accumulate
+// loss kernel (32 rows per workgroup, four wavefronts):
+//   A  fc3 forward, wave wv: rows 8 wv .. 8 wv + 7, one row per pass, fp32 accumulate
 //   B  one thread per row: de-homogenise, project, masks, robust loss and d(loss)/d(fc3 outputs)
-//   C  one thread per channel pair: fc3 weight-gradient partials and the masked input gradient dZ
+//   C  wave wv: channels 128 wv .. +127 of all 32 rows, one thread per channel pair: fc3 weight-gradient partials and the
+//      masked input gradient dZ
 // ---------------------------------------------------------------------------------------------------
 constexpr int LOSS_ROWS = 8;
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
@@ -641,22 +642,19 @@ __device__ __forceinline__ LossPre loss_prefetch(const LossArgs& a, int m0, int 
   return q;
 }
 
-// LDS scratch of the loss phases, in floats: s_s / s_ds / s_red [4 waves][LOSS_ROWS][4], s_comb [3][40][64] (waves 1..3 ->
-// wave 0), s_small [3][8]
-constexpr int LOSS_SCRATCH_FLOATS = 3 * 4 * LOSS_ROWS * 4 + 3 * 40 * 64 + 3 * 8;
+// LDS scratch of the loss phases, in floats: s_s / s_ds / s_red [4 waves][LOSS_ROWS][4]
+constexpr int LOSS_SCRATCH_FLOATS = 3 * 4 * LOSS_ROWS * 4;
 
 // The three phases for the 32 rows of workgroup `block` (four wavefronts wv = 0..3 of 64 lanes t). LDSACT = false: the fc2
 // output is read from a.act and dZ goes to a.dZ (loss_kernel). LDSACT = true: both live in the swizzled LDS tile `Xt`
-// (act_off) of the chain kernel, dZ overwrites the activations in place and is ALSO written to a.dZ. The four waves meet
-// once (__syncthreads: every wave of the workgroup must arrive, also waves that do not run this function).
-template <bool LDSACT>
+// (act_off) of the chain kernel and dZ overwrites the activations in place (the caller copies the tile to a.dZ). The four waves
+// meet once, through `sync` (loss_kernel: __syncthreads; the chain kernel: its flag barrier).
+template <bool LDSACT, class Sync>
 __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, const int wv, const int t, uint16_t* Xt, float* scratch,
-                                          const LossPre pre) {
+                                          const LossPre pre, Sync sync) {
   float (*s_s)[4] = reinterpret_cast<float (*)[4]>(scratch + wv * LOSS_ROWS * 4);
   float (*s_ds)[4] = reinterpret_cast<float (*)[4]>(scratch + (4 + wv) * LOSS_ROWS * 4);
   float (*s_red)[4] = reinterpret_cast<float (*)[4]>(scratch + (8 + wv) * LOSS_ROWS * 4);
-  float (*s_comb)[40][64] = reinterpret_cast<float (*)[40][64]>(scratch + 12 * LOSS_ROWS * 4);
-  float (*s_small)[8] = reinterpret_cast<float (*)[8]>(scratch + 12 * LOSS_ROWS * 4 + 3 * 40 * 64);
   const int l = t;
   const int m0 = (block * 4 + wv) * LOSS_ROWS;
   const int n = a.n, no = a.no;
@@ -678,6 +676,9 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
         for (int e = 0; e < 8; ++e) w3[j][e] = 0.f;
       }
     }
+    float b3v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b3v[j] = (j < no) ? a.b3[j] : 0.f;   // (not inside the row loop: a dependent load per row)
 #pragma unroll
     for (int rr = 0; rr < LOSS_ROWS; ++rr) {
       const int r = rr, m = m0 + r;
@@ -700,13 +701,10 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
         p[j] = sacc;
       }
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
+      for (int j = 0; j < 4; ++j) p[j] = wave_sum63(p[j]);   // DPP (the 24 ds_bpermute per row of a shuffle butterfly were most of phase A)
+      if (l == 63) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p[j] += __shfl_xor(p[j], off);
-      }
-      if (l == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s_s[r][j] = (j < no) ? p[j] + a.b3[j] : 0.f;
+        for (int j = 0; j < 4; ++j) s_s[r][j] = (j < no) ? p[j] + b3v[j] : 0.f;
       }
     }
   }
@@ -890,101 +888,71 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
   if (!a.idx) return;  // inference: no gradients
   if (a.dbg == 2) return;
 
-  float stat = 0.f;
-  if (t < 3)
-    for (int r = 0; r < LOSS_ROWS; ++r) stat += s_red[r][t];   // fixed-order sum over this wave's rows
+  // ---- the four waves meet once: phase C reads every row's ds and, in the chain kernel, overwrites activations that the other
+  // waves' phase A has read
+  sync();
 
-  // ---- phase C: lane t owns channels 8t .. 8t+7 (16-byte row segments in and out)
+  // ---- phase C: wave wv owns channels 128 wv .. 128 wv + 127 of ALL 32 rows, lane t two of them; the row sums of the fc3 weight
+  // gradient and of the fc2 bias gradient (the bf16-rounded dZ values) run over the rows in order inside one lane, so a workgroup
+  // emits ONE partial per 32 rows without any cross-wave combine
   {
-    float w3[4][8], gw[4][8], bsum[8];
+    const int ch = wv * 128 + 2 * t;
+    const int mb = block * 4 * LOSS_ROWS;
+    float w3[4][2], gw[4][2], bsum[2] = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (j < no) {
-        const uint4 v = *reinterpret_cast<const uint4*>(a.W3 + (size_t)j * 512 + 8 * t);
-        unpack4(make_uint2(v.x, v.y), &w3[j][0]);
-        unpack4(make_uint2(v.z, v.w), &w3[j][4]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) w3[j][e] = 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gw[j][e] = 0.f;
+      const uint32_t v = (j < no) ? *reinterpret_cast<const uint32_t*>(a.W3 + (size_t)j * 512 + ch) : 0u;
+      w3[j][0] = __uint_as_float(v << 16);
+      w3[j][1] = __uint_as_float(v & 0xffff0000u);
+      gw[j][0] = gw[j][1] = 0.f;
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
-#pragma unroll
-    for (int r = 0; r < LOSS_ROWS; ++r) {
-      const int m = min(m0 + r, n - 1);  // rows past the end carry ds == 0 and are not stored
-      const uint4 v = LDSACT ? *reinterpret_cast<const uint4*>(&Xt[act_off(wv * LOSS_ROWS + r, 8 * t)])
-                             : *reinterpret_cast<const uint4*>(a.act + (size_t)m * 512 + 8 * t);
-      float x[8], d[8];
-      unpack4(make_uint2(v.x, v.y), &x[0]);
-      unpack4(make_uint2(v.z, v.w), &x[4]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) d[e] = 0.f;
+    const float (*ds_all)[4] = reinterpret_cast<const float (*)[4]>(scratch + 4 * LOSS_ROWS * 4);
+#pragma unroll 4
+    for (int r = 0; r < 4 * LOSS_ROWS; ++r) {
+      const int m = min(mb + r, n - 1);   // rows past the end carry ds == 0 and are not stored
+      const uint32_t v = LDSACT ? *reinterpret_cast<const uint32_t*>(&Xt[act_off(r, ch)]) : *reinterpret_cast<const uint32_t*>(a.act + (size_t)m * 512 + ch);
+      const float x[2] = {__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+      float d[2] = {0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float dsj = s_ds[r][j];
+        const float dsj = ds_all[r][j];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 2; ++e) {
           d[e] = fmaf(dsj, w3[j][e], d[e]);
           gw[j][e] = fmaf(dsj, x[e], gw[j][e]);
         }
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
+      for (int e = 0; e < 2; ++e)
         if (!(x[e] > 0.f)) d[e] = 0.f;  // relu mask of the fc2 output
-      const uint2 lo = pack4(d[0], d[1], d[2], d[3]), hi = pack4(d[4], d[5], d[6], d[7]);
-      // chain kernel: the gradient replaces the activations of this row in the LDS tile (rows past the end become zero rows)
-      if (LDSACT) *reinterpret_cast<uint4*>(&Xt[act_off(wv * LOSS_ROWS + r, 8 * t)]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      if (m0 + r < n) {
-        *reinterpret_cast<uint4*>(a.dZ + (size_t)m * 512 + 8 * t) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        float q[8];
-        unpack4(lo, &q[0]);
-        unpack4(hi, &q[4]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bsum[e] += q[e];   // bias gradient of fc2: the bf16-rounded values, in row order
+      const uint32_t pk = pack2(d[0], d[1]);
+      // chain kernel: the gradient replaces the activations in the LDS tile (rows past the end become zero rows); the tile is
+      // copied to a.dZ by the caller
+      if (LDSACT) *reinterpret_cast<uint32_t*>(&Xt[act_off(r, ch)]) = pk;
+      else if (mb + r < n) *reinterpret_cast<uint32_t*>(a.dZ + (size_t)m * 512 + ch) = pk;
+      if (mb + r < n) {
+        bsum[0] += __uint_as_float(pk << 16);   // bias gradient of fc2: the bf16-rounded values, in row order
+        bsum[1] += __uint_as_float(pk & 0xffff0000u);
       }
     }
-    float fb3 = 0.f;
-    if (t < no)
-      for (int r = 0; r < LOSS_ROWS; ++r) fb3 += s_ds[r][t];
-    // combine the four waves in wave order: ((w0 + w1) + w2) + w3
-    if (wv > 0) {
+    *reinterpret_cast<float2*>(a.bias_partials + (size_t)block * 512 + ch) = make_float2(bsum[0], bsum[1]);
+    float* gp = a.fc3_partials + (size_t)block * a.fc3_stride;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s_comb[wv - 1][j * 8 + e][t] = gw[j][e];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s_comb[wv - 1][32 + e][t] = bsum[e];
-    }
-    if (wv > 0 && t < 4) s_small[wv - 1][t] = stat;
-    if (wv > 0 && t < no) s_small[wv - 1][4 + t] = fb3;
-    __syncthreads();
+    for (int j = 0; j < 4; ++j)
+      if (j < no) *reinterpret_cast<float2*>(gp + (size_t)j * 512 + ch) = make_float2(gw[j][0], gw[j][1]);
     if (wv == 0) {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) gw[j][e] += s_comb[u][j * 8 + e][t];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bsum[e] += s_comb[u][32 + e][t];
-        if (t < 3) stat += s_small[u][t];
-        if (t < no) fb3 += s_small[u][4 + t];
+      // fc3 bias gradient and the statistics: sums over the 32 rows in row order
+      const float (*red_all)[4] = reinterpret_cast<const float (*)[4]>(scratch + 8 * LOSS_ROWS * 4);
+      if (t < no) {
+        float fb3 = 0.f;
+        for (int r = 0; r < 4 * LOSS_ROWS; ++r) fb3 += ds_all[r][t];
+        gp[(size_t)no * 512 + t] = fb3;
       }
-      float* bp = a.bias_partials + (size_t)block * 512 + 8 * t;
-      *reinterpret_cast<float4*>(bp) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
-      *reinterpret_cast<float4*>(bp + 4) = make_float4(bsum[4], bsum[5], bsum[6], bsum[7]);
-      float* gp = a.fc3_partials + (size_t)block * a.fc3_stride;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < no) {
-          *reinterpret_cast<float4*>(gp + (size_t)j * 512 + 8 * t) = make_float4(gw[j][0], gw[j][1], gw[j][2], gw[j][3]);
-          *reinterpret_cast<float4*>(gp + (size_t)j * 512 + 8 * t + 4) = make_float4(gw[j][4], gw[j][5], gw[j][6], gw[j][7]);
-        }
-      if (t < no) gp[(size_t)no * 512 + t] = fb3;
-      if (t < 3) a.stat_partials[(size_t)block * 4 + t] = stat;
+      if (t < 3) {
+        float stat = 0.f;
+        for (int r = 0; r < 4 * LOSS_ROWS; ++r) stat += red_all[r][t];
+        a.stat_partials[(size_t)block * 4 + t] = stat;
+      }
     }
   }
 }
@@ -994,7 +962,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   __shared__ float scratch[LOSS_SCRATCH_FLOATS];
   const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
   const LossPre pre = loss_prefetch(a, (blockIdx.x * 4 + wv) * LOSS_ROWS, t);
-  loss_body<false>(a, blockIdx.x, wv, t, nullptr, scratch, pre);
+  loss_body<false>(a, blockIdx.x, wv, t, nullptr, scratch, pre, [] { __syncthreads(); });
 }
 
 // ---------------------------------------------------------------------------------------------------

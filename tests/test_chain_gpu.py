@@ -1,8 +1,9 @@
-"""GPU: the one-launch chain kernel (head_chain.hip, default) against the per-layer launches (ACEZ_CHAIN=0: rowgemm80 /
-loss_kernel, the round-1 path) on identical inputs. Same MFMA instruction, same K order and the same rounding points, so
+"""GPU: the one-launch chain kernel (head_chain.hip, ACEZ_CHAIN=1) against the per-layer launches (default: rowgemm80 /
+loss_kernel) on identical inputs. Same MFMA instruction, same K order and the same rounding points, so
 every activation, every propagated gradient, the weight-gradient slabs, the fc3 gradient and the statistics must agree BIT
 FOR BIT; only the bias gradients are summed over different row groups (32-row workgroups vs 80-row tiles) and agree to fp32
-rounding. Parity with the oracle / the reference goldens is test_head_gpu.py, which runs on the chain path."""
+rounding. Parity with the oracle / the reference goldens is test_head_gpu.py (default path); the oracle comparison at the end of this file
+runs the same check on the chain path."""
 import os
 
 import numpy as np

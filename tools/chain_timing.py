@@ -45,6 +45,12 @@ def run(chain, patches, steps, pose="none"):
 if __name__ == "__main__":
     patches = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    if len(sys.argv) > 3:   # ablation sweep of the chain kernel (timing only: results are wrong with any switch set)
+        for dbg in sys.argv[3].split(","):
+            os.environ["ACEZ_CHAIN_DBG"] = dbg
+            print("ACEZ_CHAIN_DBG=" + dbg, end="  ")
+            run("1", patches, steps)
+        sys.exit(0)
     for chain in ("1", "0"):
         run(chain, patches, steps)
     for chain in ("1", "0"):

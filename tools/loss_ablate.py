@@ -1,0 +1,7 @@
+import os, sys
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+import chain_timing
+for d in ("0", "1", "2"):
+    os.environ["ACEZ_LOSS_DBG"] = d
+    print("ACEZ_LOSS_DBG=" + d, end="  ")
+    chain_timing.run("0", 1000000, 200)
