@@ -2,8 +2,8 @@
 loss_kernel) on identical inputs. Same MFMA instruction, same K order and the same rounding points, so
 every activation, every propagated gradient, the weight-gradient slabs, the fc3 gradient and the statistics must agree BIT
 FOR BIT; only the bias gradients are summed over different row groups (32-row workgroups vs 80-row tiles) and agree to fp32
-rounding. Parity with the oracle / the reference goldens is test_head_gpu.py (default path); the oracle comparison at the end of this file
-runs the same check on the chain path."""
+rounding. Parity with the oracle / the reference goldens is test_head_gpu.py (default path); bit-equality with that path is what
+this file adds for the chain kernel."""
 import os
 
 import numpy as np
@@ -87,8 +87,12 @@ def test_chain_fused_step_equals_backward_update():
     """acez_train_step (slabs handed to the optimiser) and backward + update give bitwise equal parameters on the chain path."""
     prob, flat0 = helpers.golden_problem()
     cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
-    a = _trainer(prob, flat0, cfg)
-    b = _trainer(prob, flat0, cfg)
+    os.environ["ACEZ_CHAIN"] = "1"
+    try:
+        a = _trainer(prob, flat0, cfg)
+        b = _trainer(prob, flat0, cfg)
+    finally:
+        os.environ.pop("ACEZ_CHAIN", None)
     for idx in helpers.golden_batches(prob, 6):
         di = torch.from_numpy(idx.astype(np.int64)).cuda()
         a.step(di)
