@@ -30,11 +30,49 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <functional>
+#include <random>
 #include <vector>
 
 #include "det_math.h"
 
 namespace {
+
+// ----------------------------------------------------------------------------------------------------
+// Test-time options (oracle_set_options): which 6x6 solver the LM step uses and which random stream sampleHypotheses draws from.
+//   solver 0 (default)  D4': Cholesky, eigen pseudo-inverse only when a pivot is not safely positive (what the GPU kernel runs)
+//   solver 1            always the eigen pseudo-inverse == cv::solve(DECOMP_SVD) of the symmetric system (what OpenCV runs)
+//   rng 0 (default)     D1: counter-based stream keyed by (seed, frame, hypothesis, try, draw)
+//   rng 1               reference style (thread_rand.cpp:13-42,68-71): one std::mt19937 per OpenMP thread, seeded seed + tid ONCE per
+//                       process (init() is guarded by a static flag, dsacstar.cpp:80 calls init, not forceInit), irand(a, b) =
+//                       std::uniform_int_distribution<int>(a, b - 1); hypothesis h is drawn by the thread libgomp's static schedule
+//                       gives it (dsacstar_util.h:162 "#pragma omp parallel for", no schedule clause): contiguous blocks of
+//                       ceil / floor (nH / T) iterations in thread order. The streams continue across calls until
+//                       oracle_rng_reset(). NOTE: uniform_int_distribution is the one of THIS compiler's libstdc++ (GCC >= 11:
+//                       Lemire's method); a reference built with an older GCC draws differently.
+// ----------------------------------------------------------------------------------------------------
+int g_solver_mode = 0, g_rng_mode = 0, g_rng_threads = 1;
+std::vector<std::mt19937> g_generators;
+bool g_rng_initialised = false;
+void ref_rng_init(unsigned seed) {
+  if (g_rng_initialised) return;
+  g_generators.clear();
+  for (int i = 0; i < g_rng_threads; ++i) {
+    g_generators.push_back(std::mt19937());
+    g_generators[i].seed((unsigned)i + seed);
+  }
+  g_rng_initialised = true;
+}
+int ref_irand(int incMin, int excMax, int tid) {
+  std::uniform_int_distribution<int> dist(incMin, excMax - 1);
+  return dist(g_generators[tid]);
+}
+// libgomp static schedule without chunk size: thread t of T gets q + (t < r) consecutive iterations, q = n / T, r = n % T
+int ref_thread_of(int h, int n) {
+  const int T = g_rng_threads, q = n / T, r = n % T;
+  const int big = r * (q + 1);
+  return (h < big) ? h / (q + 1) : r + (q ? (h - big) / q : 0);
+}
 
 // ----------------------------------------------------------------------------------------------------
 // D1: counter-based random stream
@@ -635,6 +673,7 @@ void solve_sym6(const double A_in[36], const double b[6], double x[6]) {
 // cv::solve(DECOMP_SVD) would behave. Fixed operation order: the oracle and the kernel run the same sequence.
 // ----------------------------------------------------------------------------------------------------
  void solve_normal6(const double A[36], const double b[6], double x[6]) {
+  if (g_solver_mode == 1) { solve_sym6(A, b, x); return; }
   double L[36], Linv[6], y[6];
   bool ok = true;
   for (int j = 0; j < 6; ++j) {
@@ -763,7 +802,8 @@ void lm_step(const LMAccum& acc, const double prevParam[6], int lambdaLg10, doub
   for (int i = 0; i < 6; ++i) param[i] = prevParam[i] - x[i];
 }
 
-void solve_pnp_iterative(const Frame& f, const std::vector<uint8_t>& flags, const Cam& k, Pose* pose) {
+typedef std::function<void(const double*, bool, LMAccum*)> AccumFn;
+void lm_solve(const AccumFn& accumulate, Pose* pose) {
   const int max_iter = 20;
   const double epsilon = 1.1920928955078125e-07;  // FLT_EPSILON
   double param[6] = {pose->r[0], pose->r[1], pose->r[2], pose->t[0], pose->t[1], pose->t[2]};
@@ -771,7 +811,7 @@ void solve_pnp_iterative(const Frame& f, const std::vector<uint8_t>& flags, cons
   int lambdaLg10 = -3, iters = 0;
   double prevErrNorm = 1.7976931348623157e308, errNorm;
   LMAccum acc, tmp;
-  lm_accumulate(f, flags, param, k, true, &acc);  // state STARTED -> CALC_J
+  accumulate(param, true, &acc);  // state STARTED -> CALC_J
   for (;;) {
     // CALC_J
     for (int i = 0; i < 6; ++i) prevParam[i] = param[i];
@@ -779,7 +819,7 @@ void solve_pnp_iterative(const Frame& f, const std::vector<uint8_t>& flags, cons
     if (iters == 0) prevErrNorm = sqrt(acc.errsq);
     // CHECK_ERR
     for (;;) {
-      lm_accumulate(f, flags, param, k, false, &tmp);
+      accumulate(param, false, &tmp);
       errNorm = sqrt(tmp.errsq);
       if (errNorm > prevErrNorm) {
         if (++lambdaLg10 <= 16) {
@@ -799,12 +839,41 @@ void solve_pnp_iterative(const Frame& f, const std::vector<uint8_t>& flags, cons
     const double rel = sqrt(dn) / (sqrt(pn) + 2.220446049250313e-16);  // cvNorm(param, prevParam, CV_RELATIVE_L2)
     if (++iters >= max_iter || rel < epsilon) break;
     prevErrNorm = errNorm;
-    lm_accumulate(f, flags, param, k, true, &acc);
+    accumulate(param, true, &acc);
   }
   for (int i = 0; i < 3; ++i) {
     pose->r[i] = param[i];
     pose->t[i] = param[3 + i];
   }
+}
+
+void solve_pnp_iterative(const Frame& f, const std::vector<uint8_t>& flags, const Cam& k, Pose* pose) {
+  lm_solve([&](const double* param, bool withJ, LMAccum* out) { lm_accumulate(f, flags, param, k, withJ, out); }, pose);
+}
+
+// the same solver on an arbitrary list of correspondences (float object / image points), accumulated in list order: used to
+// consume golden vectors of cv::solvePnP(ITERATIVE, useExtrinsicGuess) produced in the reference's environment
+void solve_pnp_iterative_pts(const float* obj, const float* img, int n, const Cam& k, Pose* pose) {
+  lm_solve(
+      [&](const double* param, bool withJ, LMAccum* out) {
+        double R[9], dRdr[27];
+        rodrigues(param, R, withJ ? dRdr : nullptr);
+        for (int i = 0; i < 36; ++i) out->JtJ[i] = 0;
+        for (int i = 0; i < 6; ++i) out->JtErr[i] = 0;
+        out->errsq = 0;
+        for (int p = 0; p < n; ++p) {
+          double u, v, Ju[6], Jv[6];
+          project(R, param + 3, k, obj[3 * p], obj[3 * p + 1], obj[3 * p + 2], &u, &v, withJ ? dRdr : nullptr, Ju, Jv);
+          const double eu = u - (double)img[2 * p], ev = v - (double)img[2 * p + 1];
+          if (withJ)
+            for (int a = 0; a < 6; ++a) {
+              for (int b = 0; b < 6; ++b) out->JtJ[a * 6 + b] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+              out->JtErr[a] += Ju[a] * eu + Jv[a] * ev;
+            }
+          out->errsq += eu * eu + ev * ev;
+        }
+      },
+      pose);
 }
 
 // [upstream] cv::Mat::inv() of a 4x4 double matrix (DECOMP_LU, hal::LU64f): returns false if singular
@@ -859,6 +928,7 @@ int oracle_forward_rgb(const float* sc, int64_t strideC, int64_t strideH, int64_
   if (maxRefSteps <= 0) maxRefSteps = 100;  // MAX_REF_STEPS, dsacstar.cpp:47
 
   // ---- sampleHypotheses (dsacstar_util.h:135-221)
+  if (g_rng_mode == 1) ref_rng_init((unsigned)randomSeed);   // ThreadRand::init(randomSeed), dsacstar.cpp:80
   std::vector<Pose> hyps(ransacHypotheses);
   for (int h = 0; h < ransacHypotheses; h++) {
     Pose cur;
@@ -867,8 +937,8 @@ int oracle_forward_rgb(const float* sc, int64_t strideC, int64_t strideH, int64_
       const uint64_t key = try_key(randomSeed, frameId, (uint32_t)h, (uint32_t)t);
       float obj[4][3], img[4][2];
       for (int j = 0; j < 4; j++) {
-        const int x = irand(key, 2 * j, W);
-        const int y = irand(key, 2 * j + 1, H);
+        const int x = g_rng_mode == 1 ? ref_irand(0, W, ref_thread_of(h, ransacHypotheses)) : irand(key, 2 * j, W);   // x first, then y
+        const int y = g_rng_mode == 1 ? ref_irand(0, H, ref_thread_of(h, ransacHypotheses)) : irand(key, 2 * j + 1, H);
         img[j][0] = (float)f.px(x);
         img[j][1] = (float)f.py(y);
         f.coord(x, y, obj[j]);
@@ -995,6 +1065,23 @@ int oracle_forward_rgb(const float* sc, int64_t strideC, int64_t strideH, int64_
       for (int x = 0; x < W; ++x) outMask[y * W + x] = inlierMap.empty() ? 0 : inlierMap[(size_t)x * H + y];
   }
   return 0;
+}
+
+// ---- options ------------------------------------------------------------------------------------------
+void oracle_set_options(int solver_mode, int rng_mode, int rng_threads) {
+  g_solver_mode = solver_mode;
+  g_rng_mode = rng_mode;
+  g_rng_threads = rng_threads > 0 ? rng_threads : 1;
+  g_rng_initialised = false;
+}
+void oracle_rng_reset() { g_rng_initialised = false; }
+// cv::solvePnP(obj, img, K, noArray, rvec, tvec, useExtrinsicGuess = true, SOLVEPNP_ITERATIVE) on a point list
+void oracle_pnp_iterative_pts(const float* obj3n, const float* img2n, int n, float focal, float ppx, float ppy, double* pose6) {
+  Cam k{(double)focal, (double)focal, (double)ppx, (double)ppy};
+  Pose p;
+  for (int i = 0; i < 3; ++i) { p.r[i] = pose6[i]; p.t[i] = pose6[3 + i]; }
+  solve_pnp_iterative_pts(obj3n, img2n, n, k, &p);
+  for (int i = 0; i < 3; ++i) { pose6[i] = p.r[i]; pose6[3 + i] = p.t[i]; }
 }
 
 // ---- unit hooks --------------------------------------------------------------------------------------

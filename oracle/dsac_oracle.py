@@ -123,3 +123,21 @@ def pnp_iterative(sc, sub, focal, ppx, ppy, flags_hw, pose6):
     lib().oracle_pnp_iterative(_p(sc), C.c_int64(st[0]), C.c_int64(st[1]), C.c_int64(st[2]), H, W, int(sub), C.c_float(focal),
                                C.c_float(ppx), C.c_float(ppy), _p(fl), _p(pose))
     return pose
+
+
+def set_options(solver="cholesky", rng="counter", rng_threads=1):
+    """solver: 'cholesky' (default, what the GPU kernel runs) | 'svd' (always the eigen pseudo-inverse == cv::solve(DECOMP_SVD));
+    rng: 'counter' (default) | 'mt19937' (reference style, thread_rand.cpp: per-thread generators seeded seed + tid once)."""
+    lib().oracle_set_options({"cholesky": 0, "svd": 1}[solver], {"counter": 0, "mt19937": 1}[rng], int(rng_threads))
+
+
+def rng_reset():
+    lib().oracle_rng_reset()
+
+
+def pnp_iterative_pts(obj, img, focal, ppx, ppy, pose6):
+    obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    pose = np.array(pose6, np.float64)
+    lib().oracle_pnp_iterative_pts(_p(obj), _p(img), obj.shape[0], C.c_float(focal), C.c_float(ppx), C.c_float(ppy), _p(pose))
+    return pose
