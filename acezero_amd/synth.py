@@ -32,7 +32,7 @@ def random_cameras(rng, n, room=(6.0, 4.0, 3.0)):
 
 
 def make_training_problem(seed=2089, n_images=10, views_per_image=2, patches_per_view=256, focal=525.0,
-                          height=480, width=640, feature_noise=0.5):
+                          height=480, width=640, feature_noise=0.5, feature_gain=0.5):
     """Returns a dict of numpy arrays (float32 / int32) describing a training buffer.
 
     Geometry follows ace_trainer.py:372-436: a view is one (image, augmentation pass); a patch is one sampled
@@ -71,11 +71,11 @@ def make_training_problem(seed=2089, n_images=10, views_per_image=2, patches_per
         gt[sl] = (cam[:3, :3] @ xc + cam[:3, 3:4]).T
     mean = gt.mean(axis=0).astype(np.float32)
     proj = rng.normal(0, 1.0, size=(3, 512))
-    feats = np.tanh((gt - mean) @ proj * 0.5) + feature_noise * rng.normal(0, 1.0, size=(n, 512))
+    feats = np.tanh((gt - mean) @ proj * feature_gain) + feature_noise * rng.normal(0, 1.0, size=(n, 512))
     return {
         "features": feats.astype(np.float32), "target_px": target_px, "view_idx": view_idx,
         "view_aug_inv": view_aug_inv, "view_K": view_K, "view_Kinv": view_Kinv, "view_image": view_image,
-        "image_pose_inv": image_pose_inv, "mean": mean, "gt_coords": gt, "focal": np.float32(focal),
+        "image_pose_inv": image_pose_inv, "mean": mean, "gt_coords": gt, "focal": np.float32(focal), "feature_proj": proj,
         # ground-truth scene coordinates as the depth-based targets of ace_trainer.py:338 (a quarter of them "missing" = zeros)
         "target_crds": np.where((np.arange(n) % 4 == 3)[:, None], 0.0, gt).astype(np.float32),
     }

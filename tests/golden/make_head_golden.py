@@ -93,6 +93,7 @@ def full_cfg(c):
 
 
 def run_reference(cfg, prob, flat0, batches):
+    nb, homog = cfg.get("num_head_blocks", 1), cfg.get("use_homogeneous", True)
     opt = types.SimpleNamespace(
         use_half=False, depth_min=cfg["depth_min"], depth_max=cfg["depth_max"], depth_target=cfg["depth_target"],
         repro_loss_hard_clamp=cfg["hard_clamp"], learning_rate_cooldown_trigger_px_threshold=cfg["inlier_px_threshold"],
@@ -101,13 +102,13 @@ def run_reference(cfg, prob, flat0, batches):
         learning_rate_min=cfg["lr_min"], learning_rate_max=cfg["lr_max"], learning_rate_warmup_iterations=cfg["warmup_iterations"],
         learning_rate_warmup_learning_rate=cfg["warmup_lr"], learning_rate_cooldown_iterations=cfg["cooldown_iterations"],
         learning_rate_cooldown_trigger_percent_threshold=cfg["cooldown_trigger_percent"])
-    head = ace_network.Head(torch.from_numpy(prob["mean"]), 1, True)
-    P = head_oracle.HeadParams(flat0.clone(), 1, True)
+    head = ace_network.Head(torch.from_numpy(prob["mean"]), nb, homog)
+    P = head_oracle.HeadParams(flat0.clone(), nb, homog)
     sd = head.state_dict()
-    for l, name in enumerate(head_oracle.head_layer_names(1)):
+    for l, name in enumerate(head_oracle.head_layer_names(nb)):
         sd[name + ".weight"] = P.W[l].clone().view(512, 512, 1, 1)
         sd[name + ".bias"] = P.b[l].clone()
-    sd["fc3.weight"] = P.W3.clone().view(4, 512, 1, 1)
+    sd["fc3.weight"] = P.W3.clone().view(4 if homog else 3, 512, 1, 1)
     sd["fc3.bias"] = P.b3.clone()
     head.load_state_dict(sd)
     head.train()
@@ -206,14 +207,18 @@ def run_reference(cfg, prob, flat0, batches):
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     only = sys.argv[1:]   # optional: names of the configurations to (re)generate
-    for name, c in CONFIGS.items():
+    from tests import helpers   # the "trained regime" configurations and their problem live next to the tests that consume them
+    for name, c in list(CONFIGS.items()) + list(helpers.TRAINED_CONFIGS.items()):
         if only and name not in only:
             continue
-        cfg = full_cfg(c)
-        prob = synth.make_training_problem(seed=SEED, n_images=6, views_per_image=2, patches_per_view=128)
-        # the trainer stores features in half precision; keep them bf16-representable so both modes see the same inputs
-        prob["features"] = torch.from_numpy(prob["features"]).to(torch.bfloat16).to(torch.float32).numpy()
-        flat0 = head_oracle.init_params(SEED + 1)
+        if name in helpers.TRAINED_CONFIGS:
+            prob, flat0, cfg = helpers.problem_for(name)
+        else:
+            cfg = full_cfg(c)
+            prob = synth.make_training_problem(seed=SEED, n_images=6, views_per_image=2, patches_per_view=128)
+            # the trainer stores features in half precision; keep them bf16-representable so both modes see the same inputs
+            prob["features"] = torch.from_numpy(prob["features"]).to(torch.bfloat16).to(torch.float32).numpy()
+            flat0 = head_oracle.init_params(SEED + 1)
         rng = np.random.default_rng(SEED + 2)
         n = prob["features"].shape[0]
         batches = [rng.permutation(n)[:B] for _ in range(cfg["steps"])]

@@ -67,3 +67,33 @@ def test_encoder_rows_feed_the_head_layout():
     assert rows.dtype == torch.bfloat16 and rows.shape == (2 * 8 * 12, 512)
     f = enc(img)
     assert torch.equal(rows[1 * 96 + 3 * 12 + 5].float().cpu(), f[1, :, 3, 5].cpu())
+
+
+@pytest.mark.parametrize("hw", [(480, 640), (480, 741)])   # 7-Scenes frames; Mip-NeRF 360 garden at images_4 (BASELINE configs 1-3)
+def test_encoder_and_regressor_at_baseline_frame_sizes(hw):
+    """The sizes at which conv12 / conv3x3p / convgemm512 pick their real tilings and chunking (only toy frames were
+    compared with the oracle): encoder features and the scene-coordinate maps of Regressor.forward against the bf16 oracles."""
+    from acezero_amd.encoder import Encoder, output_size
+    from acezero_amd.network import Regressor
+    from oracle import head_oracle
+    from tests.test_pipeline_gpu import _head_state_dict
+    h, w = hw
+    n = 3
+    sd = encoder_oracle.init_weights(seed=4099)
+    img = torch.from_numpy(synth.make_gray_images(seed=31 + w, n=n, h=h, w=w))
+    orc = encoder_oracle.EncoderOracle(sd, "bf16")
+    ref = orc.forward(img)
+    oh, ow = output_size(h, w)
+    out = Encoder(sd, max_frames=n, max_h=h, max_w=w)(img).cpu()
+    assert out.shape == ref.shape == (n, 512, oh, ow) and (oh, ow) == (60, (w + 7) // 8)
+    assert _rel(out, ref) < 4e-3, _rel(out, ref)
+    assert float((out - ref).abs().max()) < 0.03 * float(ref.abs().max())
+    hsd, flat = _head_state_dict()
+    net = Regressor.create_from_split_state_dict(sd, hsd, max_frames=n, max_h=h, max_w=w)
+    sc = net(img).cpu()
+    rows = orc.features_rows(img)
+    mean = torch.tensor([1.0, -2.0, 0.5])
+    Xo = head_oracle.HeadOracle(flat, mean, 1, True, mode="bf16").scene_coordinates(rows).view(n, oh, ow, 3).permute(0, 3, 1, 2)
+    err = (sc - Xo).abs().max().item()
+    scale = (Xo - mean.view(1, 3, 1, 1)).abs().max().item()
+    assert err < 2e-2 * scale, (err, scale)

@@ -21,7 +21,8 @@ def _rel(a, b):
 
 def _trainer(prob, flat0, cfg, max_batch=helpers.B, global_batch=None):
     from acezero_amd.head import HeadTrainer
-    tr = HeadTrainer(prob["mean"], max_batch=max_batch, global_batch=global_batch or cfg["global_batch"], loss_type=cfg["loss_type"],
+    tr = HeadTrainer(prob["mean"], num_head_blocks=cfg.get("num_head_blocks", 1), use_homogeneous=cfg.get("use_homogeneous", True),
+                     max_batch=max_batch, global_batch=global_batch or cfg["global_batch"], loss_type=cfg["loss_type"],
                      schedule=cfg["schedule"], iterations=cfg["iterations"], lr_min=cfg["lr_min"], lr_max=cfg["lr_max"],
                      warmup_iterations=cfg["warmup_iterations"], warmup_lr=cfg["warmup_lr"], cooldown_iterations=cfg["cooldown_iterations"],
                      cooldown_trigger_percent=cfg["cooldown_trigger_percent"], refine_calibration=cfg["refine_calibration"],
@@ -51,10 +52,9 @@ def test_inference_scene_coordinates_match_oracle():
     assert _rel(X - prob["mean"], g["coords0"] - prob["mean"]) < 3e-2
 
 
-@pytest.mark.parametrize("name", list(helpers.HEAD_CONFIGS))
+@pytest.mark.parametrize("name", list(helpers.HEAD_CONFIGS) + list(helpers.TRAINED_CONFIGS))
 def test_training_steps_match_oracle_and_golden(name):
-    prob, flat0 = helpers.golden_problem()
-    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS[name], prob)
+    prob, flat0, cfg = helpers.problem_for(name)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     tr = _trainer(prob, flat0, cfg)
     mlp = cfg["pose_refinement"] in ("mlp", "naive")
@@ -89,7 +89,13 @@ def test_training_steps_match_oracle_and_golden(name):
         go = rec["grad"].numpy()
         # bf16 roundings of activations / propagated gradients flip by one ulp between the two summation orders: 3-5e-3 on the
         # full gradient vector, depending on the step
-        assert _rel(grad[:n_params], go) < 8e-3, _rel(grad[:n_params], go)
+        # (trained regime: residuals of a few pixels, and the L1 norm of the 2-vector / the l1 losses have gradient sign(du): a
+        # residual that a one-ulp bf16 flip moves across zero flips that patch's whole contribution -- measured up to 3.6e-2)
+        assert _rel(grad[:n_params], go) < (5e-2 if name in helpers.TRAINED_CONFIGS else 8e-3), _rel(grad[:n_params], go)
+        if name in helpers.TRAINED_CONFIGS:
+            cosine = float(np.dot(grad[:n_params].astype(np.float64), go.astype(np.float64)) /
+                           (np.linalg.norm(grad[:n_params].astype(np.float64)) * np.linalg.norm(go.astype(np.float64))))
+            assert cosine > 0.999, cosine
         if mlp:
             assert _rel(grad[n_params + 4:], rec["pose_grad"].numpy()) < 5e-3, _rel(grad[n_params + 4:], rec["pose_grad"].numpy())
             pose_before = tr.pose_params.cpu().numpy().copy()
@@ -117,7 +123,10 @@ def test_training_steps_match_oracle_and_golden(name):
                 # weight by ~lr with the sign of a bf16-vs-fp32 gradient, so only the scale of the drift is bounded
                 np.testing.assert_allclose(tr.current_poses(), g["poses"][it], atol=1e-5 if it <= cfg["pose_refinement_wait"] else 5e-2)
     loss, _ = tr.log(0, min(5, int(g["steps_run"])))
-    np.testing.assert_allclose(loss, g["loss"][:len(loss)], rtol=3e-2)      # vs the reference (fp32): bf16-level agreement
+    # vs the reference's own fp32 run: bf16-level agreement. 3 % in the untrained regime; in the trained regime the loss is made of
+    # few-pixel reprojection errors and the 8-bit mantissa of the bf16 weights / activations moves it by up to 9 % (the bf16-mode
+    # oracle reproduces the GPU's numbers to 2e-3 above; the reference's fp16 autocast has three more mantissa bits)
+    np.testing.assert_allclose(loss, g["loss"][:len(loss)], rtol=0.12 if name in helpers.TRAINED_CONFIGS else 3e-2)
     assert tr.state()["max_iterations"] == int(g["max_iterations"][-1])
 
 
@@ -219,3 +228,81 @@ def test_alternative_kernel_paths_stay_correct(env, monkeypatch):
     n = flat0.numel()
     assert _rel(tr.grad[:n].cpu().numpy(), ref.grad[:n].cpu().numpy()) < 8e-3
     assert abs(float(tr.grad[n]) - float(ref.grad[n])) < 2e-3 * abs(float(ref.grad[n]))
+
+
+def _big_trained(patches_per_view=2048):
+    prob, flat0 = helpers.trained_problem(patches_per_view=patches_per_view)   # 6 images x 2 views x 2048 = 24576 patches
+    cfg = helpers.full_cfg(helpers.TRAINED_CONFIGS["head_trained_1cyclepoly"], prob)
+    cfg.update(global_batch=5120, schedule="constant", lr_min=0.00005, iterations=100)
+    return prob, flat0, cfg
+
+
+@pytest.mark.parametrize("regime", ["untrained", "trained"])
+def test_baseline_batch_5120_step_matches_oracle(regime):
+    """BASELINE's configuration (batch 5120, default head) against the oracle itself, not only through properties: one step on a
+    24 576-patch buffer, in the untrained regime (losses ~35, no inliers) and in the trained one (batch_inliers ~0.86)."""
+    if regime == "trained":
+        prob, flat0, cfg = _big_trained()
+    else:
+        from acezero_amd import synth
+        prob = synth.make_training_problem(seed=helpers.SEED + 7, n_images=24, views_per_image=2, patches_per_view=512)
+        prob["features"] = torch.from_numpy(prob["features"]).to(torch.bfloat16).to(torch.float32).numpy()
+        flat0 = head_oracle.init_params(helpers.SEED + 1)
+        cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_dyntanh_circle"], prob)
+        cfg["global_batch"] = 5120
+    tr = _trainer(prob, flat0, cfg, max_batch=5120, global_batch=5120)
+    orc = head_oracle.TrainerOracle(flat0.clone(), prob["mean"], cfg, mode="bf16")
+    rng = np.random.default_rng(17)
+    idx = rng.permutation(prob["features"].shape[0])[:5120]
+    b = helpers.torch_batch(prob, idx)
+    rec = orc.step(b["features"], b)
+    tr.backward(torch.from_numpy(idx.astype(np.int64)).cuda())
+    torch.cuda.synchronize()
+    n = flat0.numel()
+    grad = tr.grad.cpu().numpy()
+    X = tr.last_scene_coords(5120)
+    assert _rel(X - prob["mean"], rec["X"].numpy() - prob["mean"]) < REL
+    assert abs(grad[n] / 5120 - rec["loss"]) < 2e-3 * abs(rec["loss"])
+    assert abs(grad[n + 1] / 5120 - rec["inliers"]) <= 3.0 / 5120
+    if regime == "trained":
+        assert rec["inliers"] > 0.8
+    assert _rel(grad[:n], rec["grad"].numpy()) < 8e-3, _rel(grad[:n], rec["grad"].numpy())
+
+
+@pytest.mark.parametrize("regime", ["untrained", "trained"])
+def test_ten_free_running_steps_stay_close_to_the_oracle(regime):
+    """No re-synchronisation of weights or optimiser state between steps (test_training_steps_match_oracle_and_golden compares
+    every step in isolation): ten consecutive steps of the GPU and of the bf16 oracle from the same start, at BASELINE's batch.
+    Stated drift bound (measured, MI355X): per-step loss within 1 % (untrained) / 3 % (trained), batch inliers within 0.5 % of the
+    batch; the accumulated parameter movement agrees to 0.3 of its own norm in the untrained regime (AdamW divides by sqrt(v):
+    weights whose gradient is at the bf16 noise level still move by +-lr per step, with the sign of that noise) and to < 0.1 in
+    the trained regime, with a cosine > 0.95 in both."""
+    if regime == "trained":
+        prob, flat0, cfg = _big_trained()
+    else:
+        from acezero_amd import synth
+        prob = synth.make_training_problem(seed=helpers.SEED + 7, n_images=24, views_per_image=2, patches_per_view=512)
+        prob["features"] = torch.from_numpy(prob["features"]).to(torch.bfloat16).to(torch.float32).numpy()
+        flat0 = head_oracle.init_params(helpers.SEED + 1)
+        cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
+        cfg.update(global_batch=5120, warmup_iterations=1000, iterations=100, cooldown_trigger_percent=0.7)
+    tr = _trainer(prob, flat0, cfg, max_batch=5120, global_batch=5120)
+    orc = head_oracle.TrainerOracle(flat0.clone(), prob["mean"], cfg, mode="bf16")
+    rng = np.random.default_rng(23)
+    lo, li = [], []
+    for it in range(10):
+        idx = rng.permutation(prob["features"].shape[0])[:5120]
+        b = helpers.torch_batch(prob, idx)
+        rec = orc.step(b["features"], b)
+        tr.step(torch.from_numpy(idx.astype(np.int64)).cuda())
+        lo.append(rec["loss"]); li.append(rec["inliers"])
+    loss, inl = tr.log(0, 10)
+    tol = 3e-2 if regime == "trained" else 1e-2
+    np.testing.assert_allclose(loss, lo, rtol=tol)
+    np.testing.assert_allclose(inl, li, atol=0.005)
+    d_gpu = tr.params.cpu().numpy() - flat0.numpy()
+    d_orc = orc.head.p.flat.numpy() - flat0.numpy()
+    assert _rel(d_gpu, d_orc) < (0.10 if regime == "trained" else 0.40), _rel(d_gpu, d_orc)
+    cosine = float(np.dot(d_gpu.astype(np.float64), d_orc.astype(np.float64)) / (np.linalg.norm(d_gpu.astype(np.float64)) * np.linalg.norm(d_orc.astype(np.float64))))
+    assert cosine > 0.95, cosine
+    assert tr.state()["iteration"] == 10 and abs(tr.state()["lr"] - orc.sched.lr) < 1e-15

@@ -9,11 +9,10 @@ from oracle import head_oracle
 from tests import helpers
 
 
-@pytest.mark.parametrize("name", list(helpers.HEAD_CONFIGS))
+@pytest.mark.parametrize("name", list(helpers.HEAD_CONFIGS) + list(helpers.TRAINED_CONFIGS))
 def test_oracle_fp32_matches_reference_golden(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
-    prob, flat0 = helpers.golden_problem()
-    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS[name], prob)
+    prob, flat0, cfg = helpers.problem_for(name)
     batches = helpers.golden_batches(prob, cfg["steps"])
     pose_flat = None
     if cfg["pose_refinement"] == "mlp":
@@ -42,11 +41,19 @@ def test_oracle_fp32_matches_reference_golden(name, golden_dir):
             np.testing.assert_allclose(tr.pose.flat.detach().numpy()[::stride], g["pose_params_sel"][it], atol=2e-6 if it < 3 else 3e-3)
         snaps[it] = tr.head.p.flat.clone().numpy()
     assert len(losses) == int(g["steps_run"])
+    if name in helpers.TRAINED_CONFIGS:
+        assert min(inl) > 0.8, "the trained-regime fixtures exist to exercise batch_inliers > 0.7"
+    if name == "head_trained_1cyclepoly":
+        # the cool-down trigger fired on real inlier counts (ace_schedule.py:86-101): max_iterations = 3 + 6, training stopped there
+        assert maxit[-1] == 9 and len(losses) == 9 and int(g["max_iterations"][-1]) == 9
     np.testing.assert_allclose(lrs, g["lr"], rtol=1e-12)
     np.testing.assert_array_equal(maxit, g["max_iterations"])
     np.testing.assert_allclose(inl, g["inliers"], atol=1.5 / helpers.B)
     # the first steps pin the arithmetic; later ones only bound the drift (mask/sign flips amplify 1e-7 differences)
-    np.testing.assert_allclose(losses[:5], g["loss"][:5], rtol=2e-5)
+    # (trained regime: the first loss pins the arithmetic; from the second step on the tiny gradients of a converged problem make
+    # AdamW's m / (sqrt(v) + eps) amplify last-bit differences -- 1e-4 relative on the loss, measured)
+    np.testing.assert_allclose(losses[:1], g["loss"][:1], rtol=2e-5)
+    np.testing.assert_allclose(losses[:5], g["loss"][:5], rtol=3e-4 if name in helpers.TRAINED_CONFIGS else 2e-5)
     np.testing.assert_allclose(losses, g["loss"], rtol=3e-2)
     sel = g["param_sel"]
     np.testing.assert_allclose(snaps[0][sel], g["params_after_first"], rtol=0, atol=2e-6)
