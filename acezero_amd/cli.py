@@ -14,6 +14,7 @@ schedule and early stopping, head checkpoints, pose files -- follows the referen
 import argparse
 import logging
 import math
+import os
 import time
 from pathlib import Path
 
@@ -180,7 +181,8 @@ def train_parser():
     p.add_argument("output_map_file", type=Path, help="target file for the trained head")
     _add(p, TRAIN_FLAGS)
     p.add_argument("--feature_buffer", type=Path, default=None, help="[additive] .npz training buffer (acez_train_buffer layout)")
-    p.add_argument("--num_gpus", type=int, default=1, help="[additive] informational; multi-GPU runs are launched with torchrun")
+    p.add_argument("--num_gpus", type=int, default=1, help="[additive] informational; multi-GPU reconstructions are launched as "
+                   "`torchrun --nproc-per-node G ace_zero.py ...` (the mapping rounds inside are data parallel)")
     return p
 
 
@@ -522,7 +524,18 @@ def ace_zero_main(argv=None):
     import torch
     from .session import ReconstructionSession, default_options, write_pose_file
     opt = ace_zero_parser().parse_args(argv)
-    logging.basicConfig(level=logging.INFO)
+    # `torchrun --nproc-per-node G ace_zero.py ...`: one process per GPU (RCCL). Frames, buffer and registration are sharded inside
+    # the session; rank 0 writes the files. Without torchrun this is the single-GPU run.
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if not dist.is_initialized():
+            dist.init_process_group(os.environ.get("ACEZ_DIST_BACKEND", "nccl"))
+        if opt.export_point_cloud:
+            raise SystemExit("--export_point_cloud True runs on one GPU: export from the written pose file with export_point_cloud.py")
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING)
     opt.results_folder.mkdir(parents=True, exist_ok=True)
     files, frames, fscale, rgb = load_frames(opt.rgb_files, opt.image_resolution, return_rgb=True)
     depth = load_depth_maps(opt.depth_files, len(files), frames.shape[2:]) if opt.depth_files is not None else None
@@ -537,6 +550,10 @@ def ace_zero_main(argv=None):
         over["seed_network"] = torch.load(opt.seed_network, map_location="cpu")
     ses = ReconstructionSession(torch.load(_default_encoder_path(opt.encoder_path), map_location="cpu"), frames, opt=default_options(**over), depth=depth)
     res = ses.reconstruct()
+    if rank != 0:                                                       # every rank holds the same result; rank 0 writes it
+        import torch.distributed as dist
+        dist.barrier()
+        return 0
     for h in res["history"]:                                            # the files ace_zero.py leaves behind (SURVEY 8b "process/file contract")
         write_pose_file(opt.results_folder / f"poses_{h['id']}.txt", files, h["poses"], h["confidence"], h["focal"] / fscale)
         torch.save(h["head"], opt.results_folder / f"{h['id']}.pt")
@@ -550,6 +567,9 @@ def ace_zero_main(argv=None):
     rates = [float((res["confidence"] > t).mean()) for t in (500, 1000, 2000, 4000)]
     _logger.info(f"Reconstructed in {res['seconds'] / 60:.1f} minutes, {res['iterations']} iterations; "
                  "registration rate @500/@1000/@2000/@4000: " + " ".join(f"{r * 100:.1f}%" for r in rates))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     return 0
 
 

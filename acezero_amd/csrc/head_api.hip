@@ -633,6 +633,9 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused) {
   ACEZ_REQUIRE(tr, "null trainer");
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   hipStream_t s = (hipStream_t)stream;
+  // two updates without a backward in between (a data-parallel rank whose shard holds no row of a batch zeroes its gradient and
+  // only takes part in the all-reduce): the schedule bookkeeping of the previous step must not be lost
+  flush_post(tr, s);
   AdamArgs a;
   fill_adam_args(tr, a);
   if (fused) { a.slabs = tr->slabs; a.nslabs = tr->nslabs; a.slab_stride = tr->n_wide; a.tail = tr->last_reduce; }

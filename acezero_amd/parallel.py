@@ -38,6 +38,28 @@ def split_batch_by_owner(global_batch_indices, shard_lo, shard_hi):
     return (global_batch_indices[m] - shard_lo).contiguous()
 
 
+def epoch_local_batches(perm, batch, shard_lo, shard_hi):
+    """split_batch_by_owner for a whole epoch at once: `perm` is the epoch's global permutation (every rank draws the same one),
+    consumed in consecutive slices of `batch` rows with the last partial slice dropped (ace_trainer.py:473-474). Returns
+    (local, offsets): this rank's rows of batch b are local[offsets[b]:offsets[b + 1]] (re-based to the shard, in batch order).
+    One host synchronisation per EPOCH (the per-batch counts) instead of one per step."""
+    nb = int(perm.numel()) // batch
+    p = perm[:nb * batch]
+    m = (p >= shard_lo) & (p < shard_hi)
+    local = (p[m] - shard_lo).contiguous()
+    counts = m.view(nb, batch).sum(dim=1).cpu().tolist()
+    offsets = [0]
+    for c in counts:
+        offsets.append(offsets[-1] + int(c))
+    return local, offsets
+
+
+def rank_world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
 class DataParallelTrainer:
     """Wraps a trainer exposing backward(indices), grad (flat tensor incl. statistics) and update()."""
 
@@ -47,14 +69,18 @@ class DataParallelTrainer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     def step(self, local_indices):
-        self.trainer.backward(local_indices)
+        if local_indices.numel() > 0:
+            self.trainer.backward(local_indices)
+        else:
+            self.trainer.grad.zero_()     # this shard holds no row of the batch: it contributes nothing to the sum
         if self.world > 1:
             dist.all_reduce(self.trainer.grad, op=dist.ReduceOp.SUM, group=self.group)
         self.trainer.update()
 
 
-def gather_registrations(local_frame_ids, local_poses, local_inliers, n_frames, group=None):
-    """Collect per-frame results on every rank in frame order. local_poses [k,4,4] f32, local_inliers [k] i32."""
+def gather_registrations(local_frame_ids, local_poses, local_inliers, n_frames, group=None, expect=None):
+    """Collect per-frame results on every rank in frame order. local_poses [k,4,4] f32, local_inliers [k] i32. `expect`: the frame
+    ids that must have been registered by some rank (default: all n_frames)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         order = torch.argsort(torch.as_tensor(local_frame_ids))
         return local_poses[order], local_inliers[order]
@@ -70,5 +96,6 @@ def gather_registrations(local_frame_ids, local_poses, local_inliers, n_frames, 
         poses[idx] = p
         inl[idx] = c
         seen[idx] = True
-    assert bool(seen.all()), "some frames were not registered by any rank"
+    need = seen if expect is None else seen[torch.as_tensor(expect, dtype=torch.long)]
+    assert bool(need.all()), "some frames were not registered by any rank"
     return poses, inl

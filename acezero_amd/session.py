@@ -27,7 +27,10 @@ import torch
 from . import _native as N
 from . import dsacstar
 from .encoder import Encoder, output_size
+import torch.distributed as dist
+
 from .head import HeadTrainer, _ptr, _stream, epoch_permutations
+from .parallel import epoch_local_batches, gather_registrations, rank_world
 
 _logger = logging.getLogger("acezero_amd.session")
 
@@ -106,9 +109,15 @@ def view_depth(depth_11hw, grid, oh, ow):
 
 
 class ReconstructionSession:
-    def __init__(self, encoder_state_dict, images, opt=None, depth=None, device=None, chunk=32):
+    def __init__(self, encoder_state_dict, images, opt=None, depth=None, device=None, chunk=32, group=None):
         """images [n,1,H,W] float32 normalised (dataset.py:150-153), any device; depth [n,H/8,W/8] camera z at the feature-map
-        pixel centres (metres, 0 = invalid) or None -- only the seed images' maps are read."""
+        pixel centres (metres, 0 = invalid) or None -- only the seed images' maps are read.
+
+        Under torch.distributed (one process per GPU, `torchrun ace_zero.py ...`) every rank holds all normalised frames (1.2 MB
+        each) but encodes and caches the features of ITS frames only (frame i -> rank i % world, parallel.frames_of_rank):
+        registration is sharded by frame with one gather of the poses, a mapping round shards the training buffer by image and
+        sums the flat gradient bucket with one all-reduce per step (global batch unchanged), the seed trials run on different
+        ranks side by side. Every rank takes the same decisions from the same gathered numbers; rank 0 writes the files."""
         if not torch.cuda.is_available():
             raise RuntimeError("ReconstructionSession needs a GPU: every stage is a HIP kernel (no CPU fallback)")
         self.opt = opt or default_options()
@@ -122,11 +131,15 @@ class ReconstructionSession:
         self._aug_rng = np.random.default_rng(self.opt.base_seed + 77)
         self.oh, self.ow = output_size(H, W)
         self.hw = self.oh * self.ow
-        self.features = torch.empty((self.n, self.hw, self.enc.out_channels), dtype=torch.bfloat16, device=self.dev)
+        self.group = group
+        self.rank, self.world = rank_world(group)
+        self.owned = np.arange(self.rank, self.n, self.world)            # parallel.frames_of_rank; local slot of frame g: g // world
+        self.features = torch.empty((len(self.owned), self.hw, self.enc.out_channels), dtype=torch.bfloat16, device=self.dev)
         t0 = time.time()
-        for c0 in range(0, self.n, chunk):
-            c1 = min(self.n, c0 + chunk)
-            self.enc.features_rows(self.images[c0:c1], out=self.features[c0:c1].view(-1, self.enc.out_channels))
+        own = torch.from_numpy(self.owned).to(self.dev)
+        for c0 in range(0, len(self.owned), chunk):
+            c1 = min(len(self.owned), c0 + chunk)
+            self.enc.features_rows(self.images[own[c0:c1]], out=self.features[c0:c1].view(-1, self.enc.out_channels))
         torch.cuda.synchronize(self.dev)
         self.depth = None if depth is None else depth.to(self.dev, torch.float32)
         f_ext = float(self.opt.use_external_focal_length)
@@ -134,24 +147,32 @@ class ReconstructionSession:
         self.ppx, self.ppy = W / 2.0, H / 2.0                                            # dataset.py:411-412
         self.history = []
         self._views_sampled = 0
-        _logger.info(f"Encoded {self.n} frames in {time.time() - t0:.2f}s; features resident: {self.features.numel() * 2 / 2 ** 30:.2f} GiB")
+        _logger.info(f"Encoded {len(self.owned)} of {self.n} frames in {time.time() - t0:.2f}s (rank {self.rank} of {self.world}); "
+                     f"features resident: {self.features.numel() * 2 / 2 ** 30:.2f} GiB")
+
+    def _slots(self, frame_ids):
+        """Positions in self.features of frames this rank owns."""
+        ids = np.asarray(frame_ids, np.int64)
+        if np.any(ids % self.world != self.rank):
+            raise ValueError("frame not owned by this rank")
+        return torch.from_numpy(ids // self.world).to(self.dev)
 
     # ------------------------------------------------------------------------------------------------ mapping (train_ace.py)
     def _K(self, focal):
         return torch.tensor([[focal, 0, self.ppx], [0, focal, self.ppy], [0, 0, 1.0]], dtype=torch.float32)
 
-    def _fill_buffer(self, image_ids, poses_c2w, focal, with_depth):
+    def _fill_buffer(self, image_ids, poses_c2w, focal, with_depth, total=None):
         """TrainerACE.create_training_buffer (ace_trainer.py:293-452) on cached features, views not augmented."""
         o = self.opt
         ids = torch.as_tensor(list(image_ids), dtype=torch.long, device=self.dev)
         m = len(ids)
-        total = min(o.max_training_buffer_size, o.max_dataset_passes * m * o.samples_per_image)
+        total = total if total is not None else min(o.max_training_buffer_size, o.max_dataset_passes * m * o.samples_per_image)
         C = self.enc.out_channels
         feats = torch.empty((total, C), dtype=torch.bfloat16, device=self.dev)
         px = torch.empty((total, 2), dtype=torch.float32, device=self.dev)
         vidx = torch.empty((total,), dtype=torch.int32, device=self.dev)
         pix = torch.empty((total,), dtype=torch.int32, device=self.dev)
-        src = self.features[ids].reshape(-1, C)                          # one copy of the mapped images' feature maps
+        src = self.features[self._slots(ids.cpu().numpy())].reshape(-1, C)   # one copy of the mapped images' feature maps
         mask = None
         if with_depth:                                                  # pixels without a depth are not sampled (dataset.py:384-386 zero them)
             d = self.depth[ids]
@@ -214,14 +235,14 @@ class ReconstructionSession:
         r[:, 0, 0], r[:, 0, 1], r[:, 1, 0], r[:, 1, 1] = torch.cos(a), torch.sin(a), -torch.sin(a), torch.cos(a)
         return r
 
-    def _fill_buffer_augmented(self, image_ids, poses_c2w, focal, with_depth):
+    def _fill_buffer_augmented(self, image_ids, poses_c2w, focal, with_depth, total=None):
         """create_training_buffer with --use_aug True: every pass re-encodes a freshly augmented view of every mapped image and
         samples it with its validity mask. The views of a pass are grouped by canvas size and processed in batches."""
         from .buffer import BufferBuilder
         o = self.opt
         ids = torch.as_tensor([int(i) for i in image_ids], dtype=torch.long)
         m = len(ids)
-        total = min(o.max_training_buffer_size, o.max_dataset_passes * m * o.samples_per_image)
+        total = total if total is not None else min(o.max_training_buffer_size, o.max_dataset_passes * m * o.samples_per_image)
         bld = BufferBuilder(self.enc, capacity=total, samples_per_image=o.samples_per_image, seed=o.base_seed + 4095 + self._views_sampled)
         poses_c2w = torch.as_tensor(poses_c2w, dtype=torch.float64).reshape(m, 4, 4)
         pose_inv = torch.linalg.inv(poses_c2w).to(torch.float32)
@@ -271,19 +292,52 @@ class ReconstructionSession:
         return buf
 
     def map(self, image_ids, poses_c2w, focal, *, iterations, loss_type, schedule, lr_max, refinement="none", pose_wait=0,
-            refine_calibration=False, load_weights=None, with_depth=False, tag="map"):
+            refine_calibration=False, load_weights=None, with_depth=False, tag="map", data_parallel=None):
         """One train_ace.py run (ace_trainer.py:TrainerACE.train): returns {"head": fp16 state_dict, "poses_w2c": [m,3,4] refined,
-        "focal": refined focal, "iterations", "seconds", "patches_per_s", "batch_inliers"}."""
+        "focal": refined focal, "iterations", "seconds", "patches_per_s", "batch_inliers"}.
+
+        data_parallel (default: whenever the process group has more than one rank and there are at least as many images as ranks):
+        the mapped images are dealt to the ranks, every rank fills its share of the buffer from its images, and every step is
+        backward -> all-reduce of the flat gradient bucket -> update with the reference's batch composition: all ranks draw the same
+        permutation of the GLOBAL buffer and take the rows of each 5120-slice that live in their shard (parallel.epoch_local_batches;
+        the loss is a sum / 5120, ace_trainer.py:612-613, so the summed gradient is the single-GPU gradient of that batch). Replicas
+        stay bit-identical without a weight broadcast, so every rank returns the same result."""
         o = self.opt
         t0 = time.time()
-        fill = self._fill_buffer_augmented if self.opt.use_aug else self._fill_buffer
-        buf = fill(image_ids, poses_c2w, focal, with_depth)
+        image_ids = [int(i) for i in image_ids]
+        m = len(image_ids)
+        poses_c2w = torch.as_tensor(poses_c2w, dtype=torch.float32).reshape(-1, 4, 4)
+        dp = (self.world > 1 and m >= self.world) if data_parallel is None else bool(data_parallel and self.world > 1)
+        fill = self._fill_buffer_augmented if o.use_aug else self._fill_buffer
+        total = min(o.max_training_buffer_size, o.max_dataset_passes * m * o.samples_per_image)
+        if dp:
+            # augmented fill re-encodes every view, so any rank can take any image: deal them by position; the plain fill reads the
+            # cached feature maps, which live on the frame's owner
+            owner = [(j if o.use_aug else image_ids[j]) % self.world for j in range(m)]
+            counts = [owner.count(r) for r in range(self.world)]
+            if min(counts) == 0:
+                raise RuntimeError("data-parallel mapping: a rank owns none of the mapped images (use --use_aug True or fewer GPUs)")
+            shares = [total * c // m for c in counts]
+            for r in range(total - sum(shares)):
+                shares[r % self.world] += 1
+            mine = [j for j in range(m) if owner[j] == self.rank]
+            buf = fill([image_ids[j] for j in mine], poses_c2w[mine], focal, with_depth, total=shares[self.rank])
+            # per-image table: ALL mapped images on every rank (the pose network / the per-image pose parameters are replicated and
+            # their gradient is part of the all-reduced bucket); the views of this shard point into it by global position
+            buf["view_image"] = torch.as_tensor(mine, dtype=torch.int32)[buf["view_image"].long()]
+            buf["image_pose_inv"] = torch.linalg.inv(poses_c2w.double()).float()
+            shard_lo = sum(shares[:self.rank])
+            n = total
+        else:
+            buf = fill(image_ids, poses_c2w, focal, with_depth)
+            shard_lo, n = 0, int(buf["features"].shape[0])
         torch.cuda.synchronize(self.dev)
         t_fill = time.time() - t0
-        n = int(buf["features"].shape[0])
+        n_local = int(buf["features"].shape[0])
+        if dp and n_local != shares[self.rank]:
+            raise RuntimeError(f"rank {self.rank} filled {n_local} buffer rows instead of its share of {shares[self.rank]}")
         if n < o.batch_size:
             raise ValueError(f"training buffer of {n} patches is smaller than one batch ({o.batch_size})")
-        poses_c2w = torch.as_tensor(poses_c2w, dtype=torch.float32).reshape(-1, 4, 4)
         if load_weights is not None:
             mean = load_weights["mean"].float().view(3)                  # Regressor.create_from_split_state_dict keeps the stored mean
         else:
@@ -312,8 +366,19 @@ class ReconstructionSession:
         perms = epoch_permutations(n, o.base_seed + 8191, self.dev)       # ace_trainer.py:79-80 seed of the training generator
         while not done:                                                  # TrainerACE.train / run_epoch (ace_trainer.py:454-497)
             perm = next(perms)
-            for b0 in range(0, n - o.batch_size + 1, o.batch_size):
-                tr.step(perm[b0:b0 + o.batch_size])
+            if dp:
+                local, offs = epoch_local_batches(perm, o.batch_size, shard_lo, shard_lo + n_local)
+            for b in range(n // o.batch_size):
+                if dp:
+                    rows = local[offs[b]:offs[b + 1]]
+                    if rows.numel() > 0:
+                        tr.backward(rows)
+                    else:
+                        tr.grad.zero_()
+                    dist.all_reduce(tr.grad, op=dist.ReduceOp.SUM, group=self.group)   # RCCL: head + pose gradients, loss / inlier / focal statistics
+                    tr.update()
+                else:
+                    tr.step(perm[b * o.batch_size:(b + 1) * o.batch_size])
                 launched += 1
                 if launched % 64 == 0:                                   # the only host synchronisation of the loop
                     st = tr.state()
@@ -329,40 +394,64 @@ class ReconstructionSession:
                "poses_w2c": tr.current_poses(), "focal": float(st["focal_scale"] * focal) if refine_calibration else float(focal),
                "iterations": int(st["iteration"]), "seconds": dt, "fill_seconds": t_fill, "loop_seconds": t_loop,
                "patches_per_s": st["iteration"] * o.batch_size / t_loop,
-               "batch_inliers": float(st["batch_inliers"]), "loss": float(st["loss"]), "buffer": n}
-        _logger.info(f"[{tag}] {len(list(image_ids))} images, {n} patches, {out['iterations']} iterations in {dt:.2f}s (buffer {t_fill:.2f}s, loop {t_loop:.2f}s), "
-                     f"batch inliers {out['batch_inliers'] * 100:.1f}%, focal {out['focal']:.1f}")
+               "batch_inliers": float(st["batch_inliers"]), "loss": float(st["loss"]), "buffer": n, "data_parallel": bool(dp)}
+        _logger.info(f"[{tag}] {m} images, {n} patches{' over %d ranks' % self.world if dp else ''}, {out['iterations']} iterations in {dt:.2f}s "
+                     f"(buffer {t_fill:.2f}s, loop {t_loop:.2f}s), batch inliers {out['batch_inliers'] * 100:.1f}%, focal {out['focal']:.1f}")
         tr.close()
         return out
 
     # ---------------------------------------------------------------------------------------- registration (register_mapping.py)
-    def scene_coordinates(self, head_sd, first=0, count=None):
-        """Head.forward on the cached features of frames [first, first+count): float32 [count,3,oh,ow] on the device."""
-        count = self.n - first if count is None else count
+    def scene_coordinates(self, head_sd, frame_ids=None):
+        """Head.forward on the cached features of the given frames (default: every frame this rank owns): float32 [k,3,oh,ow] on
+        the device."""
+        ids = self.owned if frame_ids is None else np.asarray(frame_ids, np.int64)
+        count = len(ids)
+        out = torch.empty((count, 3, self.oh, self.ow), dtype=torch.float32, device=self.dev)
+        if count == 0:
+            return out
+        slots = self._slots(ids)
         nb = sum(1 for k in head_sd if k.endswith("c0.weight"))
         head = HeadTrainer(head_sd["mean"].float().view(3), num_head_blocks=nb, use_homogeneous=head_sd["fc3.weight"].shape[0] == 4,
                            max_batch=min(count, 64) * self.hw, iterations=1, device=self.dev.index)
         head.load_state_dict(head_sd)
-        out = torch.empty((count, 3, self.oh, self.ow), dtype=torch.float32, device=self.dev)
+        contiguous = bool(np.all(np.diff(slots.cpu().numpy()) == 1)) if count > 1 else True
         for c0 in range(0, count, 64):
             c1 = min(count, c0 + 64)
-            rows = self.features[first + c0:first + c1].view(-1, self.enc.out_channels)
+            rows = (self.features[int(slots[c0]):int(slots[c0]) + (c1 - c0)] if contiguous else self.features[slots[c0:c1]]).reshape(-1, self.enc.out_channels)
             N.check(N.lib().acez_head_forward_maps(head._h, _ptr(rows), c1 - c0, self.oh, self.ow, _ptr(out[c0:c1]), _stream()))
         torch.cuda.synchronize(self.dev)
         head.close()
         return out
 
     def register(self, head_sd, focal, max_estimates=-1, tag="register", max_tries=16):
-        """register_mapping.py:201-276 for every frame: (poses cam->world [k,4,4] float32, inlier counts [k] int32)."""
+        """register_mapping.py:201-276: (poses cam->world [k,4,4] float32, inlier counts [k] int32, frame ids [k]).
+
+        max_estimates > 0 scores a random subset like the reference does: register_mapping.py iterates a DataLoader(shuffle=True)
+        under torch.manual_seed(base_seed) and stops after max_estimates frames (:122-147,256) -- a seeded permutation of the frame
+        ids here (a different stream, the same law), NOT the first k frames of the sequence. Frames are sharded over the ranks
+        (frame i -> rank i % world); the random stream of a frame is keyed by its id, so the result does not depend on the
+        partition, and one gather returns every frame's result to every rank."""
         o = self.opt
-        k = self.n if max_estimates <= 0 else min(self.n, max_estimates)
+        if max_estimates <= 0 or max_estimates >= self.n:
+            ids = np.arange(self.n)
+        else:
+            g = torch.Generator().manual_seed(int(o.register_seed))
+            ids = np.sort(torch.randperm(self.n, generator=g)[:max_estimates].numpy())
         t0 = time.time()
-        sc = self.scene_coordinates(head_sd, 0, k)
+        mine = ids[ids % self.world == self.rank]
+        sc = self.scene_coordinates(head_sd, mine)
         prm = dict(hyps=o.ransac_iterations, thr=o.ransac_threshold, alpha=float(o.inlieralpha), max_reproj=float(o.maxpixelerror), sub=8, max_tries=max_tries)
-        poses, inl, _ = dsacstar.register_batch(sc, [(focal, self.ppx, self.ppy)] * k, prm, o.register_seed, list(range(k)), want_masks=False)
-        poses, inl = poses.cpu().numpy(), inl.cpu().numpy()
+        if len(mine):
+            poses, inl, _ = dsacstar.register_batch(sc, [(focal, self.ppx, self.ppy)] * len(mine), prm, o.register_seed, [int(i) for i in mine], want_masks=False)
+            poses, inl = poses.cpu(), inl.cpu().to(torch.int32)
+        else:
+            poses, inl = torch.zeros(0, 4, 4), torch.zeros(0, dtype=torch.int32)
+        if self.world > 1:
+            full_p, full_i = gather_registrations([int(i) for i in mine], poses, inl, self.n, self.group, expect=ids)
+            poses, inl = full_p[ids], full_i[ids]
+        poses, inl = poses.numpy(), inl.numpy()
         rate = float((inl > o.registration_confidence).mean())
-        _logger.info(f"[{tag}] {k} frames in {time.time() - t0:.2f}s, {rate * 100:.1f}% above confidence {o.registration_confidence}")
+        _logger.info(f"[{tag}] {len(ids)} frames in {time.time() - t0:.2f}s, {rate * 100:.1f}% above confidence {o.registration_confidence}")
         return poses, inl
 
     # --------------------------------------------------------------------------------------------------- the loop (ace_zero.py)
@@ -375,10 +464,13 @@ class ReconstructionSession:
         rows = self.opt.max_dataset_passes * self.opt.samples_per_image
         if rows < self.opt.batch_size:                                   # one image gives passes x samples rows (10 240 by default = two batches)
             raise ValueError(f"a seed image yields {rows} buffer rows, fewer than one batch of {self.opt.batch_size}: raise --max_dataset_passes")
-        m = self.map([img], torch.eye(4).unsqueeze(0), self.focal0, iterations=o.seed_iterations, loss_type=o.repro_loss_type,
-                     schedule=o.learning_rate_schedule, lr_max=o.learning_rate_max, with_depth=True, tag=f"iteration0_seed{seed_idx}")
-        _, inl = self.register(m["head"], self.focal0, max_estimates=o.max_estimates_seed_scoring, tag=f"iteration0_seed{seed_idx}_fastcheck")
-        return m, float((inl > o.registration_confidence).mean())
+        return self.map([img], torch.eye(4).unsqueeze(0), self.focal0, iterations=o.seed_iterations, loss_type=o.repro_loss_type,
+                        schedule=o.learning_rate_schedule, lr_max=o.learning_rate_max, with_depth=True, tag=f"iteration0_seed{seed_idx}",
+                        data_parallel=False)
+
+    def score_seed(self, seed_idx, m):
+        _, inl = self.register(m["head"], self.focal0, max_estimates=self.opt.max_estimates_seed_scoring, tag=f"iteration0_seed{seed_idx}_fastcheck")
+        return float((inl > self.opt.registration_confidence).mean())
 
     def reconstruct(self):
         o = self.opt
@@ -389,7 +481,20 @@ class ReconstructionSession:
         else:
             np.random.seed(o.random_seed)                                # ace_zero.py:181-183
             seeds = np.random.uniform(size=o.try_seeds)
-            trials = [self.map_seed(i, s) for i, s in enumerate(seeds)]
+            if self.world == 1:
+                trials = []
+                for i, sd_ in enumerate(seeds):                          # ace_zero.py:185-215: map, then score, seed after seed
+                    mp_ = self.map_seed(i, sd_)
+                    trials.append((mp_, self.score_seed(i, mp_)))
+            else:
+                # a seed trial maps ONE image (nothing to shard): trial i runs on rank i % world, side by side with the others; its
+                # head is then handed to every rank and scored by all of them together (sharded registration)
+                maps = [self.map_seed(i, sd_) if i % self.world == self.rank else None for i, sd_ in enumerate(seeds)]
+                for i in range(len(maps)):
+                    box = [maps[i]]
+                    dist.broadcast_object_list(box, src=i % self.world, group=self.group)
+                    maps[i] = box[0]
+                trials = [(mp_, self.score_seed(i, mp_)) for i, mp_ in enumerate(maps)]
             best = int(np.argmax([r for _, r in trials]))
             current, first_id, seed_rates = trials[best][0], f"iteration0_seed{best}", [r for _, r in trials]
         poses, conf = self.register(current["head"], focal, tag=first_id)
@@ -438,8 +543,10 @@ class ReconstructionSession:
         (xyz [N,3] float32, source [N] = position in the registered list * hw + map pixel). OpenCV convention by default, as
         ace_zero.py requests it (--convention opencv, :398)."""
         from .pointcloud import filter_scene_coordinates
-        sel = np.flatnonzero(np.asarray(confidence) > self.opt.registration_confidence)
-        sc = self.scene_coordinates(head_sd)[torch.from_numpy(sel).to(self.dev)]
+        sel = np.flatnonzero(np.asarray(confidence) >= self.opt.registration_confidence)   # load_dataset_ace keeps confidence >= threshold
+        if self.world > 1:
+            raise NotImplementedError("point-cloud export runs on one GPU (python export_point_cloud.py on the written pose file)")
+        sc = self.scene_coordinates(head_sd, sel)
         pinv = torch.linalg.inv(torch.from_numpy(np.asarray(poses_c2w, np.float64)[sel])).to(torch.float32)
         K = self._K(focal).repeat(len(sel), 1, 1)
         xyz, src, _, _ = filter_scene_coordinates(sc, pinv, K, filter_depth, dense, len(sel), seed=self.opt.random_seed, opengl=opengl)

@@ -68,9 +68,12 @@ def make_buffer(n_patches, device, seed):
     return prob, feats, target_px, view_idx
 
 
-def bench_training(args, rank, world, device, pose_refinement=None, steps=None, buffer_patches=None):
+def bench_training(args, rank, world, device, pose_refinement=None, steps=None, buffer_patches=None, strong=False):
     """pose_refinement None -> args.pose_refinement (the headline leg); 'mlp' -> ace_zero's non-seed mapping iterations
-    (--pose_refinement mlp --refine_calibration True, ace_zero.py:86,97,262-264)."""
+    (--pose_refinement mlp --refine_calibration True, ace_zero.py:86,97,262-264).
+    strong=True: the REFERENCE's step on N GPUs -- the global batch stays 5120, every rank draws the same permutation of the global
+    buffer and runs the rows of each slice that live in its shard (about 5120 / N), one all-reduce of the gradient bucket per step
+    (what `torchrun ace_zero.py` runs inside a mapping round); strong=False: 5120 rows per GPU, global batch 5120 N (weak)."""
     pose_refinement = pose_refinement or args.pose_refinement
     steps = steps or args.steps
     buffer_patches = buffer_patches or args.buffer_patches
@@ -79,18 +82,26 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
     per_rank = buffer_patches // world
     prob, feats, target_px, view_idx = make_buffer(per_rank, device, 2089 + rank)
     total_iters = steps + args.warmup + 64
-    tr = HeadTrainer(prob["mean"], max_batch=BATCH, global_batch=BATCH * world, loss_type="tanh", schedule="1cyclepoly",
+    tr = HeadTrainer(prob["mean"], max_batch=BATCH, global_batch=BATCH if strong else BATCH * world, loss_type="tanh", schedule="1cyclepoly",
                      iterations=max(total_iters, 25000), lr_min=0.0005, lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005,
                      cooldown_iterations=5000, pose_refinement=pose_refinement,
                      refine_calibration=pose_refinement != "none", focal_init=float(prob["focal"]))   # ace_zero.py:105-123 mapping settings
     tr.load_flat(torch.from_numpy(synth.init_head_params(1)))
     tr.set_buffer(feats, target_px, view_idx, prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"], prob["view_image"],
                   prob["image_pose_inv"])
-    g = torch.Generator(device=device).manual_seed(8191 + rank)
-    perm = torch.randperm(per_rank, generator=g, device=device)               # ace_trainer.py:466
-    nb = per_rank // BATCH
-    batches = [perm[i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(nb, total_iters))]
     dist = torch.distributed if world > 1 else None
+    if strong and world > 1:
+        from acezero_amd.parallel import epoch_local_batches
+        g = torch.Generator(device=device).manual_seed(8191)                      # the same permutation on every rank
+        perm = torch.randperm(per_rank * world, generator=g, device=device)
+        local, offs = epoch_local_batches(perm, BATCH, rank * per_rank, (rank + 1) * per_rank)
+        nb = len(offs) - 1
+        batches = [local[offs[i]:offs[i + 1]] for i in range(min(nb, total_iters))]
+    else:
+        g = torch.Generator(device=device).manual_seed(8191 + rank)
+        perm = torch.randperm(per_rank, generator=g, device=device)               # ace_trainer.py:466
+        nb = per_rank // BATCH
+        batches = [perm[i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(nb, total_iters))]
 
     def step(i):
         idx = batches[i % len(batches)]
@@ -278,6 +289,21 @@ def cpu_baseline():
         orc.step(b["features"], b)
         steps += 1
     t_train = (time.perf_counter() - t0) / max(steps, 1)
+    kind, train_what = "port", f"{steps} steps of 5120 patches, oracle/head_oracle.py fp32 on torch-CPU with {tcores} of {cores} host threads"
+    if os.path.isdir("/root/reference"):
+        # the reference itself (build container only: /root/reference does not exist on the GPU box): the unmodified
+        # TrainerACE.training_step through the stub-import recipe of tests/golden/make_head_golden.py
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("make_head_golden", os.path.join(ROOT, "tests", "golden", "make_head_golden.py"))
+            mk = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mk)
+            t_ref, n_ref = mk.time_reference_step(batch=BATCH, budget_s=12.0, max_steps=40, threads=tcores)
+            t_train, kind = t_ref, "reference"
+            train_what = (f"{n_ref} calls of the reference's TrainerACE.training_step (ace_trainer.py:499-679) at 5120 patches, CPU PyTorch fp32, "
+                          f"{tcores} of {cores} host threads (the reference pins them to 1 at import, ace_trainer.py:5-8: overridden)")
+        except Exception as e:   # noqa: BLE001 -- a broken reference import must not take the bench down
+            train_what += f" (reference import failed: {type(e).__name__})"
     fr = synth.make_registration_frames(seed=5, n_frames=16)
     dsac_oracle.lib()
 
@@ -288,6 +314,10 @@ def cpu_baseline():
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(one, range(nfr)))
     t_reg = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(min(12, cores)) as ex:   # register_mapping.py:6-9 runs dsacstar with OMP_NUM_THREADS = 12
+        list(ex.map(one, range(16 * min(12, cores))))
+    t_reg12 = (time.perf_counter() - t0) / (16 * min(12, cores))
     # encoder (the end-to-end registration leg's dominant cost): torch conv2d fp32 on the host cores, 2 frames of 480 x 640
     from oracle import encoder_oracle
     enc = encoder_oracle.EncoderOracle(encoder_oracle.init_weights(seed=4099), "fp32")
@@ -305,10 +335,13 @@ def cpu_baseline():
     for rep in range(4):
         cloud_oracle.point_cloud(frc["scene_coords"], pinv, [Kc] * 8, 100.0, False, 1000)
     t_cloud = (time.perf_counter() - t0) / 32
-    return {"value": BATCH / t_train, "unit": "patches/s", "cores": tcores, "kind": "port",
+    return {"value": BATCH / t_train, "unit": "patches/s", "cores": tcores, "kind": kind,
+            "kind_note": "reference = the reference's own training_step (only where /root/reference exists); port = oracle/ restatement "
+                         "(the GPU box has no reference checkout). The registration figures are always the oracle port: the reference's "
+                         "dsacstar needs OpenCV 4.4.0, which is not available.",
+            "registration_images_per_s_12_threads": 1.0 / t_reg12,
             "point_cloud_frames_per_s": 1.0 / t_cloud,
-            "sample": f"{steps} steps of 5120 patches, oracle/head_oracle.py fp32 on torch-CPU with {tcores} of {cores} host threads; "
-                      f"registration: {nfr} frames, oracle/dsac_oracle.cpp, {cores} threads",
+            "sample": train_what + f"; registration: {nfr} frames, oracle/dsac_oracle.cpp, {cores} threads (and with the reference's 12)",
             "registration_images_per_s": nfr / t_reg,
             "encoder_images_per_s": 1.0 / t_enc,
             "encoder_sample": f"2 frames of 480x640, oracle/encoder_oracle.py (torch conv2d fp32), {tcores} threads"}
@@ -335,13 +368,16 @@ def main():
 
     dt, st, prof = bench_training(args, rank, world, device)
     dt_ref, st_ref, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000))
+    dt_strong = None
+    if world > 1:   # the reference's step (global batch 5120) split over the ranks
+        dt_strong, st_strong, _ = bench_training(args, rank, world, device, steps=args.steps, buffer_patches=min(args.buffer_patches, 2_000_000), strong=True)
     nreg, dt_reg, reg_ok = bench_registration(args, rank, world, device)
     pipe = bench_pipeline(args, rank, world, device)
     sess = bench_session(args, device) if world == 1 and args.session_frames > 0 else None
     if world > 1:
-        t = torch.tensor([dt, dt_reg, dt_ref], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, dt_reg, dt_ref, dt_strong], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt, dt_reg, dt_ref = float(t[0]), float(t[1]), float(t[2])
+        dt, dt_reg, dt_ref, dt_strong = float(t[0]), float(t[1]), float(t[2]), float(t[3])
     if rank == 0:
         patches_per_s = BATCH * world * args.steps / dt
         gemm_ms, gemm_n = 0.0, 0
@@ -350,10 +386,13 @@ def main():
             gemm_n += prof[k][1]
         avg_s = gemm_ms / max(gemm_n, 1) * 1e-3
         achieved = BATCH * GEMM_FLOP_PER_LAUNCH_PER_ROW / avg_s / 1e12 if avg_s > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "r01_rowgemm_hbm_traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf):   # NOT measured in this run: the PMC passes need rocprofv3 around the process (tools/prof_r02.sh)
             traffic = json.load(open(tf)).get("bytes_per_launch")
+            traffic_source = "profiles/r01_rowgemm_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes; a stored measurement, not this run)"
+        wg_s = prof["wgrad"][0] / max(prof["wgrad"][1], 1) * 1e-3
+        wg_tflops = BATCH * 8 * GEMM_FLOP_PER_LAUNCH_PER_ROW / wg_s / 1e12 if wg_s > 0 else 0.0
         out = {
             "metric": "ACE patches/sec", "value": patches_per_s, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -363,6 +402,10 @@ def main():
                        "buffer_patches": args.buffer_patches, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "parallelism": f"dp{world}"},
             "whole_step_flop_frac_of_mfma_peak": patches_per_s / world * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS * 1e12),
+            "strong_scaling": None if dt_strong is None else {
+                "metric": "ACE patches/sec, the reference's step: global batch 5120 split over the ranks by buffer shard, one gradient all-reduce per step",
+                "value": BATCH * args.steps / dt_strong, "unit": "patches/s", "ms_per_step": dt_strong / args.steps * 1e3, "scaling": "strong",
+                "global_batch": BATCH, "rows_per_gpu": BATCH / world},
             "refinement_step": {"metric": "ACE patches/sec with --pose_refinement mlp --refine_calibration True (every non-seed mapping iteration of ace_zero.py)",
                                 "value": BATCH * world * 100 / dt_ref, "unit": "patches/s", "ms_per_step": dt_ref / 100 * 1e3, "steps": 100,
                                 "n_images": 1000, "final_loss": st_ref["loss"]},
@@ -386,9 +429,13 @@ def main():
                                    "map_bytes_per_s": pipe["cloud_frames"] * world * 57600 / pipe["cloud_s"]},
             "roofline": {"bound": "mfma", "kernel": "rowgemm80_kernel (5120x512x512 bf16, fwd + dgrad launches)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": gemm_n,
                          "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()},
                          "note": "HIP events on the launch stream around each chain of dependent rowgemm launches (8 fwd, 7 dgrad per step): average start-to-start cadence incl. the ~1-2 us kernel boundary; rocprofv3 kernel durations are in profiles/"},
+            "roofline_wgrad": {"bound": "mfma", "kernel": "wgrad_kernel (8 layers x 512x512x5120 bf16 in one launch)", "achieved": wg_tflops,
+                               "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_tflops / MFMA_PEAK_TFLOPS, "traffic": None,
+                               "avg_launch_us": wg_s * 1e6},
             "final_loss": st["loss"],
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N = 1 only

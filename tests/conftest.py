@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests marked `gpu` need an MI355X: on a machine without one they are skipped (not failed), so a plain `pytest tests` is green
+    in the build container; the product itself still raises without a GPU (tests/test_abi.py::test_no_silent_cpu_fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a GPU (MI355X): run with `-m gpu` on the GPU box")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

@@ -204,6 +204,37 @@ def run_reference(cfg, prob, flat0, batches):
     return rec, snaps, coords0
 
 
+def time_reference_step(batch=5120, budget_s=12.0, max_steps=40, threads=None):
+    """Seconds per TrainerACE.training_step of the REFERENCE on this host's cores (CPU PyTorch fp32) at `batch` patches: bench.py's
+    cpu_baseline, kind "reference", when /root/reference is present (the reference pins BLAS / OpenMP to one thread at import,
+    ace_trainer.py:5-8; overridden here and stated with the number)."""
+    global B
+    if threads:
+        torch.set_num_threads(threads)
+    cfg = full_cfg(CONFIGS["head_tanh_1cyclepoly"])
+    cfg.update(global_batch=batch, lr_min=0.0005, lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005, cooldown_iterations=5000,
+               cooldown_trigger_percent=0.7, iterations=25000)
+    prob = synth.make_training_problem(seed=3, n_images=20, views_per_image=2, patches_per_view=128)
+    flat0 = head_oracle.init_params(1)
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, prob["features"].shape[0], batch)
+    old_B, B = B, batch
+    try:
+        t_steps = []
+        run_reference(cfg, prob, flat0, [idx])                     # warm-up (allocations, thread pools)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < budget_s and n < max_steps:
+            t1 = time.perf_counter()
+            run_reference(cfg, prob, flat0, [idx, idx][:1])
+            t_steps.append(time.perf_counter() - t1)
+            n += 1
+    finally:
+        B = old_B
+    # run_reference rebuilds the head and the optimiser for every call; the step itself is the bulk (0.2-0.4 s of a call)
+    return float(np.median(t_steps)), n
+
+
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     only = sys.argv[1:]   # optional: names of the configurations to (re)generate

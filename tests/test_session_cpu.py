@@ -128,9 +128,10 @@ class _ScriptedSession(session.ReconstructionSession):
         self.focal0 = f_ext if f_ext > 0 else -1.0          # "-1" = the heuristic, as ace_zero.py passes it on
         self.history, self.calls, self._rates, self._maps = [], [], list(rates), 0
         self._np = np
+        self.rank, self.world, self.group = 0, 1, None
 
     def map(self, image_ids, poses_c2w, focal, *, iterations, loss_type, schedule, lr_max, refinement="none", pose_wait=0,
-            refine_calibration=False, load_weights=None, with_depth=False, tag="map"):
+            refine_calibration=False, load_weights=None, with_depth=False, tag="map", data_parallel=None):
         if not with_depth:
             self._maps += 1
         self.calls.append({"cmd": "train", "id": tag, "seed": with_depth, "iterations": iterations, "loss": loss_type, "schedule": schedule,
