@@ -248,10 +248,16 @@ def save_feature_buffer(path, prob, image_files=None, with_depth_targets=False):
 
 # ------------------------------------------------------------------------------------------------------------ train
 def train_main(argv=None):
-    import torch
-    from .head import HeadTrainer
     opt = train_parser().parse_args(argv)
     logging.basicConfig(level=logging.INFO)
+    return train_with_options(opt)
+
+
+def train_with_options(opt):
+    """The body of train_ace.py after argument parsing: what the reference runs as TrainerACE(options).train() (train_ace.py:240-241;
+    the top-level ace_trainer.TrainerACE shim calls this)."""
+    import torch
+    from .head import HeadTrainer
     if opt.batch_size % 512 != 0:
         raise SystemExit("batch_size must be a multiple of 512 (train_ace.py:138)")
     if opt.feature_buffer is None:

@@ -20,6 +20,14 @@ from . import _native as N
 
 _ctx = {}
 _calls = 0
+_verbose = False
+
+
+def set_verbose(on=True):
+    """The reference prints eight progress lines per frame (dsacstar.cpp:101-174); silent by default here, opt-in for parity of the
+    console output (stage names as in the reference; the stages run inside one kernel, so there is one time for all of them)."""
+    global _verbose
+    _verbose = bool(on)
 MAX_REF_STEPS = 100  # dsacstar.cpp:47
 
 
@@ -63,10 +71,18 @@ def forward_rgb(sceneCoordinates, outPose, ransacHypotheses, inlierThreshold, fo
     ctx = _context(1, H, W, dev)
     prm = _params(ransacHypotheses, inlierThreshold, inlierAlpha, maxReproj, subSampling, max_hypotheses_tries)
     intr = N.Intrinsics(float(focalLength), float(ppointX), float(ppointY))
+    import time
+    t0 = time.perf_counter()
+    if _verbose:
+        print("Sampling " + str(int(ransacHypotheses)) + " hypotheses.", flush=True)
     if sc.is_cuda:
         poses, inl, _ = register_batch(sc[0][None], [intr], prm, randomSeed, [frame_id], want_masks=False)
         outPose.copy_(poses[0].to(outPose.device))
-        return int(inl[0].item())
+        count = int(inl[0].item())
+        if _verbose:
+            print(f"Calculating scores. / Drawing final hypothesis. / Refining winning pose: done in {(time.perf_counter() - t0) * 1e3:.2f}ms. "
+                  f"Inliers: {count}", flush=True)
+        return count
     pose = np.zeros(16, np.float32)
     inliers = C.c_int32(0)
     st = sc.stride()
@@ -74,6 +90,9 @@ def forward_rgb(sceneCoordinates, outPose, ransacHypotheses, inlierThreshold, fo
                                            C.c_uint64(int(randomSeed)), C.c_uint64(frame_id), pose.ctypes.data_as(C.c_void_p),
                                            C.byref(inliers), None))
     outPose.copy_(torch.from_numpy(pose.reshape(4, 4)))
+    if _verbose:
+        print(f"Calculating scores. / Drawing final hypothesis. / Refining winning pose: done in {(time.perf_counter() - t0) * 1e3:.2f}ms. "
+              f"Inliers: {int(inliers.value)}", flush=True)
     return int(inliers.value)
 
 

@@ -135,3 +135,20 @@ def test_export_point_cloud_from_visualization_buffer(tmp_path):
         cli.export_point_cloud_main([str(tmp_path / "pc.txt"), "--visualization_buffer", str(tmp_path / "buf.pkl"), "--dense_point_cloud", "True"])
     c = cli.source_colours(np.arange(2 * 16 * 24 * 3, dtype=np.uint8).reshape(2, 16, 24, 3), np.array([1, 0]), np.array([4, 0]), 3)
     assert c.shape == (2, 3) and np.array_equal(c[1], np.arange(2 * 16 * 24 * 3, dtype=np.uint8).reshape(2, 16, 24, 3)[0, 4, 4])
+
+
+def test_reference_module_names_are_importable():
+    """register_mapping.py:12 does `import dsacstar`, train_ace.py:20 `from ace_trainer import TrainerACE` (surface names)."""
+    import inspect
+    import dsacstar
+    from ace_trainer import TrainerACE
+    sig = inspect.signature(dsacstar.forward_rgb)
+    assert list(sig.parameters) == ["sceneCoordinates", "outPose", "ransacHypotheses", "inlierThreshold", "focalLength", "ppointX", "ppointY",
+                                    "inlierAlpha", "maxReproj", "subSampling", "randomSeed", "max_hypotheses_tries"]   # dsacstar.cpp:66-78
+    from acezero_amd import cli
+    opt = cli.train_parser().parse_args(["frames/*.png", "out/map.pt"])
+    tr = TrainerACE(opt)
+    assert hasattr(tr, "train") and tr.options is opt
+    opt.batch_size = 5000
+    with pytest.raises(ValueError):
+        TrainerACE(opt)
