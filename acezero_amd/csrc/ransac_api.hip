@@ -8,12 +8,15 @@
 //               minimal-set draws run 64 at a time on the lanes (each lane: 4 draws -> P3P -> 4-point check);
 //               __ballot + first-set-bit picks the first accepted try = what the sequential loop would keep
 //   score       getReproErrs + getHypScores (:316-343,:356-446): the same wavefront projects all N pixels of its
-//               hypothesis from LDS, lane-strided fp64 partial sums, __shfl_xor butterfly (order 32,16,..,1)
+//               hypothesis from LDS, lane-strided fp64 partial sums, one butterfly (order 32,16,..,1)
 //   select      softMax + draw(argmax) (:684-752) by one lane
-//   refine      refineHyp (:522-597): all 256 threads; Levenberg-Marquardt PnP (cvFindExtrinsicCameraParams2 +
-//               CvLevMarq) with J^T J / J^T e / |e|^2 accumulated per thread over its pixels, reduced by shuffle
-//               butterflies inside each wavefront and a fixed-order sum over the 4 wavefronts through LDS; the
-//               6x6 solve runs redundantly on every lane (no divergence, no broadcast)
+//   refine      refineHyp (:522-597): all 256 threads. Every round classifies all pixels against the threshold and
+//               COMPACTS the inliers into an LDS list in scan order -- the reference's own localImgPts / localObjPts
+//               (:545-560) -- so that the Levenberg-Marquardt passes of solvePnP(ITERATIVE) (cvFindExtrinsicCameraParams2
+//               + CvLevMarq) touch inliers only: list entry j belongs to thread j % 256, J^T J / J^T e / |e|^2 are
+//               accumulated per thread, reduced inside each wavefront by a TRANSPOSING butterfly (v_permlane32_swap,
+//               v_permlane16_swap, DPP: 28 sums cost 29 cross-lane steps instead of 168) and summed over the 4
+//               wavefronts in a fixed order through LDS; the 6x6 solve runs on wavefront 0.
 // Nothing is written to HBM between stages except the diagnostics (hypothesis poses / scores).
 // Roofline: per frame 57.6 KB in, ~5 KB out; the kernel is fp64-VALU/latency bound.
 #include <hip/hip_runtime.h>
@@ -35,7 +38,9 @@ struct FrameParam {
 struct RansacArgs {
   const float* sc;  // [n][3][H][W]
   const FrameParam* fp;
+  float* big;       // [n][3][Npad] transposed copies, only for frames that do not fit the LDS (GC instantiation)
   int H, W, N, hyps, max_tries, sub, max_ref_steps;
+  uint32_t h_magic;  // ceil(2^32 / H): p / H == __umulhi(p, h_magic) for p < 2^16 (H >= 2)
   float thr, alpha, max_reproj;
   uint64_t seed;
   double* hyp_poses;  // [n][hyps][6]
@@ -47,11 +52,82 @@ struct RansacArgs {
   uint8_t* out_masks; // [n][H][W] or null
 };
 
-__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src); }
-__device__ __forceinline__ double wave_tree(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
+// ---- cross-lane sums of doubles without the LDS crossbar --------------------------------------------------------------------
+// All of them realise the butterfly v_l + v_(l ^ off), off = 32, 16, 8, 4, 2, 1 (the order of oracle tree64): IEEE addition is
+// commutative, so which partner supplies the left operand does not matter and every lane ends with the same bits.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// a[32..63] <-> b[0..31]
+__device__ __forceinline__ void swap_halves(double& a, double& b) {
+  const u32x2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const u32x2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi.x, (int)lo.x);
+  b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+// odd 16-lane rows of a <-> even rows of b
+__device__ __forceinline__ void swap_rows(double& a, double& b) {
+  const u32x2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const u32x2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi.x, (int)lo.x);
+  b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_d(double old, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, BANK, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, BANK, false);
+  return __hiloint2double(hi, lo);
+}
+// offsets 8, 4, 2, 1 inside each row of 16 lanes
+__device__ __forceinline__ double row_tree(double v) {
+  v = v + dpp_d<0x128, 0xf>(v, v);          // row_ror:8 = lane ^ 8
+  double t = dpp_d<0x104, 0x5>(v, v);        // row_shl:4 on lanes 0-3, 8-11 (read lane + 4)
+  t = dpp_d<0x114, 0xa>(t, v);               // row_shr:4 on lanes 4-7, 12-15 (read lane - 4)  -> lane ^ 4
+  v = v + t;
+  v = v + dpp_d<0x4E, 0xf>(v, v);            // quad_perm [2,3,0,1] = lane ^ 2
+  v = v + dpp_d<0xB1, 0xf>(v, v);            // quad_perm [1,0,3,2] = lane ^ 1
   return v;
+}
+__device__ __forceinline__ double wave_tree(double v) {
+  double a = v, b = v;
+  swap_halves(a, b);
+  v = a + b;
+  a = v; b = v;
+  swap_rows(a, b);
+  v = a + b;
+  return row_tree(v);
+}
+// 28 sums at once: after the two swap levels row r of the wavefront works on quantities 7r .. 7r+6 only
+__device__ __forceinline__ void wave_tree28(const double acc[28], double out7[7]) {
+  double h[14];
+#pragma unroll
+  for (int j = 0; j < 14; ++j) {
+    double a = acc[j], b = acc[14 + j];
+    swap_halves(a, b);   // lanes < 32: (own acc[j], acc[j] of lane + 32); lanes >= 32: (acc[14 + j] of lane - 32, own acc[14 + j])
+    h[j] = a + b;
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    double a = h[j], b = h[7 + j];
+    swap_rows(a, b);
+    out7[j] = row_tree(a + b);
+  }
+}
+
+// x = p / H for p < 2^16 (see RansacArgs::h_magic)
+__device__ __forceinline__ int div_h(int p, int H, uint32_t magic) { return H == 1 ? p : (int)__umulhi((uint32_t)p, magic); }
+
+// detm::exp_ with 32-bit integer steps (|x * INV_LN2| < 1100, so the int conversion, k / 2 and the exponent words are the same
+// values as the 64-bit ones of det_math.h; every floating-point operation is identical)
+__device__ __forceinline__ double exp_dev(double x) {
+  if (x != x) return x;
+  if (x > 709.0) return __hiloint2double(0x7ff00000, 0);
+  if (x < -745.0) return 0.0;
+  const double kf = x * detm::INV_LN2;
+  const int k = (int)(kf + (kf >= 0 ? 0.5 : -0.5));
+  const double kd = (double)k;
+  const double r = (x - kd * detm::LN2_HI) - kd * detm::LN2_LO;
+  const double p = (0x1.0000000000000p+0 + r * (0x1.0000000000000p+0 + r * (0x1.0000000000000p-1 + r * (0x1.5555555555555p-3 + r * (0x1.555555555555fp-5 + r * (0x1.1111111111114p-7 + r * (0x1.6c16c16c1321dp-10 + r * (0x1.a01a01a018130p-13 + r * (0x1.a01a01b4cf7bbp-16 + r * (0x1.71de3a60775bep-19 + r * (0x1.27e4beb6f974bp-22 + r * (0x1.ae6415b4ca760p-26 + r * (0x1.1f9e46dddd4e5p-29 + r * 0x1.61e0dace500bbp-33)))))))))))));
+  const int k1 = k / 2, k2 = k - k1;
+  return (p * __hiloint2double((k1 + 1023) << 20, 0)) * __hiloint2double((k2 + 1023) << 20, 0);
 }
 
 // reprojection error of one pixel exactly as getReproErrs stores it (float, clamped)
@@ -103,34 +179,52 @@ __device__ bool inv4x4(const double Ain[16], double out[16]) {
   return true;
 }
 
-constexpr int MAX_PIX_PER_THREAD = 32;  // N <= 8192
+// ---- LDS layout (host and device agree through these helpers) ---------------------------------------------------------------
+//   [3][Npad] float   scene coordinates in scan order (LDS instantiation only)
+//   [Npad]    uint16  the current inlier list
+//   region            one fp64 area used twice: while sampling / scoring / selecting it holds the scores [hyps] and the sampled
+//                     poses [hyps][6]; both are dead once the best hypothesis is chosen, and the refinement reuses it for the LM
+//                     step hand-over (6 doubles, padded to 8), the double-buffered reduction scratch [2][4][28] and the compaction
+//                     counts [64][4] int. Keeping the two apart cost 1.8 KB more and, with 64 hypotheses, the second workgroup
+//                     of a CU (round 1: 20 ms vs 12 ms).
+//   [8] int           best hypothesis
+// 60x80 (7-Scenes): 70.1 KB, 60x93 (Mip-NeRF 360 at 480 px): 81.7 KB with 64 hypotheses -> two workgroups per CU in both cases.
+constexpr int MAX_ROWS = 64;                        // pixels per thread (inlier flags are one 64-bit word): N <= 16384
+constexpr int RED_DOUBLES = 8 + 2 * 4 * 28;         // step hand-over + reduction scratch
+constexpr int REGION_MIN = RED_DOUBLES + MAX_ROWS * 4 / 2;
+__host__ __device__ inline int region_doubles(int hyps) { return 7 * hyps > REGION_MIN ? 7 * hyps : REGION_MIN; }
+__host__ __device__ inline size_t lds_bytes(int N, int hyps, bool coords_in_hbm) {
+  const size_t Npad = (size_t)((N + 3) & ~3);
+  return (coords_in_hbm ? 0 : 12 * Npad) + 2 * Npad + 8 * (size_t)region_doubles(hyps) + 8 * sizeof(int);
+}
 
+// GC: the frame does not fit the LDS (more than ~11 400 scene coordinates): its scan-order copy lives in an HBM workspace (L2
+// resident, 12 N bytes) and every stage reads it from there; same arithmetic, same order, same bits.
+template <bool GC>
 __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = a.N, H = a.H, W = a.W;
   const int Npad = (N + 3) & ~3;
-  float* sX = reinterpret_cast<float*>(smem_raw);
+  const int frame = blockIdx.x;
+  float* sX = GC ? a.big + (size_t)frame * 3 * Npad : reinterpret_cast<float*>(smem_raw);
   float* sY = sX + Npad;
   float* sZ = sY + Npad;
-  float* sErr = sZ + Npad;
-  // one fp64 region of max(7 * hyps, 232) doubles, used twice: during sampling / scoring / selection it holds the scores [hyps] and
-  // the sampled poses [hyps][6]; both are dead once the best hypothesis is chosen, and the refinement reuses the region for the LM
-  // step hand-over (6 doubles, padded to 8) and the double-buffered block-reduction scratch [2][4][28]. Keeping the two apart cost
-  // 1.8 KB more: 64 hypotheses then exceeded half of the 160 KiB LDS by 576 bytes and ran ONE workgroup per CU (20 ms vs 12 ms).
-  double* sRegion = reinterpret_cast<double*>(sErr + Npad);
+  uint16_t* sList = reinterpret_cast<uint16_t*>(smem_raw + (GC ? 0 : 12 * (size_t)Npad));
+  double* sRegion = reinterpret_cast<double*>(sList + Npad);
   double* sScores = sRegion;                              // [hyps]
   double* sHyp = sScores + a.hyps;                        // [hyps][6] sampled poses
   double* sRed = sRegion + 8;                             // [2][4][28] (refinement only)
-  const int region = (7 * a.hyps > 232) ? 7 * a.hyps : 232;
-  int* sInt = reinterpret_cast<int*>(sRegion + region);   // [8]: best, counts[4]
+  int* sCnt = reinterpret_cast<int*>(sRegion + RED_DOUBLES);   // [rows][4] (refinement only)
+  int* sInt = reinterpret_cast<int*>(sRegion + region_doubles(a.hyps));   // [8]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int frame = blockIdx.x;
   const FrameParam fp = a.fp[frame];
   const Cam k{(double)fp.focal, (double)fp.focal, (double)fp.ppx, (double)fp.ppy};
   const float* sc = a.sc + (size_t)frame * 3 * N;
+  const uint32_t magic = a.h_magic;
+  const int half = a.sub / 2;
 
-  // ---- load: memory order i = y*W + x  ->  LDS order p = x*H + y
+  // ---- load: memory order i = y*W + x  ->  scan order p = x*H + y
   for (int i = tid; i < N; i += 256) {
     const int y = i / W, x = i - y * W;
     const int p = x * H + y;
@@ -167,8 +261,8 @@ __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
         for (int j = 0; j < 4; j++) {
           const int x = rsm::irand(key, 2 * j, W);
           const int y = rsm::irand(key, 2 * j + 1, H);
-          img[j][0] = (float)(x * a.sub + a.sub / 2);
-          img[j][1] = (float)(y * a.sub + a.sub / 2);
+          img[j][0] = (float)(x * a.sub + half);
+          img[j][1] = (float)(y * a.sub + half);
           const int p = x * H + y;
           obj[j][0] = sX[p];
           obj[j][1] = sY[p];
@@ -224,10 +318,14 @@ __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
     rsm::rodrigues(res.r, R, nullptr);
     double acc = 0;
     for (int p = lane; p < N; p += 64) {
-      const int x = p / H, y = p - x * H;
-      const float e = pixel_err(R, res.t, k, sX[p], sY[p], sZ[p], x * a.sub + a.sub / 2, y * a.sub + a.sub / 2, a.max_reproj);
-      double softThreshold = inlierBeta * (e - a.thr);
-      softThreshold = 1 / (1 + detm::exp_(-softThreshold));
+      const int x = div_h(p, H, magic), y = p - x * H;
+      const float e = pixel_err(R, res.t, k, sX[p], sY[p], sZ[p], x * a.sub + half, y * a.sub + half, a.max_reproj);
+      const float beta_e = inlierBeta * (e - a.thr);
+      // beyond 40 the sigmoid is exactly 1 in fp64 (exp(-40) = 4e-18 < 2^-53, so 1 + exp(-x) == 1) and the pixel adds exactly +0:
+      // far outliers -- nearly every pixel of a wrong hypothesis -- skip the exponential and the division
+      if (beta_e > 40.f) continue;
+      double softThreshold = beta_e;
+      softThreshold = 1 / (1 + exp_dev(-softThreshold));
       acc += 1 - softThreshold;
     }
     double score = wave_tree(acc);
@@ -275,83 +373,133 @@ __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) param[i] = hp[i];
   }
-  const int npix = (N - tid + 255) / 256;  // pixels p = tid + 256 i owned by this thread
+  const int rows = (N + 255) >> 8;  // thread tid looks at pixels p = tid + 256 i, i < rows (p < N)
 
-  auto recompute_errs = [&](const double* prm) {
+  // bit i of the result: pixel tid + 256 i is an inlier of prm (getReproErrs + the threshold test of refineHyp, :536-560)
+  auto classify = [&](const double* prm) -> uint64_t {
     double R[9];
     rsm::rodrigues(prm, R, nullptr);
-    for (int i = 0; i < npix; ++i) {
+    uint64_t flags = 0;
+    for (int i = 0; i < rows; ++i) {
       const int p = tid + 256 * i;
-      const int x = p / H, y = p - x * H;
-      sErr[p] = pixel_err(R, prm + 3, k, sX[p], sY[p], sZ[p], x * a.sub + a.sub / 2, y * a.sub + a.sub / 2, a.max_reproj);
+      if (p >= N) break;
+      const int x = div_h(p, H, magic), y = p - x * H;
+      const float e = pixel_err(R, prm + 3, k, sX[p], sY[p], sZ[p], x * a.sub + half, y * a.sub + half, a.max_reproj);
+      if (e < a.thr) flags |= 1ull << i;
     }
+    return flags;
   };
-  int red_parity = 0;
-  // block reduction of 28 doubles in the canonical order; every thread receives the result
-  auto block_reduce28 = [&](double* acc) {
-    double* buf = sRed + red_parity * (4 * 28);
-#pragma unroll
-    for (int i = 0; i < 28; ++i) {
-      const double v = wave_tree(acc[i]);
-      if (lane == 0) buf[wave * 28 + i] = v;
+  // the inliers in scan order (ascending p): counts per (row, wavefront) through LDS, positions from ballots. Returns their number.
+  auto compact = [&](uint64_t flags) -> int {
+    for (int i = 0; i < rows; ++i) {
+      const unsigned long long m = __ballot((flags >> i) & 1ull);
+      if (lane == 0) sCnt[i * 4 + wave] = __popcll(m);
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 28; ++i) acc[i] = ((buf[0 * 28 + i] + buf[1 * 28 + i]) + buf[2 * 28 + i]) + buf[3 * 28 + i];
-    red_parity ^= 1;
-  };
-  auto lm_accumulate = [&](const double* prm, unsigned flags, bool withJ, LMAccum* out) {
-    double R[9], dRdr[27];
-    rsm::rodrigues(prm, R, withJ ? dRdr : nullptr);
-    double acc[28];
-#pragma unroll
-    for (int i = 0; i < 28; ++i) acc[i] = 0;
-    for (int i = 0; i < npix; ++i) {
-      if (!((flags >> i) & 1u)) continue;
-      const int p = tid + 256 * i;
-      const int x = p / H, y = p - x * H;
-      double u, v, Ju[6], Jv[6];
-      rsm::project(R, prm + 3, k, sX[p], sY[p], sZ[p], &u, &v, withJ ? dRdr : nullptr, Ju, Jv);
-      const double eu = u - (double)(float)(x * a.sub + a.sub / 2), ev = v - (double)(float)(y * a.sub + a.sub / 2);
-      if (withJ) {
-        int q = 0;
-#pragma unroll
-        for (int aa = 0; aa < 6; ++aa)
-#pragma unroll
-          for (int bb = aa; bb < 6; ++bb) {
-            acc[q] = acc[q] + Ju[aa] * Ju[bb];
-            acc[q] = acc[q] + Jv[aa] * Jv[bb];
-            ++q;
-          }
-#pragma unroll
-        for (int aa = 0; aa < 6; ++aa) {
-          acc[21 + aa] = acc[21 + aa] + Ju[aa] * eu;
-          acc[21 + aa] = acc[21 + aa] + Jv[aa] * ev;
-        }
-      }
-      acc[27] = acc[27] + eu * eu;
-      acc[27] = acc[27] + ev * ev;
+    int run = 0;
+    for (int i = 0; i < rows; ++i) {
+      const bool f = (flags >> i) & 1ull;
+      const unsigned long long m = __ballot(f);
+      const int4 c = reinterpret_cast<const int4*>(sCnt)[i];
+      const int base = run + (wave > 0 ? c.x : 0) + (wave > 1 ? c.y : 0) + (wave > 2 ? c.z : 0);
+      const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      if (f) sList[base + below] = (uint16_t)(tid + 256 * i);
+      run += (c.x + c.y) + (c.z + c.w);
     }
-    block_reduce28(acc);
-    if (withJ) {
+    __syncthreads();
+    return run;
+  };
+  int red_parity = 0;
+  // sums over the workgroup in the canonical order (oracle tree256); the 27 Jacobian sums are only read by wavefront 0, the one
+  // that solves for the step; |e|^2 drives the control flow of every thread
+  auto reduce28 = [&](double* acc, LMAccum* out) {
+    double* buf = sRed + red_parity * (4 * 28);
+    double r7[7];
+    wave_tree28(acc, r7);
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) buf[wave * 28 + 7 * (lane >> 4) + j] = r7[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double s[27];
+#pragma unroll
+      for (int i = 0; i < 27; ++i) s[i] = ((buf[0 * 28 + i] + buf[1 * 28 + i]) + buf[2 * 28 + i]) + buf[3 * 28 + i];
       int q = 0;
 #pragma unroll
       for (int aa = 0; aa < 6; ++aa)
 #pragma unroll
         for (int bb = aa; bb < 6; ++bb) {
-          out->JtJ[aa * 6 + bb] = acc[q];
-          out->JtJ[bb * 6 + aa] = acc[q];
+          out->JtJ[aa * 6 + bb] = s[q];
+          out->JtJ[bb * 6 + aa] = s[q];
           ++q;
         }
 #pragma unroll
-      for (int aa = 0; aa < 6; ++aa) out->JtErr[aa] = acc[21 + aa];
+      for (int aa = 0; aa < 6; ++aa) out->JtErr[aa] = s[21 + aa];
     }
-    out->errsq = acc[27];
+    out->errsq = ((buf[0 * 28 + 27] + buf[1 * 28 + 27]) + buf[2 * 28 + 27]) + buf[3 * 28 + 27];
+    red_parity ^= 1;
+  };
+  auto reduce1 = [&](double e) -> double {
+    double* buf = sRed + red_parity * (4 * 28);
+    const double v = wave_tree(e);
+    if (lane == 0) buf[wave * 28 + 27] = v;
+    __syncthreads();
+    red_parity ^= 1;
+    return ((buf[0 * 28 + 27] + buf[1 * 28 + 27]) + buf[2 * 28 + 27]) + buf[3 * 28 + 27];
+  };
+  // J^T J, J^T e and |e|^2 over the inlier list
+  auto accumulate_J = [&](const double* prm, int cnt, LMAccum* out) {
+    double R[9], dRdr[27];
+    rsm::rodrigues(prm, R, dRdr);
+    double acc[28];
+#pragma unroll
+    for (int i = 0; i < 28; ++i) acc[i] = 0;
+    for (int j = tid; j < cnt; j += 256) {
+      const int p = sList[j];
+      const int x = div_h(p, H, magic), y = p - x * H;
+      double u, v, Ju[6], Jv[6];
+      rsm::project(R, prm + 3, k, sX[p], sY[p], sZ[p], &u, &v, dRdr, Ju, Jv);
+      const double eu = u - (double)(float)(x * a.sub + half), ev = v - (double)(float)(y * a.sub + half);
+      int q = 0;
+#pragma unroll
+      for (int aa = 0; aa < 6; ++aa)
+#pragma unroll
+        for (int bb = aa; bb < 6; ++bb) {
+          acc[q] = acc[q] + Ju[aa] * Ju[bb];
+          acc[q] = acc[q] + Jv[aa] * Jv[bb];
+          ++q;
+        }
+#pragma unroll
+      for (int aa = 0; aa < 6; ++aa) {
+        acc[21 + aa] = acc[21 + aa] + Ju[aa] * eu;
+        acc[21 + aa] = acc[21 + aa] + Jv[aa] * ev;
+      }
+      acc[27] = acc[27] + eu * eu;
+      acc[27] = acc[27] + ev * ev;
+    }
+    reduce28(acc, out);
+  };
+  // |e|^2 only (CvLevMarq's CHECK_ERR state)
+  auto accumulate_E = [&](const double* prm, int cnt) -> double {
+    double R[9];
+    rsm::rodrigues(prm, R, nullptr);
+    double acc = 0;
+    for (int j = tid; j < cnt; j += 256) {
+      const int p = sList[j];
+      const int x = div_h(p, H, magic), y = p - x * H;
+      double u, v;
+      rsm::project(R, prm + 3, k, sX[p], sY[p], sZ[p], &u, &v, nullptr, nullptr, nullptr);
+      const double eu = u - (double)(float)(x * a.sub + half), ev = v - (double)(float)(y * a.sub + half);
+      acc = acc + eu * eu;
+      acc = acc + ev * ev;
+    }
+    return reduce1(acc);
   };
   auto lm_step = [&](const LMAccum& acc, const double* prevParam, int lambdaLg10, double* prm) {
-    // The 6x6 solve is serial fp64 work with identical inputs on every lane (Cholesky: ~2 us; its eigen fallback ~55 us): only wavefront 0 runs it and
-    // hands the step over through LDS, which leaves the other three SIMDs to the second workgroup of this CU
-    // (every lm_step is followed by an lm_accumulate, whose block reduction orders the next overwrite of sStep).
+    // The 6x6 solve is serial fp64 work with identical inputs on every lane (Cholesky: ~2 us; its eigen fallback ~55 us): only
+    // wavefront 0 runs it and hands the step over through LDS, which leaves the other three SIMDs to the second workgroup of
+    // this CU (every lm_step is followed by an accumulation, whose block reduction orders the next overwrite of sStep).
     double* sStep = sRegion;   // the scores / sampled poses are dead after the selection
     if (wave == 0) {
       const double lambda = detm::pow10i(lambdaLg10);
@@ -366,29 +514,16 @@ __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
     for (int i = 0; i < 6; ++i) prm[i] = prevParam[i] - sStep[i];
   };
 
-  recompute_errs(param);
-  unsigned bestInliers = 4, acc_flags = 0;
+  uint64_t flags = classify(param), acc_flags = 0;
+  unsigned bestInliers = 4;
   bool have_map = false;
   const int max_ref = a.max_ref_steps > 0 ? a.max_ref_steps : 100;
   for (int rStep = 0; rStep < max_ref; rStep++) {
-    unsigned flags = 0;
-    int cnt = 0;
-    for (int i = 0; i < npix; ++i)
-      if (sErr[tid + 256 * i] < a.thr) {
-        flags |= 1u << i;
-        cnt++;
-      }
-    // workgroup-wide inlier count (integer: order-free)
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
-    __syncthreads();  // previous readers of sInt[1..4] are done
-    if (lane == 0) sInt[1 + wave] = cnt;
-    __syncthreads();
-    const unsigned total = (unsigned)(sInt[1] + sInt[2] + sInt[3] + sInt[4]);
-    if (total <= bestInliers) break;
-    bestInliers = total;
+    const int cnt = compact(flags);
+    if ((unsigned)cnt <= bestInliers) break;
+    bestInliers = (unsigned)cnt;
 
-    // solvePnP(ITERATIVE, useExtrinsicGuess) on the flagged pixels
+    // solvePnP(ITERATIVE, useExtrinsicGuess) on the inlier list
     {
       const int max_iter = 20;
       const double epsilon = 1.1920928955078125e-07;
@@ -397,15 +532,14 @@ __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
       for (int i = 0; i < 6; ++i) prm[i] = param[i];
       int lambdaLg10 = -3, iters = 0;
       double prevErrNorm = 1.7976931348623157e308, errNorm;
-      LMAccum acc, tmp;
-      lm_accumulate(prm, flags, true, &acc);
+      LMAccum acc;
+      accumulate_J(prm, cnt, &acc);
       for (;;) {
         for (int i = 0; i < 6; ++i) prevParam[i] = prm[i];
         lm_step(acc, prevParam, lambdaLg10, prm);
         if (iters == 0) prevErrNorm = sqrt(acc.errsq);
         for (;;) {
-          lm_accumulate(prm, flags, false, &tmp);
-          errNorm = sqrt(tmp.errsq);
+          errNorm = sqrt(accumulate_E(prm, cnt));
           if (errNorm > prevErrNorm) {
             if (++lambdaLg10 <= 16) {
               lm_step(acc, prevParam, lambdaLg10, prm);
@@ -424,23 +558,24 @@ __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
         const double rel = sqrt(dn) / (sqrt(pn) + 2.220446049250313e-16);
         if (++iters >= max_iter || rel < epsilon) break;
         prevErrNorm = errNorm;
-        lm_accumulate(prm, flags, true, &acc);
+        accumulate_J(prm, cnt, &acc);
       }
 #pragma unroll
       for (int i = 0; i < 6; ++i) param[i] = prm[i];
     }
     acc_flags = flags;
     have_map = true;
-    recompute_errs(param);
+    flags = classify(param);
   }
 
   // ---- outputs
   if (a.out_masks) {
     uint8_t* mk = a.out_masks + (size_t)frame * N;
-    for (int i = 0; i < npix; ++i) {
+    for (int i = 0; i < rows; ++i) {
       const int p = tid + 256 * i;
-      const int x = p / H, y = p - x * H;
-      mk[y * W + x] = (have_map && ((acc_flags >> i) & 1u)) ? 1 : 0;
+      if (p >= N) break;
+      const int x = div_h(p, H, magic), y = p - x * H;
+      mk[y * W + x] = (have_map && ((acc_flags >> i) & 1ull)) ? 1 : 0;
     }
   }
   if (tid == 0) {
@@ -464,15 +599,29 @@ __global__ __launch_bounds__(256, 2) void ransac_kernel(RansacArgs a) {
 // ====================================================================================================
 // C ABI
 // ====================================================================================================
+namespace {
+constexpr int PARAM_SLOTS = 4;
+// One pinned + device copy of the per-frame parameter block per call in flight: acez_register_rgb_device never waits for the
+// stream it launches on (only for the call PARAM_SLOTS launches ago, whose kernel has long finished in any pipelined use).
+struct ParamSlot {
+  FrameParam* h = nullptr;  // pinned
+  FrameParam* d = nullptr;
+  hipEvent_t done = nullptr;
+  bool in_flight = false;
+};
+}  // namespace
+
 struct acez_ransac {
   int device = 0;
   int max_frames = 0, max_h = 0, max_w = 0, max_hyps = 0;
-  FrameParam* d_fp = nullptr;
-  FrameParam* h_fp = nullptr;  // pinned
+  ParamSlot slot[PARAM_SLOTS];
+  int next_slot = 0;
   double* d_hyp_poses = nullptr;
   double* d_scores = nullptr;
   int* d_best = nullptr;
   double* d_refined = nullptr;
+  float* d_big = nullptr;      // scan-order copies of frames that do not fit the LDS, allocated on first use
+  size_t big_floats = 0;
   // staging for the host-buffer entry point
   float* d_sc = nullptr;
   float* d_pose = nullptr;
@@ -483,6 +632,7 @@ struct acez_ransac {
 
 static int ensure_hyps(acez_ransac* ctx, int hyps) {
   if (hyps <= ctx->max_hyps) return ACEZ_OK;
+  ACEZ_HIP_CHECK(hipDeviceSynchronize());   // earlier launches may still write the old buffers
   if (ctx->d_hyp_poses) (void)hipFree(ctx->d_hyp_poses);
   if (ctx->d_scores) (void)hipFree(ctx->d_scores);
   ctx->d_hyp_poses = nullptr;
@@ -495,12 +645,18 @@ static int ensure_hyps(acez_ransac* ctx, int hyps) {
 
 extern "C" void acez_ransac_destroy(acez_ransac* ctx) {
   if (!ctx) return;
-  if (ctx->d_fp) (void)hipFree(ctx->d_fp);
-  if (ctx->h_fp) (void)hipHostFree(ctx->h_fp);
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (ParamSlot& s : ctx->slot) {
+    if (s.d) (void)hipFree(s.d);
+    if (s.h) (void)hipHostFree(s.h);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
   if (ctx->d_hyp_poses) (void)hipFree(ctx->d_hyp_poses);
   if (ctx->d_scores) (void)hipFree(ctx->d_scores);
   if (ctx->d_best) (void)hipFree(ctx->d_best);
   if (ctx->d_refined) (void)hipFree(ctx->d_refined);
+  if (ctx->d_big) (void)hipFree(ctx->d_big);
   if (ctx->d_sc) (void)hipFree(ctx->d_sc);
   if (ctx->d_pose) (void)hipFree(ctx->d_pose);
   if (ctx->d_inl) (void)hipFree(ctx->d_inl);
@@ -511,7 +667,12 @@ extern "C" void acez_ransac_destroy(acez_ransac* ctx) {
 extern "C" int acez_ransac_create(acez_ransac** out, int max_frames, int max_h, int max_w, int device) {
   ACEZ_REQUIRE(out, "null pointer");
   ACEZ_REQUIRE(max_frames > 0 && max_h > 0 && max_w > 0, "sizes must be positive");
-  ACEZ_REQUIRE((int64_t)max_h * max_w <= 256 * MAX_PIX_PER_THREAD, "at most 8192 scene coordinates per frame");
+  if ((int64_t)max_h * max_w > 256 * MAX_ROWS) {
+    acez::set_error("%d x %d = %lld scene coordinates per frame: the DSAC* kernel handles at most %d (e.g. 96 x 170, a 768 x 1360 image "
+                    "at output stride 8); lower the image resolution (ace_zero.py --image_resolution, dataset.py:40) -- the reference's "
+                    "CPU loop has no such limit", max_h, max_w, (long long)max_h * max_w, 256 * MAX_ROWS);
+    return ACEZ_ERR_INVALID;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     (void)hipGetLastError();
@@ -532,17 +693,20 @@ extern "C" int acez_ransac_create(acez_ransac** out, int max_frames, int max_h, 
       rc = ACEZ_ERR_HIP;
     }
   };
-  A((void**)&ctx->d_fp, (size_t)max_frames * sizeof(FrameParam));
+  for (ParamSlot& s : ctx->slot) {
+    A((void**)&s.d, (size_t)max_frames * sizeof(FrameParam));
+    if (rc == ACEZ_OK && (hipHostMalloc((void**)&s.h, (size_t)max_frames * sizeof(FrameParam)) != hipSuccess ||
+                          hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)) {
+      acez::set_error("hipHostMalloc / hipEventCreate failed");
+      rc = ACEZ_ERR_HIP;
+    }
+  }
   A((void**)&ctx->d_best, (size_t)max_frames * sizeof(int));
   A((void**)&ctx->d_refined, (size_t)max_frames * 6 * sizeof(double));
   A((void**)&ctx->d_sc, (size_t)3 * max_h * max_w * sizeof(float));
   A((void**)&ctx->d_pose, 16 * sizeof(float));
   A((void**)&ctx->d_inl, sizeof(int));
   A((void**)&ctx->d_mask, (size_t)max_h * max_w);
-  if (rc == ACEZ_OK && hipHostMalloc((void**)&ctx->h_fp, (size_t)max_frames * sizeof(FrameParam)) != hipSuccess) {
-    acez::set_error("hipHostMalloc failed");
-    rc = ACEZ_ERR_HIP;
-  }
   if (rc == ACEZ_OK) rc = ensure_hyps(ctx, 64);
   if (rc != ACEZ_OK) {
     acez_ransac_destroy(ctx);
@@ -559,35 +723,55 @@ extern "C" int acez_register_rgb_device(acez_ransac* ctx, const float* d_scene_c
   ACEZ_REQUIRE(ctx && d_scene_coords && params && h_intrinsics && d_out_poses && d_out_inliers, "null pointer");
   ACEZ_REQUIRE(n_frames > 0 && n_frames <= ctx->max_frames, "n_frames exceeds the context's max_frames");
   ACEZ_REQUIRE(h > 0 && w > 0 && h <= ctx->max_h && w <= ctx->max_w, "frame larger than the context was created for");
+  ACEZ_REQUIRE((int64_t)h * w <= 256 * MAX_ROWS, "at most 16384 scene coordinates per frame");
   ACEZ_REQUIRE(params->hypotheses > 0 && params->max_tries > 0, "hypotheses and max_tries must be positive");
   ACEZ_REQUIRE(params->subsampling > 0 && params->inlier_threshold > 0.f, "subsampling and inlier_threshold must be positive");
   ACEZ_HIP_CHECK(hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   int rc = ensure_hyps(ctx, params->hypotheses);
   if (rc != ACEZ_OK) return rc;
-  // the pinned parameter block is reused by every call: wait for earlier work that may still read it
-  ACEZ_HIP_CHECK(hipStreamSynchronize(s));
-  for (int i = 0; i < n_frames; ++i) {
-    ctx->h_fp[i].focal = h_intrinsics[i].focal;
-    ctx->h_fp[i].ppx = h_intrinsics[i].ppx;
-    ctx->h_fp[i].ppy = h_intrinsics[i].ppy;
-    ctx->h_fp[i].pad = 0.f;
-    ctx->h_fp[i].frame_id = h_frame_ids ? h_frame_ids[i] : (uint64_t)i;
+  const int N = h * w;
+  const int Npad = (N + 3) & ~3;
+  const size_t lds_full = lds_bytes(N, params->hypotheses, false);
+  const bool gc = lds_full > 160 * 1024;
+  const size_t lds = gc ? lds_bytes(N, params->hypotheses, true) : lds_full;
+  ACEZ_REQUIRE(lds <= 160 * 1024, "too many hypotheses for the 160 KB LDS of a CU");
+  if (gc && ctx->big_floats < (size_t)ctx->max_frames * 3 * Npad) {
+    ACEZ_HIP_CHECK(hipDeviceSynchronize());
+    if (ctx->d_big) (void)hipFree(ctx->d_big);
+    ctx->d_big = nullptr;
+    ctx->big_floats = 0;
+    ACEZ_HIP_CHECK(hipMalloc((void**)&ctx->d_big, (size_t)ctx->max_frames * 3 * Npad * sizeof(float)));
+    ctx->big_floats = (size_t)ctx->max_frames * 3 * Npad;
   }
-  ACEZ_HIP_CHECK(hipMemcpyAsync(ctx->d_fp, ctx->h_fp, (size_t)n_frames * sizeof(FrameParam), hipMemcpyHostToDevice, s));
+  ParamSlot& slot = ctx->slot[ctx->next_slot];
+  ctx->next_slot = (ctx->next_slot + 1) % PARAM_SLOTS;
+  if (slot.in_flight) ACEZ_HIP_CHECK(hipEventSynchronize(slot.done));
+  for (int i = 0; i < n_frames; ++i) {
+    slot.h[i].focal = h_intrinsics[i].focal;
+    slot.h[i].ppx = h_intrinsics[i].ppx;
+    slot.h[i].ppy = h_intrinsics[i].ppy;
+    slot.h[i].pad = 0.f;
+    slot.h[i].frame_id = h_frame_ids ? h_frame_ids[i] : (uint64_t)i;
+  }
+  ACEZ_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, (size_t)n_frames * sizeof(FrameParam), hipMemcpyHostToDevice, s));
   RansacArgs a;
-  a.sc = d_scene_coords; a.fp = ctx->d_fp; a.H = h; a.W = w; a.N = h * w; a.hyps = params->hypotheses;
+  a.sc = d_scene_coords; a.fp = slot.d; a.big = ctx->d_big; a.H = h; a.W = w; a.N = N; a.hyps = params->hypotheses;
+  a.h_magic = h > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)h - 1) / (uint64_t)h) : 0u;
   a.max_tries = params->max_tries; a.sub = params->subsampling; a.max_ref_steps = params->max_ref_steps;
   a.thr = params->inlier_threshold; a.alpha = params->inlier_alpha; a.max_reproj = params->max_reproj; a.seed = seed;
   a.hyp_poses = ctx->d_hyp_poses; a.scores = ctx->d_scores; a.best = ctx->d_best; a.refined = ctx->d_refined;
   a.out_poses = d_out_poses; a.out_inliers = d_out_inliers; a.out_masks = d_out_masks;
-  const int Npad = (a.N + 3) & ~3;
-  const int region = 7 * params->hypotheses > 232 ? 7 * params->hypotheses : 232;   // see the layout comment in ransac_kernel
-  const size_t lds = (size_t)4 * Npad * sizeof(float) + (size_t)region * sizeof(double) + 8 * sizeof(int);
-  ACEZ_REQUIRE(lds <= 160 * 1024, "frame + hypotheses do not fit the 160 KB LDS of a CU");
-  ACEZ_HIP_CHECK(hipFuncSetAttribute((const void*)ransac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(ransac_kernel, dim3(n_frames), dim3(256), lds, s, a);
+  if (gc) {
+    ACEZ_HIP_CHECK(hipFuncSetAttribute((const void*)ransac_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ransac_kernel<true>, dim3(n_frames), dim3(256), lds, s, a);
+  } else {
+    ACEZ_HIP_CHECK(hipFuncSetAttribute((const void*)ransac_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ransac_kernel<false>, dim3(n_frames), dim3(256), lds, s, a);
+  }
   ACEZ_HIP_CHECK(hipGetLastError());
+  ACEZ_HIP_CHECK(hipEventRecord(slot.done, s));
+  slot.in_flight = true;
   ctx->last_hyps = params->hypotheses;
   return ACEZ_OK;
 }

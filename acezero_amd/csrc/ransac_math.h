@@ -271,26 +271,75 @@ ACEZ_HD inline int solve_deg4(double a, double b, double c, double d, double e, 
 }
 
 // ----------------------------------------------------------------------------------------------------
+// Small arrays that must live in registers on the GPU: a dynamically indexed local array is placed in scratch memory there (every
+// access a round trip to the vector cache), so dynamic positions are read and written through compare-and-select chains and every
+// loop over such an array is fully unrolled. On the host the same code is ordinary scalar code.
+// ----------------------------------------------------------------------------------------------------
+ACEZ_HD inline double pick4(const double v[4], int i) {
+  double r = v[0];
+  r = (i == 1) ? v[1] : r;
+  r = (i == 2) ? v[2] : r;
+  r = (i == 3) ? v[3] : r;
+  return r;
+}
+ACEZ_HD inline void put4(double v[4], int i, double x) {
+  v[0] = (i == 0) ? x : v[0];
+  v[1] = (i == 1) ? x : v[1];
+  v[2] = (i == 2) ? x : v[2];
+  v[3] = (i == 3) ? x : v[3];
+}
+// the stable insertion sort p3p.cpp / solvepnp.cpp run on up to four solutions (strict >, inner loop stops at the first pair in
+// order), on the keys and a permutation instead of on the poses themselves
+ACEZ_HD inline void insertion_sort4(double key[4], int ord[4], int m) {
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    bool moving = i < m;
+#pragma unroll
+    for (int j = i; j > 0; --j) {
+      const bool sw = moving && key[j - 1] > key[j];
+      const double ka = key[j - 1], kb = key[j];
+      const int oa = ord[j - 1], ob = ord[j];
+      key[j - 1] = sw ? kb : ka;
+      key[j] = sw ? ka : kb;
+      ord[j - 1] = sw ? ob : oa;
+      ord[j] = sw ? oa : ob;
+      moving = sw;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
 // cyclic Jacobi eigen-solver for a symmetric NxN matrix (Numerical Recipes form; p3p.cpp jacobi_4x4 for N = 4)
-// A is destroyed; D receives the eigenvalues, U the eigenvectors (columns).
+// A is destroyed; D receives the eigenvalues, U the eigenvectors (columns). For N = 4 (once per P3P solution, on every lane of the
+// sampling wavefronts) the pair loops are unrolled so that A, U, D stay in registers; N = 6 (the rare fallback of the LM solve) is
+// left rolled.
 // ----------------------------------------------------------------------------------------------------
 template <int N>
 ACEZ_HD inline bool jacobi_sym(double* A, double* D, double* U) {
+  constexpr int UNR = (N <= 4) ? N : 1;
   double B[N], Z[N];
+#pragma unroll UNR
   for (int i = 0; i < N; ++i)
+#pragma unroll UNR
     for (int j = 0; j < N; ++j) U[i * N + j] = (i == j) ? 1. : 0.;
+#pragma unroll UNR
   for (int i = 0; i < N; ++i) {
     B[i] = A[i * N + i];
     D[i] = B[i];
     Z[i] = 0;
   }
+#pragma unroll 1
   for (int iter = 0; iter < 50; iter++) {
     double sum = 0;
+#pragma unroll UNR
     for (int i = 0; i < N - 1; ++i)
+#pragma unroll UNR
       for (int j = i + 1; j < N; ++j) sum += fabs(A[i * N + j]);
     if (sum == 0.0) return true;
     const double tresh = (iter < 3) ? 0.2 * sum / (double)(N * N) : 0.0;
+#pragma unroll UNR
     for (int i = 0; i < N - 1; i++) {
+#pragma unroll UNR
       for (int j = i + 1; j < N; j++) {
         const double Aij = A[i * N + j];
         const double eps_machine = 100.0 * fabs(Aij);
@@ -314,21 +363,25 @@ ACEZ_HD inline bool jacobi_sym(double* A, double* D, double* U) {
           const double c = 1.0 / sqrt(1 + t * t);
           const double s = t * c;
           const double tau = s / (1.0 + c);
+#pragma unroll UNR
           for (int k = 0; k <= i - 1; k++) {
             const double g = A[k * N + i], h = A[k * N + j];
             A[k * N + i] = g - s * (h + g * tau);
             A[k * N + j] = h + s * (g - h * tau);
           }
+#pragma unroll UNR
           for (int k = i + 1; k <= j - 1; k++) {
             const double g = A[i * N + k], h = A[k * N + j];
             A[i * N + k] = g - s * (h + g * tau);
             A[k * N + j] = h + s * (g - h * tau);
           }
+#pragma unroll UNR
           for (int k = j + 1; k < N; k++) {
             const double g = A[i * N + k], h = A[j * N + k];
             A[i * N + k] = g - s * (h + g * tau);
             A[j * N + k] = h + s * (g - h * tau);
           }
+#pragma unroll UNR
           for (int k = 0; k < N; k++) {
             const double g = U[k * N + i], h = U[k * N + j];
             U[k * N + i] = g - s * (h + g * tau);
@@ -337,6 +390,7 @@ ACEZ_HD inline bool jacobi_sym(double* A, double* D, double* U) {
         }
       }
     }
+#pragma unroll UNR
     for (int i = 0; i < N; i++) {
       B[i] += Z[i];
       D[i] = B[i];
@@ -356,7 +410,8 @@ struct P3P {
     inv_fx = 1. / fx; inv_fy = 1. / fy; cx_fx = cx / fx; cy_fy = cy / fy;
   }
 
-  ACEZ_HD int solve_for_lengths(double lengths[4][3], double distances[3], double cosines[3]) {
+  // p3p::solve_for_lengths: the depths (X, Y, Z) of the three points along their viewing rays, one triple per admissible root
+  ACEZ_HD int solve_for_lengths(double lenX[4], double lenY[4], double lenZ[4], const double distances[3], const double cosines[3]) {
     const double p = cosines[0] * 2, q = cosines[1] * 2, r = cosines[2] * 2;
     const double inv_d22 = 1. / (distances[2] * distances[2]);
     const double a = inv_d22 * (distances[0] * distances[0]);
@@ -381,8 +436,9 @@ struct P3P {
     int nb_solutions = 0;
     const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
     const double inv_b0 = 1. / b0;
+#pragma unroll 1
     for (int i = 0; i < n; i++) {
-      const double x = real_roots[i];
+      const double x = pick4(real_roots, i);
       if (x <= 0) continue;
       const double x2 = x * x;
       const double b1 =
@@ -400,22 +456,26 @@ struct P3P {
       const double Z = distances[2] / sqrt(v);
       const double X = x * Z;
       const double Y = y * Z;
-      lengths[nb_solutions][0] = X;
-      lengths[nb_solutions][1] = Y;
-      lengths[nb_solutions][2] = Z;
+      put4(lenX, nb_solutions, X);
+      put4(lenY, nb_solutions, Y);
+      put4(lenZ, nb_solutions, Z);
       nb_solutions++;
     }
     return nb_solutions;
   }
 
-  ACEZ_HD bool align(double M_end[3][3], double X0, double Y0, double Z0, double X1, double Y1, double Z1, double X2, double Y2, double Z2,
-             double R[3][3], double T[3]) {
+  // p3p::align: rotation + translation that carry the three world points onto the three camera-frame points (Horn's quaternion
+  // method: the eigenvector of the largest eigenvalue of a symmetric 4x4)
+  ACEZ_HD void align(const double M_end[3][3], double X0, double Y0, double Z0, double X1, double Y1, double Z1, double X2, double Y2, double Z2,
+                     double R[3][3], double T[3]) {
     double C_start[3], C_end[3];
+#pragma unroll
     for (int i = 0; i < 3; i++) C_end[i] = (M_end[0][i] + M_end[1][i] + M_end[2][i]) / 3;
     C_start[0] = (X0 + X1 + X2) / 3;
     C_start[1] = (Y0 + Y1 + Y2) / 3;
     C_start[2] = (Z0 + Z1 + Z2) / 3;
     double s[9];
+#pragma unroll
     for (int j = 0; j < 3; j++) {
       s[0 * 3 + j] = (X0 * M_end[0][j] + X1 * M_end[1][j] + X2 * M_end[2][j]) / 3 - C_end[j] * C_start[0];
       s[1 * 3 + j] = (Y0 * M_end[0][j] + Y1 * M_end[1][j] + Y2 * M_end[2][j]) / 3 - C_end[j] * C_start[1];
@@ -434,11 +494,16 @@ struct P3P {
     Qs[3 * 4 + 2] = Qs[2 * 4 + 3] = s[2 * 3 + 1] + s[1 * 3 + 2];
     jacobi_sym<4>(Qs, evs, U);
     int i_ev = 0;
-    double ev_max = evs[i_ev];
+    double ev_max = evs[0];
+#pragma unroll
     for (int i = 1; i < 4; i++)
-      if (evs[i] > ev_max) ev_max = evs[i_ev = i];
+      if (evs[i] > ev_max) {
+        ev_max = evs[i];
+        i_ev = i;
+      }
     double q[4];
-    for (int i = 0; i < 4; i++) q[i] = U[i * 4 + i_ev];
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = pick4(&U[i * 4], i_ev);
     const double q02 = q[0] * q[0], q12 = q[1] * q[1], q22 = q[2] * q[2], q32 = q[3] * q[3];
     const double q0_1 = q[0] * q[1], q0_2 = q[0] * q[2], q0_3 = q[0] * q[3];
     const double q1_2 = q[1] * q[2], q1_3 = q[1] * q[3];
@@ -452,125 +517,113 @@ struct P3P {
     R[2][0] = 2. * (q1_3 - q0_2);
     R[2][1] = 2. * (q2_3 + q0_1);
     R[2][2] = q02 + q32 - q12 - q22;
+#pragma unroll
     for (int i = 0; i < 3; i++) T[i] = C_end[i] - (R[i][0] * C_start[0] + R[i][1] * C_start[1] + R[i][2] * C_start[2]);
-    return true;
-  }
-
-  // mu/mv are pixel coordinates (extract_points re-applies fx, cx to the normalised input)
-  ACEZ_HD int solve(double R[4][3][3], double t[4][3], double mu0, double mv0, double X0, double Y0, double Z0, double mu1, double mv1,
-            double X1, double Y1, double Z1, double mu2, double mv2, double X2, double Y2, double Z2, double mu3, double mv3,
-            double X3, double Y3, double Z3) {
-    double mk0, mk1, mk2, norm;
-    mu0 = inv_fx * mu0 - cx_fx;
-    mv0 = inv_fy * mv0 - cy_fy;
-    norm = sqrt(mu0 * mu0 + mv0 * mv0 + 1);
-    mk0 = 1. / norm; mu0 *= mk0; mv0 *= mk0;
-    mu1 = inv_fx * mu1 - cx_fx;
-    mv1 = inv_fy * mv1 - cy_fy;
-    norm = sqrt(mu1 * mu1 + mv1 * mv1 + 1);
-    mk1 = 1. / norm; mu1 *= mk1; mv1 *= mk1;
-    mu2 = inv_fx * mu2 - cx_fx;
-    mv2 = inv_fy * mv2 - cy_fy;
-    norm = sqrt(mu2 * mu2 + mv2 * mv2 + 1);
-    mk2 = 1. / norm; mu2 *= mk2; mv2 *= mk2;
-    mu3 = inv_fx * mu3 - cx_fx;
-    mv3 = inv_fy * mv3 - cy_fy;
-    double distances[3];
-    distances[0] = sqrt((X1 - X2) * (X1 - X2) + (Y1 - Y2) * (Y1 - Y2) + (Z1 - Z2) * (Z1 - Z2));
-    distances[1] = sqrt((X0 - X2) * (X0 - X2) + (Y0 - Y2) * (Y0 - Y2) + (Z0 - Z2) * (Z0 - Z2));
-    distances[2] = sqrt((X0 - X1) * (X0 - X1) + (Y0 - Y1) * (Y0 - Y1) + (Z0 - Z1) * (Z0 - Z1));
-    double cosines[3];
-    cosines[0] = mu1 * mu2 + mv1 * mv2 + mk1 * mk2;
-    cosines[1] = mu0 * mu2 + mv0 * mv2 + mk0 * mk2;
-    cosines[2] = mu0 * mu1 + mv0 * mv1 + mk0 * mk1;
-    double lengths[4][3] = {};
-    const int n = solve_for_lengths(lengths, distances, cosines);
-    int nb_solutions = 0;
-    double reproj_errors[4];
-    for (int i = 0; i < n; i++) {
-      double M_orig[3][3];
-      M_orig[0][0] = lengths[i][0] * mu0; M_orig[0][1] = lengths[i][0] * mv0; M_orig[0][2] = lengths[i][0] * mk0;
-      M_orig[1][0] = lengths[i][1] * mu1; M_orig[1][1] = lengths[i][1] * mv1; M_orig[1][2] = lengths[i][1] * mk1;
-      M_orig[2][0] = lengths[i][2] * mu2; M_orig[2][1] = lengths[i][2] * mv2; M_orig[2][2] = lengths[i][2] * mk2;
-      if (!align(M_orig, X0, Y0, Z0, X1, Y1, Z1, X2, Y2, Z2, R[nb_solutions], t[nb_solutions])) continue;
-      const double X3p = R[nb_solutions][0][0] * X3 + R[nb_solutions][0][1] * Y3 + R[nb_solutions][0][2] * Z3 + t[nb_solutions][0];
-      const double Y3p = R[nb_solutions][1][0] * X3 + R[nb_solutions][1][1] * Y3 + R[nb_solutions][1][2] * Z3 + t[nb_solutions][1];
-      const double Z3p = R[nb_solutions][2][0] * X3 + R[nb_solutions][2][1] * Y3 + R[nb_solutions][2][2] * Z3 + t[nb_solutions][2];
-      const double mu3p = X3p / Z3p;
-      const double mv3p = Y3p / Z3p;
-      reproj_errors[nb_solutions] = (mu3p - mu3) * (mu3p - mu3) + (mv3p - mv3) * (mv3p - mv3);
-      nb_solutions++;
-    }
-    for (int i = 1; i < nb_solutions; i++) {  // insertion sort by the 4th point's error
-      for (int j = i; j > 0 && reproj_errors[j - 1] > reproj_errors[j]; j--) {
-        double tmp = reproj_errors[j]; reproj_errors[j] = reproj_errors[j - 1]; reproj_errors[j - 1] = tmp;
-        for (int a = 0; a < 3; ++a) {
-          for (int b = 0; b < 3; ++b) { tmp = R[j][a][b]; R[j][a][b] = R[j - 1][a][b]; R[j - 1][a][b] = tmp; }
-          tmp = t[j][a]; t[j][a] = t[j - 1][a]; t[j - 1][a] = tmp;
-        }
-      }
-    }
-    return nb_solutions;
   }
 };
 
 // ----------------------------------------------------------------------------------------------------
 // [upstream] solvePnP(SOLVEPNP_P3P) = solveP3P + take the first solution (solvepnp.cpp)
 //   obj: 4 float 3-D points, img: 4 float pixel positions. Returns false when there is no solution.
+// p3p::solve sorts its up-to-four solutions by the reprojection error of the 4th point, solveP3P converts each to (rvec, tvec) and
+// sorts again by the total reprojection error of the four points, solvePnP keeps the first. Here every solution is finished as
+// soon as its depths are known -- pose, 4th-point error, Rodrigues vector, total error -- and the two stable sorts run on the keys
+// and a permutation; the arithmetic per solution and the winner are the same.
 // ----------------------------------------------------------------------------------------------------
 ACEZ_HD inline bool solve_pnp_p3p(const float obj[4][3], const float img[4][2], const Cam& k, Pose* out) {
-  // undistortPoints without distortion: output keeps the input depth (float)
+  // undistortPoints without distortion: output keeps the input depth (float); p3p::extract_points: back to pixels in double
   const double ifx = 1. / k.fx, ify = 1. / k.fy;
-  float un[4][2];
+  double mu[4], mv[4];
+#pragma unroll
   for (int i = 0; i < 4; ++i) {
-    un[i][0] = (float)(((double)img[i][0] - k.cx) * ifx);
-    un[i][1] = (float)(((double)img[i][1] - k.cy) * ify);
+    const float unx = (float)(((double)img[i][0] - k.cx) * ifx);
+    const float uny = (float)(((double)img[i][1] - k.cy) * ify);
+    mu[i] = (double)unx * k.fx + k.cx;
+    mv[i] = (double)uny * k.fy + k.cy;
   }
-  // p3p::extract_points: back to pixels in double
-  double pts[4][5];
-  for (int i = 0; i < 4; ++i) {
-    pts[i][0] = (double)un[i][0] * k.fx + k.cx;
-    pts[i][1] = (double)un[i][1] * k.fy + k.cy;
-    pts[i][2] = obj[i][0];
-    pts[i][3] = obj[i][1];
-    pts[i][4] = obj[i][2];
-  }
+  const double X0 = obj[0][0], Y0 = obj[0][1], Z0 = obj[0][2], X1 = obj[1][0], Y1 = obj[1][1], Z1 = obj[1][2];
+  const double X2 = obj[2][0], Y2 = obj[2][1], Z2 = obj[2][2], X3 = obj[3][0], Y3 = obj[3][1], Z3 = obj[3][2];
   P3P solver(k);
-  double Rs[4][3][3] = {}, ts[4][3] = {};
-  const int solutions =
-      solver.solve(Rs, ts, pts[0][0], pts[0][1], pts[0][2], pts[0][3], pts[0][4], pts[1][0], pts[1][1], pts[1][2], pts[1][3], pts[1][4],
-                   pts[2][0], pts[2][1], pts[2][2], pts[2][3], pts[2][4], pts[3][0], pts[3][1], pts[3][2], pts[3][3], pts[3][4]);
-  if (solutions == 0) return false;
-  double rvecs[4][3], errs[4];
-  for (int i = 0; i < solutions; ++i) {
-    double Rm[9];
+  // p3p::solve: unit viewing rays of the first three points, the 4th stays in normalised image coordinates
+  double mk[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    mu[i] = solver.inv_fx * mu[i] - solver.cx_fx;
+    mv[i] = solver.inv_fy * mv[i] - solver.cy_fy;
+    const double norm = sqrt(mu[i] * mu[i] + mv[i] * mv[i] + 1);
+    mk[i] = 1. / norm;
+    mu[i] *= mk[i];
+    mv[i] *= mk[i];
+  }
+  mu[3] = solver.inv_fx * mu[3] - solver.cx_fx;
+  mv[3] = solver.inv_fy * mv[3] - solver.cy_fy;
+  double distances[3];
+  distances[0] = sqrt((X1 - X2) * (X1 - X2) + (Y1 - Y2) * (Y1 - Y2) + (Z1 - Z2) * (Z1 - Z2));
+  distances[1] = sqrt((X0 - X2) * (X0 - X2) + (Y0 - Y2) * (Y0 - Y2) + (Z0 - Z2) * (Z0 - Z2));
+  distances[2] = sqrt((X0 - X1) * (X0 - X1) + (Y0 - Y1) * (Y0 - Y1) + (Z0 - Z1) * (Z0 - Z1));
+  double cosines[3];
+  cosines[0] = mu[1] * mu[2] + mv[1] * mv[2] + mk[1] * mk[2];
+  cosines[1] = mu[0] * mu[2] + mv[0] * mv[2] + mk[0] * mk[2];
+  cosines[2] = mu[0] * mu[1] + mv[0] * mv[1] + mk[0] * mk[1];
+  double lenX[4] = {0, 0, 0, 0}, lenY[4] = {0, 0, 0, 0}, lenZ[4] = {0, 0, 0, 0};
+  const int n = solver.solve_for_lengths(lenX, lenY, lenZ, distances, cosines);
+  if (n == 0) return false;
+
+  double rv[3][4], tv[3][4], err4[4] = {0, 0, 0, 0}, errAll[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rv[a][q] = tv[a][q] = 0;
+#pragma unroll 1
+  for (int i = 0; i < n; i++) {
+    const double l0 = pick4(lenX, i), l1 = pick4(lenY, i), l2 = pick4(lenZ, i);
+    double M_orig[3][3];
+    M_orig[0][0] = l0 * mu[0]; M_orig[0][1] = l0 * mv[0]; M_orig[0][2] = l0 * mk[0];
+    M_orig[1][0] = l1 * mu[1]; M_orig[1][1] = l1 * mv[1]; M_orig[1][2] = l1 * mk[1];
+    M_orig[2][0] = l2 * mu[2]; M_orig[2][1] = l2 * mv[2]; M_orig[2][2] = l2 * mk[2];
+    double R[3][3], t[3];
+    solver.align(M_orig, X0, Y0, Z0, X1, Y1, Z1, X2, Y2, Z2, R, t);
+    const double X3p = R[0][0] * X3 + R[0][1] * Y3 + R[0][2] * Z3 + t[0];
+    const double Y3p = R[1][0] * X3 + R[1][1] * Y3 + R[1][2] * Z3 + t[1];
+    const double Z3p = R[2][0] * X3 + R[2][1] * Y3 + R[2][2] * Z3 + t[2];
+    const double mu3p = X3p / Z3p;
+    const double mv3p = Y3p / Z3p;
+    const double e4 = (mu3p - mu[3]) * (mu3p - mu[3]) + (mv3p - mv[3]) * (mv3p - mv[3]);
+    // solveP3P: rotation matrix -> Rodrigues vector, then the total reprojection error of (rvec, tvec) through projectPoints
+    double Rm[9], rvec[3], R2[9];
+#pragma unroll
     for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) Rm[a * 3 + b] = Rs[i][a][b];
-    rodrigues_inv(Rm, rvecs[i]);
-    double R2[9];
-    rodrigues(rvecs[i], R2, nullptr);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) Rm[a * 3 + b] = R[a][b];
+    rodrigues_inv(Rm, rvec);
+    rodrigues(rvec, R2, nullptr);
     double e = 0;
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
       double u, v;
-      project(R2, ts[i], k, obj[j][0], obj[j][1], obj[j][2], &u, &v, nullptr, nullptr, nullptr);
+      project(R2, t, k, obj[j][0], obj[j][1], obj[j][2], &u, &v, nullptr, nullptr, nullptr);
       const double ex = (double)img[j][0] - u, ey = (double)img[j][1] - v;
       e += ex * ex;
       e += ey * ey;
     }
-    errs[i] = e;
-  }
-  for (int i = 1; i < solutions; i++) {  // stable insertion sort by total reprojection error
-    for (int j = i; j > 0 && errs[j - 1] > errs[j]; j--) {
-      double tmp = errs[j]; errs[j] = errs[j - 1]; errs[j - 1] = tmp;
-      for (int a = 0; a < 3; ++a) {
-        tmp = rvecs[j][a]; rvecs[j][a] = rvecs[j - 1][a]; rvecs[j - 1][a] = tmp;
-        tmp = ts[j][a]; ts[j][a] = ts[j - 1][a]; ts[j - 1][a] = tmp;
-      }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      put4(rv[a], i, rvec[a]);
+      put4(tv[a], i, t[a]);
     }
+    put4(err4, i, e4);
+    put4(errAll, i, e);
   }
+  int ord[4] = {0, 1, 2, 3};
+  insertion_sort4(err4, ord, n);        // p3p::solve: by the 4th point's error
+  double key[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) key[j] = pick4(errAll, ord[j]);
+  insertion_sort4(key, ord, n);         // solveP3P: by the total error (stable: ties keep the order above)
+#pragma unroll
   for (int a = 0; a < 3; ++a) {
-    out->r[a] = rvecs[0][a];
-    out->t[a] = ts[0][a];
+    out->r[a] = pick4(rv[a], ord[0]);
+    out->t[a] = pick4(tv[a], ord[0]);
   }
   return true;
 }

@@ -35,11 +35,12 @@ def _context(max_frames, h, w, device):
     key = (device,)
     c = _ctx.get(key)
     if c is None or c["frames"] < max_frames or c["h"] < h or c["w"] < w:
-        if c is not None:
-            N.lib().acez_ransac_destroy(c["h_"])
-        hnd = C.c_void_p()
         mf, mh, mw = max(max_frames, c["frames"] if c else 1), max(h, c["h"] if c else 0), max(w, c["w"] if c else 0)
-        N.check(N.lib().acez_ransac_create(C.byref(hnd), mf, mh, mw, device))
+        hnd = C.c_void_p()
+        N.check(N.lib().acez_ransac_create(C.byref(hnd), mf, mh, mw, device))   # raises before the old context is touched
+        if c is not None:
+            del _ctx[key]
+            N.lib().acez_ransac_destroy(c["h_"])                                  # waits for the launches still using it
         c = {"h_": hnd, "frames": mf, "h": mh, "w": mw}
         _ctx[key] = c
     return c["h_"]

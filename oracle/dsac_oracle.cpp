@@ -20,7 +20,8 @@
 //       (thread_rand.cpp:13-42; SURVEY.md section 8c "RNG parity caveat").
 //   D2  reductions over pixels (soft inlier score; J^T J, J^T e, |e|^2 of the LM solver) use a fixed
 //       interleaved-partials + pairwise-tree order (64-way resp. 256-way) instead of a sequential left fold, so
-//       that a wavefront / workgroup can reproduce them bit-for-bit.
+//       that a wavefront / workgroup can reproduce them bit-for-bit. The LM sums run over the inlier LIST in the
+//       reference's scan order (entry j -> partial j % 256), the soft score over all pixels (pixel p -> partial p % 64).
 //   D3  transcendental functions are the deterministic kernels of det_math.h instead of libm.
 //   D4  the 6x6 damped normal equations are solved by a Cholesky factorisation, falling back to a Jacobi eigen-decomposition
 //       with OpenCV's SVBkSb threshold when a pivot is not safely positive (cv::solve(DECOMP_SVD) of a symmetric matrix:
@@ -748,14 +749,21 @@ void lm_accumulate(const Frame& f, const std::vector<uint8_t>& flags, const doub
   rodrigues(param, R, withJ ? dRdr : nullptr);
   const double* t = param + 3;
   const int N = f.W * f.H;
-  // 28 quantities x 256 partials
+  // the inlier list in scan order: refineHyp's localImgPts / localObjPts (dsacstar_util.h:545-560), the order in which
+  // cvFindExtrinsicCameraParams2 walks its correspondences
+  static thread_local std::vector<int> list;
+  list.clear();
+  for (int p = 0; p < N; ++p)
+    if (flags[p]) list.push_back(p);
+  const int cnt = (int)list.size();
+  // 28 quantities x 256 partials: list entry j adds to partial j % 256
   static thread_local std::vector<double> part;
   part.assign(28 * 256, 0.0);
   for (int lane = 0; lane < 256; ++lane) {
     double acc[28];
     for (int i = 0; i < 28; ++i) acc[i] = 0;
-    for (int p = lane; p < N; p += 256) {
-      if (!flags[p]) continue;
+    for (int j = lane; j < cnt; j += 256) {
+      const int p = list[j];
       const int x = p / f.H, y = p % f.H;
       float c[3];
       f.coord(x, y, c);
