@@ -38,15 +38,22 @@ class BufferBuilder:
     def full(self):
         return self.n >= self.capacity
 
-    def add_views(self, image_v1hw, mask_v1hw, aug_pose_inv_v44, pose_inv_v44, K_v33, Kinv_v33, image_index_v, want_pixels=False, check_empty=True):
-        """One dataloader batch (the reference uses batch size 1; any number of same-sized views works here)."""
+    def add_views(self, image_v1hw, mask_v1hw, aug_pose_inv_v44, pose_inv_v44, K_v33, Kinv_v33, image_index_v, want_pixels=False, check_empty=True,
+                  mask_at_feature_resolution=False):
+        """One dataloader batch (the reference uses batch size 1; any number of same-sized views works here).
+        mask_at_feature_resolution: mask_v1hw is already [v,1,oh,ow] (a mask combined with per-cell data such as depth validity): it is
+        used as is -- up- and down-sampling it through the image resolution is not the identity when h or w is not a multiple of 8."""
         if self.full:
             return 0
         v, _, h, w = image_v1hw.shape
         oh, ow = output_size(h, w)
         # mask at feature resolution, nearest neighbour (ace_trainer.py:373-374)
         if mask_v1hw is not None:
-            m = F.interpolate(mask_v1hw.to(self.dev, torch.float32), size=(oh, ow), mode="nearest") > 0
+            if mask_at_feature_resolution:
+                assert tuple(mask_v1hw.shape[-2:]) == (oh, ow), (tuple(mask_v1hw.shape), (oh, ow))
+                m = mask_v1hw.to(self.dev) > 0
+            else:
+                m = F.interpolate(mask_v1hw.to(self.dev, torch.float32), size=(oh, ow), mode="nearest") > 0
             # views without a valid pixel are skipped (ace_trainer.py:377-378); the test costs a host synchronisation per call,
             # callers that know their masks are never empty (rotations of a few degrees) switch it off
             keep = m.flatten(1).any(dim=1) if check_empty else None
@@ -55,7 +62,8 @@ class BufferBuilder:
                 if len(sel) == 0:
                     return 0
                 return self.add_views(image_v1hw[sel], mask_v1hw[sel], aug_pose_inv_v44[sel], pose_inv_v44[sel], K_v33[sel],
-                                      Kinv_v33[sel], [image_index_v[int(i)] for i in sel], want_pixels=want_pixels, check_empty=False)
+                                      Kinv_v33[sel], [image_index_v[int(i)] for i in sel], want_pixels=want_pixels, check_empty=False,
+                                      mask_at_feature_resolution=mask_at_feature_resolution)
             mask_u8 = m.to(torch.uint8).contiguous()
         else:
             mask_u8 = None

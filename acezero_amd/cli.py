@@ -499,8 +499,15 @@ def load_frames(rgb_glob, image_resolution=480, files=None, return_rgb=False):
             rgbs.append(np.asarray(small, np.uint8))
         if size is None:
             size = g.shape
+            from .session import check_frame_size
+            try:
+                check_frame_size(*size)                                  # before the other frames are decoded
+            except RuntimeError as e:
+                raise SystemExit(str(e))
         elif g.shape != size:
-            raise SystemExit(f"{f}: resized frame is {g.shape}, the first one {size}; the in-process session needs one frame size")
+            raise SystemExit(f"{f}: resized frame is {g.shape}, the first one {size}: the in-process session batches frames of ONE size "
+                             "(the reference's batch-size-1 loaders accept mixed sizes); crop or pad the images to a common aspect ratio, "
+                             "or run the differently sized images as separate scenes")
         frames.append((g - 0.4) / 0.25)
         factor = sc
     if return_rgb:

@@ -11,10 +11,13 @@ round is head + RANSAC on cached features.
     ses = ReconstructionSession(encoder_state_dict, images_n1hw, depth=seed_depth_nhw)     # opt = default_options(...)
     result = ses.reconstruct()          # {"poses": cam->world [n,4,4], "confidence": [n], "focal": f, "head": state_dict, ...}
 
-Option names and defaults are ace_zero.py's (:41-177).  What is NOT here is the image pipeline (file decoding, resizing,
-augmentation: dataset.py) and ZoeDepth: frames arrive as normalised grey tensors, views are not augmented (--use_aug False
-semantics) and a seed needs a depth map for its image (ace_zero.py's --depth_files path; the reference falls back to a
-network download otherwise).  There is no CPU fallback.
+Option names and defaults are ace_zero.py's (:41-177).  What is NOT here is file decoding / resizing (dataset.py, done by the
+caller: frames arrive as normalised grey tensors) and ZoeDepth: a seed needs a depth map for its image (ace_zero.py's
+--depth_files path; the reference falls back to a network download otherwise).  With use_aug (the default, as in the reference)
+every buffer pass re-encodes freshly rotated / rescaled / brightness-jittered views (dataset.py:268-356) warped on the GPU.
+With torch.distributed initialised (torchrun ace_zero.py) the frames, the buffer and the registration are sharded over the ranks
+and mapping is data parallel (parallel.py).  Frames must fit the DSAC* kernel: at most 16384 scene coordinates (H/8 x W/8).
+There is no CPU fallback.
 """
 import logging
 import math
@@ -33,6 +36,18 @@ from .head import HeadTrainer, _ptr, _stream, epoch_permutations
 from .parallel import epoch_local_batches, gather_registrations, rank_world
 
 _logger = logging.getLogger("acezero_amd.session")
+
+
+MAX_SCENE_COORDINATES = 16384   # per frame: the DSAC* kernel's inlier word (ransac_api.hip MAX_ROWS x 256 threads)
+
+
+def check_frame_size(h, w):
+    """The registration kernel handles frames of up to 16384 scene coordinates (480 x 2184, 768 x 1360, ...); the reference's CPU loop
+    has no limit. Raise early, with the remedy, instead of failing after every frame has been encoded."""
+    oh, ow = output_size(h, w)
+    if oh * ow > MAX_SCENE_COORDINATES:
+        raise RuntimeError(f"{h} x {w} frames give {oh} x {ow} = {oh * ow} scene coordinates, the DSAC* kernel registers at most "
+                           f"{MAX_SCENE_COORDINATES} per frame: lower --image_resolution (dataset.py:40 rescales the short side to it)")
 
 
 def default_options(**over):
@@ -123,6 +138,7 @@ class ReconstructionSession:
         self.opt = opt or default_options()
         n, _, H, W = images.shape
         self.n, self.H, self.W = int(n), int(H), int(W)
+        check_frame_size(int(H), int(W))                                 # before any frame is encoded
         amax = float(self.opt.aug_scale) if self.opt.use_aug else 1.0
         self.enc = Encoder.from_state_dict(encoder_state_dict, max_frames=chunk, max_h=int(math.ceil(H * amax)) + 8,
                                            max_w=int(math.ceil(W * amax)) + 8, device=device)
@@ -249,6 +265,7 @@ class ReconstructionSession:
         chunk = 16
         crds = []
         while not bld.full:
+            rows_before = bld.n
             levels, scales, angles, jit = self._draw_augmentations(m)
             for lv in np.unique(levels):
                 sel = np.flatnonzero(levels == lv)
@@ -276,15 +293,23 @@ class ReconstructionSession:
                         dv = view_depth(self.depth[int(ids[j])][None, None], grid[k:k + 1], oh, ow)
                         valid = (dv > 0) & (dv <= 1000)
                         mk = torch.nn.functional.interpolate(masks[k:k + 1].float(), size=(oh, ow), mode="nearest")[0, 0] > 0
-                        full_mask = torch.nn.functional.interpolate((mk & valid).float()[None, None], size=(hs, ws), mode="nearest")
-                        took = bld.add_views(views[k:k + 1], full_mask, rot_inv[k:k + 1], pose_inv[j:j + 1], K[None], Kinv[None], [int(j)], want_pixels=True)
+                        took = bld.add_views(views[k:k + 1], (mk & valid).float()[None, None], rot_inv[k:k + 1], pose_inv[j:j + 1], K[None], Kinv[None],
+                                             [int(j)], want_pixels=True, mask_at_feature_resolution=True)
                         if took:
                             pix = bld.last_pixels[:took].long()
                             dd = dv[pix // ow, pix % ow]
                             px = bld.target_px[n0:n0 + took]
                             eye = torch.stack([(px[:, 0] - ws / 2.0) / f * dd, (px[:, 1] - hs / 2.0) / f * dd, dd, torch.ones_like(dd)], dim=1)
                             T = (poses_c2w[j].to(torch.float32) @ torch.linalg.inv(rot_inv[k])).to(self.dev)   # pose @ pose_rot (dataset.py:381)
-                            crds.append(eye @ T[:3].T)
+                            xyz = eye @ T[:3].T
+                            xyz[(dd <= 0) | (dd > 1000)] = 0                 # "unavailable" marker (dataset.py:384-386); unreachable through the mask
+                            crds.append(xyz)
+            if with_depth and bld.n == rows_before:
+                # the reference samples without looking at the depth and cannot stall; here depth-less cells are masked out, so a seed
+                # image without any usable depth would never fill the buffer
+                raise RuntimeError("no training sample in a whole pass over images %s: their depth maps have no value in (0, 1000] inside "
+                                   "the augmented views (all zeros, wrong units, or a depth file that belongs to another image)"
+                                   % [int(i) for i in ids.tolist()])
         self._views_sampled += bld.n_views
         buf = bld.finish()
         if with_depth:

@@ -181,3 +181,16 @@ def test_train_ace_and_register_mapping_scripts_on_image_files(tmp_path):
     idx = [files.index(f) for f in fl]
     dt, ang = _pose_err(poses, gt[idx])
     assert np.median(dt) < 0.01 and np.median(ang) < 0.5
+
+
+def test_seed_without_usable_depth_raises_instead_of_hanging():
+    """a depth map without a value in (0, 1000] never added a buffer row and the fill loop spun forever."""
+    from acezero_amd.session import ReconstructionSession, check_frame_size
+    seq = synth.render_room_sequence(seed=2089, n_frames=4, arc_deg=4.0, device="cuda")
+    esd = {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights_bandpass(seed=4099).items()}
+    ses = ReconstructionSession(esd, seq["images"], opt=_opt(seq), depth=torch.zeros_like(seq["depth"]))
+    with pytest.raises(RuntimeError, match="depth maps have no value"):
+        ses.map_seed(0, 0.3)
+    with pytest.raises(RuntimeError, match="16384"):
+        check_frame_size(1088, 1936)
+    check_frame_size(480, 2184)
