@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--pose-refinement", default="none", choices=["none", "mlp"])   # ace_zero.py:86 maps every non-seed iteration with mlp
     ap.add_argument("--session-frames", type=int, default=120, help="frames of the in-process ACE0 reconstruction leg (N = 1 only; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed training steps (the leg rocprofv3 is pointed at: tools/prof_r02.sh)")
     # control-flow smoke of the N > 1 path on a ONE-GPU box: every rank on cuda:0, gloo instead of RCCL (not a measurement)
     ap.add_argument("--smoke-same-device", action="store_true")
     return ap.parse_args()
@@ -167,6 +168,27 @@ def bench_registration(args, rank, world, device):
     dt = (time.perf_counter() - t0) / reps
     ok = float((inl > 1000).float().mean())
     return n, dt, ok
+
+
+def ransac_roofline(images_per_s):
+    """ransac_kernel is fp64-VALU bound (57.6 KB in, 5 KB out per frame: no HBM or MFMA roof applies). Counter-based: the vector
+    instructions per frame come from the committed PMC pass (profiles/r02_ransac_pmc.json, SQ_INSTS_VALU / frames of the same
+    2048-frame launch), the rate from the live run; peak = 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz fp64 lane-operations
+    (= the 78.6 TFLOP/s fp64 vector peak / 2 flops per FMA)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_ransac_pmc.json")
+    peak = 256 * 4 * 16 * 2.4e9 / 1e12
+    out = {"bound": "valu_fp64", "kernel": "ransac_kernel<false> (one 256-thread workgroup per 60x80 frame)", "peak": peak,
+           "unit": "T lane-ops/s", "achieved": None, "frac": None, "traffic": None}
+    try:
+        c = json.load(open(path))["ransac_kernel"]
+        insts_per_frame = c["SQ_INSTS_VALU"]["mean_per_launch"] / 2048
+        out.update(achieved=images_per_s * insts_per_frame * 64 / 1e12, valu_insts_per_frame=insts_per_frame,
+                   lane_utilisation=c["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (c["SQ_INSTS_VALU"]["mean_per_launch"] * 64),
+                   source="profiles/r02_ransac_pmc.json (static instruction count) x live images/s")
+        out["frac"] = out["achieved"] / peak
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
 
 
 ENC_FLOP_PER_FRAME = 58.37e9    # 480x640: sum over the 11 convolutions of 2*Ho*Wo*Cin*Cout*k*k (ace_network.py:26-40)
@@ -367,6 +389,18 @@ def main():
     assert world == args.gpus or world == 1, (world, args.gpus)
 
     dt, st, prof = bench_training(args, rank, world, device)
+    if args.headline_only:
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t[0])
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "ACE patches/sec", "value": BATCH * world * args.steps / dt, "unit": "patches/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "headline_only": True,
+                              "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()}, "final_loss": st["loss"]}))
+        return
     dt_ref, st_ref, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000))
     dt_strong = None
     if world > 1:   # the reference's step (global batch 5120) split over the ranks
@@ -387,10 +421,10 @@ def main():
         avg_s = gemm_ms / max(gemm_n, 1) * 1e-3
         achieved = BATCH * GEMM_FLOP_PER_LAUNCH_PER_ROW / avg_s / 1e12 if avg_s > 0 else 0.0
         traffic, traffic_source = None, None
-        tf = os.path.join(ROOT, "profiles", "r01_rowgemm_hbm_traffic.json")
-        if os.path.exists(tf):   # NOT measured in this run: the PMC passes need rocprofv3 around the process (tools/prof_r02.sh)
+        tf = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r02_rowgemm_hbm_traffic.json", "r01_rowgemm_hbm_traffic.json")) if os.path.exists(f)), "")
+        if tf:   # NOT measured in this run: the PMC passes need rocprofv3 around the process (tools/prof_r02.sh)
             traffic = json.load(open(tf)).get("bytes_per_launch")
-            traffic_source = "profiles/r01_rowgemm_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes; a stored measurement, not this run)"
+            traffic_source = "profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes; a stored measurement, not this run)"
         wg_s = prof["wgrad"][0] / max(prof["wgrad"][1], 1) * 1e-3
         wg_tflops = BATCH * 8 * GEMM_FLOP_PER_LAUNCH_PER_ROW / wg_s / 1e12 if wg_s > 0 else 0.0
         out = {
@@ -436,6 +470,7 @@ def main():
             "roofline_wgrad": {"bound": "mfma", "kernel": "wgrad_kernel (8 layers x 512x512x5120 bf16 in one launch)", "achieved": wg_tflops,
                                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_tflops / MFMA_PEAK_TFLOPS, "traffic": None,
                                "avg_launch_us": wg_s * 1e6},
+            "roofline_ransac": ransac_roofline(nreg * world / dt_reg),
             "final_loss": st["loss"],
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N = 1 only
