@@ -22,6 +22,7 @@ struct acez_trainer {
   int64_t n_wide = 0, n_params = 0, fc3_off = 0;
   int64_t fc3_stride = 0;
   int nslabs = 1;
+  int wgrad_tile = 128;
   int max_batch = 0;
   int last_n = 0;
   // device allocations
@@ -161,7 +162,10 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   if (const char* e = getenv("ACEZ_GEMM_TILE")) tr->gemm_tile = atoi(e) == 128 ? 128 : 80;
   if (const char* e = getenv("ACEZ_CHAIN")) tr->chain = atoi(e) != 0;
   if (tr->fused_fwd) tr->chain = false;
-  tr->nslabs = 256 / (16 * tr->L);
+  // wgrad_kernel: 16 tiles per layer; wgrad256_kernel (ACEZ_WGRAD_TILE=256, measured alternative: -2.8 us of wgrad, +2.4 us of
+  // adamw for the two extra slabs): 8; as many row slabs as fill the 256 CUs
+  if (const char* e = getenv("ACEZ_WGRAD_TILE")) tr->wgrad_tile = atoi(e) == 256 ? 256 : 128;
+  tr->nslabs = 256 / ((tr->wgrad_tile == 128 ? 16 : 8) * tr->L);
   if (tr->nslabs < 1) tr->nslabs = 1;
 
   int rc = ACEZ_OK;
@@ -601,7 +605,8 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.n_layers = tr->L; a.st = st; a.zeros = tr->zeros; a.dbg = 0;
     ProfScope ps(tr, s, KC_WGRAD);
     const int groups = tr->L * tr->nslabs;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
+    if (tr->wgrad_tile == 128) hipLaunchKernelGGL(wgrad_kernel, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(wgrad256_kernel, dim3(64 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
   }
   {
     GradReduceArgs a{};

@@ -610,6 +610,126 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// wgrad256: the same product on 256 (dZ columns) x 128 (In columns) workgroup tiles, four multiplier waves of 128 x 64 each.
+// Why: wgrad_kernel is bound by the LDS, not by MFMA issue -- per 16-row step its four 64 x 64 waves read 4 x 4 KiB of transposed
+// fragments while the DMA writes 8 KiB of new stage data, 1.5 LDS-cycles per MFMA-cycle (measured: 53 % of the MFMA rate) -- and
+// behind that by the L2 -> LDS fill (1.31 MB per workgroup at ~70 GB/s per CU = 19 us). A 128 x 64 wave tile needs 6 fragments
+// per 8 MFMAs instead of 4 per 4, and a 256 x 128 workgroup tile 0.98 MB per workgroup: 1.1 LDS-cycles per MFMA-cycle and 25 % less
+// fill. 8 tiles x 8 layers x 4 row slabs = 256 workgroups; the slabs are summed in slab order by adamw / grad_reduce as before.
+// Stage = [Z0 | Z1 | X], three [64 m][128] sub-tiles in the layout of wgrad_kernel (Z0 / Z1: the two column halves of the dZ tile),
+// 3-slot ring (144 KiB).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WGRAD_THREADS) void wgrad256_kernel(WgradArgs a) {
+  const int active = a.st ? a.st->active : 1;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[3][3][64 * 128];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool loader = w >= 4;
+  const int cw = w & 3, wn = cw >> 1, wc = cw & 1;
+  const int lw = w - 4;
+  constexpr int GPL = 16 / WGRAD_LOADERS;       // 4-row DMA groups per loader, stage and sub-tile
+  // the 8 tiles of a (layer, slab) group on one XCD (workgroup b runs on XCD b % 8): their 4x / 2x re-reads of dZ / In hit its L2
+  const int b = blockIdx.x;
+  const int xcd = b & 7, jx = b >> 3;
+  const int group = xcd + 8 * (jx >> 3), tile = jx & 7;
+  if (group >= a.n_layers * a.nslabs) return;
+  const int layer = group / a.nslabs, slab = group - layer * a.nslabs;
+  const int n0 = (tile >> 2) * 256, c0 = (tile & 3) * 128;
+  const uint16_t* __restrict__ Z = a.dZ[layer];
+  const uint16_t* __restrict__ X = a.In[layer];
+  const int M = a.M;
+  const int rows_per_slab = ((M + a.nslabs * 64 - 1) / (a.nslabs * 64)) * 64;
+  const int mb = slab * rows_per_slab;
+  const int me = min(M, mb + rows_per_slab);
+  const int KT = (me > mb) ? (me - mb + 63) >> 6 : 0;
+
+  const int prow = l >> 4, pq = l & 15;
+  auto issue = [&](int kt, int slot) {
+#pragma unroll
+    for (int j = 0; j < GPL; ++j) {
+      const int srow = (lw * GPL + j) * 4 + prow;
+      const int lchunk = ((((pq >> 1) ^ ((srow & 3) << 1)) << 1) | (pq & 1)) * 8;  // element offset of the source chunk
+      const int m = mb + kt * 64 + srow;
+      const bool ok = m < me;
+      const uint16_t* gz = ok ? Z + (size_t)m * 512 + n0 + lchunk : a.zeros + pq * 8;
+      const uint16_t* gx = ok ? X + (size_t)m * 512 + c0 + lchunk : a.zeros + pq * 8;
+      __builtin_amdgcn_global_load_lds((gvoid_t*)gz, (lvoid_t*)&smem[slot][0][(lw * GPL + j) * 4 * 128], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(ok ? gz + 128 : gz), (lvoid_t*)&smem[slot][1][(lw * GPL + j) * 4 * 128], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)gx, (lvoid_t*)&smem[slot][2][(lw * GPL + j) * 4 * 128], 16, 0, 0);
+    }
+  };
+
+  if (loader) {
+    if (a.dbg & 4) {
+      for (int kt = 0; kt < KT; ++kt) __builtin_amdgcn_s_barrier();
+      return;
+    }
+    if (KT > 0) issue(0, 0);
+    if (KT > 1) issue(1, 1);
+    int slot = 2;                                  // slot of stage kt + 2
+    for (int kt = 0; kt < KT; ++kt) {
+      // stages issued so far: 0 .. min(kt + 1, KT - 1); a loader has 3 * GPL DMA instructions per stage in flight
+      if (kt + 1 < KT) ACEZ_VMCNT_C(3 * GPL);
+      else ACEZ_VMCNT(0);
+      __builtin_amdgcn_s_barrier();  // stage kt has landed; the multipliers are done with stage kt - 1, whose slot is refilled
+      if (kt + 2 < KT) issue(kt + 2, slot);
+      slot = (slot == 2) ? 0 : slot + 1;
+    }
+    return;
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int offA[4], offB[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) offA[i] = tr_base(32 * i, l);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) offB[j] = tr_base(wc * 64 + 32 * j, l);
+  int slot = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    __builtin_amdgcn_s_barrier();
+    if (!(a.dbg & 2)) {
+      const uint16_t* sz = &smem[slot][wn][0];
+      const uint16_t* sx = &smem[slot][2][0];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 fa[4], fb[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sz + offA[i] + kk * 16 * 128);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = tr_frag(sx + offB[j] + kk * 16 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    slot = (slot == 2) ? 0 : slot + 1;
+  }
+
+  if (a.dbg & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
+  if (!active) return;
+  float* __restrict__ G = a.slabs + (size_t)slab * a.slab_stride;
+  const int h = l >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + (l & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        G[a.w_off[layer] + (size_t)n * 512 + c] = acc[i][j][r];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // loss kernel (32 rows per workgroup, four wavefronts):
 //   A  fc3 forward, wave wv: rows 8 wv .. 8 wv + 7, one row per pass, fp32 accumulate
 //   B  one thread per row: de-homogenise, project, masks, robust loss and d(loss)/d(fc3 outputs)
