@@ -239,10 +239,10 @@ def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     only = sys.argv[1:]   # optional: names of the configurations to (re)generate
     from tests import helpers   # the "trained regime" configurations and their problem live next to the tests that consume them
-    for name, c in list(CONFIGS.items()) + list(helpers.TRAINED_CONFIGS.items()):
+    for name, c in list(CONFIGS.items()) + list(helpers.TRAINED_CONFIGS.items()) + [("head_focal_drift", helpers.FOCAL_DRIFT)]:
         if only and name not in only:
             continue
-        if name in helpers.TRAINED_CONFIGS:
+        if name in helpers.TRAINED_CONFIGS or name == "head_focal_drift":
             prob, flat0, cfg = helpers.problem_for(name)
         else:
             cfg = full_cfg(c)
