@@ -952,232 +952,7 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// conv3x3q: conv3x3p with the stage loop software-pipelined in registers (round 2). In conv3x3p a multiplier wave issues the
-// LDS reads of a fragment group, waits for them, issues its four MFMAs, and only then the next reads (the 168-register budget of
-// a 12-wave workgroup leaves 16 registers for fragments): with every wave of the CU reading at once an LDS read takes ~400
-// cycles to come back, so a 128-cycle MFMA group costs ~580 cycles of wave time and the two multiplier waves of a SIMD keep the
-// matrix pipe 41 % busy (SQ_VALU_MFMA_BUSY_CYCLES). Here the workgroup has EIGHT waves (two per SIMD, 256 registers each) that
-// multiply AND issue the LDS-DMA themselves (2 weight instructions per wave and stage, 4 patch instructions per wave and
-// 32-channel chunk: ~150 cycles of issue per ~2000-cycle stage), and the fragments are double-buffered: while the 8 MFMAs of one
-// 16-wide K step run, the 6 fragment reads of the next step (the other half of the stage, or the first half of the next stage,
-// after its barrier) are in flight. Same tile, same LDS layout, same K order, hence the same bits as conv3x3p.
-// ---------------------------------------------------------------------------------------------------
-template <bool RELU, bool HAS_ADD>
-__global__ __launch_bounds__(512) void conv3x3q_kernel(ConvGemmArgs a) {
-  constexpr int WSTAGE = 256 * 32;            // elements per weight slot
-  constexpr int PATCH = P3_ROWS * 32;         // elements per patch buffer
-  __shared__ __attribute__((aligned(16))) uint16_t smem[65536 + 32];
-  uint16_t* const sPatch = smem + 4 * WSTAGE;
-  uint16_t* const sZero = smem + 65536;       // 64 bytes of zeros: the target of every padded tap
-  const int t = threadIdx.x, l = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int M = a.M, Co = a.Co, Kp = a.Kp, Wi = a.Wi;
-  const int ntiles = Co >> 8;
-  const int mtiles = (M + 255) >> 8;
-  const int per_xcd = (mtiles + 7) >> 3;
-  const int jx = blockIdx.x >> 3;
-  const int mt = (blockIdx.x & 7) * per_xcd + jx / ntiles;
-  if (mt >= mtiles) return;
-  const int n0 = (jx % ntiles) << 8, m0 = mt << 8;
-  const int NC = a.Ci >> 5;                   // 32-channel chunks
-  const int S = NC * 9;                       // stages: chunk-major, tap-minor
-  if (t < 32) {                               // visible after the first barrier of the stage loop
-    sZero[t] = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-
-  // ---- this wave's share of the LDS-DMA: a DMA instruction covers 16 rows x 64 bytes
-  const int lrow = l >> 2, lch = l & 3;
-  const uint16_t* gW[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (w * 2 + j) * 16 + lrow;
-    gW[j] = a.W + (size_t)(n0 + row) * Kp + (lch ^ ((row >> 2) & 3)) * 8;
-  }
-  // patch rows (w * 4 + j) * 16 + lrow, j < 4 (waves 0..6: 448 rows): global pixel m0 - Wi - 1 + row, clamped
-  const int burst_n = (w < 7) ? 4 : 0;
-  const uint16_t* gP[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (w * 4 + j) * 16 + lrow;
-    const int g = min(max(m0 - Wi - 1 + row, 0), M - 1);
-    gP[j] = a.In + ((size_t)g << a.ci_shift) + (lch ^ ((row >> 2) & 3)) * 8;
-  }
-  const bool no_dma = a.dbg & 4, no_mfma = a.dbg & 2;   // ablations (timing only)
-  auto issue_w = [&](int s) {
-    if (no_dma) return;
-    const int cc = s / 9, tap = s - cc * 9;
-    const int koff = tap * a.Ci + cc * 32;
-    uint16_t* slot = smem + (s & 3) * WSTAGE;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + koff), (lvoid_t*)(slot + (w * 2 + j) * 16 * 32), 16, 0, 0);
-  };
-  auto issue_patch = [&](int cc) {
-    if (burst_n == 0 || no_dma) return;
-    uint16_t* buf = sPatch + (cc & 1) * PATCH;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(gP[j] + cc * 32), (lvoid_t*)(buf + (w * 4 + j) * 16 * 32), 16, 0, 0);
-  };
-  int burst_at = -100;                        // stage after whose barrier the last patch burst was issued
-  // wait until this wave's pieces of W(s) (and of every older transfer) have landed. Younger and already issued: the weight stages
-  // s+1 .. min(s+3 at s = 0, s+2 otherwise) (2 instructions each) and, for s = b+1 .. b+3, the patch burst issued at stage b.
-  auto wait_stage = [&](int s) {
-    const int later = (s == 0) ? min(3, S - 1) : min(2, S - 1 - s);
-    const bool burst_young = s >= burst_at + 1 && s <= burst_at + 3;
-    switch (2 * later + (burst_young ? burst_n : 0)) {
-      case 0: ACEZ_VMCNT(0); break;
-      case 2: ACEZ_VMCNT(2); break;
-      case 4: ACEZ_VMCNT(4); break;
-      case 6: ACEZ_VMCNT(6); break;
-      case 8: ACEZ_VMCNT(8); break;
-      default: ACEZ_VMCNT(10); break;
-    }
-  };
-
-  // ---- multiplier side
-  const int wm = w >> 2, wn = w & 3;
-  const int fr = l & 31, fh = l >> 5;
-  // this lane's four output rows (one per row fragment): patch row of tap (0, 0) and the validity of the nine taps
-  const int q00 = wm * 128 + fr;                // row fragment j: q00 + 32 j; tap (ky, kx): + ky * Wi + kx
-  unsigned vmask[4];
-  {
-    const int hw = a.Hi * Wi;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int p = m0 + q00 + j * 32;
-      const int rem = p % hw;
-      const int y = rem / Wi, x = rem - y * Wi;
-      unsigned mk = 0;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int iy = y + ky - 1, ix = x + kx - 1;
-          if (p < M && iy >= 0 && iy < a.Hi && ix >= 0 && ix < Wi) mk |= 1u << (ky * 3 + kx);
-        }
-      vmask[j] = mk;
-    }
-  }
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // fragment addresses of a stage (tap `tap` of chunk `cc`, weight slot s & 3)
-  const uint16_t* bp[4];
-  int bsw[4];
-  const uint16_t* sW = smem;
-  auto stage_addresses = [&](int s, int cc, int tap) {
-    sW = smem + (s & 3) * WSTAGE;
-    const uint16_t* sP = sPatch + (cc & 1) * PATCH;
-    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-    const int toff = ky * Wi + kx;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = q00 + j * 32 + toff;
-      const bool ok = (vmask[j] >> tap) & 1u;
-      bp[j] = ok ? sP + q * 32 : sZero;
-      bsw[j] = ok ? (q >> 2) & 3 : 0;
-    }
-  };
-  auto load_frags = [&](int kk, bf16x8 (&fa)[2], bf16x8 (&fb)[4]) {
-    if (no_mfma) return;
-    const int c = kk * 2 + fh;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz32(wn * 64 + i * 32 + fr, c)]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bp[j] + ((c ^ bsw[j]) << 3));
-  };
-  auto multiply = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[4]) {
-    if (no_mfma) return;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-  };
-
-  issue_patch(0);
-  for (int s = 0; s < 4 && s < S; ++s) issue_w(s);
-  wait_stage(0);
-  __builtin_amdgcn_s_barrier();                 // W(0) and patch 0 have landed
-  if (NC > 1) {
-    issue_patch(1);
-    burst_at = 0;
-  }
-  bf16x8 faA[2], fbA[4], faB[2], fbB[4];
-  int cc = 0, tap = 0;
-  stage_addresses(0, 0, 0);
-  load_frags(0, faA, fbA);
-  for (int s = 0; s + 1 < S; ++s) {
-    load_frags(1, faB, fbB);                    // second half of stage s: in flight while the first half multiplies
-    multiply(faA, fbA);
-    if (++tap == 9) { tap = 0; ++cc; }
-    wait_stage(s + 1);
-    __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0): this wave's reads of stage s are complete (faB / fbB hold them)
-    __builtin_amdgcn_s_barrier();               // W(s+1) (and its patch) landed everywhere; nobody reads stage s any more
-    if (s + 4 < S) issue_w(s + 4);              // into the slot of stage s
-    if (tap == 0 && cc + 1 < NC) {              // s + 1 is the first stage of chunk cc: the other patch buffer is free
-      issue_patch(cc + 1);
-      burst_at = s + 1;
-    }
-    if (!(a.dbg & 128)) stage_addresses(s + 1, cc, tap);   // ablation 128 (timing only): every stage reads the fragments of stage 0
-    load_frags(0, faA, fbA);                    // first half of stage s + 1: in flight while the second half of s multiplies
-    multiply(faB, fbB);
-  }
-  load_frags(1, faB, fbB);                      // the last stage
-  multiply(faA, fbA);
-  multiply(faB, fbB);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                 // everybody has left the K loop: all of LDS is free
-  if (HAS_ADD) {
-    // residual tile [256][256] -> LDS, 128 DMA instructions of 2 rows x 512 bytes (16 per wave)
-    for (int j = 0; j < 16; ++j) {
-      const int row = (w * 16 + j) * 2 + (l >> 5);
-      const uint16_t* g = a.add + (size_t)min(m0 + row, M - 1) * Co + n0 + (((l & 31) ^ (row & 31)) << 3);
-      __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(smem + (w * 16 + j) * 2 * 256), 16, 0, 0);
-    }
-    ACEZ_VMCNT(0);
-    __builtin_amdgcn_s_barrier();               // residual tile landed
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ml = wm * 128 + j * 32 + fr;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int nl = wn * 64 + i * 32 + 8 * q + 4 * fh;
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
-        float v[4] = {acc[i][j][4 * q + 0] + b.x, acc[i][j][4 * q + 1] + b.y, acc[i][j][4 * q + 2] + b.z, acc[i][j][4 * q + 3] + b.w};
-        if (RELU) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        }
-        uint16_t* po = &smem[st_off256(ml, nl)];
-        if (HAS_ADD) {
-          float ad[4];
-          unpack4(*reinterpret_cast<const uint2*>(po), ad);
-          if (a.round_before_add) unpack4(pack4(v[0], v[1], v[2], v[3]), v);
-          v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
-        }
-        *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
-      }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  for (int q = t; q < 256 * 32; q += 512) {
-    const int row = q >> 5, ch = q & 31, m = m0 + row;
-    if (m < M)
-      *reinterpret_cast<uint4*>(a.out + (size_t)m * Co + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&smem[row * 256 + ((ch ^ (row & 31)) << 3)]);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// conv3x3r: the lean stage loop (round 2). Ablation of conv3x3p / conv3x3q on MI355X (tools/enc_kstats.sh): with the LDS-DMA AND
+// conv3x3r: the lean stage loop (round 2). Ablation of conv3x3p on MI355X (tools/enc_kstats.sh): with the LDS-DMA AND
 // the MFMAs switched off the 3x3 kernels still take 50 % of their time; loads add 10 %, MFMAs 40 %. The "skeleton" is the stage
 // loop itself: per 32-wide K stage a wave executes ~180 scalar / vector / branch instructions (tap decode, nine-way validity
 // selects, swizzled fragment addresses, the vmcnt switch, slot arithmetic) around its 16 MFMAs -- ~1250 cycles of in-order issue
@@ -1189,7 +964,10 @@ __global__ __launch_bounds__(512) void conv3x3q_kernel(ConvGemmArgs a) {
 //     has its own copy of the nine stage bodies (no branches on "is there a next stage / a next patch");
 //   * DMA source pointers advance by scalar increments.
 // A stage is then 16 MFMAs + 12 ds_read_b128 + 2 global_load_lds + ~14 VALU + ~10 SALU + one barrier. Eight waves that multiply and
-// load (as conv3x3q), fragments double-buffered in registers. Same tile, same K order, same rounding as conv3x3p.
+// load their own operands (2 weight + amortised 0.5 patch DMA instructions per wave and stage), fragments double-buffered in
+// registers (while the 8 MFMAs of one 16-wide K step run, the 6 fragment reads of the next are in flight; that alone, on top of
+// conv3x3p's loop, measured +1 %: the loop's instruction count was the limiter, not LDS latency). Same tile, same K order, same
+// rounding as conv3x3p.
 // LDS (bytes): [0, 64 K) four weight slots; [64 K, 96 K) and [96 K, 128 K) patch slots of 512 rows x 64 B (rows 0..447 data, row 511
 // zero); the epilogue tile reuses all 128 KiB.
 // ---------------------------------------------------------------------------------------------------
@@ -1428,18 +1206,12 @@ void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s, int tile_m
     const int ntiles = g.Co / 256, mtiles = (g.M + 255) / 256;
     const dim3 grid(8 * ntiles * ((mtiles + 7) / 8)), blk(768);
     static const int wring = [] { const char* e = getenv("ACEZ_P3_WRING"); return (e && atoi(e) == 6) ? 6 : 4; }();
-    static const int pipelined = [] { const char* e = getenv("ACEZ_P3Q"); return e ? atoi(e) : 2; }();   // 2: conv3x3r, 1: conv3x3q, 0: conv3x3p
+    static const int lean = [] { const char* e = getenv("ACEZ_P3Q"); return e ? atoi(e) : 2; }();   // 2 (default): conv3x3r, 0: conv3x3p
     if (!relu) abort();
-    if (pipelined == 2) {
+    if (lean) {
       const dim3 blkq(512);
       if (g.add) hipLaunchKernelGGL((conv3x3r_kernel<true, true>), grid, blkq, 0, s, g);
       else hipLaunchKernelGGL((conv3x3r_kernel<true, false>), grid, blkq, 0, s, g);
-      return;
-    }
-    if (pipelined) {
-      const dim3 blkq(512);
-      if (g.add) hipLaunchKernelGGL((conv3x3q_kernel<true, true>), grid, blkq, 0, s, g);
-      else hipLaunchKernelGGL((conv3x3q_kernel<true, false>), grid, blkq, 0, s, g);
       return;
     }
     if (g.add) {
