@@ -1202,7 +1202,10 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
 void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s, int tile_mode) {
   const bool patch_ok = g.ksize == 3 && g.stride == 1 && g.pad == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.Wi <= (P3_ROWS - 258) / 2 &&
                         g.Ci % 32 == 0 && g.Co % 256 == 0 && g.K == g.Kp;
-  if (patch_ok && (tile_mode == 3 || (tile_mode == 0 && (int64_t)((g.M + 255) / 256) * (g.Co / 256) >= 4 * 256))) {
+  // the patch kernel pays from one tile per CU on (16 frames of 480x640 at Co = 256: 0.0925 -> 0.0775 ms per frame against the
+  // 80-row / 256 x 128 kernels; 32 frames: 0.0715 -> 0.067); round 1's conv3x3p needed four waves of tiles to win
+  static const int patch_min_tiles = [] { const char* e = getenv("ACEZ_PATCH_MIN_TILES"); return e ? atoi(e) : 256; }();
+  if (patch_ok && (tile_mode == 3 || (tile_mode == 0 && (int64_t)((g.M + 255) / 256) * (g.Co / 256) >= patch_min_tiles))) {
     const int ntiles = g.Co / 256, mtiles = (g.M + 255) / 256;
     const dim3 grid(8 * ntiles * ((mtiles + 7) / 8)), blk(768);
     static const int wring = [] { const char* e = getenv("ACEZ_P3_WRING"); return (e && atoi(e) == 6) ? 6 : 4; }();
