@@ -194,3 +194,48 @@ def test_seed_without_usable_depth_raises_instead_of_hanging():
     with pytest.raises(RuntimeError, match="16384"):
         check_frame_size(1088, 1936)
     check_frame_size(480, 2184)
+
+
+def test_reference_import_lines_train_and_register(tmp_path):
+    """the reference's own import lines (`from ace_trainer import TrainerACE`, train_ace.py:20,240-241; `import
+    dsacstar`, register_mapping.py:12,229) on top of the MI355X path: TrainerACE(options).train() writes the head, dsacstar.forward_rgb
+    registers a frame from the scene coordinates that head predicts."""
+    import dsacstar
+    from ace_trainer import TrainerACE
+    from PIL import Image
+    from acezero_amd import cli
+    from acezero_amd.network import Regressor
+    seq = synth.render_room_sequence(seed=11, n_frames=24, arc_deg=12.0, device="cuda")
+    img = ((seq["images"][:, 0] * 0.25 + 0.4).clamp(0, 1) * 255).round().to(torch.uint8).cpu().numpy()
+    files = []
+    for i in range(len(img)):
+        files.append(str(tmp_path / f"rgb_{i:04d}.png"))
+        Image.fromarray(np.stack([img[i]] * 3, -1)).save(files[-1])
+    esd = {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights_bandpass(seed=4099).items()}
+    torch.save(esd, tmp_path / "encoder.pt")
+    gt = seq["poses"].cpu().numpy().astype(np.float64)
+    with open(tmp_path / "poses_in.txt", "w") as f:
+        for i in range(len(img)):
+            cli.write_pose_line(f, files[i], np.linalg.inv(gt[i]), 2000, seq["focal"])
+    out = tmp_path / "map" / "scene.pt"
+    options = cli.train_parser().parse_args([str(tmp_path / "rgb_*.png"), str(out), "--use_ace_pose_file", str(tmp_path / "poses_in.txt"), "--encoder_path",
+                                             str(tmp_path / "encoder.pt"), "--iterations", "2000", "--learning_rate_schedule", "1cyclepoly",
+                                             "--learning_rate_max", "0.003", "--repro_loss_type", "tanh", "--learning_rate_cooldown_iterations", "400",
+                                             "--aug_rotation", "2", "--aug_scale", "1.06"])
+    trainer = TrainerACE(options)
+    assert trainer.train() == 0 and out.exists()
+    options.batch_size = 5000
+    with pytest.raises(ValueError):
+        TrainerACE(options)
+    # register_mapping.py:201-242 in the reference's shape: network forward, then dsacstar.forward_rgb on a 1x3xHxW tensor
+    head_sd = torch.load(out)
+    net = Regressor.create_from_split_state_dict(esd, head_sd, max_frames=4, max_h=480, max_w=640)
+    dsacstar.reset_call_counter(0)
+    errs = []
+    for i in (3, 11, 19):
+        sc = net(seq["images"][i:i + 1]).float().cpu()                   # register_mapping.py:213
+        out_pose = torch.zeros(4, 4)
+        inliers = dsacstar.forward_rgb(sc, out_pose, 64, 10.0, seq["focal"], 320.0, 240.0, 100.0, 100.0, 8, 2089, 1000000)
+        assert isinstance(inliers, int) and inliers > 1000
+        errs.append(np.linalg.norm(out_pose.numpy()[:3, 3] - gt[i][:3, 3]))
+    assert max(errs) < 0.02, errs
