@@ -43,7 +43,7 @@ class Encoder:
         N.check(N.lib().acez_encoder_create(C.byref(h), wp, bp, self.out_channels, int(max_frames), int(max_h), int(max_w),
                                             self.device.index))
         self._h = h
-        self.max_h, self.max_w = int(max_h), int(max_w)
+        self.max_h, self.max_w, self.max_frames = int(max_h), int(max_w), int(max_frames)
 
     @classmethod
     def from_state_dict(cls, state_dict, **kw):

@@ -21,6 +21,7 @@ There is no CPU fallback.
 """
 import logging
 import math
+import os
 import time
 from types import SimpleNamespace
 
@@ -262,7 +263,10 @@ class ReconstructionSession:
         bld = BufferBuilder(self.enc, capacity=total, samples_per_image=o.samples_per_image, seed=o.base_seed + 4095 + self._views_sampled)
         poses_c2w = torch.as_tensor(poses_c2w, dtype=torch.float64).reshape(m, 4, 4)
         pose_inv = torch.linalg.inv(poses_c2w).to(torch.float32)
-        chunk = 16
+        # views per warp / encoder / sampling batch (<= the encoder's max_frames). 32 instead of 16: the 3x3 patch kernel gets a full
+        # wave of tiles per layer (1000-frame session: 8 M rows in 0.95 s instead of 1.10 s)
+        chunk = int(os.environ.get("ACEZ_AUG_CHUNK", "32"))
+        chunk = max(1, min(chunk, self.enc.max_frames))
         crds = []
         while not bld.full:
             rows_before = bld.n
