@@ -91,7 +91,7 @@ __device__ __forceinline__ uint32_t pos4_relu(uint2 y) {
 // order, and a C++ release / acquire here would drain vmcnt (the loaders' DMA pipeline, the multipliers' tile stores).
 __device__ __forceinline__ void chain_loss(const LossArgs& a, int block, int wv, int t, uint16_t* Xt, float* scratch, int64_t pre_p, int pre_view,
                                            int pre_img, float pre_tu, float pre_tv) {
-  loss_body<true>(a, block, wv, t, Xt, scratch, LossPre{pre_p, pre_view, pre_img, pre_tu, pre_tv}, [] {
+  loss_body<true, false>(a, block, wv, t, Xt, scratch, LossPre{pre_p, pre_view, pre_img, pre_tu, pre_tv}, [] {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's ds rows are written
     __builtin_amdgcn_s_barrier();                        // LB1
   });

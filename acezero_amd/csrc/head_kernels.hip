@@ -769,29 +769,40 @@ constexpr int LOSS_SCRATCH_FLOATS = 3 * 4 * LOSS_ROWS * 4;
 // output is read from a.act and dZ goes to a.dZ (loss_kernel). LDSACT = true: both live in the swizzled LDS tile `Xt`
 // (act_off) of the chain kernel and dZ overwrites the activations in place (the caller copies the tile to a.dZ). The four waves
 // meet once, through `sync` (loss_kernel: __syncthreads; the chain kernel: its flag barrier).
-template <bool LDSACT, class Sync>
+// PRE_INSIDE (loss_kernel): the per-row index chain of phase B (idx -> view -> image) is started here, BEHIND the loads of phase A:
+// vmcnt completes in order, so a dependent chain issued first holds every later load behind its three round trips.
+template <bool LDSACT, bool PRE_INSIDE, class Sync>
 __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, const int wv, const int t, uint16_t* Xt, float* scratch,
-                                          const LossPre pre, Sync sync) {
+                                          LossPre pre, Sync sync) {
   float (*s_s)[4] = reinterpret_cast<float (*)[4]>(scratch + wv * LOSS_ROWS * 4);
   float (*s_ds)[4] = reinterpret_cast<float (*)[4]>(scratch + (4 + wv) * LOSS_ROWS * 4);
   float (*s_red)[4] = reinterpret_cast<float (*)[4]>(scratch + (8 + wv) * LOSS_ROWS * 4);
   const int l = t;
   const int m0 = (block * 4 + wv) * LOSS_ROWS;
   const int n = a.n, no = a.no;
+
+  // ---- phase A. All of its loads are issued before anything is computed (as written row by row, every row's load was followed by
+  // a full wait: twelve serial round trips).
+  // (chain kernel, LDSACT: the rows are LDS reads issued where they are used -- batching them costs 60 registers the 768-thread
+  // kernel does not have)
+  uint4 w3raw[4], xraw[LDSACT ? 1 : LOSS_ROWS];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w3raw[j] = *reinterpret_cast<const uint4*>(a.W3 + (size_t)(j < no ? j : 0) * 512 + l * 8);
+  if (!LDSACT) {
+#pragma unroll
+    for (int rr = 0; rr < LOSS_ROWS; ++rr) xraw[LDSACT ? 0 : rr] = *reinterpret_cast<const uint4*>(a.act + (size_t)min(m0 + rr, n - 1) * 512 + l * 8);
+  }
+  if (PRE_INSIDE) pre = loss_prefetch(a, m0, t);
   const int64_t pre_p = pre.p;
   const int pre_view = pre.view, pre_img = pre.img;
   const float pre_tu = pre.tu, pre_tv = pre.tv;
-
-  // ---- phase A
   {
     float w3[4][8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (j < no) {
-        const uint4 v = *reinterpret_cast<const uint4*>(a.W3 + (size_t)j * 512 + l * 8);
-        unpack4(make_uint2(v.x, v.y), &w3[j][0]);
-        unpack4(make_uint2(v.z, v.w), &w3[j][4]);
-      } else {
+      unpack4(make_uint2(w3raw[j].x, w3raw[j].y), &w3[j][0]);
+      unpack4(make_uint2(w3raw[j].z, w3raw[j].w), &w3[j][4]);
+      if (j >= no) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) w3[j][e] = 0.f;
       }
@@ -803,12 +814,10 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
     for (int rr = 0; rr < LOSS_ROWS; ++rr) {
       const int r = rr, m = m0 + r;
       float x[8];
-      if (m < n) {
-        const uint4 v = LDSACT ? *reinterpret_cast<const uint4*>(&Xt[act_off(wv * LOSS_ROWS + r, l * 8)])
-                               : *reinterpret_cast<const uint4*>(a.act + (size_t)m * 512 + l * 8);
-        unpack4(make_uint2(v.x, v.y), &x[0]);
-        unpack4(make_uint2(v.z, v.w), &x[4]);
-      } else {
+      const uint4 xr = LDSACT ? *reinterpret_cast<const uint4*>(&Xt[act_off(wv * LOSS_ROWS + r, l * 8)]) : xraw[LDSACT ? 0 : rr];
+      unpack4(make_uint2(xr.x, xr.y), &x[0]);
+      unpack4(make_uint2(xr.z, xr.w), &x[4]);
+      if (!(m < n)) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = 0.f;
       }
@@ -1019,18 +1028,28 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
     const int ch = wv * 128 + 2 * t;
     const int mb = block * 4 * LOSS_ROWS;
     float w3[4][2], gw[4][2], bsum[2] = {0.f, 0.f};
+    // every load of the phase first (row by row, a load was followed by a full wait: 32 serial round trips)
+    uint32_t w3c[4], xv[LDSACT ? 1 : 4 * LOSS_ROWS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w3c[j] = *reinterpret_cast<const uint32_t*>(a.W3 + (size_t)(j < no ? j : 0) * 512 + ch);
+    if (!LDSACT) {
+#pragma unroll
+      for (int r = 0; r < 4 * LOSS_ROWS; ++r)   // rows past the end carry ds == 0 and are not stored
+        xv[LDSACT ? 0 : r] = *reinterpret_cast<const uint32_t*>(a.act + (size_t)min(mb + r, n - 1) * 512 + ch);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint32_t v = (j < no) ? *reinterpret_cast<const uint32_t*>(a.W3 + (size_t)j * 512 + ch) : 0u;
+      const uint32_t v = (j < no) ? w3c[j] : 0u;
       w3[j][0] = __uint_as_float(v << 16);
       w3[j][1] = __uint_as_float(v & 0xffff0000u);
       gw[j][0] = gw[j][1] = 0.f;
     }
     const float (*ds_all)[4] = reinterpret_cast<const float (*)[4]>(scratch + 4 * LOSS_ROWS * 4);
-#pragma unroll 4
+    constexpr int C_UNROLL = LDSACT ? 4 : 4 * LOSS_ROWS;
+#pragma unroll C_UNROLL
     for (int r = 0; r < 4 * LOSS_ROWS; ++r) {
-      const int m = min(mb + r, n - 1);   // rows past the end carry ds == 0 and are not stored
-      const uint32_t v = LDSACT ? *reinterpret_cast<const uint32_t*>(&Xt[act_off(r, ch)]) : *reinterpret_cast<const uint32_t*>(a.act + (size_t)m * 512 + ch);
+      const int m = min(mb + r, n - 1);
+      const uint32_t v = LDSACT ? *reinterpret_cast<const uint32_t*>(&Xt[act_off(r, ch)]) : xv[LDSACT ? 0 : r];
       const float x[2] = {__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
       float d[2] = {0.f, 0.f};
 #pragma unroll
@@ -1081,8 +1100,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   if (a.st && !a.st->active) return;
   __shared__ float scratch[LOSS_SCRATCH_FLOATS];
   const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
-  const LossPre pre = loss_prefetch(a, (blockIdx.x * 4 + wv) * LOSS_ROWS, t);
-  loss_body<false>(a, blockIdx.x, wv, t, nullptr, scratch, pre, [] { __syncthreads(); });
+  loss_body<false, true>(a, blockIdx.x, wv, t, nullptr, scratch, LossPre{0, 0, 0, 0.f, 0.f}, [] { __syncthreads(); });
 }
 
 // ---------------------------------------------------------------------------------------------------
