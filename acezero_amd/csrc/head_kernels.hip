@@ -796,6 +796,18 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
   const int64_t pre_p = pre.p;
   const int pre_view = pre.view, pre_img = pre.img;
   const float pre_tu = pre.tu, pre_tv = pre.tv;
+  // phase B's per-view / per-image matrices (augmentation, pose, intrinsics: 37 floats of a row's lane): with PRE_INSIDE they are
+  // fetched here, as soon as view and image are known, and arrive while phase A computes
+  float Am[12], Tm[16], Km[9];
+  const bool early_mats = PRE_INSIDE && a.idx && t < LOSS_ROWS && m0 + t < n;
+  if (early_mats) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Am[i] = a.view_aug_inv[(size_t)pre_view * 12 + i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Tm[i] = a.image_pose_inv[(size_t)pre_img * 16 + i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Km[i] = a.view_K[(size_t)pre_view * 9 + i];
+  }
   {
     float w3[4][8];
 #pragma unroll
@@ -880,11 +892,19 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
       if (a.idx) {  // training: geometry + loss (skipped for pure inference)
         const float tu = pre_tu, tv = pre_tv;
         const int view = pre_view;
-        const float* A = a.view_aug_inv + (size_t)view * 12;
-        const float* T = a.image_pose_inv + (size_t)pre_img * 16;
+        if (!PRE_INSIDE) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) Am[i] = a.view_aug_inv[(size_t)view * 12 + i];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Tm[i] = a.image_pose_inv[(size_t)pre_img * 16 + i];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Km[i] = a.view_K[(size_t)view * 9 + i];
+        }
+        const float* A = Am;
+        const float* T = Tm;
         float K[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) K[i] = a.view_K[(size_t)view * 9 + i];
+        for (int i = 0; i < 9; ++i) K[i] = Km[i];
         float kscale = 0.f;
         if (a.refine_calibration) {
           // refine_calibration.py:34-53: K[:2,:2] = (1+g) * f0 * (K00/f0) * I2
