@@ -531,6 +531,13 @@ __global__ __launch_bounds__(1024) void convgemm256_kernel(ConvGemmArgs a) {
       }
     }
     __builtin_amdgcn_s_barrier();
+    // the eight bias vectors of this lane, fetched once before the tile is touched (inside the loops every one of the
+    // 16-32 loads was followed by a full wait: as many serial L2 round trips per tile)
+    float4 bv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * fh);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ml = wm * 64 + j * 32 + fr;
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(1024) void convgemm256_kernel(ConvGemmArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int nl = wn * 64 + i * 32 + 8 * q + 4 * fh;
-          const float4 b = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+          const float4 b = bv[i][q];
           float v[4] = {acc[i][j][4 * q + 0] + b.x, acc[i][j][4 * q + 1] + b.y, acc[i][j][4 * q + 2] + b.z, acc[i][j][4 * q + 3] + b.w};
           if (RELU) {
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
@@ -697,6 +704,13 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
     }
     __builtin_amdgcn_s_barrier();     // ring free
     if (HAS_ADD) __builtin_amdgcn_s_barrier();
+    // the eight bias vectors of this lane, fetched once before the tile is touched (inside the loops every one of the
+    // 16-32 loads was followed by a full wait: as many serial L2 round trips per tile)
+    float4 bv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * fh);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ml = wm * 128 + j * 32 + fr;
@@ -705,7 +719,7 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int nl = wn * 64 + i * 32 + 8 * q + 4 * fh;
-          const float4 b = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+          const float4 b = bv[i][q];
           float v[4] = {acc[i][j][4 * q + 0] + b.x, acc[i][j][4 * q + 1] + b.y, acc[i][j][4 * q + 2] + b.z, acc[i][j][4 * q + 3] + b.w};
           if (RELU) {
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
@@ -918,6 +932,13 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
     }
     __builtin_amdgcn_s_barrier();     // LDS free
     if (HAS_ADD) __builtin_amdgcn_s_barrier();
+    // the eight bias vectors of this lane, fetched once before the tile is touched (inside the loops every one of the
+    // 16-32 loads was followed by a full wait: as many serial L2 round trips per tile)
+    float4 bv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * fh);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ml = wm * 128 + j * 32 + fr;
@@ -926,7 +947,7 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int nl = wn * 64 + i * 32 + 8 * q + 4 * fh;
-          const float4 b = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+          const float4 b = bv[i][q];
           float v[4] = {acc[i][j][4 * q + 0] + b.x, acc[i][j][4 * q + 1] + b.y, acc[i][j][4 * q + 2] + b.z, acc[i][j][4 * q + 3] + b.w};
           if (RELU) {
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
@@ -1166,6 +1187,13 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
     ACEZ_VMCNT(0);
     __builtin_amdgcn_s_barrier();             // residual tile landed
   }
+  // the eight bias vectors of this lane, fetched once before the tile is touched (inside the loops every one of the
+  // 16-32 loads was followed by a full wait: as many serial L2 round trips per tile)
+  float4 bv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * fh);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int ml = wm * 128 + j * 32 + fr;
@@ -1174,7 +1202,7 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int nl = wn * 64 + i * 32 + 8 * q + 4 * fh;
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + n0 + nl);
+        const float4 b = bv[i][q];
         float v[4] = {acc[i][j][4 * q + 0] + b.x, acc[i][j][4 * q + 1] + b.y, acc[i][j][4 * q + 2] + b.z, acc[i][j][4 * q + 3] + b.w};
         if (RELU) {
           v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);

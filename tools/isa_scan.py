@@ -56,8 +56,36 @@ def scan(path):
             cnt("scratch_"), cnt("global_load_dword"), cnt("s_nop")))
 
 
+def scan_serial_loads(path):
+    """Kernels whose global loads are each followed by a FULL wait: `global_load ...; s_waitcnt vmcnt(0)` pairs are serial memory
+    round trips (~1 us each under load). Found loss_kernel's 12 + 32 of them in round 2 (19.7 -> 15.7 us once its loads were issued
+    up front). A kernel is listed when it has >= 6 plain global loads and at least half as many full waits as loads."""
+    unit = os.path.basename(path).split("-hip-")[0]
+    name, loads, w0, wn = None, 0, 0, 0
+    for ln in open(path):
+        m = re.match(r"^(_Z\S+):", ln)
+        if m:
+            name, loads, w0, wn = m.group(1), 0, 0, 0
+        if not name:
+            continue
+        if "global_load" in ln and "lds" not in ln:
+            loads += 1
+        if re.search(r"s_waitcnt.*vmcnt\(0\)", ln):
+            w0 += 1
+        elif re.search(r"s_waitcnt.*vmcnt\(\d+\)", ln):
+            wn += 1
+        if "s_endpgm" in ln:
+            if loads >= 6 and 2 * w0 >= loads:
+                print("%-12s %-60s global loads %3d  vmcnt(0) waits %3d  counted waits %3d   <- serial round trips?" % (
+                    unit, re.sub(r"^_ZN\d*[a-z_]*\d+", "", name)[:60], loads, w0, wn))
+            name = None
+
+
 if __name__ == "__main__":
     compile_units()
     for f in sorted(os.listdir(OUT)):
         if f.endswith("gfx950.s"):
             scan(os.path.join(OUT, f))
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith("gfx950.s"):
+            scan_serial_loads(os.path.join(OUT, f))
