@@ -413,14 +413,37 @@ __global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
     __builtin_amdgcn_s_barrier();       // output tiles complete
   }
   // ------------------------------------------------------------------ all eight waves: copy the tiles out
-#pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    const int q = t + 512 * it, row = q >> 4, ch = q & 15, m = m0 + row;
-    if (q < 1280 && m < M) {
-      const size_t o = (size_t)m * N + n0 + ch * 8;
-      const int so = row * 128 + ((ch ^ (row & 15)) << 3);
-      *reinterpret_cast<uint4*>(a.out_main + o) = *reinterpret_cast<const uint4*>(&stB[so]);
-      if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o) = *reinterpret_cast<const uint4*>(&stA[so]);
+  // All LDS reads first, into distinct registers, then the stores: as a read-store loop the compiler reused one register quadruple
+  // and every read waited -- vmcnt(0) -- for the previous store to COMPLETE (its data register must not be overwritten while the
+  // store is in flight): 2-5 serial store round trips at the end of each of the step's 15 launches.
+  {
+    const int q0 = t, q1 = t + 512, q2 = t + 1024;
+    const int so0 = (q0 >> 4) * 128 + (((q0 & 15) ^ ((q0 >> 4) & 15)) << 3);
+    const int so1 = (q1 >> 4) * 128 + (((q1 & 15) ^ ((q1 >> 4) & 15)) << 3);
+    const int so2 = (q2 < 1280) ? (q2 >> 4) * 128 + (((q2 & 15) ^ ((q2 >> 4) & 15)) << 3) : 0;
+    const uint4 m0v = *reinterpret_cast<const uint4*>(&stB[so0]);
+    const uint4 m1v = *reinterpret_cast<const uint4*>(&stB[so1]);
+    const uint4 m2v = *reinterpret_cast<const uint4*>(&stB[so2]);
+    uint4 a0v = m0v, a1v = m1v, a2v = m2v;
+    if (AUX != AUX_NONE) {
+      a0v = *reinterpret_cast<const uint4*>(&stA[so0]);
+      a1v = *reinterpret_cast<const uint4*>(&stA[so1]);
+      a2v = *reinterpret_cast<const uint4*>(&stA[so2]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (also keeps the reads above this point)
+    const int r0 = m0 + (q0 >> 4), r1 = m0 + (q1 >> 4), r2 = m0 + (q2 >> 4);
+    const size_t o0 = (size_t)r0 * N + n0 + (q0 & 15) * 8, o1 = (size_t)r1 * N + n0 + (q1 & 15) * 8, o2 = (size_t)r2 * N + n0 + (q2 & 15) * 8;
+    if (r0 < M) {
+      *reinterpret_cast<uint4*>(a.out_main + o0) = m0v;
+      if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o0) = a0v;
+    }
+    if (r1 < M) {
+      *reinterpret_cast<uint4*>(a.out_main + o1) = m1v;
+      if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o1) = a1v;
+    }
+    if (q2 < 1280 && r2 < M) {
+      *reinterpret_cast<uint4*>(a.out_main + o2) = m2v;
+      if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o2) = a2v;
     }
   }
   if (HAS_MASK && a.bias_partials) {
