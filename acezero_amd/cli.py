@@ -442,10 +442,16 @@ def register_main(argv=None):
     torch.manual_seed(opt.base_seed)
     data = np.load(opt.feature_file, allow_pickle=False)
     files = [str(x) for x in data["image_files"]]
-    n = len(files) if opt.max_estimates <= 0 else min(len(files), opt.max_estimates)
+    # --max_estimates: a seeded random subset, as the reference's DataLoader(shuffle=True) under torch.manual_seed(base_seed) gives
+    # (register_mapping.py:122-147,256), in file order -- not the first n frames
+    if opt.max_estimates <= 0 or opt.max_estimates >= len(files):
+        ids = np.arange(len(files))
+    else:
+        ids = np.sort(torch.randperm(len(files), generator=torch.Generator().manual_seed(int(opt.base_seed)))[:opt.max_estimates].numpy())
+    n = len(ids)
     t0 = time.time()
     if "scene_coordinates" in data.files:
-        sc = torch.from_numpy(data["scene_coordinates"][:n].astype(np.float32)).cuda()
+        sc = torch.from_numpy(data["scene_coordinates"][ids].astype(np.float32)).cuda()
     else:
         sd = torch.load(opt.network, map_location="cpu")
         nb = sum(1 for k in sd if k.endswith("c0.weight"))
@@ -453,22 +459,22 @@ def register_main(argv=None):
                            iterations=1)
         head.load_state_dict(sd)                                    # fp16 checkpoint -> fp32 masters -> bf16 compute copies
         h, w = int(data["h"]), int(data["w"])
-        feats = torch.from_numpy(data["features"][:n].astype(np.float32)).cuda().reshape(-1, 512)
+        feats = torch.from_numpy(data["features"][ids].astype(np.float32)).cuda().reshape(-1, 512)
         sc = head.get_scene_coordinates(feats).reshape(n, h, w, 3).permute(0, 3, 1, 2).contiguous()
     f_ext = opt.use_external_focal_length
     focal = np.broadcast_to(np.asarray(data["focal"], np.float32), (len(files),)) if f_ext < 0 else np.full(len(files), f_ext, np.float32)
     ppx = np.broadcast_to(np.asarray(data["ppx"], np.float32), (len(files),))
     ppy = np.broadcast_to(np.asarray(data["ppy"], np.float32), (len(files),))
     prm = dict(hyps=opt.hypotheses, thr=opt.threshold, alpha=opt.inlieralpha, max_reproj=opt.maxpixelerror, sub=8, max_tries=opt.hypotheses_max_tries)
-    poses, inl, _ = dsacstar.register_batch(sc, [(focal[i], ppx[i], ppy[i]) for i in range(n)], prm, opt.base_seed, list(range(n)),
+    poses, inl, _ = dsacstar.register_batch(sc, [(focal[i], ppx[i], ppy[i]) for i in ids], prm, opt.base_seed, [int(i) for i in ids],
                                             want_masks=False)
     poses, inl = poses.cpu().numpy(), inl.cpu().numpy()
     out_dir = Path(opt.network).parent
     pose_log_file = out_dir / f"poses_{opt.session}.txt"
     with open(pose_log_file, "w") as f:
-        for i in range(n):
-            _logger.info(f"Frame: {files[i]}, Confidence: {int(inl[i])}")
-            write_pose_line(f, files[i], np.linalg.inv(poses[i].astype(np.float64)), int(inl[i]), float(focal[i]))   # :261-276
+        for k, i in enumerate(ids):
+            _logger.info(f"Frame: {files[i]}, Confidence: {int(inl[k])}")
+            write_pose_line(f, files[i], np.linalg.inv(poses[k].astype(np.float64)), int(inl[k]), float(focal[i]))   # :261-276
     dt = time.time() - t0
     _logger.info(f"Registered {n} images in {dt:.2f}s ({n / max(dt, 1e-9):.0f} images/s) -> {pose_log_file}")
     return 0

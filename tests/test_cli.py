@@ -100,6 +100,15 @@ def test_train_then_register_end_to_end(tmp_path):
         T[:3, 3] = [float(x) for x in t[5:8]]
         np.testing.assert_allclose(np.linalg.inv(T)[:3, 3], fr["poses"][i][:3, 3], atol=0.03)   # file stores world->cam
         assert float(t[9]) > 1000
+    # --max_estimates: a seeded random subset in file order (register_mapping.py:122-147,256), the same frames get the same poses
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "register_mapping.py"), "synthetic/*.png", str(out), "--feature_file", str(ff),
+                        "--session", "sub", "--hypotheses", "32", "--hypotheses_max_tries", "16", "--max_estimates", "3"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sub = [l.split() for l in open(tmp_path / "poses_sub.txt").read().strip().split("\n")]
+    want = sorted(torch.randperm(5, generator=torch.Generator().manual_seed(1305))[:3].tolist())   # register_mapping.py default --base_seed
+    assert [t[0] for t in sub] == [f"f{i}.png" for i in want]
+    full = {t[0]: t for t in lines}
+    assert all(t == full[t[0]] for t in sub)
 
 
 def test_pose_files_are_the_reference_format_both_ways(golden_dir, tmp_path):
