@@ -192,3 +192,48 @@ def test_reference_style_mt19937_stream():
                 np.testing.assert_allclose(a[0]["hyp_poses"][0], pose6, rtol=0, atol=0)
     finally:
         dsac_oracle.set_options()
+
+
+def test_scores_selection_and_mask_recomputed_in_numpy():
+    """getHypScores / softMax + argmax / the final inlier map (dsacstar_util.h:316-343, 356-446, 684-752, 522-597) recomputed with
+    numpy from the oracle's OWN hypothesis poses and refined pose: soft inlier score = alpha / (W H) * sum_px (1 - sigmoid(beta (e -
+    tau))), beta = 5 / tau, e = min(|reprojection error|, maxReproj); selected = argmax; mask = (e(refined) < tau), count = its sum.
+    Different code (vectorised float64 numpy, scipy's Rodrigues), same numbers up to the float32 roundings the reference applies."""
+    thr, alpha, maxr, sub = 10.0, 100.0, 100.0, 8
+    fr = synth.make_registration_frames(seed=123, n_frames=3)
+    H, W = fr["scene_coords"].shape[2:]
+    xs = (np.arange(W) * sub + sub // 2).astype(np.float64)
+    ys = (np.arange(H) * sub + sub // 2).astype(np.float64)
+    gx, gy = np.meshgrid(xs, ys)                                         # [H, W]
+    for i in range(3):
+        sc = fr["scene_coords"][i]
+        r = dsac_oracle.forward_rgb(sc, 32, thr, fr["focal"], fr["ppx"], fr["ppy"], alpha, maxr, sub, 1305, i, 16)
+        X = sc.reshape(3, -1).T.astype(np.float64)
+
+        def errors(pose6):
+            Rm = Rotation.from_rotvec(pose6[:3]).as_matrix()
+            Xc = X @ Rm.T + pose6[3:]
+            z = np.where(Xc[:, 2] != 0, Xc[:, 2], 1.0)
+            u = fr["focal"] * Xc[:, 0] / z + fr["ppx"]
+            v = fr["focal"] * Xc[:, 1] / z + fr["ppy"]
+            e = np.hypot(gx.ravel() - u, gy.ravel() - v)
+            return np.minimum(e, maxr).reshape(H, W)
+
+        beta = 5.0 / thr
+        scores = np.array([alpha / (W * H) * np.sum(1.0 - 1.0 / (1.0 + np.exp(-beta * (errors(p) - thr)))) for p in r["hyp_poses"]])
+        np.testing.assert_allclose(scores, r["scores"], rtol=2e-5, atol=1e-6)   # the reference rounds every error to float32
+        assert int(np.argmax(scores)) == r["best"]
+        # refineHyp (:522-597) returns the inlier map that PRODUCED the final pose (the set of the last accepted round), and stops when a
+        # round's count does not exceed the best so far: the final pose's own inliers are therefore no more than the returned count,
+        # and the two sets differ by the few pixels that crossed the threshold in the last round
+        e = errors(r["refined"])
+        near = np.abs(e - thr) < 1e-3                                         # float32 rounding of the error decides these
+        mask = r["mask"].astype(bool)
+        assert int(mask.sum()) == r["inliers"]
+        assert int((e < thr).sum()) <= r["inliers"] + int(near.sum())
+        assert int(((e < thr) ^ mask).sum()) <= max(5, r["inliers"] // 25)                # a few percent of the set
+        # the returned pose is the inverse of the refined (rvec, tvec): camera -> world
+        T = np.eye(4)
+        T[:3, :3] = Rotation.from_rotvec(r["refined"][:3]).as_matrix()
+        T[:3, 3] = r["refined"][3:]
+        np.testing.assert_allclose(r["pose"], np.linalg.inv(T), atol=2e-6)
