@@ -74,6 +74,12 @@ struct acez_trainer {
   unsigned long long* chain_trace = nullptr;   // [2][256] s_memtime stamps (ACEZ_CHAIN_TRACE=1; acez_trainer_debug_read kind 5)
   int* chain_err = nullptr;       // sticky error word of the chain kernel (a bounded spin expired)
   std::vector<uint16_t*> dRc;     // residual-gradient buffers of the chain kernel, one per fan-in (never re-read after a rewrite)
+  // rowseq_kernel: the forward layers / the input-gradient layers as ONE launch each, kernel boundaries replaced by a same-XCD
+  // hand-off (head_kernels.hip). Default when every workgroup can be resident (grid <= CUs); ACEZ_SEQ=0 = per-layer launches.
+  bool seq = true;
+  int n_cus = 0;
+  uint32_t* seq_flags = nullptr;  // [64 row tiles][32] hand-off counters, monotonically increasing
+  uint32_t seq_base[64] = {};     // seams completed so far, per row tile
 };
 
 enum { KC_SCHED = 0, KC_GATHER, KC_GEMM_FWD, KC_LOSS, KC_GEMM_DGRAD, KC_WGRAD, KC_REDUCE, KC_ADAMW, KC_COUNT };
@@ -162,6 +168,12 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   if (const char* e = getenv("ACEZ_GEMM_TILE")) tr->gemm_tile = atoi(e) == 128 ? 128 : 80;
   if (const char* e = getenv("ACEZ_CHAIN")) tr->chain = atoi(e) != 0;
   if (tr->fused_fwd) tr->chain = false;
+  if (const char* e = getenv("ACEZ_SEQ")) tr->seq = atoi(e) != 0;
+  {
+    hipDeviceProp_t prop;
+    ACEZ_HIP_CHECK(hipGetDeviceProperties(&prop, tr->device));
+    tr->n_cus = prop.multiProcessorCount;
+  }
   // wgrad_kernel: 16 tiles per layer; wgrad256_kernel (ACEZ_WGRAD_TILE=256, measured alternative: -2.8 us of wgrad, +2.4 us of
   // adamw for the two extra slabs): 8; as many row slabs as fill the 256 CUs
   if (const char* e = getenv("ACEZ_WGRAD_TILE")) tr->wgrad_tile = atoi(e) == 256 ? 256 : 128;
@@ -190,6 +202,8 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->xyz, (size_t)tr->max_batch * 3 * sizeof(float));
   A((void**)&tr->maskbits, (size_t)tr->L * max_blocks * 512 * sizeof(uint32_t));
   A((void**)&tr->chain_err, sizeof(int));
+  A((void**)&tr->seq_flags, 64 * 32 * sizeof(uint32_t));
+  if (rc == ACEZ_OK) (void)hipMemset(tr->seq_flags, 0, 64 * 32 * sizeof(uint32_t));
   if (getenv("ACEZ_CHAIN_TRACE")) {
     A((void**)&tr->chain_trace, 512 * sizeof(unsigned long long));
     if (rc == ACEZ_OK) (void)hipMemset(tr->chain_trace, 0, 512 * sizeof(unsigned long long));
@@ -311,10 +325,40 @@ static uint16_t* launch_forward_fused(acez_trainer* tr, const uint16_t* feat, co
 }
 
 // forward chain on n rows whose input features are in `in0`; returns the fc2 output buffer
+// rowseq_kernel is usable when its workgroups wait for each other safely: all of them resident at once
+static bool seq_usable(const acez_trainer* tr, int n) {
+  const int mtiles = (n + 79) / 80;
+  return tr->seq && tr->gemm_tile == 80 && mtiles <= 64 && 32 * ((mtiles + 7) / 8) <= tr->n_cus;
+}
+
+template <bool BWD>
+static void launch_rowseq(acez_trainer* tr, const std::vector<SeqLayer>& layers, int n, const TrainState* st, hipStream_t s) {
+  const int mtiles = (n + 79) / 80;
+  for (size_t i0 = 0; i0 < layers.size(); i0 += SEQ_MAX_LAYERS) {
+    RowSeqArgs a{};
+    const int cnt = (int)std::min<size_t>(SEQ_MAX_LAYERS, layers.size() - i0);
+    for (int i = 0; i < cnt; ++i) a.layer[i] = layers[i0 + i];
+    a.n_layers = cnt; a.M = n; a.st = st; a.flags = tr->seq_flags;
+    for (int mt = 0; mt < 64; ++mt) a.base[mt] = tr->seq_base[mt];
+    hipLaunchKernelGGL(rowseq_kernel<BWD>, dim3(32 * ((mtiles + 7) / 8)), dim3(512), 0, s, a);
+    for (int mt = 0; mt < mtiles; ++mt) tr->seq_base[mt] += (uint32_t)(cnt - 1);
+    tr->prof_launches += cnt;   // accounted as layer GEMMs so that the per-layer average stays comparable
+  }
+}
+
 static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, const TrainState* st, hipStream_t s) {
   ProfScope chain_scope(tr, s, KC_GEMM_FWD);  // one event pair around the whole chain of dependent GEMM launches
   const float* P = tr->pb.d_params;
+  const bool seq = seq_usable(tr, n);
+  std::vector<SeqLayer> sq;
   auto gemm = [&](int l, const uint16_t* in, uint16_t* out_main, const uint16_t* res, uint16_t* out_aux) {
+    if (seq) {
+      SeqLayer y{};
+      y.In = in; y.W = tr->Wb + (size_t)l * 262144; y.bias = P + (int64_t)l * 262656 + 262144; y.res = res; y.out_main = out_main;
+      y.out_aux = out_aux; y.aux_mode = res ? AUX_RESIDUAL : AUX_NONE;
+      sq.push_back(y);
+      return;
+    }
     RowGemmArgs g{};
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144;
     g.add = nullptr; g.mask = nullptr; g.res = res; g.out_main = out_main; g.out_aux = out_aux;
@@ -332,6 +376,7 @@ static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, co
   const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
   gemm(f1, r, tr->out[f1], nullptr, nullptr);
   gemm(f2, tr->out[f1], tr->out[f2], nullptr, nullptr);
+  if (seq) launch_rowseq<false>(tr, sq, n, st, s);
   return tr->out[f2];
 }
 
@@ -567,7 +612,16 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   if (ps != s) ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_bwd, ps));
 
   // input-gradient chain
+  const bool seq = seq_usable(tr, n);
+  std::vector<SeqLayer> sq;
   auto dgrad = [&](int l, int l_out, const uint16_t* add, const uint16_t* mask, uint16_t* out_main, uint16_t* out_aux) {
+    if (seq) {
+      SeqLayer y{};
+      y.In = tr->dZ[l]; y.W = tr->WbT + (size_t)l * 262144; y.add = add; y.mask = mask; y.out_main = out_main; y.out_aux = out_aux;
+      y.bias_partials = tr->bias_partials + (size_t)l_out * tr->bias_layer_stride; y.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE;
+      sq.push_back(y);
+      return;
+    }
     RowGemmArgs g{};
     g.bias_partials = tr->bias_partials + (size_t)l_out * tr->bias_layer_stride;
     g.In = tr->dZ[l]; g.W = tr->WbT + (size_t)l * 262144; g.bias = nullptr; g.add = add; g.mask = mask; g.res = nullptr;
@@ -588,6 +642,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
       cur ^= 1;
     }
   }
+  if (seq) launch_rowseq<true>(tr, sq, n, st, s);
 
   delete dchain;
   }

@@ -251,21 +251,28 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
 // free both for the accumulator layout and for the row-wise copy), so every global access is a full 256-byte row.
 // ---------------------------------------------------------------------------------------------------
 
-template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX>
-__global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
-  const int active = a.st ? a.st->active : 1;
-  constexpr int STAGE = (128 + 96) * 64;  // elements per ring slot
-  __shared__ __attribute__((aligned(16))) uint16_t smem[4 * STAGE + 2 * 80 * 128];
+// One layer of one workgroup. SEQ = false: the whole of rowgemm80_kernel. SEQ = true: one link of rowseq_kernel (below), where
+// the layers of a dependent chain run in ONE launch and the kernel boundary is replaced by a same-XCD hand-off (SeqLink).
+struct SeqLink {
+  uint32_t* flag;        // per-row-tile counter in this XCD's L2 (one 128-byte line each), monotonically increasing
+  uint32_t target;       // value of *flag when the four column tiles of the layer before have stored their outputs
+  bool first, wait;      // first layer of the launch (requests its own W stages) / In is produced inside this launch
+  bool signal;           // another layer follows: bump *flag after the stores
+  const uint16_t* next_W;  // weights of the layer after (null: none): its first four W stages are requested before the epilogue
+};
+constexpr int RG80_STAGE = (128 + 96) * 64;                        // elements per ring slot
+constexpr int RG80_SMEM = 4 * RG80_STAGE + 2 * 80 * 128;           // ring + two staging tiles
+constexpr int RG80_SMEM_SEQ = RG80_SMEM + 1024;                    // + the bias-partial combine buffer (the ring is busy in SEQ mode)
+
+template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX, bool SEQ>
+__device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* smem, const int active, const int mt, const int n0,
+                                               const SeqLink& q) {
+  constexpr int STAGE = RG80_STAGE;
   uint16_t* const stA = smem + 4 * STAGE;   // `add` in / aux out
   uint16_t* const stB = stA + 80 * 128;     // mask | res in / main out
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int mtiles = (a.M + 79) / 80;
-  const int per_xcd = (mtiles + 7) >> 3;
-  const int jx = blockIdx.x >> 3;
-  const int mt = (blockIdx.x & 7) * per_xcd + (jx >> 2);
-  if (mt >= mtiles) return;
-  const int n0 = (jx & 3) * 128, m0 = mt * 80;
+  const int m0 = mt * 80;
   const int M = a.M, N = a.N;
   constexpr int K = 512, KT = 8;
   constexpr bool HAS_IN2 = HAS_MASK || AUX == AUX_RESIDUAL;
@@ -290,15 +297,19 @@ __global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
         const int row = (lw * 3 + j) * 8 + (l >> 3);
         gI[j] = a.In + (size_t)min(m0 + row, M - 1) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8;
       }
-      auto issue = [&](int kt) {
+      auto issueW = [&](int kt) {
         uint16_t* slot = smem + (kt & 3) * STAGE;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + kt * 64), (lvoid_t*)(slot + (lw * 4 + j) * 8 * 64), 16, 0, 0);
+      };
+      auto issueI = [&](int kt) {
+        uint16_t* slot = smem + (kt & 3) * STAGE;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)(slot + 128 * 64 + (lw * 3 + j) * 8 * 64), 16, 0, 0);
       };
+      auto issue = [&](int kt) { issueW(kt); issueI(kt); };
       // epilogue inputs: 4-row groups 5lw .. 5lw+4 of the [80][128] tile; lane: row + (l>>4), physical chunk l&15 receives
       // the logical chunk (l&15) ^ (row & 15)
       auto issue_tile = [&](const uint16_t* src, uint16_t* dst) {
@@ -309,11 +320,28 @@ __global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
           __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(dst + (lw * 5 + j) * 4 * 128), 16, 0, 0);
         }
       };
-      issue(0); issue(1); issue(2); issue(3);
+      if (!SEQ) {
+        issue(0); issue(1); issue(2); issue(3);
+      } else {
+        // W stages 0..3 first (requested by the layer before unless this is the first), then -- once the four column tiles
+        // of the producing layer have landed in this XCD's L2 -- the In stages
+        if (q.first) { issueW(0); issueW(1); issueW(2); issueW(3); }
+        if (q.wait) {
+          uint32_t seen;
+          do {   // sc1: past this CU's L1; the counter and the tiles live in the L2 all four workgroups share, no L2 invalidate
+            asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(q.flag) : "memory");
+            if ((int32_t)(seen - q.target) < 0) __builtin_amdgcn_s_sleep(1);
+          } while ((int32_t)(seen - q.target) < 0);
+        }
+        issueI(0); issueI(1); issueI(2); issueI(3);
+      }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         // in-order completion: everything younger than stage kt may still be in flight
-        if (kt == 0) ACEZ_VMCNT(21);
+        if (SEQ && kt == 0) ACEZ_VMCNT(9);
+        else if (SEQ && kt == 1) ACEZ_VMCNT(6);
+        else if (SEQ && kt == 2) ACEZ_VMCNT(10);
+        else if (kt == 0) ACEZ_VMCNT(21);
         else if (kt <= 4) ACEZ_VMCNT(14);
         else if (kt == 5) ACEZ_VMCNT_C(14 + E);
         else if (kt == 6) ACEZ_VMCNT_C(7 + E);
@@ -326,9 +354,14 @@ __global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
         }
       }
       ACEZ_VMCNT(0);
-      __builtin_amdgcn_s_barrier();     // epilogue inputs have landed
+      __builtin_amdgcn_s_barrier();     // epilogue inputs have landed; the ring is free
+      if (SEQ && q.next_W) {            // overlaps the epilogue: 64 KiB of the next layer's 208 KiB
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gW[j] += q.next_W - a.W;
+        issueW(0); issueW(1); issueW(2); issueW(3);
+      }
     }
-    if ((a.dbg & 1) || !active) return;
+    if (!SEQ && ((a.dbg & 1) || !active)) return;
     __builtin_amdgcn_s_barrier();       // the multipliers have written the output tiles
   } else {
     // ------------------------------------------------------------------ multiplier waves
@@ -366,7 +399,7 @@ __global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
       }
     }
     __builtin_amdgcn_s_barrier();       // epilogue inputs have landed
-    if ((a.dbg & 1) || !active) return;
+    if (!SEQ && ((a.dbg & 1) || !active)) return;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int ml = j * 16 + fr;
@@ -458,10 +491,99 @@ __global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
       const float v = bf2f(stB[st_off(row, col)]);
       sacc += (row < rows) ? v : 0.f;
     }
-    float* red = reinterpret_cast<float*>(smem);
+    float* red = reinterpret_cast<float*>(SEQ ? smem + RG80_SMEM : smem);
     red[g * 128 + col] = sacc;
-    __syncthreads();
+    if (SEQ) {   // not __syncthreads(): its fence would also wait for the next layer's W stages
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
     if (t < 128) a.bias_partials[(size_t)mt * 512 + n0 + t] = ((red[t] + red[128 + t]) + red[256 + t]) + red[384 + t];
+  }
+  if (SEQ && q.signal) {
+    ACEZ_VMCNT(0);   // this wave's stores are acknowledged by the L2 = visible to the three sibling workgroups (same XCD)
+    if (l == 0) {
+      const uint32_t one = 1;
+      asm volatile("global_atomic_add %0, %1, off" ::"v"(q.flag), "v"(one) : "memory");
+    }
+  }
+}
+
+template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX>
+__global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
+  const int active = a.st ? a.st->active : 1;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[RG80_SMEM];
+  const int mtiles = (a.M + 79) / 80;
+  const int per_xcd = (mtiles + 7) >> 3;
+  const int jx = blockIdx.x >> 3;
+  const int mt = (blockIdx.x & 7) * per_xcd + (jx >> 2);
+  if (mt >= mtiles) return;
+  rowgemm80_body<BIAS_RELU, HAS_ADD, HAS_MASK, AUX, false>(a, smem, active, mt, (jx & 3) * 128, SeqLink{});
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rowseq: the layers of a dependent GEMM chain (the 8 forward layers, or the 7 input-gradient layers) in ONE launch with
+// rowgemm80's tiling, roles, ring, K order and epilogues -- bit-identical outputs. Layer l + 1 of row tile mt reads layer l's
+// 80 x 512 output = the four column tiles of mt, which the grid decode places on ONE XCD, so the hand-off stays inside that
+// XCD's L2: every wave bumps the row tile's counter once its stores are acknowledged, the next layer's loader waves poll it
+// past their L1. No agent-scope fence (a buffer_inv sc1 / buffer_wbl2 sc1 pair per seam costs 5 - 40 us: measured with
+// tools/seam_proto.hip). Tile-local epilogue inputs (`add`, `res`) were written by the same CU or before the launch; `In` is
+// never read before it is produced, so no stale L1 line can exist. What the seam saves over a kernel boundary: the launch
+// ramp, and the next layer's first four W stages are in flight while the epilogue runs (tools/seam_proto.hip: 6.13 -> 4.88 us
+// per forward layer at 5120 rows). All workgroups must be resident (they wait for their siblings): the host only uses this
+// kernel when the grid is not larger than the number of CUs.
+// ---------------------------------------------------------------------------------------------------
+struct SeqLayer {
+  const uint16_t *In, *W;
+  const float* bias;
+  const uint16_t *add, *mask, *res;
+  uint16_t *out_main, *out_aux;
+  float* bias_partials;
+  int aux_mode, pad;
+};
+constexpr int SEQ_MAX_LAYERS = 8;
+struct RowSeqArgs {
+  SeqLayer layer[SEQ_MAX_LAYERS];
+  int n_layers, M;
+  const TrainState* st;
+  uint32_t* flags;     // [64 row tiles][32]
+  uint32_t base[64];   // per row tile: seams completed by earlier launches (a launch only touches the row tiles of ITS batch)
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t smem[RG80_SMEM_SEQ];
+  const int mtiles = (a.M + 79) / 80;
+  const int per_xcd = (mtiles + 7) >> 3;
+  const int jx = blockIdx.x >> 3;
+  const int mt = (blockIdx.x & 7) * per_xcd + (jx >> 2);
+  if (mt >= mtiles) return;
+  if (a.st && !a.st->active) {   // training has ended on the device: no work, but the counters keep step with the host's bases
+    if (threadIdx.x == 0) {      // (the same L2-local atomic as the hand-off itself)
+      const uint32_t inc = 8u * (uint32_t)(a.n_layers - 1);
+      asm volatile("global_atomic_add %0, %1, off" ::"v"(a.flags + mt * 32), "v"(inc) : "memory");
+    }
+    return;
+  }
+  const int n0 = (jx & 3) * 128;
+  for (int layer = 0; layer < a.n_layers; ++layer) {
+    const SeqLayer& y = a.layer[layer];
+    RowGemmArgs g;
+    g.In = y.In; g.W = y.W; g.bias = y.bias; g.add = y.add; g.mask = y.mask; g.res = y.res; g.out_main = y.out_main; g.out_aux = y.out_aux;
+    g.bias_partials = y.bias_partials; g.M = a.M; g.N = 512; g.K = 512; g.relu = BWD ? 0 : 1; g.aux_mode = y.aux_mode; g.st = a.st; g.dbg = 0;
+    SeqLink q;
+    q.flag = a.flags + mt * 32; q.target = (a.base[mt] + (uint32_t)layer) * 32u;   // 4 workgroups x 8 waves per seam
+    q.first = layer == 0; q.wait = layer > 0; q.signal = layer + 1 < a.n_layers;
+    q.next_W = q.signal ? a.layer[layer + 1].W : nullptr;
+    if (!BWD) {
+      if (y.aux_mode == AUX_RESIDUAL) rowgemm80_body<true, false, false, AUX_RESIDUAL, true>(g, smem, 1, mt, n0, q);
+      else rowgemm80_body<true, false, false, AUX_NONE, true>(g, smem, 1, mt, n0, q);
+    } else {
+      if (y.add) rowgemm80_body<false, true, true, AUX_UNMASKED, true>(g, smem, 1, mt, n0, q);
+      else if (y.aux_mode == AUX_UNMASKED) rowgemm80_body<false, false, true, AUX_UNMASKED, true>(g, smem, 1, mt, n0, q);
+      else rowgemm80_body<false, false, true, AUX_NONE, true>(g, smem, 1, mt, n0, q);
+    }
   }
 }
 

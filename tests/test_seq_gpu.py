@@ -1,0 +1,128 @@
+"""GPU: rowseq_kernel (head_kernels.hip; the forward layers / the input-gradient layers in ONE launch each, the kernel
+boundaries replaced by a same-XCD hand-off; the default) against the per-layer rowgemm80 launches (ACEZ_SEQ=0) on identical
+inputs. Same tiles, same ring, same K order, same epilogues, same row groups for the bias partials, so EVERYTHING must agree bit for
+bit: activations, propagated gradients, the full gradient vector, parameters and optimiser state after free-running steps. The
+hand-off is a race if it is wrong, so the comparison is also run over a few hundred steps and over ragged / tiny batches."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers
+from tests.test_chain_gpu import _big_problem
+from tests.test_head_gpu import _trainer
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(make):
+    out = []
+    for seq in ("0", "1"):
+        os.environ["ACEZ_SEQ"] = seq
+        try:
+            out.append(make())
+        finally:
+            os.environ.pop("ACEZ_SEQ", None)
+    return out
+
+
+@pytest.mark.parametrize("name,n", [("head_tanh_1cyclepoly", 5120), ("head_tanh_1cyclepoly", 80), ("head_dyntanh_circle", 637),
+                                    ("head_tanh_calib", 1000), ("head_tanh_posemlp", 2048), ("head_tanh_depth", 4097)])
+def test_one_launch_chains_equal_per_layer_launches(name, n):
+    prob = _big_problem()
+    from oracle import head_oracle
+    flat0 = head_oracle.init_params(helpers.SEED + 1)
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS[name], prob)
+    cfg["global_batch"] = n
+    ref, new = _pair(lambda: _trainer(prob, flat0, cfg, max_batch=5120))
+    rng = np.random.default_rng(5)
+    L = ref.L
+    for it in range(4):
+        idx = torch.from_numpy(rng.permutation(prob["features"].shape[0])[:n].astype(np.int64)).cuda()
+        ref.backward(idx)
+        new.backward(idx)
+        torch.cuda.synchronize()
+        for l in range(L):
+            assert np.array_equal(ref.debug_read("out", l, n), new.debug_read("out", l, n)), ("out", l, it)
+            assert np.array_equal(ref.debug_read("dZ", l, n), new.debug_read("dZ", l, n)), ("dZ", l, it)
+        for b in range(ref.nb + 2):
+            assert np.array_equal(ref.debug_read("R", b, n), new.debug_read("R", b, n)), ("R", b, it)
+        assert torch.equal(ref.grad, new.grad), it
+        ref.update()
+        new.update()
+        torch.cuda.synchronize()
+        assert torch.equal(ref.params, new.params) and ref.state() == new.state()
+
+
+def test_free_running_steps_stay_bitwise_equal():
+    """300 fused steps at BASELINE's batch: a hand-off that let a workgroup read a tile early would show up as a diverging trajectory."""
+    prob = _big_problem()
+    from oracle import head_oracle
+    flat0 = head_oracle.init_params(helpers.SEED + 1)
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
+    cfg["global_batch"] = 5120
+    cfg["iterations"] = 400
+    ref, new = _pair(lambda: _trainer(prob, flat0, cfg, max_batch=5120))
+    rng = np.random.default_rng(11)
+    batches = [torch.from_numpy(rng.permutation(prob["features"].shape[0])[:5120].astype(np.int64)).cuda() for _ in range(300)]
+    for tr in (ref, new):
+        for idx in batches:
+            tr.step(idx)
+    torch.cuda.synchronize()
+    assert torch.equal(ref.params, new.params) and torch.equal(ref.adam_m, new.adam_m) and torch.equal(ref.adam_v, new.adam_v)
+    assert ref.state() == new.state()
+
+
+def test_more_layers_than_one_launch_holds_and_inference():
+    """num_head_blocks = 2: 11 forward / 10 input-gradient layers = two launches of the sequence kernel each; 0 blocks; the plain
+    3-channel head; and the inference entry (frame-sized batches take the sequence kernel, larger ones the per-layer path)."""
+    from acezero_amd.head import HeadTrainer
+    from acezero_amd import synth
+    prob = _big_problem(n_images=8, patches_per_view=256)
+    n = 1024
+    for nb, homog in ((2, True), (0, True), (1, False)):
+        def make():
+            tr = HeadTrainer(prob["mean"], num_head_blocks=nb, use_homogeneous=homog, max_batch=n, loss_type="tanh", schedule="constant",
+                             iterations=50, lr_min=3e-4)
+            tr.load_flat(torch.from_numpy(synth.init_head_params(11, num_head_blocks=nb, use_homogeneous=homog)))
+            tr.set_buffer(prob["features"], prob["target_px"], prob["view_idx"], prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"],
+                          prob["view_image"], prob["image_pose_inv"])
+            return tr
+        ref, new = _pair(make)
+        rng = np.random.default_rng(3)
+        for it in range(5):
+            idx = torch.from_numpy(rng.permutation(prob["features"].shape[0])[:n].astype(np.int64)).cuda()
+            ref.step(idx)
+            new.step(idx)
+        torch.cuda.synchronize()
+        assert torch.equal(ref.params, new.params), (nb, homog)
+        for rows in (1, 333, 1024, 3000):
+            f = torch.from_numpy(prob["features"][:rows]).cuda()
+            assert torch.equal(ref.get_scene_coordinates(f), new.get_scene_coordinates(f)), (nb, homog, rows)
+
+
+def test_counters_keep_step_when_training_has_ended_and_batch_sizes_change():
+    """The hand-off counters are per row tile and the host keeps their bases: steps past the end of the schedule (no-ops on the
+    device), then smaller and larger inference batches, must neither hang nor differ."""
+    from acezero_amd.head import HeadTrainer
+    from acezero_amd import synth
+    prob = _big_problem(n_images=8, patches_per_view=256)
+
+    def make():
+        tr = HeadTrainer(prob["mean"], num_head_blocks=1, use_homogeneous=True, max_batch=2048, loss_type="tanh", schedule="constant",
+                         iterations=3, lr_min=3e-4)
+        tr.load_flat(torch.from_numpy(synth.init_head_params(11, num_head_blocks=1, use_homogeneous=True)))
+        tr.set_buffer(prob["features"], prob["target_px"], prob["view_idx"], prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"],
+                      prob["view_image"], prob["image_pose_inv"])
+        return tr
+    ref, new = _pair(make)
+    rng = np.random.default_rng(9)
+    for n in (2048, 2048, 700, 2048, 100, 1500):   # the schedule ends after 3 of them
+        idx = torch.from_numpy(rng.permutation(prob["features"].shape[0])[:n].astype(np.int64)).cuda()
+        ref.step(idx)
+        new.step(idx)
+        f = torch.from_numpy(prob["features"][:n // 3 + 1]).cuda()
+        assert torch.equal(ref.get_scene_coordinates(f), new.get_scene_coordinates(f)), n
+    torch.cuda.synchronize()
+    assert torch.equal(ref.params, new.params) and ref.state()["iteration"] == 3

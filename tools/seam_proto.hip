@@ -1,0 +1,253 @@
+// seam_proto.hip -- VERDICT r1 item 1(d): "build and measure one 2-layer fused kernel with a same-XCD 4-WG hand-off".
+// Timing + bit-equality experiment, not part of the library.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I acezero_amd/csrc tools/seam_proto.hip -o /tmp/seam && /tmp/seam
+//
+// rowseq_kernel runs L forward layers (bias + ReLU, the cheapest epilogue of the step) of the 5120 x 512 x 512 GEMM in ONE
+// launch with rowgemm80's tiling, roles, ring and K order. Layer l + 1 of row tile mt needs layer l's 80 x 512 output = the
+// four column tiles of mt, which rowgemm80's grid decode already places on one XCD: each wave bumps a per-row-tile counter
+// in that XCD's L2 after its stores have been acknowledged, the loader waves of the next layer poll it. What the seam can
+// hide that a kernel boundary cannot: the next layer's first four W stages (64 KiB of the 208 KiB a workgroup pulls per
+// layer) are requested BEFORE the wait, while the epilogue runs.
+// MODE bit 0: release AND acquire with agent-scope fences (buffer_wbl2 / buffer_inv sc1); bit 1: only the acquire fence;
+// 0: no fence at all -- the stores' acknowledgements and an L1-bypassing poll, valid because producer and consumers share one L2.
+#include "head_kernels.hip"
+#include <cstdio>
+#include <vector>
+#include <cstring>
+using namespace acez;
+
+struct SeqArgs {
+  const uint16_t* In;       // layer 0 input
+  const uint16_t* W;        // [L][512][512]
+  const float* bias;        // [L][512]
+  uint16_t* out[8];         // layer outputs
+  uint32_t* flags;          // [row tiles], monotonically increasing
+  uint32_t base;            // seams completed by earlier launches
+  int M, L, mode;
+};
+
+__global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
+  constexpr int STAGE = (128 + 96) * 64;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[4 * STAGE + 80 * 128];
+  uint16_t* const stB = smem + 4 * STAGE;
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int mtiles = (a.M + 79) / 80;
+  const int per_xcd = (mtiles + 7) >> 3;
+  const int jx = blockIdx.x >> 3;
+  const int mt = (blockIdx.x & 7) * per_xcd + (jx >> 2);
+  if (mt >= mtiles) return;
+  const int n0 = (jx & 3) * 128, m0 = mt * 80;
+  const int M = a.M;
+  constexpr int K = 512, KT = 8, N = 512;
+
+  for (int layer = 0; layer < a.L; ++layer) {
+    const uint16_t* In = layer ? a.out[layer - 1] : a.In;
+    const uint16_t* Wl = a.W + (size_t)layer * 512 * 512;
+    if (w >= 4) {
+      const int lw = w - 4;
+      const uint16_t* gW[4];
+      const uint16_t* gI[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = (lw * 4 + j) * 8 + (l >> 3);
+        gW[j] = Wl + (size_t)(n0 + row) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int row = (lw * 3 + j) * 8 + (l >> 3);
+        gI[j] = In + (size_t)min(m0 + row, M - 1) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8;
+      }
+      auto issueW = [&](int kt) {
+        uint16_t* slot = smem + (kt & 3) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + kt * 64), (lvoid_t*)(slot + (lw * 4 + j) * 8 * 64), 16, 0, 0);
+      };
+      auto issueI = [&](int kt) {
+        uint16_t* slot = smem + (kt & 3) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)(slot + 128 * 64 + (lw * 3 + j) * 8 * 64), 16, 0, 0);
+      };
+      if (layer == 0) { issueW(0); issueW(1); issueW(2); issueW(3); }   // later layers: requested at the end of the layer before
+      if (layer > 0) {
+        const uint32_t target = (a.base + (uint32_t)layer) * 32u;       // 4 workgroups x 8 waves per seam
+        if (a.mode & 1) {
+          while ((int32_t)(__hip_atomic_load(&a.flags[mt * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        } else {
+          // same-XCD hand-off: the counter and the tiles live in THIS XCD's L2; read it past the L1 (sc1), no L2 invalidate
+          uint32_t seen;
+          do {
+            asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(a.flags + mt * 32) : "memory");
+            if ((int32_t)(seen - target) < 0) __builtin_amdgcn_s_sleep(1);
+          } while ((int32_t)(seen - target) < 0);
+          if (a.mode & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+      }
+      issueI(0); issueI(1); issueI(2); issueI(3);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        if (kt == 0) ACEZ_VMCNT(9);
+        else if (kt == 1) ACEZ_VMCNT(6);
+        else if (kt == 2) ACEZ_VMCNT(10);
+        else if (kt <= 4) ACEZ_VMCNT(14);
+        else if (kt == 5) ACEZ_VMCNT(14);
+        else if (kt == 6) ACEZ_VMCNT(7);
+        else ACEZ_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (kt >= 1 && kt + 3 < KT) { issueW(kt + 3); issueI(kt + 3); }
+      }
+      __builtin_amdgcn_s_barrier();       // K loop over: the ring is free
+      if (layer + 1 < a.L) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gW[j] += 512 * 512;
+        issueW(0); issueW(1); issueW(2); issueW(3);
+      }
+      __builtin_amdgcn_s_barrier();       // output tile complete
+    } else {
+      f32x4 acc[2][5];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+      const int fr = l & 15, fq = l >> 4;
+      float4 bias[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) bias[i] = *reinterpret_cast<const float4*>(a.bias + layer * 512 + n0 + w * 32 + i * 16 + 4 * fq);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        const uint16_t* sW = smem + (kt & 3) * STAGE;
+        const uint16_t* sI = sW + 128 * 64;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int c = kk * 4 + fq;
+          bf16x8 fa[2], fb[5];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz(w * 32 + i * 16 + fr, c)]);
+#pragma unroll
+          for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz(j * 16 + fr, c)]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int ml = j * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int nl = w * 32 + i * 16 + 4 * fq;
+          float v[4] = {acc[i][j][0] + bias[i].x, acc[i][j][1] + bias[i].y, acc[i][j][2] + bias[i].z, acc[i][j][3] + bias[i].w};
+          *reinterpret_cast<uint2*>(&stB[st_off(ml, nl)]) = pack4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    {
+      uint16_t* out = a.out[layer];
+      const int q0 = t, q1 = t + 512, q2 = t + 1024;
+      const int so0 = (q0 >> 4) * 128 + (((q0 & 15) ^ ((q0 >> 4) & 15)) << 3);
+      const int so1 = (q1 >> 4) * 128 + (((q1 & 15) ^ ((q1 >> 4) & 15)) << 3);
+      const int so2 = (q2 < 1280) ? (q2 >> 4) * 128 + (((q2 & 15) ^ ((q2 >> 4) & 15)) << 3) : 0;
+      const uint4 m0v = *reinterpret_cast<const uint4*>(&stB[so0]);
+      const uint4 m1v = *reinterpret_cast<const uint4*>(&stB[so1]);
+      const uint4 m2v = *reinterpret_cast<const uint4*>(&stB[so2]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int r0 = m0 + (q0 >> 4), r1 = m0 + (q1 >> 4), r2 = m0 + (q2 >> 4);
+      const size_t o0 = (size_t)r0 * N + n0 + (q0 & 15) * 8, o1 = (size_t)r1 * N + n0 + (q1 & 15) * 8, o2 = (size_t)r2 * N + n0 + (q2 & 15) * 8;
+      if (r0 < M) *reinterpret_cast<uint4*>(out + o0) = m0v;
+      if (r1 < M) *reinterpret_cast<uint4*>(out + o1) = m1v;
+      if (q2 < 1280 && r2 < M) *reinterpret_cast<uint4*>(out + o2) = m2v;
+    }
+    if (layer + 1 < a.L) {
+      if (a.mode & 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (l == 0) __hip_atomic_fetch_add(&a.flags[mt * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        ACEZ_VMCNT(0);                     // stores acknowledged by this XCD's L2 = visible to the three sibling workgroups
+        if (l == 0) {
+          const uint32_t one = 1;
+          asm volatile("global_atomic_add %0, %1, off" ::"v"(a.flags + mt * 32), "v"(one) : "memory");
+        }
+      }
+    }
+  }
+}
+
+static uint16_t f2bf_host(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+int main() {
+  const int M = 5120, LMAX = 8;
+  uint16_t *In, *W; float* bias; uint32_t* flags;
+  uint16_t *outA[LMAX], *outB[LMAX];
+  CK(hipMalloc(&In, (size_t)M * 512 * 2)); CK(hipMalloc(&W, (size_t)LMAX * 512 * 512 * 2)); CK(hipMalloc(&bias, LMAX * 512 * 4));
+  CK(hipMalloc(&flags, 64 * 32 * 4)); CK(hipMemset(flags, 0, 64 * 32 * 4));
+  for (int i = 0; i < LMAX; ++i) { CK(hipMalloc(&outA[i], (size_t)M * 512 * 2)); CK(hipMalloc(&outB[i], (size_t)M * 512 * 2)); }
+  std::vector<uint16_t> h((size_t)M * 512), hw((size_t)LMAX * 512 * 512);
+  uint32_t s = 12345;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 8) & 0xffff) / 65536.f - 0.5f; };
+  for (auto& x : h) x = f2bf_host(rnd());
+  for (auto& x : hw) x = f2bf_host(rnd() * 0.12f);
+  std::vector<float> hb(LMAX * 512);
+  for (auto& x : hb) x = rnd() * 0.1f + 0.02f;
+  CK(hipMemcpy(In, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  uint32_t base = 0;
+  auto run_seq = [&](int L, int mode) {
+    SeqArgs a{};
+    a.In = In; a.W = W; a.bias = bias; a.flags = flags; a.base = base; a.M = M; a.L = L; a.mode = mode;
+    for (int i = 0; i < LMAX; ++i) a.out[i] = outB[i];
+    hipLaunchKernelGGL(rowseq_kernel, dim3(256), dim3(512), 0, 0, a);
+    base += (uint32_t)(L - 1);
+  };
+  auto run_ref = [&](int L) {
+    for (int i = 0; i < L; ++i) {
+      RowGemmArgs g{};
+      g.In = i ? outA[i - 1] : In; g.W = W + (size_t)i * 512 * 512; g.bias = bias + i * 512; g.out_main = outA[i]; g.M = M; g.N = 512; g.K = 512;
+      g.relu = 1; g.aux_mode = AUX_NONE;
+      launch_rowgemm(g, 80, 0);
+    }
+  };
+  // bit equality of the last layer's output
+  std::vector<uint16_t> ra((size_t)M * 512), rb((size_t)M * 512);
+  for (int L : {2, 4, 8}) {
+    for (int mode = 0; mode < 3; ++mode) {
+      for (int i = 0; i < LMAX; ++i) CK(hipMemset(outB[i], 0xff, (size_t)M * 512 * 2));
+      run_ref(L); run_seq(L, mode);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(ra.data(), outA[L - 1], ra.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(rb.data(), outB[L - 1], rb.size() * 2, hipMemcpyDeviceToHost));
+      size_t bad = 0, nz = 0;
+      for (size_t i = 0; i < ra.size(); ++i) { bad += ra[i] != rb[i]; nz += ra[i] != 0; }
+      printf("L=%d mode=%d: %zu mismatching of %zu (non-zero %zu)\n", L, mode, bad, ra.size(), nz);
+    }
+  }
+  for (int rep = 0; rep < 2; ++rep)
+    for (int L : {1, 2, 4, 8}) {
+      float ms_ref, ms0, ms1, ms2;
+      const int n = 200;
+      for (int i = 0; i < 10; ++i) run_ref(L);
+      CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_ref(L); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_ref, e0, e1));
+      for (int i = 0; i < 10; ++i) run_seq(L, 0);
+      CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_seq(L, 0); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms0, e0, e1));
+      for (int i = 0; i < 10; ++i) run_seq(L, 1);
+      CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_seq(L, 1); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms1, e0, e1));
+      for (int i = 0; i < 10; ++i) run_seq(L, 2);
+      CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_seq(L, 2); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms2, e0, e1));
+      if (rep) printf("L=%d  per-layer launches %7.2f us | one launch: no fences %7.2f us, acquire fence only %7.2f us, release+acquire fences %7.2f us   (per layer %.2f | %.2f / %.2f / %.2f)\n",
+                      L, ms_ref * 1e3 / n, ms0 * 1e3 / n, ms2 * 1e3 / n, ms1 * 1e3 / n, ms_ref * 1e3 / n / L, ms0 * 1e3 / n / L, ms2 * 1e3 / n / L, ms1 * 1e3 / n / L);
+    }
+  return 0;
+}
