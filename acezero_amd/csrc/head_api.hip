@@ -80,6 +80,7 @@ struct acez_trainer {
   int n_cus = 0;
   uint32_t* seq_flags = nullptr;  // [64 row tiles][32] hand-off counters, monotonically increasing
   uint32_t seq_base[64] = {};     // seams completed so far, per row tile
+  uint32_t* seq_xcc = nullptr;    // ACEZ_SEQ_XCC=1: placement record of rowseq_kernel (acez_trainer_debug_read kind 6)
 };
 
 enum { KC_SCHED = 0, KC_GATHER, KC_GEMM_FWD, KC_LOSS, KC_GEMM_DGRAD, KC_WGRAD, KC_REDUCE, KC_ADAMW, KC_COUNT };
@@ -204,6 +205,10 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->chain_err, sizeof(int));
   A((void**)&tr->seq_flags, 64 * 32 * sizeof(uint32_t));
   if (rc == ACEZ_OK) (void)hipMemset(tr->seq_flags, 0, 64 * 32 * sizeof(uint32_t));
+  if (getenv("ACEZ_SEQ_XCC")) {
+    A((void**)&tr->seq_xcc, (8 + 256) * sizeof(uint32_t));
+    if (rc == ACEZ_OK) (void)hipMemset(tr->seq_xcc, 0, (8 + 256) * sizeof(uint32_t));
+  }
   if (getenv("ACEZ_CHAIN_TRACE")) {
     A((void**)&tr->chain_trace, 512 * sizeof(unsigned long long));
     if (rc == ACEZ_OK) (void)hipMemset(tr->chain_trace, 0, 512 * sizeof(unsigned long long));
@@ -338,7 +343,7 @@ static void launch_rowseq(acez_trainer* tr, const std::vector<SeqLayer>& layers,
     RowSeqArgs a{};
     const int cnt = (int)std::min<size_t>(SEQ_MAX_LAYERS, layers.size() - i0);
     for (int i = 0; i < cnt; ++i) a.layer[i] = layers[i0 + i];
-    a.n_layers = cnt; a.M = n; a.st = st; a.flags = tr->seq_flags;
+    a.n_layers = cnt; a.M = n; a.st = st; a.flags = tr->seq_flags; a.xcc_dbg = tr->seq_xcc;
     for (int mt = 0; mt < 64; ++mt) a.base[mt] = tr->seq_base[mt];
     hipLaunchKernelGGL(rowseq_kernel<BWD>, dim3(32 * ((mtiles + 7) / 8)), dim3(512), 0, s, a);
     for (int mt = 0; mt < mtiles; ++mt) tr->seq_base[mt] += (uint32_t)(cnt - 1);
@@ -859,6 +864,7 @@ extern "C" int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, vo
   else if (kind == 3 && index >= 0 && index < tr->nslabs) { src = tr->slabs + (size_t)index * tr->n_wide; cap = tr->n_wide * 4; }
   else if (kind == 4 && index >= 0 && index < tr->L) { src = tr->bias_partials + (size_t)index * tr->bias_layer_stride; cap = tr->bias_layer_stride * 4; }
   else if (kind == 5 && tr->chain_trace) { src = tr->chain_trace; cap = 512 * 8; }
+  else if (kind == 6 && tr->seq_xcc) { src = tr->seq_xcc; cap = (8 + 256) * 4; }
   ACEZ_REQUIRE(src && bytes <= cap, "unknown buffer or size out of range");
   ACEZ_HIP_CHECK(hipMemcpyAsync(h_out, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));

@@ -378,9 +378,20 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
 #pragma unroll
       for (int i = 0; i < 2; ++i) bias[i] = *reinterpret_cast<const float4*>(a.bias + n0 + w * 32 + i * 16 + 4 * fq);
     }
+    // SEQ: a.dbg is a compile-time 0 there, the K loop becomes straight-line code and the scheduler sinks the second half's MFMAs
+    // below the next s_barrier -- their ds_reads would still be in flight when the loader waves, released by that barrier,
+    // refill the slot (only the DMA latency protects them: a rare last-bit corruption under two processes on one GPU). Keep the
+    // fragment reads of a stage complete before the wave arrives at the barrier, as the branchy non-SEQ code does by construction.
+    auto stage_barrier = [&]() {
+      if (SEQ) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    };
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-      __builtin_amdgcn_s_barrier();
+      stage_barrier();
       if (a.dbg & 2) continue;
       const uint16_t* sW = smem + (kt & 3) * STAGE;
       const uint16_t* sI = sW + 128 * 64;
@@ -398,7 +409,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
           for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_s_barrier();       // epilogue inputs have landed
+    stage_barrier();                    // epilogue inputs have landed
     if (!SEQ && ((a.dbg & 1) || !active)) return;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -549,6 +560,9 @@ struct RowSeqArgs {
   const TrainState* st;
   uint32_t* flags;     // [64 row tiles][32]
   uint32_t base[64];   // per row tile: seams completed by earlier launches (a launch only touches the row tiles of ITS batch)
+  uint32_t* xcc_dbg;   // null, or [8 + 256]: words 0..7 |= 1 << XCC_ID of the workgroups with blockIdx & 7 = word (sticky); word
+                       // 8 + 4 mt + nt = XCC_ID of the workgroup that owned tile (mt, nt) in the last launch (tests: the four column
+                       // tiles of a row tile must report the same XCD)
 };
 
 template <bool BWD>
@@ -559,6 +573,11 @@ __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
   const int jx = blockIdx.x >> 3;
   const int mt = (blockIdx.x & 7) * per_xcd + (jx >> 2);
   if (mt >= mtiles) return;
+  if (a.xcc_dbg && threadIdx.x == 0) {
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
+    atomicOr(a.xcc_dbg + (blockIdx.x & 7), 1u << xcc);
+    a.xcc_dbg[8 + mt * 4 + (jx & 3)] = xcc;
+  }
   if (a.st && !a.st->active) {   // training has ended on the device: no work, but the counters keep step with the host's bases
     if (threadIdx.x == 0) {      // (the same L2-local atomic as the hand-off itself)
       const uint32_t inc = 8u * (uint32_t)(a.n_layers - 1);

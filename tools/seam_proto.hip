@@ -120,6 +120,10 @@ __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
       for (int i = 0; i < 2; ++i) bias[i] = *reinterpret_cast<const float4*>(a.bias + layer * 512 + n0 + w * 32 + i * 16 + 4 * fq);
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
+        // (straight-line code: without this the scheduler leaves the previous stage's last ds_reads in flight across the barrier
+        //  that releases the refill of their slot -- see rowgemm80_body)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const uint16_t* sW = smem + (kt & 3) * STAGE;
         const uint16_t* sI = sW + 128 * 64;
@@ -137,6 +141,8 @@ __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
             for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
