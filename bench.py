@@ -420,11 +420,19 @@ def main():
             gemm_n += prof[k][1]
         avg_s = gemm_ms / max(gemm_n, 1) * 1e-3
         achieved = BATCH * GEMM_FLOP_PER_LAUNCH_PER_ROW / avg_s / 1e12 if avg_s > 0 else 0.0
+        seq = os.environ.get("ACEZ_SEQ", "1") != "0"
+        gemm_kernel_name = ("rowseq_kernel (the 8 forward / the 7 input-gradient 5120x512x512 bf16 layers of a step as ONE launch each; figures per layer)"
+                            if seq else "rowgemm80_kernel (5120x512x512 bf16, fwd + dgrad launches)")
+        gemm_note = ("HIP events on the launch stream around the two chain launches of a step; achieved = 15 layers' FLOPs / their summed durations = one "
+                     "layer's FLOPs / avg_launch_us (launches_timed counts layers); rocprofv3 kernel durations are in profiles/r02_kernel_stats_rocprofv3_headline_only_seq.csv"
+                     if seq else
+                     "HIP events on the launch stream around each chain of dependent rowgemm launches (8 fwd, 7 dgrad per step): average start-to-start "
+                     "cadence incl. the ~1-2 us kernel boundary; rocprofv3 kernel durations are in profiles/")
         traffic, traffic_source = None, None
         tf = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r02_rowgemm_hbm_traffic.json", "r01_rowgemm_hbm_traffic.json")) if os.path.exists(f)), "")
         if tf:   # NOT measured in this run: the PMC passes need rocprofv3 around the process (tools/prof_r02.sh)
             traffic = json.load(open(tf)).get("bytes_per_launch")
-            traffic_source = "profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes; a stored measurement, not this run)"
+            traffic_source = "profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes; a stored measurement of ONE rowgemm80 layer launch, not this run" + ("; the one-launch chain moves the same tensors, its layer inputs come from the producing XCD's L2 where they still fit -- not re-measured)" if seq else ")")
         wg_s = prof["wgrad"][0] / max(prof["wgrad"][1], 1) * 1e-3
         wg_tflops = BATCH * 8 * GEMM_FLOP_PER_LAUNCH_PER_ROW / wg_s / 1e12 if wg_s > 0 else 0.0
         out = {
@@ -461,12 +469,12 @@ def main():
                                    "value": pipe["cloud_frames"] * world / pipe["cloud_s"], "unit": "frames/s",
                                    "points_per_frame": pipe["cloud_points"] / pipe["cloud_frames"],
                                    "map_bytes_per_s": pipe["cloud_frames"] * world * 57600 / pipe["cloud_s"]},
-            "roofline": {"bound": "mfma", "kernel": "rowgemm80_kernel (5120x512x512 bf16, fwd + dgrad launches)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": gemm_kernel_name, "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": gemm_n,
                          "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()},
-                         "note": "HIP events on the launch stream around each chain of dependent rowgemm launches (8 fwd, 7 dgrad per step): average start-to-start cadence incl. the ~1-2 us kernel boundary; rocprofv3 kernel durations are in profiles/"},
+                         "note": gemm_note},
             "roofline_wgrad": {"bound": "mfma", "kernel": "wgrad_kernel (8 layers x 512x512x5120 bf16 in one launch)", "achieved": wg_tflops,
                                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_tflops / MFMA_PEAK_TFLOPS, "traffic": None,
                                "avg_launch_us": wg_s * 1e6},
