@@ -1,3 +1,9 @@
+"""Two-process stress of rowseq_kernel (run on the GPU box):  python tools/seq_stress.py WORLD STEPS SEQ
+WORLD processes share ONE GPU and step in lock step (a gloo barrier before every backward); each holds two trainers on the same
+batches -- `tr` with ACEZ_SEQ=SEQ (and the XCD placement record) and `ref` with per-layer launches -- and counts the steps whose
+gradient vectors differ in any bit; for the first such step it lists the buffers (layer, rows, columns) that differ. This is what
+found the fragment-read race of DESIGN.md section 3 "Round 2" (0): seq vs per-layer 13 and 90 of 90 steps before the fix, 0 of
+2 x 150 after; per-layer vs per-layer 0. Prints (rank, steps with siblings on different XCDs, differing steps, first difference)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -29,6 +35,10 @@ def worker(rank, world, port, q, steps, seqmode):
         dist.barrier()                         # lock step: both ranks launch their chains at the same moment
         tr.backward(idx)
         torch.cuda.synchronize()
+        if seqmode != "0":
+            x = xcc(tr)
+            sib = x[8:8 + 4 * ((m + 79) // 80)].reshape(-1, 4)
+            bad_place += int(not (sib == sib[:, :1]).all())
         ref.backward(idx)
         torch.cuda.synchronize()
         if not torch.equal(tr.grad, ref.grad):
