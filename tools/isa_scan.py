@@ -81,6 +81,38 @@ def scan_serial_loads(path):
             name = None
 
 
+def scan_reads_across_barrier(path):
+    """Kernels that refill LDS asynchronously (LDS-DMA) and pass an s_barrier with ds_reads still in flight: if that barrier is the
+    one that releases the refill of the slot being read, only the DMA latency protects the reads. Found in rowseq_kernel in round 2
+    (straight-line K loop: the scheduler had sunk the MFMAs and their waits below the barrier; a rounding-level corruption once in
+    ~50 steps with two processes on one GPU). Linear walk, lgkmcnt(N) leaves at most N reads pending. chain_kernel is listed by design:
+    it prefetches the next pair's W fragments into registers across the barrier and its ring refills a slot one pair later."""
+    unit = os.path.basename(path).split("-hip-")[0]
+    name, pending, hits, dma, barriers = None, 0, 0, 0, 0
+    for ln in open(path):
+        m = re.match(r"^(_Z\S+):", ln)
+        if m:
+            name, pending, hits, dma, barriers = m.group(1), 0, 0, 0, 0
+        if not name:
+            continue
+        if re.search(r"\bds_read", ln):
+            pending += 1
+        elif "global_load_lds" in ln:
+            dma += 1
+        else:
+            w = re.search(r"s_waitcnt.*lgkmcnt\((\d+)\)", ln)
+            if w:
+                pending = min(pending, int(w.group(1)))
+            elif re.search(r"\bs_barrier\b", ln):
+                barriers += 1
+                hits += pending > 0
+        if "s_endpgm" in ln:
+            if dma and hits:
+                print("%-12s %-60s barriers %3d, with ds_reads in flight %3d   <- is the refill of their slot released by it?" % (
+                    unit, re.sub(r"^_ZN\d*[a-z_]*\d+", "", name)[:60], barriers, hits))
+            name = None
+
+
 if __name__ == "__main__":
     compile_units()
     for f in sorted(os.listdir(OUT)):
@@ -89,3 +121,6 @@ if __name__ == "__main__":
     for f in sorted(os.listdir(OUT)):
         if f.endswith("gfx950.s"):
             scan_serial_loads(os.path.join(OUT, f))
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith("gfx950.s"):
+            scan_reads_across_barrier(os.path.join(OUT, f))
