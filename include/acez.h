@@ -256,7 +256,10 @@ int acez_trainer_get_profile(acez_trainer* tr, float* h_ms8, int32_t* h_counts8)
 /* Diagnostics for the tests: copy one intermediate device buffer of the last backward call to the host (synchronous).
  * kind 0: post-ReLU output of wide layer `index`, bf16 [n][512];  1: dZ of layer `index`, bf16 [n][512];
  * 2: residual stream `index` (0 = the gathered batch), bf16 [n][512];  3: weight-gradient slab `index`, f32 [n_wide];
- * 4: bias-gradient partial rows of layer `index`, f32 [max_batch/32][512].  No reference counterpart (autograd internals). */
+ * 4: bias-gradient partial rows of layer `index`, f32 [max_batch/32][512];  5: s_memtime stamps of the chain kernel
+ * (ACEZ_CHAIN_TRACE=1), u64 [2][256];  6: XCD placement record of the one-launch GEMM chains (ACEZ_SEQ_XCC=1), u32 [8 + 256]:
+ * words 0..7 = OR of 1 << XCC_ID over the workgroups with blockIdx & 7 = word, word 8 + 4 mt + nt = XCC_ID that ran tile
+ * (mt, nt) in the last launch.  No reference counterpart (autograd internals). */
 int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, void* h_out, int64_t bytes, void* stream);
 
 /* Current refined world->cam poses of all images, f32 [n_images][3][4] (PoseRefiner.get_all_current_poses,
