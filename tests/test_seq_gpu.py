@@ -126,3 +126,29 @@ def test_counters_keep_step_when_training_has_ended_and_batch_sizes_change():
         assert torch.equal(ref.get_scene_coordinates(f), new.get_scene_coordinates(f)), n
     torch.cuda.synchronize()
     assert torch.equal(ref.params, new.params) and ref.state()["iteration"] == 3
+
+
+def test_sibling_workgroups_share_an_xcd():
+    """The hand-off is only valid inside one XCD's L2: the four column tiles of every row tile must have run on the same XCD
+    (HW_REG_XCC_ID recorded by the kernel, ACEZ_SEQ_XCC=1; tools/seq_stress.py checks the same with two processes on the GPU)."""
+    import ctypes as C
+    from acezero_amd import _native as N
+    prob = _big_problem(n_images=8, patches_per_view=256)
+    from oracle import head_oracle
+    flat0 = head_oracle.init_params(helpers.SEED + 1)
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
+    cfg["global_batch"] = 4096
+    os.environ["ACEZ_SEQ_XCC"] = "1"
+    try:
+        tr = _trainer(prob, flat0, cfg, max_batch=4096)
+    finally:
+        os.environ.pop("ACEZ_SEQ_XCC", None)
+    rng = np.random.default_rng(2)
+    for n in (4096, 333, 2000):
+        tr.backward(torch.from_numpy(rng.permutation(prob["features"].shape[0])[:n].astype(np.int64)).cuda())
+        torch.cuda.synchronize()
+        rec = np.zeros(8 + 256, np.uint32)
+        N.check(tr.lib.acez_trainer_debug_read(tr._h, 6, 0, rec.ctypes.data_as(C.c_void_p), rec.nbytes, None))
+        sib = rec[8:8 + 4 * ((n + 79) // 80)].reshape(-1, 4)
+        assert (sib == sib[:, :1]).all(), (n, sib[(sib != sib[:, :1]).any(1)][:4])
+        assert (sib < 8).all()
