@@ -429,9 +429,11 @@ def main():
                      "HIP events on the launch stream around each chain of dependent rowgemm launches (8 fwd, 7 dgrad per step): average start-to-start "
                      "cadence incl. the ~1-2 us kernel boundary; rocprofv3 kernel durations are in profiles/")
         traffic, traffic_source = None, None
-        tf = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r02_rowgemm_hbm_traffic.json", "r01_rowgemm_hbm_traffic.json")) if os.path.exists(f)), "")
+        names = (("r02_rowseq_hbm_traffic.json",) if seq else ()) + ("r02_rowgemm_hbm_traffic.json", "r01_rowgemm_hbm_traffic.json")
+        tf = next((f for f in (os.path.join(ROOT, "profiles", n) for n in names) if os.path.exists(f)), "")
         if tf:   # NOT measured in this run: the PMC passes need rocprofv3 around the process (tools/prof_r02.sh)
-            traffic = json.load(open(tf)).get("bytes_per_launch")
+            tj = json.load(open(tf))
+            traffic = tj.get("bytes_per_layer", tj.get("bytes_per_launch"))   # per unit (one layer), like `achieved`
             traffic_source = "profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes; a stored measurement of ONE rowgemm80 layer launch, not this run" + ("; the one-launch chain moves the same tensors, its layer inputs come from the producing XCD's L2 where they still fit -- not re-measured)" if seq else ")")
         wg_s = prof["wgrad"][0] / max(prof["wgrad"][1], 1) * 1e-3
         wg_tflops = BATCH * 8 * GEMM_FLOP_PER_LAUNCH_PER_ROW / wg_s / 1e12 if wg_s > 0 else 0.0
