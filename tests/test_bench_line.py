@@ -1,0 +1,42 @@
+"""CPU: the JSON line bench.py prints (the driver's contract) assembled from mocked measurements -- every field the contract and
+the tier framing name is present and consistent; guards the assembly code, which otherwise only runs on the GPU box."""
+import io
+import json
+import sys
+from contextlib import redirect_stdout
+
+import pytest
+import torch
+
+
+@pytest.mark.parametrize("seq", ["1", "0"])
+def test_bench_json_line_contract(monkeypatch, seq):
+    import bench
+    prof = {k: [v, n] for k, (v, n) in {"sched": (0.0, 0), "gather": (0.14, 20), "gemm_fwd": (0.88, 160), "loss": (0.34, 20),
+                                        "gemm_dgrad": (0.94, 140), "wgrad": (0.58, 20), "grad_reduce": (0.0, 0), "adamw": (0.42, 20)}.items()}
+    monkeypatch.setenv("ACEZ_SEQ", seq)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(bench, "bench_training", lambda *a, **k: (300 * 155e-6 if not k.get("steps") else k["steps"] * 240e-6, {"loss": 22.3}, prof))
+    monkeypatch.setattr(bench, "bench_registration", lambda *a: (2048, 2048 / 340e3, 1.0))
+    monkeypatch.setattr(bench, "bench_pipeline", lambda *a: {"frames": 256, "e2e_s": 0.025, "encoder_ms": 16.0, "buffer_rows": 262144, "buffer_s": 0.017,
+                                                            "cloud_frames": 256, "cloud_s": 1.4e-4, "cloud_points": 256000})
+    monkeypatch.setattr(bench, "bench_session", lambda *a: {"frames": 120, "seconds": 5.4})
+    monkeypatch.setattr(bench, "cpu_baseline", lambda: {"value": 5.9e4, "unit": "patches/s", "cores": 32, "kind": "port", "sample": "mock"})
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    out = io.StringIO()
+    with redirect_stdout(out):
+        bench.main()
+    lines = [ln for ln in out.getvalue().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # ONE JSON line
+    d = json.loads(lines[0])
+    assert d["metric"] == "ACE patches/sec" and d["unit"] == "patches/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True
+    assert d["steps"] == 300 and d["warmup"] == 30 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16"
+    assert abs(d["value"] - 5120 / 155e-6) < 1 and abs(d["ms_per_step"] - 0.155) < 1e-9 and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert ("rowseq_kernel" in r["kernel"]) == (seq == "1") and r["launches_timed"] == 300
+    per_layer_us = (0.88 + 0.94) / 300 * 1e3
+    assert abs(r["avg_launch_us"] - per_layer_us) < 1e-9 and abs(r["achieved"] - 2 * 5120 * 512 * 512 / (per_layer_us * 1e-6) / 1e12) < 1e-6
+    assert r["traffic"] is None or r["traffic"] > 1e6            # bytes per layer, a stored measurement (traffic_source says which)
+    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["roofline_wgrad"]["frac"] > 0 and "roofline_ransac" in d
