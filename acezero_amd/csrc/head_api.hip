@@ -621,6 +621,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   std::vector<SeqLayer> sq;
   auto dgrad = [&](int l, int l_out, const uint16_t* add, const uint16_t* mask, uint16_t* out_main, uint16_t* out_aux) {
     if (seq) {
+      if (add && !out_aux) abort();   // rowseq_kernel<true> has the three epilogue shapes of this chain only (an `add` comes with a residual-gradient output)
       SeqLayer y{};
       y.In = tr->dZ[l]; y.W = tr->WbT + (size_t)l * 262144; y.add = add; y.mask = mask; y.out_main = out_main; y.out_aux = out_aux;
       y.bias_partials = tr->bias_partials + (size_t)l_out * tr->bias_layer_stride; y.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE;
