@@ -89,6 +89,7 @@ SYMBOLS = {
     "acez_trainer_last_scene_coords": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "acez_trainer_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "acez_trainer_get_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acez_trainer_seq_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "acez_trainer_debug_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "acez_trainer_get_poses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "acez_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

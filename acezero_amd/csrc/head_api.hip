@@ -6,6 +6,8 @@
 #include "head_chain.hip"
 #include "conv_launch.h"
 #include <stdlib.h>
+#include <string.h>
+#include <algorithm>
 #include "acez_common.h"
 #include <vector>
 #include <new>
@@ -81,6 +83,15 @@ struct acez_trainer {
   uint32_t* seq_flags = nullptr;  // [64 row tiles][32] hand-off counters, monotonically increasing
   uint32_t seq_base[64] = {};     // seams completed so far, per row tile
   uint32_t* seq_xcc = nullptr;    // ACEZ_SEQ_XCC=1: placement record of rowseq_kernel (acez_trainer_debug_read kind 6)
+  // Safety net of the hand-off (the workgroup -> XCD mapping is not an API contract): a placement probe at creation decides whether
+  // the one-launch chains are used at all; every poll is bounded and raises `seq_err` (device), which turns the optimiser /
+  // schedule kernels of that step into no-ops; the next state read (seq_fault_check) resets the counters and switches this
+  // trainer to per-layer launches for good. The abandoned iterations are not counted, so the training loop simply runs them again.
+  int* seq_err = nullptr;
+  uint32_t seq_spin_ticks = 2000000;   // 20 ms of s_memrealtime ticks (100 MHz); ACEZ_SEQ_SPIN_US overrides
+  int seq_faults = 0;                  // fall-backs taken so far
+  int seq_probe = -1;                  // -1 not run, 0 failed (seq disabled), 1 passed
+  long seq_launches = 0, seq_fault_at = -1;   // tests: ACEZ_SEQ_FAULT_AT=<n> makes the n-th launch time out
 };
 
 enum { KC_SCHED = 0, KC_GATHER, KC_GEMM_FWD, KC_LOSS, KC_GEMM_DGRAD, KC_WGRAD, KC_REDUCE, KC_ADAMW, KC_COUNT };
@@ -125,6 +136,57 @@ extern "C" void acez_trainer_destroy(acez_trainer* tr) {
     if (e) (void)hipEventDestroy(e);
   if (tr->pose_stream) (void)hipStreamDestroy(tr->pose_stream);
   delete tr;
+}
+
+// One launch with rowseq_kernel's geometry (grid of a full 64-row-tile batch, 512 threads, the same LDS) that records which XCD
+// ran each tile. The one-launch chains are enabled only on a gfx950 whose eight XCDs take the workgroups of a launch round-robin,
+// i.e. if the four column tiles of EVERY row tile report one XCD (ACEZ_SEQ_NOPROBE=1 skips the probe: tests of the fault path).
+static int seq_placement_probe(acez_trainer* tr) {
+  hipDeviceProp_t prop;
+  ACEZ_HIP_CHECK(hipGetDeviceProperties(&prop, tr->device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 || tr->n_cus < 256) { tr->seq = false; tr->seq_probe = 0; return ACEZ_OK; }
+  if (getenv("ACEZ_SEQ_NOPROBE")) return ACEZ_OK;
+  uint32_t* d_rec = nullptr;
+  ACEZ_HIP_CHECK(hipMalloc((void**)&d_rec, 256 * sizeof(uint32_t)));
+  uint32_t h[256];
+  bool ok = true;
+  for (int rep = 0; rep < 2 && ok; ++rep) {   // the full grid, and a ragged one (41 row tiles: 6 per XCD, the last XCDs short)
+    const int mtiles = rep == 0 ? 64 : 41;
+    (void)hipMemset(d_rec, 0xff, 256 * sizeof(uint32_t));
+    hipLaunchKernelGGL(seq_probe_kernel, dim3(32 * ((mtiles + 7) / 8)), dim3(512), 0, 0, d_rec, mtiles);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(h, d_rec, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+    for (int mt = 0; mt < mtiles && ok; ++mt)
+      for (int nt = 0; nt < 4; ++nt) {
+        const uint32_t x = h[mt * 4 + nt] >> 16, x0 = h[mt * 4] >> 16;
+        if (h[mt * 4 + nt] == 0xffffffffu || x > 7 || x != x0) ok = false;
+      }
+  }
+  (void)hipFree(d_rec);
+  tr->seq_probe = ok ? 1 : 0;
+  if (!ok) tr->seq = false;   // per-layer launches: correct on any placement
+  return ACEZ_OK;
+}
+
+// Read the fault word (the caller has synchronised the stream or is about to): on a fault, reset the hand-off state and switch the
+// trainer to per-layer launches. Returns 1 if a fall-back was taken.
+static int seq_fault_check(acez_trainer* tr, hipStream_t s) {
+  int err = 0;
+  if (hipMemcpyAsync(&err, tr->seq_err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 0;
+  if (!err) return 0;
+  (void)hipMemsetAsync(tr->seq_err, 0, sizeof(int), s);
+  (void)hipMemsetAsync(tr->seq_flags, 0, 64 * 32 * sizeof(uint32_t), s);
+  for (int mt = 0; mt < 64; ++mt) tr->seq_base[mt] = 0;
+  tr->seq = false;
+  ++tr->seq_faults;
+  return 1;
+}
+
+extern "C" int acez_trainer_seq_status(acez_trainer* tr, int* enabled, int* probe, int* faults) {
+  ACEZ_REQUIRE(tr, "null trainer");
+  if (enabled) *enabled = tr->seq ? 1 : 0;
+  if (probe) *probe = tr->seq_probe;
+  if (faults) *faults = tr->seq_faults;
+  return ACEZ_OK;
 }
 
 extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* cfg, const acez_param_buffers* params,
@@ -205,6 +267,10 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->chain_err, sizeof(int));
   A((void**)&tr->seq_flags, 64 * 32 * sizeof(uint32_t));
   if (rc == ACEZ_OK) (void)hipMemset(tr->seq_flags, 0, 64 * 32 * sizeof(uint32_t));
+  A((void**)&tr->seq_err, sizeof(int));
+  if (rc == ACEZ_OK) (void)hipMemset(tr->seq_err, 0, sizeof(int));
+  if (const char* e = getenv("ACEZ_SEQ_SPIN_US")) tr->seq_spin_ticks = (uint32_t)std::max(1L, atol(e)) * 100u;
+  if (const char* e = getenv("ACEZ_SEQ_FAULT_AT")) tr->seq_fault_at = atol(e);
   if (getenv("ACEZ_SEQ_XCC")) {
     A((void**)&tr->seq_xcc, (8 + 256) * sizeof(uint32_t));
     if (rc == ACEZ_OK) (void)hipMemset(tr->seq_xcc, 0, (8 + 256) * sizeof(uint32_t));
@@ -239,6 +305,10 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_HIP_CHECK(hipMemset(tr->log_loss, 0, (size_t)tr->log_cap * sizeof(float)));
   ACEZ_HIP_CHECK(hipMemset(tr->log_inl, 0, (size_t)tr->log_cap * sizeof(float)));
   ACEZ_HIP_CHECK(hipDeviceSynchronize());
+  if (tr->seq) {
+    const int prc = seq_placement_probe(tr);
+    if (prc != ACEZ_OK) { acez_trainer_destroy(tr); return prc; }
+  }
   *out = tr;
   return ACEZ_OK;
 }
@@ -297,6 +367,7 @@ static void fill_adam_args(acez_trainer* tr, AdamArgs& a) {
   a.fc3_off = tr->fc3_off; a.n_fc3 = (int64_t)tr->no * 513; a.n_params = tr->n_params;
   a.n_layers = tr->L; a.no = tr->no; a.st = tr->st;
   a.slabs = nullptr; a.nslabs = 0; a.slab_stride = 0;
+  a.fault = tr->seq_err;
 }
 
 extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
@@ -344,6 +415,9 @@ static void launch_rowseq(acez_trainer* tr, const std::vector<SeqLayer>& layers,
     const int cnt = (int)std::min<size_t>(SEQ_MAX_LAYERS, layers.size() - i0);
     for (int i = 0; i < cnt; ++i) a.layer[i] = layers[i0 + i];
     a.n_layers = cnt; a.M = n; a.st = st; a.flags = tr->seq_flags; a.xcc_dbg = tr->seq_xcc;
+    a.err = tr->seq_err; a.spin_ticks = tr->seq_spin_ticks;
+    a.fault_inject = (cnt > 1 && tr->seq_launches == tr->seq_fault_at) ? 1 : 0;
+    ++tr->seq_launches;
     for (int mt = 0; mt < 64; ++mt) a.base[mt] = tr->seq_base[mt];
     hipLaunchKernelGGL(rowseq_kernel<BWD>, dim3(32 * ((mtiles + 7) / 8)), dim3(512), 0, s, a);
     for (int mt = 0; mt < mtiles; ++mt) tr->seq_base[mt] += (uint32_t)(cnt - 1);
@@ -510,6 +584,7 @@ static PostArgs post_args(acez_trainer* tr) {
   PostArgs p;
   p.st = tr->st; p.c = tr->sc; p.grad_stats = (const float*)(tr->pb.d_grad + tr->n_params);
   p.inv_global_batch = 1.0f / (float)tr->cfg.global_batch; p.log_loss = tr->log_loss; p.log_inl = tr->log_inl; p.log_cap = tr->log_cap;
+  p.fault = tr->seq_err;
   return p;
 }
 
@@ -520,7 +595,7 @@ static void flush_post(acez_trainer* tr, hipStream_t s) {
   tr->post_pending = false;
   ProfScope ps(tr, s, KC_SCHED);
   const PostArgs p = post_args(tr);
-  hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap);
+  hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault);
 }
 
 static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n, void* stream, bool fused) {
@@ -676,6 +751,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     a.n_wide = tr->n_wide; a.n_params = tr->n_params; a.st = st;
     a.bias_partials = tr->bias_partials; a.bias_layer_stride = tr->bias_layer_stride; a.n_layers = tr->L;
     a.skip_wide = fused ? 1 : 0;
+    a.fault = tr->seq_err;
     // partial rows per layer: one per 32-row workgroup from the chain kernel / the loss kernel, one per row tile from rowgemm
     for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2 || tr->chain) ? nblk : (tr->gemm_tile == 80 ? (n + 79) / 80 : 2 * ((n + 127) / 128));
     tr->last_reduce = a;   // the fused update reduces the partials itself
@@ -711,7 +787,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused) {
   if (tr->cfg.pose_refinement != 0)
     hipLaunchKernelGGL(adamw_small_kernel, dim3((unsigned)((tr->pb.n_pose_params + 255) / 256)), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,
                        tr->pb.d_pose_v, (const float*)(tr->pb.d_grad + tr->n_params + 4), (int64_t)0, 1, tr->pb.n_pose_params,
-                       (const AdamScalars*)&tr->st->pose_adam, (const int*)&tr->st->pose_enable, (const int*)&tr->st->active);
+                       (const AdamScalars*)&tr->st->pose_adam, (const int*)&tr->st->pose_enable, (const int*)&tr->st->active, (const int*)tr->seq_err);
   tr->post_pending = true;   // sched_post: with the next step's gather, or at the next state read-out (flush_post)
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
@@ -732,6 +808,9 @@ extern "C" int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out,
   ACEZ_REQUIRE(tr && h_out, "null pointer");
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   flush_post(tr, (hipStream_t)stream);
+  // a hand-off poll of the one-launch chains expired since the last read: the steps since then were no-ops on the device; from
+  // here on this trainer uses per-layer launches (acez_trainer_seq_status reports it)
+  seq_fault_check(tr, (hipStream_t)stream);
   TrainState hs;
   int chain_err = 0;
   ACEZ_HIP_CHECK(hipMemcpyAsync(&hs, tr->st, sizeof(TrainState), hipMemcpyDeviceToHost, (hipStream_t)stream));

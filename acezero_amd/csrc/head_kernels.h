@@ -125,6 +125,7 @@ struct GradReduceArgs {
   int64_t n_wide, n_params;
   const TrainState* st;
   int skip_wide;   // fused single-GPU step: the slabs are summed by adamw_kernel itself, only the tail is reduced here
+  const int* fault;   // the trainer's rowseq fault word (null: none); written to statistics slot 3
 };
 
 struct AdamArgs {
@@ -145,6 +146,7 @@ struct AdamArgs {
   int nslabs;
   int64_t slab_stride;
   GradReduceArgs tail;   // with slabs != null: the partials of the small parameters and statistics (reduced here as well)
+  int* fault;            // the trainer's rowseq fault word: a faulted step updates nothing
 };
 
 }  // namespace acez

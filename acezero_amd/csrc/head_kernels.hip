@@ -259,6 +259,9 @@ struct SeqLink {
   bool first, wait;      // first layer of the launch (requests its own W stages) / In is produced inside this launch
   bool signal;           // another layer follows: bump *flag after the stores
   const uint16_t* next_W;  // weights of the layer after (null: none): its first four W stages are requested before the epilogue
+  int* err;              // sticky fault word of the trainer: set when the bounded poll below expires (the host then falls back to
+                         // per-layer launches, head_api.hip seq_fault_check)
+  uint32_t spin_ticks;   // poll budget in s_memrealtime ticks (100 MHz)
 };
 constexpr int RG80_STAGE = (128 + 96) * 64;                        // elements per ring slot
 constexpr int RG80_SMEM = 4 * RG80_STAGE + 2 * 80 * 128;           // ring + two staging tiles
@@ -327,11 +330,25 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         // of the producing layer have landed in this XCD's L2 -- the In stages
         if (q.first) { issueW(0); issueW(1); issueW(2); issueW(3); }
         if (q.wait) {
+          // Bounded: a sibling that never arrives (workgroups of one row tile on different XCDs -- every L2 then holds its own copy
+          // of the counter and none of them ever reaches the target --, or a sibling that is never dispatched) must not hang the
+          // stream. When the budget expires the wave raises the sticky fault word and goes on with whatever is in memory: the
+          // results of this launch are garbage, the optimiser and schedule kernels of the step see the word and do nothing, and
+          // the host switches the trainer to per-layer launches at its next state read (head_api.hip).
           uint32_t seen;
-          do {   // sc1: past this CU's L1; the counter and the tiles live in the L2 all four workgroups share, no L2 invalidate
+          uint64_t t0 = 0;
+          for (;;) {   // sc1: past this CU's L1; the counter and the tiles live in the L2 all four workgroups share, no L2 invalidate
             asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(q.flag) : "memory");
-            if ((int32_t)(seen - q.target) < 0) __builtin_amdgcn_s_sleep(1);
-          } while ((int32_t)(seen - q.target) < 0);
+            seen = __builtin_amdgcn_readfirstlane(seen);   // every lane loaded the same word: a scalar loop condition
+            if ((int32_t)(seen - q.target) >= 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            const uint64_t now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > (uint64_t)q.spin_ticks) {
+              if (l == 0) __hip_atomic_store(q.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
         }
         issueI(0); issueI(1); issueI(2); issueI(3);
       }
@@ -563,6 +580,9 @@ struct RowSeqArgs {
   uint32_t* xcc_dbg;   // null, or [8 + 256]: words 0..7 |= 1 << XCC_ID of the workgroups with blockIdx & 7 = word (sticky); word
                        // 8 + 4 mt + nt = XCC_ID of the workgroup that owned tile (mt, nt) in the last launch (tests: the four column
                        // tiles of a row tile must report the same XCD)
+  int* err;            // sticky fault word: non-zero = a poll of this trainer has expired; every launch returns at once
+  uint32_t spin_ticks; // poll budget, s_memrealtime ticks (100 MHz)
+  int fault_inject;    // tests (ACEZ_SEQ_FAULT_AT): the first seam of this launch waits for a count that never comes
 };
 
 template <bool BWD>
@@ -578,6 +598,7 @@ __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
     atomicOr(a.xcc_dbg + (blockIdx.x & 7), 1u << xcc);
     a.xcc_dbg[8 + mt * 4 + (jx & 3)] = xcc;
   }
+  if (*a.err) return;            // a poll of this trainer has expired before: nothing runs until the host has fallen back
   if (a.st && !a.st->active) {   // training has ended on the device: no work, but the counters keep step with the host's bases
     if (threadIdx.x == 0) {      // (the same L2-local atomic as the hand-off itself)
       const uint32_t inc = 8u * (uint32_t)(a.n_layers - 1);
@@ -595,6 +616,8 @@ __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
     q.flag = a.flags + mt * 32; q.target = (a.base[mt] + (uint32_t)layer) * 32u;   // 4 workgroups x 8 waves per seam
     q.first = layer == 0; q.wait = layer > 0; q.signal = layer + 1 < a.n_layers;
     q.next_W = q.signal ? a.layer[layer + 1].W : nullptr;
+    q.err = a.err; q.spin_ticks = a.spin_ticks;
+    if (a.fault_inject && layer == 1) q.target += 1u << 20;
     if (!BWD) {
       if (y.aux_mode == AUX_RESIDUAL) rowgemm80_body<true, false, false, AUX_RESIDUAL, true>(g, smem, 1, mt, n0, q);
       else rowgemm80_body<true, false, false, AUX_NONE, true>(g, smem, 1, mt, n0, q);
@@ -604,6 +627,23 @@ __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
       else rowgemm80_body<false, false, true, AUX_NONE, true>(g, smem, 1, mt, n0, q);
     }
   }
+}
+
+// Placement probe (acez_trainer_create): a launch with rowseq_kernel's grid, block size and LDS footprint that only records
+// which XCD ran tile (mt, nt) under rowseq_kernel's decode. The host enables the one-launch chains only if the four column tiles
+// of every row tile report the same XCD. (A probe cannot promise anything about later launches -- HIP makes no placement
+// contract -- which is why the hand-off itself is bounded and fault-checked; the probe keeps a part or a partition mode on which
+// the mapping does not hold from ever taking the fault path.)
+__global__ __launch_bounds__(512) void seq_probe_kernel(uint32_t* rec /*[256]*/, int mtiles) {
+  __shared__ __attribute__((aligned(16))) uint16_t smem[RG80_SMEM_SEQ];
+  const int per_xcd = (mtiles + 7) >> 3;
+  const int jx = blockIdx.x >> 3;
+  const int mt = (blockIdx.x & 7) * per_xcd + (jx >> 2);
+  if (threadIdx.x == 0) smem[0] = (uint16_t)blockIdx.x;   // keeps the allocation
+  __syncthreads();
+  if (mt >= mtiles || threadIdx.x != 0) return;
+  const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
+  rec[mt * 4 + (jx & 3)] = (xcc << 16) | smem[0];
 }
 
 // host-side dispatch on the epilogue shape (the flags of RowGemmArgs select the instantiation)
@@ -1313,6 +1353,9 @@ __device__ __forceinline__ float tail_output(const GradReduceArgs& a, int64_t k,
     const int64_t kk = k - n_bias - n_fc3;
     if (kk < 3)
       for (int b = lane; b < a.n_loss_blocks; b += 64) acc += a.stat_partials[(size_t)b * 4 + kk];
+    // slot 3: this rank's rowseq fault word. It rides in the all-reduced bucket, so that a fault on ONE rank makes EVERY rank skip
+    // the optimiser step (adamw_kernel) and the replicas stay identical
+    else if (lane == 0 && a.fault) acc = *a.fault ? 1.f : 0.f;
     dst = a.n_params + kk;
   }
 #pragma unroll
@@ -1365,10 +1408,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   if (!st->active) return;
   float lossv;
   if (a.slabs) {   // fused step: the statistics are still partials; every wave sums the loss for itself
+    if (*a.fault) return;   // a hand-off poll of rowseq_kernel expired in this step: its gradients are garbage, nothing is updated
     int64_t d;
     lossv = tail_output(a.tail, (int64_t)a.n_layers * 512 + a.n_fc3, threadIdx.x & 63, d);
   } else {
     lossv = a.grad[a.n_params];
+    if (a.grad[a.n_params + 3] != 0.f) {   // some rank's fault word, summed by the all-reduce: every rank skips the step and
+      if (blockIdx.x == 0 && threadIdx.x == 0) *a.fault = 1;   // falls back at its next state read
+      return;
+    }
   }
   if (lossv != lossv) return;  // NaN loss: the reference aborts before the optimiser step (ace_trainer.py:615-617)
   const AdamScalars s = st->adam;
@@ -1631,7 +1679,8 @@ __global__ void sched_init_kernel(TrainState* st, SchedConfig c) {
 // Executed by ONE full wavefront (all 64 lanes must call it): the lanes cooperate on the minimum of the cool-down
 // criterion ring, lane 0 does the scalar bookkeeping.
 __device__ void sched_post_wave(TrainState* st, const SchedConfig& c, const float* grad_stats, float inv_global_batch,
-                                float* log_loss, float* log_inl, int log_cap) {
+                                float* log_loss, float* log_inl, int log_cap, const int* fault) {
+  if (fault && *fault) return;   // the step was abandoned (rowseq fault): no iteration is counted, nothing is logged
   const int lane = threadIdx.x & 63;
   // every load of the wave first: the scalar state (used by lane 0), the statistics, this lane's two ring entries
   SchedHot h = load_hot(st);
@@ -1714,8 +1763,8 @@ __device__ void sched_post_wave(TrainState* st, const SchedConfig& c, const floa
 }
 
 __global__ __launch_bounds__(64) void sched_post_kernel(TrainState* st, SchedConfig c, const float* grad_stats, float inv_global_batch,
-                                                        float* log_loss, float* log_inl, int log_cap) {
-  sched_post_wave(st, c, grad_stats, inv_global_batch, log_loss, log_inl, log_cap);
+                                                        float* log_loss, float* log_inl, int log_cap, const int* fault) {
+  sched_post_wave(st, c, grad_stats, inv_global_batch, log_loss, log_inl, log_cap, fault);
 }
 
 // step_begin: the batch gather of iteration i + 1 and, in ONE extra single-wave workgroup, the schedule bookkeeping that
@@ -1729,11 +1778,12 @@ struct PostArgs {
   float* log_loss;
   float* log_inl;
   int log_cap;
+  const int* fault;
 };
 __global__ __launch_bounds__(256) void step_begin_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
                                                          uint16_t* __restrict__ out, int n, PostArgs p) {
   if (blockIdx.x == gridDim.x - 1) {
-    if (threadIdx.x < 64) sched_post_wave(p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap);
+    if (threadIdx.x < 64) sched_post_wave(p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault);
     return;
   }
   const int lane = threadIdx.x & 63;

@@ -594,8 +594,9 @@ __global__ __launch_bounds__(256) void pose_grad_reduce2_kernel(const float* row
 // torch.optim.AdamW on a small flat parameter vector with its own step counter; the gradient is the fixed-order
 // sum of `nz` partial vectors. Applied only when *enable != 0 (ace_trainer.py:634-636).
 __global__ __launch_bounds__(256) void adamw_small_kernel(float* p, float* m, float* v, const float* gpart, int64_t gstride, int nz, int64_t n,
-                                                          const AdamScalars* sc, const int* enable, const int* active) {
+                                                          const AdamScalars* sc, const int* enable, const int* active, const int* fault) {
   if (active && !*active) return;
+  if (fault && *fault) return;   // abandoned step (rowseq fault, head_kernels.hip)
   if (enable && !*enable) return;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;

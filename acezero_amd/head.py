@@ -227,6 +227,13 @@ class HeadTrainer:
                 "nan": bool(st.nan_flag), "lr": st.lr, "loss": st.last_loss, "batch_inliers": st.last_batch_inliers,
                 "focal_scale": st.focal_scale}
 
+    def seq_status(self):
+        """One-launch GEMM chains (rowseq_kernel): {'enabled', 'probe' (placement probe at creation: 1 passed, 0 failed, -1 not run),
+        'faults' (fall-backs to per-layer launches taken after an expired hand-off poll; state() performs them)}."""
+        en, pr, fl = C.c_int(0), C.c_int(0), C.c_int(0)
+        N.check(self.lib.acez_trainer_seq_status(self._h, C.byref(en), C.byref(pr), C.byref(fl)))
+        return {"enabled": bool(en.value), "probe": pr.value, "faults": fl.value}
+
     def log(self, first, count):
         loss = np.zeros(count, np.float32)
         inl = np.zeros(count, np.float32)

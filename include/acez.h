@@ -253,6 +253,13 @@ int acez_trainer_last_scene_coords(acez_trainer* tr, float* h_xyz, int n, void* 
 int acez_trainer_set_profiling(acez_trainer* tr, int enable);
 int acez_trainer_get_profile(acez_trainer* tr, float* h_ms8, int32_t* h_counts8);
 
+/* Status of the one-launch GEMM chains (rowseq_kernel): *enabled = 1 while the trainer uses them, *probe = result
+ * of the placement probe run by acez_trainer_create (1 passed, 0 failed -> per-layer launches from the start, -1 not run), *faults =
+ * number of times a bounded hand-off poll expired and the trainer fell back to per-layer launches (acez_trainer_get_state performs the
+ * fall-back; the abandoned iterations are device-side no-ops and are not counted in acez_train_state.iteration). No reference
+ * counterpart. Any pointer may be NULL. */
+int acez_trainer_seq_status(acez_trainer* tr, int* enabled, int* probe, int* faults);
+
 /* Diagnostics for the tests: copy one intermediate device buffer of the last backward call to the host (synchronous).
  * kind 0: post-ReLU output of wide layer `index`, bf16 [n][512];  1: dZ of layer `index`, bf16 [n][512];
  * 2: residual stream `index` (0 = the gathered batch), bf16 [n][512];  3: weight-gradient slab `index`, f32 [n_wide];

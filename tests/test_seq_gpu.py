@@ -152,3 +152,122 @@ def test_sibling_workgroups_share_an_xcd():
         sib = rec[8:8 + 4 * ((n + 79) // 80)].reshape(-1, 4)
         assert (sib == sib[:, :1]).all(), (n, sib[(sib != sib[:, :1]).any(1)][:4])
         assert (sib < 8).all()
+
+
+def _small_trainer(prob, iterations=50, max_batch=2048):
+    from acezero_amd.head import HeadTrainer
+    from acezero_amd import synth
+    tr = HeadTrainer(prob["mean"], num_head_blocks=1, use_homogeneous=True, max_batch=max_batch, loss_type="tanh", schedule="constant",
+                     iterations=iterations, lr_min=3e-4)
+    tr.load_flat(torch.from_numpy(synth.init_head_params(11, num_head_blocks=1, use_homogeneous=True)))
+    tr.set_buffer(prob["features"], prob["target_px"], prob["view_idx"], prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"],
+                  prob["view_image"], prob["image_pose_inv"])
+    return tr
+
+
+def test_placement_probe_passes_on_this_gpu_and_gates_the_chains():
+    """acez_trainer_create runs a launch with rowseq_kernel's geometry and enables the one-launch chains only if the four column
+    tiles of every row tile ran on one XCD (HIP does not promise the mapping). On an MI355X in SPX mode the probe passes."""
+    prob = _big_problem(n_images=8, patches_per_view=256)
+    tr = _small_trainer(prob)
+    st = tr.seq_status()
+    assert st == {"enabled": True, "probe": 1, "faults": 0}, st
+    os.environ["ACEZ_SEQ"] = "0"
+    try:
+        assert _small_trainer(prob).seq_status()["enabled"] is False
+    finally:
+        os.environ.pop("ACEZ_SEQ", None)
+
+
+@pytest.mark.parametrize("fault_at", [2, 3])   # launch 2 = the forward chain of the second step, 3 = its input-gradient chain
+def test_expired_handoff_poll_abandons_the_step_and_falls_back_to_per_layer_launches(fault_at):
+    """Fault injection (ACEZ_SEQ_FAULT_AT): one seam of one launch waits for a count that never comes -- what a sibling on a foreign
+    XCD looks like. The poll must expire (no hang), the step it happened in must leave parameters, optimiser state and iteration
+    count untouched, every later step before the next state read must be a no-op too, state() must switch the trainer to
+    per-layer launches, and from there on the trajectory must be bit-identical to a per-layer trainer fed the surviving batches."""
+    prob = _big_problem(n_images=8, patches_per_view=256)
+    os.environ.update(ACEZ_SEQ_FAULT_AT=str(fault_at), ACEZ_SEQ_SPIN_US="3000")
+    try:
+        new = _small_trainer(prob)
+    finally:
+        os.environ.pop("ACEZ_SEQ_FAULT_AT"); os.environ.pop("ACEZ_SEQ_SPIN_US")
+    os.environ["ACEZ_SEQ"] = "0"
+    try:
+        ref = _small_trainer(prob)
+    finally:
+        os.environ.pop("ACEZ_SEQ", None)
+    rng = np.random.default_rng(4)
+    batches = [torch.from_numpy(rng.permutation(prob["features"].shape[0])[:2048].astype(np.int64)).cuda() for _ in range(7)]
+    new.step(batches[0])
+    ref.step(batches[0])
+    torch.cuda.synchronize()
+    assert torch.equal(new.params, ref.params)
+    before = (new.params.clone(), new.adam_m.clone(), new.adam_v.clone())
+    new.step(batches[1])          # the faulting step
+    new.step(batches[2])          # issued before the host knows: must be a no-op as well
+    torch.cuda.synchronize()
+    assert torch.equal(new.params, before[0]) and torch.equal(new.adam_m, before[1]) and torch.equal(new.adam_v, before[2])
+    st = new.state()              # the state read performs the fall-back
+    assert st["iteration"] == 1 and not st["nan"], st
+    assert new.seq_status() == {"enabled": False, "probe": 1, "faults": 1}
+    for b in batches[3:]:
+        new.step(b)
+        ref.step(b)
+    torch.cuda.synchronize()
+    assert torch.equal(new.params, ref.params) and torch.equal(new.adam_m, ref.adam_m) and torch.equal(new.adam_v, ref.adam_v)
+    assert new.state() == ref.state()
+    f = torch.from_numpy(prob["features"][:777]).cuda()
+    assert torch.equal(new.get_scene_coordinates(f), ref.get_scene_coordinates(f))
+
+
+def test_fault_word_travels_in_the_gradient_bucket():
+    """Data-parallel flow (backward / all-reduce / update): statistics slot 3 of the bucket carries the rank's fault word, so that
+    after the all-reduce EVERY rank skips the optimiser step and the replicas stay identical. One process plays both ranks here:
+    rank A faults, rank B does not; B receives A's slot through the (emulated) sum and must skip its update and fall back too."""
+    prob = _big_problem(n_images=8, patches_per_view=256)
+    os.environ.update(ACEZ_SEQ_FAULT_AT="0", ACEZ_SEQ_SPIN_US="3000")
+    try:
+        a = _small_trainer(prob)
+    finally:
+        os.environ.pop("ACEZ_SEQ_FAULT_AT"); os.environ.pop("ACEZ_SEQ_SPIN_US")
+    b = _small_trainer(prob)
+    rng = np.random.default_rng(8)
+    idx = torch.from_numpy(rng.permutation(prob["features"].shape[0])[:2048].astype(np.int64)).cuda()
+    a.backward(idx)
+    b.backward(idx)
+    torch.cuda.synchronize()
+    assert float(a.grad[a.n_params + 3]) == 1.0 and float(b.grad[b.n_params + 3]) == 0.0
+    total = a.grad + b.grad       # the all-reduce
+    a.grad.copy_(total)
+    b.grad.copy_(total)
+    p0 = b.params.clone()
+    a.update()
+    b.update()
+    torch.cuda.synchronize()
+    assert torch.equal(b.params, p0) and torch.equal(a.params, p0)
+    assert a.state()["iteration"] == 0 and b.state()["iteration"] == 0
+    assert a.seq_status()["faults"] == 1 and b.seq_status()["faults"] == 1 and not b.seq_status()["enabled"]
+
+
+@pytest.mark.parametrize("mask", ["", "0:0-223", "0:0-7,16-255", "0:0-31,64-255"])
+def test_restricted_cu_sets_are_bit_identical_or_fall_back(mask):
+    """Foreign placement forced from outside (HSA_CU_MASK leaves some XCDs short of CUs, or the runtime reports fewer CUs): the
+    trainer must either not use the chains (probe), or be bit-identical with them, or fall back after a bounded poll --
+    tools/seq_cu_mask.py checks the surviving trajectory against per-layer launches. Never a hang, never a silent difference."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("ACEZ_SEQ", None)
+    if mask:
+        env["HSA_CU_MASK"] = mask
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "seq_cu_mask.py"), "9", "5120"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    rec = json.loads(lines[-1])
+    print("HSA_CU_MASK=%r -> %s" % (mask, rec))
+    assert rec["bit_identical"], rec
+    if not mask:
+        assert rec["probe"] == 1 and rec["enabled_at_end"] and rec["faults"] == 0, rec
