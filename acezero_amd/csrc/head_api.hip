@@ -1,7 +1,7 @@
 // head_api.hip -- C-ABI entry points of the head training / inference path (include/acez.h, group T).
 // Host-side orchestration only: every entry point enqueues kernels of head_kernels.hip on the caller's stream.
 #include "head_kernels.hip"
-#include "pose_kernels.hip"
+#include "pose_fused.hip"
 #include "head_fused.hip"
 #include "head_chain.hip"
 #include "conv_launch.h"
@@ -55,6 +55,9 @@ struct acez_trainer {
   float *pa1 = nullptr, *pa2 = nullptr, *pa3 = nullptr, *pr = nullptr, *pf1 = nullptr, *pf2 = nullptr, *pdlt = nullptr, *pose_cur = nullptr;
   float *pdT = nullptr, *pddelta = nullptr, *pdz2 = nullptr, *pdz1 = nullptr, *pdr = nullptr, *pdzc3 = nullptr, *pdzc2 = nullptr, *pdzc1 = nullptr;
   float* pose_wt = nullptr;     // [4][128][128] transposed pose-network weights (forward)
+  // mlp refinement folded into the step's own launches (pose_fused.hip); ACEZ_POSE_FUSED=0 = the separate launches of round 2
+  bool pose_fused = true;
+  bool pose_wt_valid = false;   // pose_wt matches the parameters (kept up to date by the fused optimiser epilogue of pose_mlp_wgrad_kernel)
   float* row_dT = nullptr;
   int* row_image = nullptr;
   // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
@@ -214,7 +217,9 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_REQUIRE(tr, "out of host memory");
   ACEZ_HIP_CHECK(hipGetDevice(&tr->device));
   tr->cfg = *cfg;
-  if (cfg->pose_refinement != 0 && !(getenv("ACEZ_POSE_STREAM") && atoi(getenv("ACEZ_POSE_STREAM")) == 0)) {
+  if (const char* e = getenv("ACEZ_POSE_FUSED")) tr->pose_fused = atoi(e) != 0;
+  if (cfg->pose_refinement != 2) tr->pose_fused = false;
+  if (cfg->pose_refinement != 0 && !tr->pose_fused && !(getenv("ACEZ_POSE_STREAM") && atoi(getenv("ACEZ_POSE_STREAM")) == 0)) {
     ACEZ_HIP_CHECK(hipStreamCreateWithFlags(&tr->pose_stream, hipStreamNonBlocking));
     for (hipEvent_t* e : {&tr->ev_begin, &tr->ev_pose_fwd, &tr->ev_loss, &tr->ev_pose_bwd}) ACEZ_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
@@ -378,6 +383,7 @@ extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
   const int nblk = tr->L * 64 + (tr->no * 512 + 255) / 256;
   hipLaunchKernelGGL(recast_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
   ACEZ_HIP_CHECK(hipGetLastError());
+  tr->pose_wt_valid = false;   // the caller may have rewritten the pose parameters as well
   return ACEZ_OK;
 }
 
@@ -550,6 +556,31 @@ static void pose_forward(acez_trainer* tr, const int* active, hipStream_t s) {
   hipLaunchKernelGGL(pose_mlp_fwd_kernel, dim3((a.I + PN_IMG - 1) / PN_IMG), dim3(256), 0, s, a);
 }
 
+// the layer tables of pose_mlp_wgrad_kernel; fuse: AdamW (+ refreshed transposed copies) in the tile epilogue (single-GPU step)
+static void launch_pose_wgrad(acez_trainer* tr, const int* active, bool fuse, hipStream_t s) {
+  const int I = tr->buf.n_images;
+  PoseWgradArgs w{};
+  const float* T0 = tr->buf.d_image_pose_inv;
+  const float* dY[7] = {tr->pddelta, tr->pdz2, tr->pdz1, tr->pdr, tr->pdzc3, tr->pdzc2, tr->pdzc1};
+  const float* X[7] = {tr->pf2, tr->pf1, tr->pr, T0, tr->pa2, tr->pa1, T0};
+  const int O[7] = {12, 128, 128, 128, 128, 128, 128}, K[7] = {128, 128, 128, 12, 128, 128, 12}, XP[7] = {128, 128, 128, 16, 128, 128, 16};
+  const int64_t OW[7] = {PN_F3_W, PN_F2_W, PN_F1_W, PN_SKIP_W, PN_C3_W, PN_C2_W, PN_C1_W};
+  const int64_t OB[7] = {PN_F3_B, PN_F2_B, PN_F1_B, PN_SKIP_B, PN_C3_B, PN_C2_B, PN_C1_B};
+  const int WT[7] = {-1, 3, 2, -1, 1, 0, -1};   // pose_wt holds conv2, conv3, fc1, fc2 (pose_transpose_kernel)
+  int jobs = 0;
+  for (int l = 0; l < 7; ++l) {
+    w.dY[l] = dY[l]; w.X[l] = X[l]; w.O[l] = O[l]; w.K[l] = K[l]; w.xpitch[l] = XP[l]; w.offW[l] = OW[l]; w.offB[l] = OB[l];
+    w.wt_slot[l] = WT[l];
+    w.job_start[l] = jobs;
+    jobs += ((O[l] + 15) / 16) * ((K[l] + 15) / 16);
+  }
+  w.job_start[7] = jobs;
+  w.I = I; w.grad = tr->pb.d_grad + tr->n_params + 4; w.active = active;
+  w.fuse = fuse ? 1 : 0; w.p = tr->pb.d_pose_params; w.m = tr->pb.d_pose_m; w.v = tr->pb.d_pose_v; w.Wt = tr->pose_wt;
+  w.sc = &tr->st->pose_adam; w.enable = &tr->st->pose_enable; w.fault = tr->seq_err;
+  hipLaunchKernelGGL(pose_mlp_wgrad_kernel, dim3(jobs), dim3(256), 0, s, w);
+}
+
 static void launch_pose_grad_reduce(acez_trainer* tr, int n, const int* active, hipStream_t s) {
   const int I = tr->buf.n_images;
   hipLaunchKernelGGL(pose_grad_reduce2_kernel, dim3((I + 15) / 16), dim3(256), 0, s, (const float*)tr->row_dT, (const int*)tr->row_image, n,
@@ -562,22 +593,7 @@ static void pose_backward(acez_trainer* tr, int n, const int* active, hipStream_
   launch_pose_grad_reduce(tr, n, active, s);
   const PoseNetArgs a = pose_net_args(tr, active);
   hipLaunchKernelGGL(pose_mlp_bwd_kernel, dim3((I + PN_IMG - 1) / PN_IMG), dim3(256), 0, s, a);
-  PoseWgradArgs w{};
-  const float* T0 = tr->buf.d_image_pose_inv;
-  const float* dY[7] = {tr->pddelta, tr->pdz2, tr->pdz1, tr->pdr, tr->pdzc3, tr->pdzc2, tr->pdzc1};
-  const float* X[7] = {tr->pf2, tr->pf1, tr->pr, T0, tr->pa2, tr->pa1, T0};
-  const int O[7] = {12, 128, 128, 128, 128, 128, 128}, K[7] = {128, 128, 128, 12, 128, 128, 12}, XP[7] = {128, 128, 128, 16, 128, 128, 16};
-  const int64_t OW[7] = {PN_F3_W, PN_F2_W, PN_F1_W, PN_SKIP_W, PN_C3_W, PN_C2_W, PN_C1_W};
-  const int64_t OB[7] = {PN_F3_B, PN_F2_B, PN_F1_B, PN_SKIP_B, PN_C3_B, PN_C2_B, PN_C1_B};
-  int jobs = 0;
-  for (int l = 0; l < 7; ++l) {
-    w.dY[l] = dY[l]; w.X[l] = X[l]; w.O[l] = O[l]; w.K[l] = K[l]; w.xpitch[l] = XP[l]; w.offW[l] = OW[l]; w.offB[l] = OB[l];
-    w.job_start[l] = jobs;
-    jobs += ((O[l] + 15) / 16) * ((K[l] + 15) / 16);
-  }
-  w.job_start[7] = jobs;
-  w.I = I; w.grad = tr->pb.d_grad + tr->n_params + 4; w.active = active;
-  hipLaunchKernelGGL(pose_mlp_wgrad_kernel, dim3(jobs), dim3(256), 0, s, w);
+  launch_pose_wgrad(tr, active, false, s);
 }
 
 static PostArgs post_args(acez_trainer* tr) {
@@ -612,6 +628,8 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   // Pose refinement on its own stream: the refined poses are needed by the loss phase only, so their launches run beside the
   // head's forward chain; the pose-gradient launches run beside the input-gradient chain and wgrad.
   hipStream_t ps = (pose_mlp && tr->pose_stream) ? tr->pose_stream : s;
+  // mlp refinement folded into the step's own launches (pose_fused.hip): forward beside the gather, backward beside / behind the optimiser
+  const bool pf = tr->pose_fused && !tr->chain && !tr->fused_fwd;
   const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
   const int nblk = (n + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS);
   auto pose_fwd_launches = [&](hipStream_t q) {
@@ -657,9 +675,19 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     flush_post(tr, s);
     act = launch_forward_fused(tr, (const uint16_t*)tr->buf.d_features, d_indices, n, true, st, s);
   } else {
+  if (pf && !tr->pose_wt_valid) {   // first step / after acez_trainer_sync_weights / after a split (backward + update) step
+    hipLaunchKernelGGL(pose_transpose_kernel, dim3(4, 4, 4), dim3(256), 0, s, (const float*)tr->pb.d_pose_params, tr->pose_wt, (const int*)nullptr);
+    tr->pose_wt_valid = true;
+  }
   ProfScope* psg = new ProfScope(tr, s, KC_GATHER);
   const int gblocks = (n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024;
-  if (tr->post_pending) {   // gather of this step + the schedule bookkeeping of the previous one, in one launch
+  if (pf) {   // + the pose network's forward for all images, as the first workgroups of the same launch
+    const int np = (tr->buf.n_images + PN_IMG - 1) / PN_IMG;
+    const int do_post = tr->post_pending ? 1 : 0;
+    tr->post_pending = false;
+    hipLaunchKernelGGL(step_begin_pose_kernel, dim3(np + gblocks + 1), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n,
+                       post_args(tr), do_post, pose_net_args(tr, nullptr), np);
+  } else if (tr->post_pending) {   // gather of this step + the schedule bookkeeping of the previous one, in one launch
     tr->post_pending = false;
     hipLaunchKernelGGL(step_begin_kernel, dim3(gblocks + 1), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n,
                        post_args(tr));
@@ -672,7 +700,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     ACEZ_HIP_CHECK(hipEventRecord(tr->ev_begin, s));
     ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_begin, 0));
   }
-  pose_fwd_launches(ps);
+  if (!pf) pose_fwd_launches(ps);
   if (ps != s) ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_fwd, ps));
   if (!tr->fused_fwd) act = launch_forward(tr, tr->R[0], n, st, s);
   if (ps != s) ACEZ_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_pose_fwd, 0));   // the loss kernel projects with the refined poses
@@ -688,7 +716,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     ACEZ_HIP_CHECK(hipEventRecord(tr->ev_loss, s));
     ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_loss, 0));
   }
-  pose_bwd_launches(ps);
+  if (!pf) pose_bwd_launches(ps);
   if (ps != s) ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_bwd, ps));
 
   // input-gradient chain
@@ -763,6 +791,13 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     }
   }
   if (ps != s) ACEZ_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_pose_bwd, 0));   // d_grad's pose tail: read by the all-reduce and by the pose AdamW
+  if (pf && !fused) {
+    // split flow (a data-parallel host all-reduces d_grad next): the pose gradients must be complete now -- reduce + backward chain
+    // (S1) and the weight gradients as two launches on this stream; the single-GPU step runs S1 beside the head's AdamW instead
+    const PoseNetArgs a = pose_net_args(tr, &tr->st->active);
+    hipLaunchKernelGGL(pose_s1_kernel, dim3((tr->buf.n_images + PN_IMG - 1) / PN_IMG), dim3(256), 0, s, a, (const float*)tr->row_dT, (const int*)tr->row_image, n);
+    launch_pose_wgrad(tr, &tr->st->active, false, s);
+  }
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
 }
@@ -783,7 +818,21 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused) {
   if (fused) { a.slabs = tr->slabs; a.nslabs = tr->nslabs; a.slab_stride = tr->n_wide; a.tail = tr->last_reduce; }
   const int64_t n_small = (int64_t)tr->L * 512 + (int64_t)tr->no * 513;
   const int nsmall = fused ? (int)(((n_small + 4) * 64 + 255) / 256) : (int)((n_small + 255) / 256);   // fused: a wave per output
+  const bool pf = tr->pose_fused && !tr->chain && !tr->fused_fwd;
+  if (pf && fused) {
+    // the head's AdamW with the pose network's reduce + backward chain (S1) as the first workgroups of the same launch, then the
+    // pose weight gradients with AdamW in their epilogue (S2: needs S1 of every image tile)
+    const int np = (tr->buf.n_images + PN_IMG - 1) / PN_IMG;
+    { ProfScope ps(tr, s, KC_ADAMW);
+      hipLaunchKernelGGL(adamw_pose_kernel, dim3(np + tr->L * 64 + nsmall), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active),
+                         (const float*)tr->row_dT, (const int*)tr->row_image, tr->last_n, np); }
+    launch_pose_wgrad(tr, &tr->st->active, true, s);
+    tr->post_pending = true;
+    ACEZ_HIP_CHECK(hipGetLastError());
+    return ACEZ_OK;
+  }
   { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3(tr->L * 64 + nsmall), dim3(256), 0, s, a); }
+  if (tr->cfg.pose_refinement != 0) tr->pose_wt_valid = false;   // adamw_small_kernel does not refresh the transposed copies
   if (tr->cfg.pose_refinement != 0)
     hipLaunchKernelGGL(adamw_small_kernel, dim3((unsigned)((tr->pb.n_pose_params + 255) / 256)), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,
                        tr->pb.d_pose_v, (const float*)(tr->pb.d_grad + tr->n_params + 4), (int64_t)0, 1, tr->pb.n_pose_params,

@@ -1403,7 +1403,9 @@ __device__ __forceinline__ float adamw_one(float p, float g, float& m, float& v,
   return p - s.step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+// One workgroup's share of the optimiser step (b = workgroup index inside the optimiser's part of a launch; tileT: 64 x 66 bf16 LDS).
+// The body of adamw_kernel and of adamw_pose_kernel (pose_fused.hip), where the pose network's backward runs beside it.
+__device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint16_t (*tileT)[66]) {
   const TrainState* st = a.st;
   if (!st->active) return;
   float lossv;
@@ -1414,39 +1416,51 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   } else {
     lossv = a.grad[a.n_params];
     if (a.grad[a.n_params + 3] != 0.f) {   // some rank's fault word, summed by the all-reduce: every rank skips the step and
-      if (blockIdx.x == 0 && threadIdx.x == 0) *a.fault = 1;   // falls back at its next state read
+      if (b == 0 && threadIdx.x == 0) *a.fault = 1;   // falls back at its next state read
       return;
     }
   }
   if (lossv != lossv) return;  // NaN loss: the reference aborts before the optimiser step (ace_trainer.py:615-617)
   const AdamScalars s = st->adam;
-  __shared__ uint16_t tileT[64][66];
   const int t = threadIdx.x;
-  const int b = blockIdx.x;
   const int tiles_per_layer = 64;
   if (b < a.n_layers * tiles_per_layer) {
     const int layer = b / tiles_per_layer, tl = b % tiles_per_layer;
     const int r0 = (tl >> 3) * 64, c0 = (tl & 7) * 64;
     const int64_t woff = a.w_off[layer];
-    // 64 x 64 tile: thread handles 16 elements, rows (t>>4) + 16*i, 4 consecutive cols
+    // 64 x 64 tile: thread handles 16 elements, rows (t>>4) + 16*i, 4 consecutive cols.
+    // Every load of the tile first, then the arithmetic and the stores: written as one loop (load, compute, store per row group)
+    // the loads of row group i + 1 could not be moved above the stores of row group i (same arrays, no alias information), so a
+    // workgroup made four dependent memory round trips instead of one.
     const int cc = (t & 15) * 4;
+    float4 p4[4], g4[4], m4[4], v4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rr = (t >> 4) + 16 * i;
       const int64_t o = woff + (int64_t)(r0 + rr) * 512 + c0 + cc;
-      float4 p = *reinterpret_cast<float4*>(a.params + o);
-      float4 g;
-      if (a.slabs) {   // same additions, in the same order, as grad_reduce_kernel's wide part
-        g = *reinterpret_cast<const float4*>(a.slabs + o);
-        for (int sl = 1; sl < a.nslabs; ++sl) {
-          const float4 q = *reinterpret_cast<const float4*>(a.slabs + (size_t)sl * a.slab_stride + o);
-          g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
+      p4[i] = *reinterpret_cast<const float4*>(a.params + o);
+      m4[i] = *reinterpret_cast<const float4*>(a.m + o);
+      v4[i] = *reinterpret_cast<const float4*>(a.v + o);
+      g4[i] = *reinterpret_cast<const float4*>((a.slabs ? a.slabs : a.grad) + o);
+    }
+    if (a.slabs) {   // same additions, in the same order, as grad_reduce_kernel's wide part
+      for (int sl = 1; sl < a.nslabs; ++sl) {
+        float4 q4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = (t >> 4) + 16 * i;
+          q4[i] = *reinterpret_cast<const float4*>(a.slabs + (size_t)sl * a.slab_stride + woff + (int64_t)(r0 + rr) * 512 + c0 + cc);
         }
-      } else {
-        g = *reinterpret_cast<const float4*>(a.grad + o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { g4[i].x += q4[i].x; g4[i].y += q4[i].y; g4[i].z += q4[i].z; g4[i].w += q4[i].w; }
       }
-      float4 m = *reinterpret_cast<float4*>(a.m + o);
-      float4 v = *reinterpret_cast<float4*>(a.v + o);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (t >> 4) + 16 * i;
+      const int64_t o = woff + (int64_t)(r0 + rr) * 512 + c0 + cc;
+      float4 p = p4[i], m = m4[i], v = v4[i];
+      const float4 g = g4[i];
       p.x = adamw_one(p.x, g.x, m.x, v.x, s);
       p.y = adamw_one(p.y, g.y, m.y, v.y, s);
       p.z = adamw_one(p.z, g.z, m.z, v.z, s);
@@ -1503,6 +1517,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
       if (k >= n_bias && (k - n_bias) < (int64_t)a.no * 512) a.W3b[k - n_bias] = f2bf(p);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+  __shared__ uint16_t tileT[64][66];
+  adamw_body(a, blockIdx.x, tileT);
 }
 
 // recast only (no optimiser step): used after loading weights

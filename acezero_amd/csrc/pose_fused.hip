@@ -1,0 +1,57 @@
+// pose_fused.hip -- the pose-refinement network (pose_kernels.hip; refine_poses.py:152-176,212-244) folded into launches the
+// training step makes anyway (--pose_refinement mlp: every non-seed mapping round of ace_zero.py, ace_zero.py:86).
+//
+// As its own launches -- even on a second stream -- the network cost 72 us on top of a 166 us step (BENCH_r02: 237.7 vs 165.7 us):
+// six small dependent kernels of 12-18 us each (63 workgroups at 1000 images) whose latency nothing hid, because the head's GEMM
+// workgroups own the LDS of every CU while they run and a second hardware queue makes the kernel boundaries of both queues dearer.
+// The dependency structure allows better:
+//
+//   pose forward  (S3)  needs the pose parameters of the previous step, feeds the loss kernel      -> beside the batch gather
+//   reduce + backward chain (S1) needs the loss kernel's per-row pose gradients                     -> beside the head's AdamW
+//   weight gradients + AdamW (S2) needs S1 of ALL image tiles (a grid-wide dependency)              -> one launch after it
+//
+// "Beside" = extra workgroups at the FRONT of the same launch (lowest block indices: they are dispatched first and are the
+// long pole). Only launches whose own workgroups are small qualify -- the gather (no LDS) and the optimiser (8 KiB, HBM-bound): a
+// kernel's LDS and register allocation is the same for all of its workgroups, so the GEMM launches (112-154 KiB) cannot host them.
+// The pose workgroups are unchanged bodies of pose_kernels.hip; the per-image results are the same sums in the same order.
+#include "pose_kernels.hip"
+
+namespace acez {
+
+// step_begin + S3: blocks [0, np) = pose forward tiles; then the gather blocks; the last block = the schedule bookkeeping that
+// closes the previous iteration (do_post) -- exactly step_begin_kernel. The pose forward does not look at st->active (the schedule
+// block of this very launch is rewriting it): refined poses computed for a step that turns out to be inactive are never used.
+__global__ __launch_bounds__(256, 2) void step_begin_pose_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
+                                                                 uint16_t* __restrict__ out, int n, PostArgs p, int do_post, PoseNetArgs a, int np) {
+  if ((int)blockIdx.x < np) {
+    pose_mlp_fwd_body(a, blockIdx.x);
+    return;
+  }
+  const int gb = (int)blockIdx.x - np, ngb = (int)gridDim.x - np - 1;
+  if (gb == ngb) {
+    if (do_post && threadIdx.x < 64) sched_post_wave(p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = (gb * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (ngb * blockDim.x) >> 6;
+  for (int r = wave; r < n; r += nwaves) {
+    const int64_t src = idx[r];
+    const uint4 v = *reinterpret_cast<const uint4*>(feat + src * 512 + lane * 8);
+    *reinterpret_cast<uint4*>(out + (size_t)r * 512 + lane * 8) = v;
+  }
+}
+
+// AdamW of the head + S1: blocks [0, np) = reduce + backward chain of one 16-image tile each, the rest = adamw_kernel's blocks.
+constexpr int ADAMW_POSE_SMEM = PS1_SMEM_BYTES > 64 * 66 * 2 ? PS1_SMEM_BYTES : 64 * 66 * 2;
+__global__ __launch_bounds__(256, 2) void adamw_pose_kernel(AdamArgs a, PoseNetArgs pn, const float* row_dT, const int* row_image, int n, int np) {
+  __shared__ __attribute__((aligned(16))) char smem[ADAMW_POSE_SMEM];
+  if ((int)blockIdx.x < np) {
+    if (pn.active && !*pn.active) return;
+    pose_s1_body(pn, row_dT, row_image, n, blockIdx.x, smem);
+    return;
+  }
+  adamw_body(a, (int)blockIdx.x - np, reinterpret_cast<uint16_t (*)[66]>(smem));
+}
+
+}  // namespace acez

@@ -320,10 +320,10 @@ __device__ __forceinline__ void pn_mfma_layer(const PnA<K>& A, int N, const floa
   }
 }
 
-__global__ __launch_bounds__(256) void pose_mlp_fwd_kernel(PoseNetArgs a) {
-  if (a.active && !*a.active) return;
+// refined poses of the 16 images of tile `tile` (all 256 threads of a workgroup; 25 KiB of LDS)
+__device__ __forceinline__ void pose_mlp_fwd_body(const PoseNetArgs& a, const int tile) {
   __shared__ float sT[12 * PN_IMG], sX[128 * PN_IMG], sY[128 * PN_IMG], sZ[128 * PN_IMG];
-  const int t = threadIdx.x, i0 = blockIdx.x * PN_IMG;
+  const int t = threadIdx.x, i0 = tile * PN_IMG;
   if (t < 12 * PN_IMG) {
     const int k = t / PN_IMG, i = t % PN_IMG;
     sT[k * PN_IMG + i] = (i0 + i < a.I) ? a.T0[(size_t)(i0 + i) * 16 + k] : 0.f;
@@ -360,6 +360,11 @@ __global__ __launch_bounds__(256) void pose_mlp_fwd_kernel(PoseNetArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void pose_mlp_fwd_kernel(PoseNetArgs a) {
+  if (a.active && !*a.active) return;
+  pose_mlp_fwd_body(a, blockIdx.x);
+}
+
 // Wt[l][k][n] = W_l[n][k] for the four 128 x 128 layers (conv2, conv3, fc1, fc2): 64 K elements, once per step
 __global__ __launch_bounds__(256) void pose_transpose_kernel(const float* P, float* Wt, const int* active) {
   if (active && !*active) return;
@@ -375,10 +380,10 @@ __global__ __launch_bounds__(256) void pose_transpose_kernel(const float* P, flo
   for (int j = 0; j < 32; j += 8) Wt[(size_t)l * 16384 + (bx + ty + j) * 128 + by + tx] = tile[tx][ty + j];
 }
 
-__global__ __launch_bounds__(256) void pose_mlp_bwd_kernel(PoseNetArgs a) {
-  if (a.active && !*a.active) return;
-  __shared__ float sD[12 * PN_IMG], sX[128 * PN_IMG], sY[128 * PN_IMG];
-  const int t = threadIdx.x, i0 = blockIdx.x * PN_IMG;
+// compose backward + the chain of input gradients for the 16 images of tile `tile`. dT16: gradient wrt the refined poses of these 16
+// images, [16][12] (global or LDS); sD / sX / sY: LDS, 12 x 16, 128 x 16 and 128 x 16 floats
+__device__ __forceinline__ void pose_mlp_bwd_body(const PoseNetArgs& a, const int tile, const float* dT16, float* sD, float* sX, float* sY) {
+  const int t = threadIdx.x, i0 = tile * PN_IMG;
   // compose backward (one thread per image): gradient wrt the refined pose -> gradient wrt the network output
   if (t < PN_IMG) {
     float o[12];
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256) void pose_mlp_bwd_kernel(PoseNetArgs a) {
       float Pm[12];
 #pragma unroll
       for (int k = 0; k < 12; ++k) Pm[k] = a.T0[(size_t)i * 16 + k] + a.w * a.delta[(size_t)i * 12 + k];
-      pose_orthonormalise_bwd(Pm, a.dT + (size_t)i * 12, a.ortho, a.w, o);
+      pose_orthonormalise_bwd(Pm, dT16 + t * 12, a.ortho, a.w, o);
 #pragma unroll
       for (int k = 0; k < 12; ++k) a.ddelta[(size_t)i * 12 + k] = o[k];
     }
@@ -421,10 +426,27 @@ __global__ __launch_bounds__(256) void pose_mlp_bwd_kernel(PoseNetArgs a) {
   pn_mfma_layer<128>(Ab, 128, nullptr, sX, false, nullptr, a.a1, sY, a.dzc1, i0, a.I);
 }
 
+__global__ __launch_bounds__(256) void pose_mlp_bwd_kernel(PoseNetArgs a) {
+  if (a.active && !*a.active) return;
+  __shared__ float sD[12 * PN_IMG], sX[128 * PN_IMG], sY[128 * PN_IMG];
+  pose_mlp_bwd_body(a, blockIdx.x, a.dT + (size_t)blockIdx.x * PN_IMG * 12, sD, sX, sY);
+}
+
 // dW[o][k] = sum_i dY[i][o] X[i][k], db[o] = sum_i dY[i][o] for the seven layers, on the fp32 matrix cores straight from global
 // memory: a workgroup owns one 16 x 16 tile of one layer's dW; its four waves take a quarter of the images each
 // (A(o, img) = dY[img][o], B(img, k) = X[img][k], 4 images per MFMA step) and are combined in wave order -> the FINAL gradient,
 // no partial buffers. Tiles with k-block 0 also produce the bias gradient (B = 1).
+// torch.optim.AdamW for one element of the pose parameters. No fma contraction: the function is inlined into adamw_small_kernel and
+// into the fused epilogue of pose_mlp_wgrad_kernel, and both must round identically.
+__device__ __forceinline__ float adamw_small_one(float p, float gv, float& mv, float& vv, const AdamScalars& s) {
+#pragma clang fp contract(off)
+  const float pv = p * s.decay;
+  mv = mv + (gv - mv) * s.one_minus_beta1;
+  vv = vv * s.beta2 + s.one_minus_beta2 * gv * gv;
+  const float denom = sqrtf(vv) / s.bc2_sqrt + s.eps;
+  return pv - s.step_size * (mv / denom);
+}
+
 struct PoseWgradArgs {
   const float* dY[7]; const float* X[7];
   int O[7], K[7], xpitch[7];
@@ -433,6 +455,15 @@ struct PoseWgradArgs {
   float* grad;            // pose gradient vector (d_grad + n_params + 4)
   const int* active;
   int job_start[8];       // prefix sums of ceil(O / 16) * ceil(K / 16) over the layers
+  // Fused optimiser (single-GPU step: the tile's gradient is final inside this workgroup, so AdamW -- adamw_small_kernel's arithmetic --
+  // is applied on the spot and the transposed forward copies Wt[wt_slot] of the four 128 x 128 layers are refreshed): fuse = 0 in
+  // the backward / all-reduce / update flow, where adamw_small_kernel and pose_transpose_kernel do this after the all-reduce.
+  int fuse;
+  float *p, *m, *v, *Wt;
+  int wt_slot[7];         // index into Wt[4][128][128] of the layer, -1: none
+  const AdamScalars* sc;
+  const int* enable;      // st->pose_enable (ace_trainer.py:634-636)
+  const int* fault;       // rowseq fault word: an abandoned step updates nothing
 };
 __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
   if (a.active && !*a.active) return;
@@ -495,13 +526,42 @@ __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
   }
   __syncthreads();
   if (w == 0) {
+    const bool upd = a.fuse && *a.enable && !*a.fault;
+    // every operand of the optimiser first (one round trip), then the arithmetic
+    float pw[4], mw[4], vw[4], pb[4], mb[4], vb[4];
+    AdamScalars s{};
+    if (upd) {
+      s = *a.sc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = min(o0 + 4 * lk + r, O - 1), kk = min(k0 + li, K - 1);
+        const size_t iw = a.offW[layer] + (size_t)o * K + kk, ib = a.offB[layer] + o;
+        pw[r] = a.p[iw]; mw[r] = a.m[iw]; vw[r] = a.v[iw];
+        pb[r] = a.p[ib]; mb[r] = a.m[ib]; vb[r] = a.v[ib];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int oo = 4 * lk + r, o = o0 + oo, kk = k0 + li;
       const float g = ((sAcc[0][0][oo][li] + sAcc[1][0][oo][li]) + sAcc[2][0][oo][li]) + sAcc[3][0][oo][li];
-      if (o < O && kk < K) a.grad[a.offW[layer] + (size_t)o * K + kk] = g;
-      if (want_bias && li == 0 && o < O)
-        a.grad[a.offB[layer] + o] = ((sAcc[0][1][oo][0] + sAcc[1][1][oo][0]) + sAcc[2][1][oo][0]) + sAcc[3][1][oo][0];
+      if (o < O && kk < K) {
+        const size_t iw = a.offW[layer] + (size_t)o * K + kk;
+        a.grad[iw] = g;
+        if (upd) {
+          const float pn = adamw_small_one(pw[r], g, mw[r], vw[r], s);
+          a.p[iw] = pn; a.m[iw] = mw[r]; a.v[iw] = vw[r];
+          if (a.wt_slot[layer] >= 0) a.Wt[(size_t)a.wt_slot[layer] * 16384 + (size_t)kk * 128 + o] = pn;
+        }
+      }
+      if (want_bias && li == 0 && o < O) {
+        const float gb = ((sAcc[0][1][oo][0] + sAcc[1][1][oo][0]) + sAcc[2][1][oo][0]) + sAcc[3][1][oo][0];
+        const size_t ib = a.offB[layer] + o;
+        a.grad[ib] = gb;
+        if (upd) {
+          a.p[ib] = adamw_small_one(pb[r], gb, mb[r], vb[r], s);
+          a.m[ib] = mb[r]; a.v[ib] = vb[r];
+        }
+      }
     }
   }
 }
@@ -511,19 +571,18 @@ __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
 // round trip each: (1) each wave loads its quarter of the row -> image table into registers and appends the hits of its images, in row
 // order, to an LDS list (ballot + popcount); (2) all hit rows are fetched together into LDS; (3) thread (image, component) walks the
 // lists in order and adds from LDS.
-constexpr int PGR_MAX_HITS = 1024;   // per workgroup (16 images) and pass
-__global__ __launch_bounds__(256) void pose_grad_reduce2_kernel(const float* row_dT /*[n][12]*/, const int* row_image /*[n]*/, int n,
-                                                                float* dT /*[I][12]*/, int n_images, const int* active) {
-  if (active && !*active) return;
-  __shared__ int sRow[PGR_MAX_HITS];
-  __shared__ unsigned char sRel[PGR_MAX_HITS];
-  __shared__ float sVal[PGR_MAX_HITS][12];
-  __shared__ int sCnt[4];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, i0 = blockIdx.x * 16;
-  constexpr int cap = PGR_MAX_HITS / 4;            // list capacity per wave
-  // One pass over all rows when the lists fit (many images: ~5 rows per image); otherwise (few images) passes of 1024 rows, which
+// The three phases as a body over caller-provided LDS (MAX_HITS: list capacity per workgroup and pass, a multiple of 256):
+//   sRow int[MAX_HITS], sRel u8[MAX_HITS], sVal float[MAX_HITS][12], sCnt int[4];  out192: [16][12] sums (LDS or global), written by
+// threads 0..191. Every thread of the 256-thread workgroup must call it.
+template <int MAX_HITS>
+__device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ row_dT, const int* __restrict__ row_image, const int n, const int i0,
+                                                      int* sRow, unsigned char* sRel, float (*sVal)[12], int* sCnt, float* out192) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  constexpr int cap = MAX_HITS / 4;            // list capacity per wave
+  // One pass over all rows when the lists fit (many images: ~5 rows per image); otherwise (few images) passes of MAX_HITS rows, which
   // cannot overflow. Row order is preserved either way.
   int chunk = n;
+  float result = 0.f;
   for (int attempt = 0; attempt < 2; ++attempt) {
     float acc = 0.f;                               // thread (image t / 12, component t % 12)
     bool overflow = false;
@@ -582,13 +641,50 @@ __global__ __launch_bounds__(256) void pose_grad_reduce2_kernel(const float* row
             if (sRel[wv * cap + h] == im) acc += sVal[wv * cap + h][c];
       }
     }
-    if (!overflow) {
-      if (t < 16 * 12 && i0 + t / 12 < n_images) dT[(size_t)(i0 + t / 12) * 12 + t % 12] = acc;
-      return;
-    }
-    chunk = 1024;                                  // 256 rows per wave: the lists cannot overflow
+    if (!overflow) { result = acc; break; }
+    chunk = MAX_HITS;                              // MAX_HITS / 4 rows per wave: the lists cannot overflow
     __syncthreads();
   }
+  if (t < 16 * 12) out192[t] = result;
+}
+
+constexpr int PGR_MAX_HITS = 1024;   // per workgroup (16 images) and pass
+__global__ __launch_bounds__(256) void pose_grad_reduce2_kernel(const float* row_dT /*[n][12]*/, const int* row_image /*[n]*/, int n,
+                                                                float* dT /*[I][12]*/, int n_images, const int* active) {
+  if (active && !*active) return;
+  __shared__ int sRow[PGR_MAX_HITS];
+  __shared__ unsigned char sRel[PGR_MAX_HITS];
+  __shared__ float sVal[PGR_MAX_HITS][12];
+  __shared__ int sCnt[4];
+  __shared__ float sOut[16 * 12];
+  const int t = threadIdx.x, i0 = blockIdx.x * 16;
+  pose_grad_reduce_body<PGR_MAX_HITS>(row_dT, row_image, n, i0, sRow, sRel, sVal, sCnt, sOut);
+  if (t < 16 * 12 && i0 + t / 12 < n_images) dT[(size_t)(i0 + t / 12) * 12 + t % 12] = sOut[t];   // (each thread reads its own word back)
+}
+
+// ---------------------------------------------------------------------------------------------------
+// S1 = per-image reduction of the loss kernel's per-row pose gradients + compose backward + the input-gradient chain of the pose
+// network, for one tile of 16 images, in ONE workgroup pass (was two launches, 13 + 18 us at 1000 images). 28 KiB of LDS so that
+// the workgroups can sit beside the optimiser's (adamw_pose_kernel, pose_fused.hip); the reduction's hit lists and the chain's
+// activation tiles share storage.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PS1_HITS = 512;
+constexpr int PS1_SMEM_BYTES = PS1_HITS * 4 + PS1_HITS + 16 + 16 * 12 * 4 + PS1_HITS * 12 * 4;   // sRow, sRel, sCnt, sDT, sVal | (sD, sX, sY)
+static_assert(PS1_HITS * 12 * 4 >= (12 + 128 + 128) * PN_IMG * 4, "the chain's tiles must fit in the hit-value area");
+__device__ __forceinline__ void pose_s1_body(const PoseNetArgs& a, const float* row_dT, const int* row_image, const int n, const int tile, char* smem) {
+  int* sRow = reinterpret_cast<int*>(smem);
+  unsigned char* sRel = reinterpret_cast<unsigned char*>(smem + PS1_HITS * 4);
+  int* sCnt = reinterpret_cast<int*>(smem + PS1_HITS * 5);
+  float* sDT = reinterpret_cast<float*>(smem + PS1_HITS * 5 + 16);
+  float* area = sDT + 16 * 12;
+  pose_grad_reduce_body<PS1_HITS>(row_dT, row_image, n, tile * PN_IMG, sRow, sRel, reinterpret_cast<float (*)[12]>(area), sCnt, sDT);
+  __syncthreads();   // sDT complete; the hit values are dead, their area becomes the chain's tiles
+  pose_mlp_bwd_body(a, tile, sDT, area, area + 12 * PN_IMG, area + (12 + 128) * PN_IMG);
+}
+__global__ __launch_bounds__(256) void pose_s1_kernel(PoseNetArgs a, const float* row_dT, const int* row_image, int n) {
+  if (a.active && !*a.active) return;
+  __shared__ __attribute__((aligned(16))) char smem[PS1_SMEM_BYTES];
+  pose_s1_body(a, row_dT, row_image, n, blockIdx.x, smem);
 }
 
 // torch.optim.AdamW on a small flat parameter vector with its own step counter; the gradient is the fixed-order
@@ -603,11 +699,8 @@ __global__ __launch_bounds__(256) void adamw_small_kernel(float* p, float* m, fl
   const AdamScalars s = *sc;
   float gv = 0.f;
   for (int z = 0; z < nz; ++z) gv += gpart[(int64_t)z * gstride + i];
-  float pv = p[i] * s.decay, mv = m[i], vv = v[i];
-  mv = mv + (gv - mv) * s.one_minus_beta1;
-  vv = vv * s.beta2 + s.one_minus_beta2 * gv * gv;
-  const float denom = sqrtf(vv) / s.bc2_sqrt + s.eps;
-  p[i] = pv - s.step_size * (mv / denom);
+  float mv = m[i], vv = v[i];
+  p[i] = adamw_small_one(p[i], gv, mv, vv, s);
   m[i] = mv;
   v[i] = vv;
 }

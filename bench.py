@@ -34,6 +34,24 @@ GEMM_FLOP_PER_LAUNCH_PER_ROW = 2 * 512 * 512
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
 
 
+CSRC = os.path.join(ROOT, "acezero_amd", "csrc")
+STEP_SOURCES = ("head_api.hip", "head_kernels.hip", "head_kernels.h", "gemm_common.h", "pose_kernels.hip", "pose_fused.hip")
+RANSAC_SOURCES = ("ransac_api.hip", "ransac_math.h", "det_math.h")
+WINDOWS = 5                       # timed windows of --steps steps each: `value` = mean over all of them, ms_per_step = their median
+
+
+def src_digest(files):
+    """sha256 over the named kernel sources: stored counter profiles carry it, and a stored figure is only quoted on the JSON line
+    while the running build still has the sources it was measured on (otherwise the field is null, never stale)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in files:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,11 +69,12 @@ def parse():
     return ap.parse_args()
 
 
-def make_buffer(n_patches, device, seed):
-    """Synthetic training buffer directly in HBM (geometry from acezero_amd.synth, features generated on device)."""
+def make_buffer(n_patches, device, seed, n_images=1000, grid=(80, 60)):
+    """Synthetic training buffer directly in HBM (geometry from acezero_amd.synth, features generated on device).
+    grid = feature-map size (w, h): 80 x 60 for 480x640 frames, 93 x 60 for the 480x741 frames of the garden-like leg."""
     from acezero_amd import synth
-    views = 2000
-    prob = synth.make_training_problem(seed=seed, n_images=1000, views_per_image=2, patches_per_view=8)
+    views = 2 * n_images
+    prob = synth.make_training_problem(seed=seed, n_images=n_images, views_per_image=2, patches_per_view=8, width=8 * grid[0], height=8 * grid[1])
     g = torch.Generator(device=device).manual_seed(seed)
     feats = torch.empty(n_patches, 512, dtype=torch.bfloat16, device=device)
     chunk = 1 << 20
@@ -63,13 +82,14 @@ def make_buffer(n_patches, device, seed):
         hi = min(n_patches, lo + chunk)
         feats[lo:hi] = torch.randn(hi - lo, 512, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
     view_idx = torch.randint(0, views, (n_patches,), generator=g, device=device, dtype=torch.int32)
-    gx = torch.randint(0, 80, (n_patches,), generator=g, device=device)
-    gy = torch.randint(0, 60, (n_patches,), generator=g, device=device)
+    gx = torch.randint(0, grid[0], (n_patches,), generator=g, device=device)
+    gy = torch.randint(0, grid[1], (n_patches,), generator=g, device=device)
     target_px = torch.stack([8.0 * (gx + 0.5), 8.0 * (gy + 0.5)], dim=1).float()
     return prob, feats, target_px, view_idx
 
 
-def bench_training(args, rank, world, device, pose_refinement=None, steps=None, buffer_patches=None, strong=False):
+def bench_training(args, rank, world, device, pose_refinement=None, steps=None, buffer_patches=None, strong=False, windows=WINDOWS,
+                   n_images=1000, grid=(80, 60)):
     """pose_refinement None -> args.pose_refinement (the headline leg); 'mlp' -> ace_zero's non-seed mapping iterations
     (--pose_refinement mlp --refine_calibration True, ace_zero.py:86,97,262-264).
     strong=True: the REFERENCE's step on N GPUs -- the global batch stays 5120, every rank draws the same permutation of the global
@@ -81,8 +101,8 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
     from acezero_amd import synth
     from acezero_amd.head import HeadTrainer
     per_rank = buffer_patches // world
-    prob, feats, target_px, view_idx = make_buffer(per_rank, device, 2089 + rank)
-    total_iters = steps + args.warmup + 64
+    prob, feats, target_px, view_idx = make_buffer(per_rank, device, 2089 + rank, n_images=n_images, grid=grid)
+    total_iters = windows * steps + args.warmup + 64
     tr = HeadTrainer(prob["mean"], max_batch=BATCH, global_batch=BATCH if strong else BATCH * world, loss_type="tanh", schedule="1cyclepoly",
                      iterations=max(total_iters, 25000), lr_min=0.0005, lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005,
                      cooldown_iterations=5000, pose_refinement=pose_refinement,
@@ -115,25 +135,31 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
 
     for i in range(args.warmup):
         step(i)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(args.warmup + i)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # `windows` timed windows of exactly `steps` steps, each bracketed by barrier + synchronize (the first one is the contract's
+    # timed region; a 20-step window lasts 3 ms, so one window alone moves by several percent from box to box and run to run)
+    wins = []
+    for w in range(windows):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(args.warmup + w * steps + i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wins.append(time.perf_counter() - t0)
+    dt = sum(wins) / windows          # mean time of a window of `steps` steps
     st = tr.state()
-    assert st["iteration"] == args.warmup + steps and not st["nan"], st
+    assert st["iteration"] == args.warmup + windows * steps and not st["nan"], st
+    st["window_ms_per_step"] = [w / steps * 1e3 for w in wins]
 
     # roofline leg: per-kernel-class durations from HIP events on the launch stream (outside the timed region:
     # the events themselves perturb the step time)
     # every rank runs these 20 steps (with N > 1 a step contains an all-reduce: a rank-0-only loop would deadlock)
     tr.set_profiling(True)
     for i in range(20):
-        step(args.warmup + steps + i)
+        step(args.warmup + windows * steps + i)
     torch.cuda.synchronize()
     prof = tr.get_profile()
     tr.set_profiling(False)
@@ -142,10 +168,10 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
     return dt, st, prof
 
 
-def bench_registration(args, rank, world, device):
+def bench_registration(args, rank, world, device, h=60, w=80, frames=None):
     from acezero_amd import dsacstar, synth
-    n = args.reg_frames // world
-    base = synth.make_registration_frames(seed=1305 + rank, n_frames=64)
+    n = (frames or args.reg_frames) // world
+    base = synth.make_registration_frames(seed=1305 + rank, n_frames=64, h=h, w=w)
     sc = torch.from_numpy(base["scene_coords"]).to(device)
     reps = (n + 63) // 64
     sc = sc.repeat(reps, 1, 1, 1)[:n].contiguous()
@@ -180,11 +206,17 @@ def ransac_roofline(images_per_s):
     out = {"bound": "valu_fp64", "kernel": "ransac_kernel<false> (one 256-thread workgroup per 60x80 frame)", "peak": peak,
            "unit": "T lane-ops/s", "achieved": None, "frac": None, "traffic": None}
     try:
+        side = json.load(open(path.replace(".json", ".digest.json")))
+        if side.get("source_digest") != src_digest(RANSAC_SOURCES):   # the kernel has changed since the counter pass: nothing stale is quoted
+            out["stored_profile"] = "profiles/r02_ransac_pmc.json does not match the running build's ransac sources: not used"
+            return out
         c = json.load(open(path))["ransac_kernel"]
         insts_per_frame = c["SQ_INSTS_VALU"]["mean_per_launch"] / 2048
         out.update(achieved=images_per_s * insts_per_frame * 64 / 1e12, valu_insts_per_frame=insts_per_frame,
                    lane_utilisation=c["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (c["SQ_INSTS_VALU"]["mean_per_launch"] * 64),
-                   source="profiles/r02_ransac_pmc.json (static instruction count) x live images/s")
+                   stored_profile={"file": "profiles/r02_ransac_pmc.json", "source_digest": side["source_digest"],
+                                   "what": "SQ_INSTS_VALU / frames of one 2048-frame launch (a STORED instruction count, checked against the "
+                                           "running build's ransac sources); `achieved` = that count x the LIVE images/s of this run"})
         out["frac"] = out["achieved"] / peak
     except (OSError, KeyError, ValueError):
         pass
@@ -398,10 +430,16 @@ def main():
             torch.distributed.destroy_process_group()
         if rank == 0:
             print(json.dumps({"metric": "ACE patches/sec", "value": BATCH * world * args.steps / dt, "unit": "patches/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "headline_only": True,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(np.median(st["window_ms_per_step"])),
+                              "ms_per_step_mean": dt / args.steps * 1e3, "window_ms_per_step": st["window_ms_per_step"], "headline_only": True,
+                              "pose_refinement": args.pose_refinement,
                               "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()}, "final_loss": st["loss"]}))
         return
     dt_ref, st_ref, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000))
+    # BASELINE configs[2] (Mip-NeRF 360 garden-like): 185 frames of 480x741 -> 60x93 maps, focal refinement in the loop
+    dt_gar, st_gar, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000),
+                                       n_images=185, grid=(93, 60))
+    ngar, dt_gar_reg, gar_ok = bench_registration(args, rank, world, device, h=60, w=93, frames=1024)
     dt_strong = None
     if world > 1:   # the reference's step (global batch 5120) split over the ranks
         dt_strong, st_strong, _ = bench_training(args, rank, world, device, steps=args.steps, buffer_patches=min(args.buffer_patches, 2_000_000), strong=True)
@@ -409,9 +447,10 @@ def main():
     pipe = bench_pipeline(args, rank, world, device)
     sess = bench_session(args, device) if world == 1 and args.session_frames > 0 else None
     if world > 1:
-        t = torch.tensor([dt, dt_reg, dt_ref, dt_strong], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, dt_reg, dt_ref, dt_strong, dt_gar, dt_gar_reg] + st["window_ms_per_step"], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt, dt_reg, dt_ref, dt_strong = float(t[0]), float(t[1]), float(t[2]), float(t[3])
+        dt, dt_reg, dt_ref, dt_strong, dt_gar, dt_gar_reg = (float(x) for x in t[:6])
+        st["window_ms_per_step"] = [float(x) for x in t[6:]]
     if rank == 0:
         patches_per_s = BATCH * world * args.steps / dt
         gemm_ms, gemm_n = 0.0, 0
@@ -424,22 +463,35 @@ def main():
         gemm_kernel_name = ("rowseq_kernel (the 8 forward / the 7 input-gradient 5120x512x512 bf16 layers of a step as ONE launch each; figures per layer)"
                             if seq else "rowgemm80_kernel (5120x512x512 bf16, fwd + dgrad launches)")
         gemm_note = ("HIP events on the launch stream around the two chain launches of a step; achieved = 15 layers' FLOPs / their summed durations = one "
-                     "layer's FLOPs / avg_launch_us (launches_timed counts layers); rocprofv3 kernel durations are in profiles/r02_kernel_stats_rocprofv3_headline_only_seq.csv"
+                     "layer's FLOPs / avg_launch_us (launches_timed counts layers); rocprofv3 kernel durations are in profiles/r03_kernel_stats_rocprofv3_headline_only_trace.csv"
                      if seq else
                      "HIP events on the launch stream around each chain of dependent rowgemm launches (8 fwd, 7 dgrad per step): average start-to-start "
                      "cadence incl. the ~1-2 us kernel boundary; rocprofv3 kernel durations are in profiles/")
-        traffic, traffic_source = None, None
-        names = (("r02_rowseq_hbm_traffic.json",) if seq else ()) + ("r02_rowgemm_hbm_traffic.json", "r01_rowgemm_hbm_traffic.json")
-        tf = next((f for f in (os.path.join(ROOT, "profiles", n) for n in names) if os.path.exists(f)), "")
-        if tf:   # NOT measured in this run: the PMC passes need rocprofv3 around the process (tools/prof_r02.sh)
+        # Counter figures cannot be collected inside this run (they need rocprofv3 around the process: tools/prof_r03.sh); the stored
+        # pass is quoted only if it was taken on the sources this build was compiled from, and it names the kernel it belongs to.
+        traffic, traffic_source, mfma_busy, stored = None, None, None, None
+        tf = os.path.join(ROOT, "profiles", "r03_step_hbm_traffic.json")
+        if seq and os.path.exists(tf):
             tj = json.load(open(tf))
-            traffic = tj.get("bytes_per_layer", tj.get("bytes_per_launch"))   # per unit (one layer), like `achieved`
-            traffic_source = "profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes; a stored measurement of ONE rowgemm80 layer launch, not this run" + ("; the one-launch chain moves the same tensors, its layer inputs come from the producing XCD's L2 where they still fit -- not re-measured)" if seq else ")")
+            if tj.get("source_digest") == src_digest(STEP_SOURCES):
+                ks = {k: v for k, v in tj["kernels"].items() if "rowseq_kernel" in k and "bytes_per_layer" in v}
+                if len(ks) == 2:
+                    layers = sum(v["layers_per_launch"] for v in ks.values())
+                    traffic = sum(v["bytes_per_launch"] for v in ks.values()) / layers       # per unit (one layer), like `achieved`
+                    if all("mfma_busy_frac" in v for v in ks.values()):
+                        mfma_busy = sum(v["mfma_busy_frac"] * v["avg_ns"] for v in ks.values()) / sum(v["avg_ns"] for v in ks.values())
+                    traffic_source = ("profiles/r03_step_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE (separate passes) of "
+                                      "rowseq_kernel<false> (8 layers) and rowseq_kernel<true> (7 layers), the kernels timed here, per layer; a STORED "
+                                      "measurement taken on the same kernel sources as this build (source_digest matches)")
+                    stored = {"file": "profiles/r03_step_hbm_traffic.json", "source_digest": tj["source_digest"], "kernels": sorted(ks)}
+            else:
+                traffic_source = "profiles/r03_step_hbm_traffic.json was measured on different kernel sources than this build: not quoted"
         wg_s = prof["wgrad"][0] / max(prof["wgrad"][1], 1) * 1e-3
         wg_tflops = BATCH * 8 * GEMM_FLOP_PER_LAUNCH_PER_ROW / wg_s / 1e12 if wg_s > 0 else 0.0
         out = {
             "metric": "ACE patches/sec", "value": patches_per_s, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": float(np.median(st["window_ms_per_step"])), "ms_per_step_mean": dt / args.steps * 1e3,
+            "window_ms_per_step": st["window_ms_per_step"], "windows": WINDOWS, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "7-Scenes-chess-like ace_zero mapping step: 8M-patch bf16 feature buffer in HBM, batch 5120 per GPU, "
                                    "default head (1 block, 2 103 300 params), tanh loss, 1cyclepoly AdamW, pose_refinement " + args.pose_refinement,
@@ -449,10 +501,18 @@ def main():
             "strong_scaling": None if dt_strong is None else {
                 "metric": "ACE patches/sec, the reference's step: global batch 5120 split over the ranks by buffer shard, one gradient all-reduce per step",
                 "value": BATCH * args.steps / dt_strong, "unit": "patches/s", "ms_per_step": dt_strong / args.steps * 1e3, "scaling": "strong",
+                "collective": os.environ.get("ACEZ_DP_MODE", "sharded"),
                 "global_batch": BATCH, "rows_per_gpu": BATCH / world},
             "refinement_step": {"metric": "ACE patches/sec with --pose_refinement mlp --refine_calibration True (every non-seed mapping iteration of ace_zero.py)",
                                 "value": BATCH * world * 100 / dt_ref, "unit": "patches/s", "ms_per_step": dt_ref / 100 * 1e3, "steps": 100,
+                                "ms_per_step_median": float(np.median(st_ref["window_ms_per_step"])), "window_ms_per_step": st_ref["window_ms_per_step"],
                                 "n_images": 1000, "final_loss": st_ref["loss"]},
+            "garden_like": {"metric": "BASELINE configs[2] shape: 185 frames of 480x741 (60x93 feature maps), --pose_refinement mlp --refine_calibration True",
+                            "training": {"value": BATCH * world * 100 / dt_gar, "unit": "patches/s", "ms_per_step": dt_gar / 100 * 1e3,
+                                         "ms_per_step_median": float(np.median(st_gar["window_ms_per_step"])), "n_images": 185,
+                                         "focal_scale_after": st_gar["focal_scale"], "final_loss": st_gar["loss"]},
+                            "registration": {"value": ngar * world / dt_gar_reg, "unit": "images/s", "frames": ngar * world, "map": "60x93",
+                                             "hypotheses": 32, "max_tries": 16, "frac_frames_registered": gar_ok}},
             "registration": {"metric": "DSAC* images-registered/sec", "value": nreg * world / dt_reg, "unit": "images/s",
                              "frames": nreg * world, "hypotheses": 32, "max_tries": 16, "frac_frames_registered": reg_ok,
                              "note": "RANSAC only, 60x80 scene coordinates resident in HBM"},
@@ -473,7 +533,7 @@ def main():
                                    "map_bytes_per_s": pipe["cloud_frames"] * world * 57600 / pipe["cloud_s"]},
             "roofline": {"bound": "mfma", "kernel": gemm_kernel_name, "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": traffic_source,
+                         "traffic_source": traffic_source, "mfma_busy_frac": mfma_busy, "stored_profile": stored,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": gemm_n,
                          "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()},
                          "note": gemm_note},

@@ -17,8 +17,10 @@ def test_bench_json_line_contract(monkeypatch, seq):
     monkeypatch.setenv("ACEZ_SEQ", seq)
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
-    monkeypatch.setattr(bench, "bench_training", lambda *a, **k: (300 * 155e-6 if not k.get("steps") else k["steps"] * 240e-6, {"loss": 22.3}, prof))
-    monkeypatch.setattr(bench, "bench_registration", lambda *a: (2048, 2048 / 340e3, 1.0))
+    wins = [0.1551, 0.1549, 0.1550, 0.1620, 0.1548]             # five timed windows: the median is quoted, the mean gives `value`
+    monkeypatch.setattr(bench, "bench_training", lambda *a, **k: (300 * sum(wins) / 5 * 1e-3 if not k.get("steps") else k["steps"] * 240e-6,
+                                                                  {"loss": 22.3, "focal_scale": 1.01, "window_ms_per_step": list(wins)}, prof))
+    monkeypatch.setattr(bench, "bench_registration", lambda *a, **k: (2048, 2048 / 340e3, 1.0))
     monkeypatch.setattr(bench, "bench_pipeline", lambda *a: {"frames": 256, "e2e_s": 0.025, "encoder_ms": 16.0, "buffer_rows": 262144, "buffer_s": 0.017,
                                                             "cloud_frames": 256, "cloud_s": 1.4e-4, "cloud_points": 256000})
     monkeypatch.setattr(bench, "bench_session", lambda *a: {"frames": 120, "seconds": 5.4})
@@ -32,11 +34,17 @@ def test_bench_json_line_contract(monkeypatch, seq):
     d = json.loads(lines[0])
     assert d["metric"] == "ACE patches/sec" and d["unit"] == "patches/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True
     assert d["steps"] == 300 and d["warmup"] == 30 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16"
-    assert abs(d["value"] - 5120 / 155e-6) < 1 and abs(d["ms_per_step"] - 0.155) < 1e-9 and "workload" in d["config"]
+    assert abs(d["value"] - 5120 / (sum(wins) / 5 * 1e-3)) < 1 and abs(d["ms_per_step"] - 0.1550) < 1e-9 and "workload" in d["config"]
+    assert d["windows"] == 5 and d["window_ms_per_step"] == wins and abs(d["ms_per_step_mean"] - sum(wins) / 5) < 1e-9
+    assert d["garden_like"]["training"]["n_images"] == 185 and d["garden_like"]["registration"]["map"] == "60x93"
+    assert d["refinement_step"]["ms_per_step"] > 0 and "mfma_busy_frac" in d["roofline"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert ("rowseq_kernel" in r["kernel"]) == (seq == "1") and r["launches_timed"] == 300
     per_layer_us = (0.88 + 0.94) / 300 * 1e3
     assert abs(r["avg_launch_us"] - per_layer_us) < 1e-9 and abs(r["achieved"] - 2 * 5120 * 512 * 512 / (per_layer_us * 1e-6) / 1e12) < 1e-6
-    assert r["traffic"] is None or r["traffic"] > 1e6            # bytes per layer, a stored measurement (traffic_source says which)
+    # bytes per layer: a stored counter pass, quoted only while its source digest matches the running build (else null, never stale)
+    assert r["traffic"] is None or (r["traffic"] > 1e6 and r["stored_profile"]["source_digest"] == bench.src_digest(bench.STEP_SOURCES))
+    rr = d["roofline_ransac"]
+    assert rr["frac"] is None or rr["stored_profile"]["source_digest"] == bench.src_digest(bench.RANSAC_SOURCES)
     assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["roofline_wgrad"]["frac"] > 0 and "roofline_ransac" in d

@@ -1,0 +1,90 @@
+"""GPU: --pose_refinement mlp folded into the step's own launches (acezero_amd/csrc/pose_fused.hip: the pose network's forward as
+the first workgroups of the gather launch, its reduction + backward chain as the first workgroups of the head's AdamW launch, its
+weight gradients with AdamW in the tile epilogue) against the separate launches of round 2 (ACEZ_POSE_FUSED=0) and against the
+split backward / update flow a data-parallel host uses. The per-image sums run in the same order and the optimiser arithmetic is
+one un-contracted function inlined at every site, so everything must agree BIT FOR BIT: refined poses, pose gradients, pose
+parameters and their AdamW state, and the head's parameters. Reference: refine_poses.py:152-176,212-244, ace_trainer.py:620-640."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import head_oracle
+from tests import helpers
+from tests.test_head_gpu import _trainer
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n_images, patches_per_view=128):
+    from acezero_amd import synth
+    return synth.make_training_problem(seed=11, n_images=n_images, views_per_image=2, patches_per_view=patches_per_view)
+
+
+def _mk(prob, cfg, fused, max_batch):
+    os.environ["ACEZ_POSE_FUSED"] = fused
+    try:
+        return _trainer(prob, head_oracle.init_params(helpers.SEED + 1), cfg, max_batch=max_batch)
+    finally:
+        os.environ.pop("ACEZ_POSE_FUSED", None)
+
+
+def _same(a, b):
+    return (torch.equal(a.params, b.params) and torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v) and
+            torch.equal(a.pose_params, b.pose_params) and torch.equal(a.pose_m, b.pose_m) and torch.equal(a.pose_v, b.pose_v))
+
+
+@pytest.mark.parametrize("name,n_images,n", [("head_tanh_posemlp", 37, 1024), ("head_tanh_posemlp", 1000, 5120),
+                                             ("head_tanh_posemlp_procrustes", 16, 333), ("head_tanh_posemlp", 3, 2048)])
+def test_fused_pose_launches_equal_separate_launches_bitwise(name, n_images, n):
+    """37 images: ragged last tile; 1000 images at batch 5120: BASELINE's refinement step; 16: exactly one tile; 3 images and 2048 rows:
+    ~680 rows per image overflow the one-pass hit lists (the multi-pass fall-back of the reduction)."""
+    prob = _problem(n_images, patches_per_view=max(128, 2 * n // (2 * n_images) + 1))
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS[name], prob)
+    cfg.update(global_batch=n, pose_refinement_wait=2, refine_calibration=True)
+    old, new, split = _mk(prob, cfg, "0", n), _mk(prob, cfg, "1", n), _mk(prob, cfg, "1", n)
+    rng = np.random.default_rng(5)
+    N = prob["features"].shape[0]
+    for it in range(6):
+        idx = torch.from_numpy(rng.permutation(N)[:min(n, N)].astype(np.int64)).cuda()
+        for tr in (old, new):
+            tr.step(idx)
+        split.backward(idx)
+        g_split = split.grad.clone()
+        split.update()
+        torch.cuda.synchronize()
+        assert _same(old, new), (it, "fused vs separate launches")
+        assert _same(new, split), (it, "fused single-GPU step vs backward / update")
+        np.testing.assert_array_equal(old.current_poses(), new.current_poses())
+        # the pose gradient the data-parallel host all-reduces is the one the fused step applied
+        assert torch.equal(new.grad[new.n_params + 4:], g_split[new.n_params + 4:]), it
+        assert old.state() == new.state() == split.state()
+    moved = (new.pose_params.cpu() - torch.as_tensor(helpers_pose0(new))).abs().max()
+    assert float(moved) > 0        # the pose optimiser did step after the wait
+
+
+def helpers_pose0(tr):
+    from acezero_amd.head import init_pose_network
+    return init_pose_network(helpers.SEED + 3).numpy()
+
+
+def test_loaded_pose_parameters_reach_the_fused_forward():
+    """The fused forward reads transposed weight copies that the fused optimiser epilogue keeps current; parameters written from
+    outside (checkpoint load) followed by sync_weights() must be picked up too."""
+    prob = _problem(20)
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_posemlp"], prob)
+    cfg.update(global_batch=512)
+    a, b = _mk(prob, cfg, "1", 512), _mk(prob, cfg, "0", 512)
+    idx = torch.from_numpy(np.arange(512, dtype=np.int64)).cuda()
+    for tr in (a, b):
+        tr.step(idx)
+    g = torch.Generator().manual_seed(3)
+    newp = (torch.rand(a.pose_params.numel(), generator=g) * 0.2 - 0.1).cuda()
+    for tr in (a, b):
+        tr.pose_params.copy_(newp)
+        tr.sync_weights()
+        tr.step(idx)
+    torch.cuda.synchronize()
+    assert _same(a, b)
+    np.testing.assert_array_equal(a.current_poses(), b.current_poses())
