@@ -111,11 +111,14 @@ def lib():
     """Load (building first if needed) libacez.so and declare every prototype."""
     global _lib
     if _lib is None:
-        path = _build.build()
+        other = os.environ.get("ACEZ_LIB")   # diagnostics only (tools/lib_ab.sh): time an older build of the library on the same box
+        path = other or _build.build()
         if not os.path.exists(path):
             raise RuntimeError("libacez.so is missing and could not be built: the HIP extension is mandatory")
         L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
+            if other and not hasattr(L, name):
+                continue
             fn = getattr(L, name)  # AttributeError here means the library does not export the ABI
             fn.restype = res
             fn.argtypes = args

@@ -43,6 +43,7 @@ struct acez_trainer {
   float *log_loss = nullptr, *log_inl = nullptr;
   int log_cap = 0;
   TrainState* st = nullptr;
+  TrainState* st_infer = nullptr;   // schedule-free launches (inference) get this always-active state, so that a rowseq fault can switch them off too
   // pose refinement runs on its own stream, beside the head's GEMM chains (6 launches, ~65 us if serialised at 1000 images)
   hipStream_t pose_stream = nullptr;
   hipEvent_t ev_begin = nullptr, ev_pose_fwd = nullptr, ev_loss = nullptr, ev_pose_bwd = nullptr;
@@ -57,6 +58,9 @@ struct acez_trainer {
   float* pose_wt = nullptr;     // [4][128][128] transposed pose-network weights (forward)
   // mlp refinement folded into the step's own launches (pose_fused.hip); ACEZ_POSE_FUSED=0 = the separate launches of round 2
   bool pose_fused = true;
+  // images per pose workgroup of the fused path: 16 (pose_kernels.hip), 8 or 4 (pose_small.hip); ACEZ_POSE_TILE sets both, ACEZ_POSE_TILE_FWD
+  // the forward alone (the global layouts do not depend on the tile size)
+  int pose_tile = 4, pose_tile_fwd = 4;
   bool pose_wt_valid = false;   // pose_wt matches the parameters (kept up to date by the fused optimiser epilogue of pose_mlp_wgrad_kernel)
   float* row_dT = nullptr;
   int* row_image = nullptr;
@@ -90,8 +94,8 @@ struct acez_trainer {
   // the one-launch chains are used at all; every poll is bounded and raises `seq_err` (device), which turns the optimiser /
   // schedule kernels of that step into no-ops; the next state read (seq_fault_check) resets the counters and switches this
   // trainer to per-layer launches for good. The abandoned iterations are not counted, so the training loop simply runs them again.
-  int* seq_err = nullptr;
-  uint32_t seq_spin_ticks = 2000000;   // 20 ms of s_memrealtime ticks (100 MHz); ACEZ_SEQ_SPIN_US overrides
+  int* seq_err = nullptr;              // = (int*)(seq_flags + 64 * 32): one allocation, so that the kernel needs no second pointer
+  uint32_t seq_spin_limit = 40000;     // polls (>= ~0.5 us each: at least ~20 ms); ACEZ_SEQ_SPIN_US overrides (2 polls per us)
   int seq_faults = 0;                  // fall-backs taken so far
   int seq_probe = -1;                  // -1 not run, 0 failed (seq disabled), 1 passed
   long seq_launches = 0, seq_fault_at = -1;   // tests: ACEZ_SEQ_FAULT_AT=<n> makes the n-th launch time out
@@ -176,8 +180,11 @@ static int seq_fault_check(acez_trainer* tr, hipStream_t s) {
   int err = 0;
   if (hipMemcpyAsync(&err, tr->seq_err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 0;
   if (!err) return 0;
-  (void)hipMemsetAsync(tr->seq_err, 0, sizeof(int), s);
-  (void)hipMemsetAsync(tr->seq_flags, 0, 64 * 32 * sizeof(uint32_t), s);
+  (void)hipMemsetAsync(tr->seq_flags, 0, (64 * 32 + 1) * sizeof(uint32_t), s);   // counters + fault word (the poll budget behind them stays)
+  hipLaunchKernelGGL(sched_reactivate_kernel, dim3(1), dim3(64), 0, s, tr->st);
+  const int one = 1;
+  (void)hipMemcpyAsync(&tr->st_infer->active, &one, sizeof(int), hipMemcpyHostToDevice, s);
+  (void)hipStreamSynchronize(s);
   for (int mt = 0; mt < 64; ++mt) tr->seq_base[mt] = 0;
   tr->seq = false;
   ++tr->seq_faults;
@@ -217,8 +224,13 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_REQUIRE(tr, "out of host memory");
   ACEZ_HIP_CHECK(hipGetDevice(&tr->device));
   tr->cfg = *cfg;
+  if (const char* e = getenv("ACEZ_FUSED_FWD")) tr->fused_fwd = atoi(e) != 0;
+  if (const char* e = getenv("ACEZ_CHAIN")) tr->chain = atoi(e) != 0;
+  if (tr->fused_fwd) tr->chain = false;
   if (const char* e = getenv("ACEZ_POSE_FUSED")) tr->pose_fused = atoi(e) != 0;
-  if (cfg->pose_refinement != 2) tr->pose_fused = false;
+  if (const char* e = getenv("ACEZ_POSE_TILE")) { const int v = atoi(e); tr->pose_tile = tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
+  if (const char* e = getenv("ACEZ_POSE_TILE_FWD")) { const int v = atoi(e); tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
+  if (cfg->pose_refinement != 2 || tr->chain || tr->fused_fwd) tr->pose_fused = false;   // (the opt-in row-persistent kernels keep round 2's pose launches)
   if (cfg->pose_refinement != 0 && !tr->pose_fused && !(getenv("ACEZ_POSE_STREAM") && atoi(getenv("ACEZ_POSE_STREAM")) == 0)) {
     ACEZ_HIP_CHECK(hipStreamCreateWithFlags(&tr->pose_stream, hipStreamNonBlocking));
     for (hipEvent_t* e : {&tr->ev_begin, &tr->ev_pose_fwd, &tr->ev_loss, &tr->ev_pose_bwd}) ACEZ_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -232,10 +244,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->n_params = params->n_params;
   tr->fc3_stride = ((int64_t)tr->no * 513 + 3) & ~3LL;
   tr->max_batch = cfg->max_batch;
-  if (const char* e = getenv("ACEZ_FUSED_FWD")) tr->fused_fwd = atoi(e) != 0;
   if (const char* e = getenv("ACEZ_GEMM_TILE")) tr->gemm_tile = atoi(e) == 128 ? 128 : 80;
-  if (const char* e = getenv("ACEZ_CHAIN")) tr->chain = atoi(e) != 0;
-  if (tr->fused_fwd) tr->chain = false;
   if (const char* e = getenv("ACEZ_SEQ")) tr->seq = atoi(e) != 0;
   {
     hipDeviceProp_t prop;
@@ -270,11 +279,11 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->xyz, (size_t)tr->max_batch * 3 * sizeof(float));
   A((void**)&tr->maskbits, (size_t)tr->L * max_blocks * 512 * sizeof(uint32_t));
   A((void**)&tr->chain_err, sizeof(int));
-  A((void**)&tr->seq_flags, 64 * 32 * sizeof(uint32_t));
-  if (rc == ACEZ_OK) (void)hipMemset(tr->seq_flags, 0, 64 * 32 * sizeof(uint32_t));
-  A((void**)&tr->seq_err, sizeof(int));
-  if (rc == ACEZ_OK) (void)hipMemset(tr->seq_err, 0, sizeof(int));
-  if (const char* e = getenv("ACEZ_SEQ_SPIN_US")) tr->seq_spin_ticks = (uint32_t)std::max(1L, atol(e)) * 100u;
+  A((void**)&tr->seq_flags, (64 * 32 + 32) * sizeof(uint32_t));
+  if (rc == ACEZ_OK) (void)hipMemset(tr->seq_flags, 0, (64 * 32 + 32) * sizeof(uint32_t));
+  tr->seq_err = reinterpret_cast<int*>(tr->seq_flags + 64 * 32);
+  if (const char* e = getenv("ACEZ_SEQ_SPIN_US")) tr->seq_spin_limit = (uint32_t)std::max(1L, atol(e)) * 2u;
+  if (rc == ACEZ_OK) (void)hipMemcpy(tr->seq_flags + 64 * 32 + 1, &tr->seq_spin_limit, sizeof(uint32_t), hipMemcpyHostToDevice);
   if (const char* e = getenv("ACEZ_SEQ_FAULT_AT")) tr->seq_fault_at = atol(e);
   if (getenv("ACEZ_SEQ_XCC")) {
     A((void**)&tr->seq_xcc, (8 + 256) * sizeof(uint32_t));
@@ -291,6 +300,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->log_loss, (size_t)tr->log_cap * sizeof(float));
   A((void**)&tr->log_inl, (size_t)tr->log_cap * sizeof(float));
   A((void**)&tr->st, sizeof(TrainState));
+  A((void**)&tr->st_infer, sizeof(TrainState));
   if (rc != ACEZ_OK) { acez_trainer_destroy(tr); return rc; }
 
   SchedConfig& sc = tr->sc;
@@ -306,6 +316,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   hipLaunchKernelGGL(sched_init_kernel, dim3(1), dim3(64), 0, 0, tr->st, sc);
   ACEZ_HIP_CHECK(hipGetLastError());
   ACEZ_HIP_CHECK(hipMemset(tr->zeros, 0, 1024));
+  { TrainState one{}; one.active = 1; ACEZ_HIP_CHECK(hipMemcpy(tr->st_infer, &one, sizeof(TrainState), hipMemcpyHostToDevice)); }
   ACEZ_HIP_CHECK(hipMemset(tr->chain_err, 0, sizeof(int)));
   ACEZ_HIP_CHECK(hipMemset(tr->log_loss, 0, (size_t)tr->log_cap * sizeof(float)));
   ACEZ_HIP_CHECK(hipMemset(tr->log_inl, 0, (size_t)tr->log_cap * sizeof(float)));
@@ -420,11 +431,13 @@ static void launch_rowseq(acez_trainer* tr, const std::vector<SeqLayer>& layers,
     RowSeqArgs a{};
     const int cnt = (int)std::min<size_t>(SEQ_MAX_LAYERS, layers.size() - i0);
     for (int i = 0; i < cnt; ++i) a.layer[i] = layers[i0 + i];
-    a.n_layers = cnt; a.M = n; a.st = st; a.flags = tr->seq_flags; a.xcc_dbg = tr->seq_xcc;
-    a.err = tr->seq_err; a.spin_ticks = tr->seq_spin_ticks;
-    a.fault_inject = (cnt > 1 && tr->seq_launches == tr->seq_fault_at) ? 1 : 0;
-    ++tr->seq_launches;
+    a.n_layers = cnt; a.M = n; a.st = st ? st : tr->st_infer; a.flags = tr->seq_flags; a.xcc_dbg = tr->seq_xcc;
     for (int mt = 0; mt < 64; ++mt) a.base[mt] = tr->seq_base[mt];
+    // tests (ACEZ_SEQ_FAULT_AT): this launch is told that a million seams have completed before it -- every hand-off then waits
+    // for a count that never comes, which is what a sibling on a foreign XCD looks like
+    if (cnt > 1 && tr->seq_launches == tr->seq_fault_at)
+      for (int mt = 0; mt < 64; ++mt) a.base[mt] += 1u << 20;
+    ++tr->seq_launches;
     hipLaunchKernelGGL(rowseq_kernel<BWD>, dim3(32 * ((mtiles + 7) / 8)), dim3(512), 0, s, a);
     for (int mt = 0; mt < mtiles; ++mt) tr->seq_base[mt] += (uint32_t)(cnt - 1);
     tr->prof_launches += cnt;   // accounted as layer GEMMs so that the per-layer average stays comparable
@@ -578,7 +591,10 @@ static void launch_pose_wgrad(acez_trainer* tr, const int* active, bool fuse, hi
   w.I = I; w.grad = tr->pb.d_grad + tr->n_params + 4; w.active = active;
   w.fuse = fuse ? 1 : 0; w.p = tr->pb.d_pose_params; w.m = tr->pb.d_pose_m; w.v = tr->pb.d_pose_v; w.Wt = tr->pose_wt;
   w.sc = &tr->st->pose_adam; w.enable = &tr->st->pose_enable; w.fault = tr->seq_err;
-  hipLaunchKernelGGL(pose_mlp_wgrad_kernel, dim3(jobs), dim3(256), 0, s, w);
+  static const int wb = getenv("ACEZ_POSE_WB") ? atoi(getenv("ACEZ_POSE_WB")) : 32;   // operand steps requested per round trip
+  if (wb == 16) hipLaunchKernelGGL(pose_mlp_wgrad_kernel<16>, dim3(jobs), dim3(64 * PW_WAVES), 0, s, w);
+  else if (wb == 64) hipLaunchKernelGGL(pose_mlp_wgrad_kernel<64>, dim3(jobs), dim3(64 * PW_WAVES), 0, s, w);
+  else hipLaunchKernelGGL(pose_mlp_wgrad_kernel<32>, dim3(jobs), dim3(64 * PW_WAVES), 0, s, w);
 }
 
 static void launch_pose_grad_reduce(acez_trainer* tr, int n, const int* active, hipStream_t s) {
@@ -682,11 +698,13 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   ProfScope* psg = new ProfScope(tr, s, KC_GATHER);
   const int gblocks = (n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024;
   if (pf) {   // + the pose network's forward for all images, as the first workgroups of the same launch
-    const int np = (tr->buf.n_images + PN_IMG - 1) / PN_IMG;
+    const int T = tr->pose_tile_fwd, np = (tr->buf.n_images + T - 1) / T;
     const int do_post = tr->post_pending ? 1 : 0;
     tr->post_pending = false;
-    hipLaunchKernelGGL(step_begin_pose_kernel, dim3(np + gblocks + 1), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n,
-                       post_args(tr), do_post, pose_net_args(tr, nullptr), np);
+#define ACEZ_SBP(TT) hipLaunchKernelGGL(step_begin_pose_kernel<TT>, dim3(np + gblocks + 1), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, \
+                                        d_indices, tr->R[0], n, post_args(tr), do_post, pose_net_args(tr, nullptr), np)
+    if (T == 16) ACEZ_SBP(16); else if (T == 4) ACEZ_SBP(4); else ACEZ_SBP(8);
+#undef ACEZ_SBP
   } else if (tr->post_pending) {   // gather of this step + the schedule bookkeeping of the previous one, in one launch
     tr->post_pending = false;
     hipLaunchKernelGGL(step_begin_kernel, dim3(gblocks + 1), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n,
@@ -795,7 +813,10 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     // split flow (a data-parallel host all-reduces d_grad next): the pose gradients must be complete now -- reduce + backward chain
     // (S1) and the weight gradients as two launches on this stream; the single-GPU step runs S1 beside the head's AdamW instead
     const PoseNetArgs a = pose_net_args(tr, &tr->st->active);
-    hipLaunchKernelGGL(pose_s1_kernel, dim3((tr->buf.n_images + PN_IMG - 1) / PN_IMG), dim3(256), 0, s, a, (const float*)tr->row_dT, (const int*)tr->row_image, n);
+    const int T = tr->pose_tile, np = (tr->buf.n_images + T - 1) / T;
+#define ACEZ_S1(TT) hipLaunchKernelGGL(pose_s1t_kernel<TT>, dim3(np), dim3(256), 0, s, a, (const float*)tr->row_dT, (const int*)tr->row_image, n)
+    if (T == 16) ACEZ_S1(16); else if (T == 4) ACEZ_S1(4); else ACEZ_S1(8);
+#undef ACEZ_S1
     launch_pose_wgrad(tr, &tr->st->active, false, s);
   }
   ACEZ_HIP_CHECK(hipGetLastError());
@@ -816,16 +837,18 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused) {
   AdamArgs a;
   fill_adam_args(tr, a);
   if (fused) { a.slabs = tr->slabs; a.nslabs = tr->nslabs; a.slab_stride = tr->n_wide; a.tail = tr->last_reduce; }
-  const int64_t n_small = (int64_t)tr->L * 512 + (int64_t)tr->no * 513;
-  const int nsmall = fused ? (int)(((n_small + 4) * 64 + 255) / 256) : (int)((n_small + 255) / 256);   // fused: a wave per output
+  const int nsmall = adamw_small_blocks(tr->L, (int64_t)tr->no * 513, fused);   // small-parameter workgroups come first in the grid
   const bool pf = tr->pose_fused && !tr->chain && !tr->fused_fwd;
   if (pf && fused) {
     // the head's AdamW with the pose network's reduce + backward chain (S1) as the first workgroups of the same launch, then the
     // pose weight gradients with AdamW in their epilogue (S2: needs S1 of every image tile)
-    const int np = (tr->buf.n_images + PN_IMG - 1) / PN_IMG;
+    const int T = tr->pose_tile, np = (tr->buf.n_images + T - 1) / T;
     { ProfScope ps(tr, s, KC_ADAMW);
-      hipLaunchKernelGGL(adamw_pose_kernel, dim3(np + tr->L * 64 + nsmall), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active),
-                         (const float*)tr->row_dT, (const int*)tr->row_image, tr->last_n, np); }
+#define ACEZ_AP(TT) hipLaunchKernelGGL(adamw_pose_kernel<TT>, dim3(np + tr->L * 64 + nsmall), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active), \
+                                       (const float*)tr->row_dT, (const int*)tr->row_image, tr->last_n, np)
+      if (T == 16) ACEZ_AP(16); else if (T == 4) ACEZ_AP(4); else ACEZ_AP(8);
+#undef ACEZ_AP
+    }
     launch_pose_wgrad(tr, &tr->st->active, true, s);
     tr->post_pending = true;
     ACEZ_HIP_CHECK(hipGetLastError());
@@ -1007,7 +1030,15 @@ extern "C" int acez_trainer_get_poses(acez_trainer* tr, float* h_poses34, void* 
   hipStream_t s = (hipStream_t)stream;
   const int I = tr->buf.n_images;
   const float* src = tr->buf.d_image_pose_inv;
-  if (tr->cfg.pose_refinement == 2) {
+  if (tr->cfg.pose_refinement == 2 && tr->pose_fused && tr->pose_tile_fwd != 16) {
+    const PoseNetArgs a = pose_net_args(tr, nullptr);
+    const int T = tr->pose_tile_fwd, np = (I + T - 1) / T;
+    hipLaunchKernelGGL(pose_transpose_kernel, dim3(4, 4, 4), dim3(256), 0, s, a.P, tr->pose_wt, (const int*)nullptr);
+    if (T == 4) hipLaunchKernelGGL(pose_fwd_t_kernel<4>, dim3(np), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pose_fwd_t_kernel<8>, dim3(np), dim3(256), 0, s, a);
+    ACEZ_HIP_CHECK(hipGetLastError());
+    src = tr->pose_cur;
+  } else if (tr->cfg.pose_refinement == 2) {
     pose_forward(tr, nullptr, s);
     ACEZ_HIP_CHECK(hipGetLastError());
     src = tr->pose_cur;

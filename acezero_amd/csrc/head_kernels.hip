@@ -259,9 +259,9 @@ struct SeqLink {
   bool first, wait;      // first layer of the launch (requests its own W stages) / In is produced inside this launch
   bool signal;           // another layer follows: bump *flag after the stores
   const uint16_t* next_W;  // weights of the layer after (null: none): its first four W stages are requested before the epilogue
-  int* err;              // sticky fault word of the trainer: set when the bounded poll below expires (the host then falls back to
-                         // per-layer launches, head_api.hip seq_fault_check)
-  uint32_t spin_ticks;   // poll budget in s_memrealtime ticks (100 MHz)
+  uint32_t flag_index;   // flag = flags + flag_index; the trainer's sticky fault word is flags[64 * 32]: set when the bounded poll
+                         // below expires (the host then falls back to per-layer launches, head_api.hip seq_fault_check); the poll budget
+                         // (a number of polls) is flags[64 * 32 + 1]
 };
 constexpr int RG80_STAGE = (128 + 96) * 64;                        // elements per ring slot
 constexpr int RG80_SMEM = 4 * RG80_STAGE + 2 * 80 * 128;           // ring + two staging tiles
@@ -335,17 +335,19 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
           // stream. When the budget expires the wave raises the sticky fault word and goes on with whatever is in memory: the
           // results of this launch are garbage, the optimiser and schedule kernels of the step see the word and do nothing, and
           // the host switches the trainer to per-layer launches at its next state read (head_api.hip).
-          uint32_t seen;
-          uint64_t t0 = 0;
+          uint32_t seen, spins = 0;
           for (;;) {   // sc1: past this CU's L1; the counter and the tiles live in the L2 all four workgroups share, no L2 invalidate
             asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(q.flag) : "memory");
             seen = __builtin_amdgcn_readfirstlane(seen);   // every lane loaded the same word: a scalar loop condition
             if ((int32_t)(seen - q.target) >= 0) break;
             __builtin_amdgcn_s_sleep(1);
-            const uint64_t now = __builtin_amdgcn_s_memrealtime();
-            if (t0 == 0) t0 = now;
-            else if (now - t0 > (uint64_t)q.spin_ticks) {
-              if (l == 0) __hip_atomic_store(q.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the budget is counted in polls (>= ~0.5 us each: an L2 round trip + the sleep) and looked up every 256th poll only --
+            // flags[64 * 32 + 1], next to the fault word flags[64 * 32] -- so that the hand-off carries no state but the counter
+            if ((++spins & 255u) == 0 && spins > __builtin_nontemporal_load(q.flag - q.flag_index + 64 * 32 + 1)) {
+              if (l == 0) {   // the fault word, and the step is switched off: every later kernel of this trainer starts with `if (!st->active) return`
+                __hip_atomic_store(q.flag - q.flag_index + 64 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.st) __hip_atomic_store(const_cast<int*>(&a.st->active), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
               break;
             }
           }
@@ -575,14 +577,13 @@ struct RowSeqArgs {
   SeqLayer layer[SEQ_MAX_LAYERS];
   int n_layers, M;
   const TrainState* st;
-  uint32_t* flags;     // [64 row tiles][32]
+  uint32_t* flags;     // [64 row tiles][32] hand-off counters + [64 * 32] the fault word
   uint32_t base[64];   // per row tile: seams completed by earlier launches (a launch only touches the row tiles of ITS batch)
   uint32_t* xcc_dbg;   // null, or [8 + 256]: words 0..7 |= 1 << XCC_ID of the workgroups with blockIdx & 7 = word (sticky); word
                        // 8 + 4 mt + nt = XCC_ID of the workgroup that owned tile (mt, nt) in the last launch (tests: the four column
                        // tiles of a row tile must report the same XCD)
-  int* err;            // sticky fault word: non-zero = a poll of this trainer has expired; every launch returns at once
-  uint32_t spin_ticks; // poll budget, s_memrealtime ticks (100 MHz)
-  int fault_inject;    // tests (ACEZ_SEQ_FAULT_AT): the first seam of this launch waits for a count that never comes
+                       // flags[64 * 32] = the sticky fault word (non-zero: a poll of this trainer has expired, every launch returns at
+                       // once), flags[64 * 32 + 1] = the poll budget
 };
 
 template <bool BWD>
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
     atomicOr(a.xcc_dbg + (blockIdx.x & 7), 1u << xcc);
     a.xcc_dbg[8 + mt * 4 + (jx & 3)] = xcc;
   }
-  if (*a.err) return;            // a poll of this trainer has expired before: nothing runs until the host has fallen back
+  // (after an expired poll the fault handler has cleared `active`: nothing of this trainer runs until the host has fallen back)
   if (a.st && !a.st->active) {   // training has ended on the device: no work, but the counters keep step with the host's bases
     if (threadIdx.x == 0) {      // (the same L2-local atomic as the hand-off itself)
       const uint32_t inc = 8u * (uint32_t)(a.n_layers - 1);
@@ -616,8 +617,7 @@ __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
     q.flag = a.flags + mt * 32; q.target = (a.base[mt] + (uint32_t)layer) * 32u;   // 4 workgroups x 8 waves per seam
     q.first = layer == 0; q.wait = layer > 0; q.signal = layer + 1 < a.n_layers;
     q.next_W = q.signal ? a.layer[layer + 1].W : nullptr;
-    q.err = a.err; q.spin_ticks = a.spin_ticks;
-    if (a.fault_inject && layer == 1) q.target += 1u << 20;
+    q.flag_index = (uint32_t)(mt * 32);
     if (!BWD) {
       if (y.aux_mode == AUX_RESIDUAL) rowgemm80_body<true, false, false, AUX_RESIDUAL, true>(g, smem, 1, mt, n0, q);
       else rowgemm80_body<true, false, false, AUX_NONE, true>(g, smem, 1, mt, n0, q);
@@ -1363,8 +1363,64 @@ __device__ __forceinline__ float tail_output(const GradReduceArgs& a, int64_t k,
   return acc;
 }
 
+// Eight consecutive tail outputs k0 .. k0 + 7 by ONE wavefront: the partial-row loads of all eight are issued before anything is
+// summed (one memory round trip for the eight, not eight), then each output is reduced exactly as tail_output does it (same
+// lane-strided sums, same butterfly: identical bits). acc[j] / dst[j] are valid in every lane; dst[j] = -1 past the end.
+__device__ __forceinline__ void tail_output8(const GradReduceArgs& a, int64_t k0, int lane, float acc[8], int64_t dst[8]) {
+  const int64_t n_bias = (int64_t)a.n_layers * 512;
+  const int64_t n_fc3 = a.n_params - a.n_wide;
+  const int64_t n_out = n_bias + n_fc3 + 4;
+  float v[8][3];   // up to 192 partial rows per output (rowseq: 64 row tiles, loss: 160 workgroups at batch 5120); more are looped below
+  const float* base[8];
+  int cnt[8];
+  int64_t stride[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t k = k0 + j;
+    base[j] = a.stat_partials; cnt[j] = 0; stride[j] = 0; dst[j] = -1;
+    if (k < n_bias) {
+      const int layer = (int)(k >> 9), c = (int)(k & 511);
+      base[j] = a.bias_partials + (size_t)layer * a.bias_layer_stride + c; cnt[j] = a.bias_count[layer]; stride[j] = 512;
+      dst[j] = (int64_t)layer * 262656 + 262144 + c;
+    } else if (k < n_bias + n_fc3) {
+      base[j] = a.fc3_partials + (k - n_bias); cnt[j] = a.n_loss_blocks; stride[j] = a.fc3_stride;
+      dst[j] = a.n_wide + (k - n_bias);
+    } else if (k < n_out) {
+      const int64_t kk = k - n_bias - n_fc3;
+      if (kk < 3) { base[j] = a.stat_partials + kk; cnt[j] = a.n_loss_blocks; stride[j] = 4; }
+      dst[j] = a.n_params + kk;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int b = lane + 64 * u;
+      const float x = base[j][(size_t)min(b, max(cnt[j] - 1, 0)) * stride[j]];   // unconditional load, masked afterwards
+      v[j][u] = b < cnt[j] ? x : 0.f;
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (lane + 64 * u < cnt[j]) s += v[j][u];          // the additions tail_output performs, in its order (b = lane, lane + 64, ...)
+    for (int b = lane + 192; b < cnt[j]; b += 64) s += base[j][(size_t)b * stride[j]];
+    const int64_t k = k0 + j;
+    if (k == n_out - 1 && lane == 0 && a.fault) s = *a.fault ? 1.f : 0.f;   // statistics slot 3: the fault word (see tail_output)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    acc[j] = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
-  if (a.st && !a.st->active) return;
+  if (a.st && !a.st->active) {
+    // switched off by a rowseq fault in THIS step (not by the end of the schedule): the bucket keeps whatever it held, but statistics
+    // slot 3 must still tell the other ranks, which then all skip the optimiser step
+    if (a.fault && *a.fault && blockIdx.x == 0 && threadIdx.x == 0) a.grad[a.n_params + 3] = 1.f;
+    return;
+  }
   const int wide_blocks = (int)((a.n_wide / 4 + 255) / 256);
   const int bx = (int)blockIdx.x + (a.skip_wide ? wide_blocks : 0);
   if (bx < wide_blocks) {  // weights: 16-byte loads, slabs summed in slab order
@@ -1403,37 +1459,32 @@ __device__ __forceinline__ float adamw_one(float p, float g, float& m, float& v,
   return p - s.step_size * (m / denom);
 }
 
+// Workgroups of the optimiser's part of a launch: the first adamw_small_blocks() handle the small parameters (biases, fc3) and, in
+// the fused step, the statistics; then one workgroup per 64 x 64 weight tile. (Small first: each of them is a chain of dependent
+// round trips -- partials -> butterfly -> p, m, v -> store -- that should run under the streaming tile blocks, not after them.)
+__host__ __device__ inline int adamw_small_blocks(int n_layers, int64_t n_fc3, bool fused) {
+  const int64_t n_small = (int64_t)n_layers * 512 + n_fc3;
+  return fused ? (int)(((n_small + 4 + 7) / 8 * 64 + 255) / 256)   // fused: a wavefront per EIGHT outputs (tail_output8)
+               : (int)((n_small + 255) / 256);
+}
+
 // One workgroup's share of the optimiser step (b = workgroup index inside the optimiser's part of a launch; tileT: 64 x 66 bf16 LDS).
 // The body of adamw_kernel and of adamw_pose_kernel (pose_fused.hip), where the pose network's backward runs beside it.
 __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint16_t (*tileT)[66]) {
   const TrainState* st = a.st;
   if (!st->active) return;
-  float lossv;
-  if (a.slabs) {   // fused step: the statistics are still partials; every wave sums the loss for itself
-    if (*a.fault) return;   // a hand-off poll of rowseq_kernel expired in this step: its gradients are garbage, nothing is updated
-    int64_t d;
-    lossv = tail_output(a.tail, (int64_t)a.n_layers * 512 + a.n_fc3, threadIdx.x & 63, d);
-  } else {
-    lossv = a.grad[a.n_params];
-    if (a.grad[a.n_params + 3] != 0.f) {   // some rank's fault word, summed by the all-reduce: every rank skips the step and
-      if (b == 0 && threadIdx.x == 0) *a.fault = 1;   // falls back at its next state read
-      return;
-    }
-  }
-  if (lossv != lossv) return;  // NaN loss: the reference aborts before the optimiser step (ace_trainer.py:615-617)
-  const AdamScalars s = st->adam;
   const int t = threadIdx.x;
-  const int tiles_per_layer = 64;
-  if (b < a.n_layers * tiles_per_layer) {
-    const int layer = b / tiles_per_layer, tl = b % tiles_per_layer;
-    const int r0 = (tl >> 3) * 64, c0 = (tl & 7) * 64;
-    const int64_t woff = a.w_off[layer];
-    // 64 x 64 tile: thread handles 16 elements, rows (t>>4) + 16*i, 4 consecutive cols.
-    // Every load of the tile first, then the arithmetic and the stores: written as one loop (load, compute, store per row group)
-    // the loads of row group i + 1 could not be moved above the stores of row group i (same arrays, no alias information), so a
-    // workgroup made four dependent memory round trips instead of one.
-    const int cc = (t & 15) * 4;
-    float4 p4[4], g4[4], m4[4], v4[4];
+  const int nsmall = adamw_small_blocks(a.n_layers, a.n_fc3, a.slabs != nullptr);
+  const bool tile = b >= nsmall;
+  // ---- tile blocks: every load of the 64 x 64 tile is issued FIRST (before the loss reduction below, which is a memory round trip
+  // of its own, and before any store: written as one load / compute / store loop per row group, the loads of row group i + 1 could
+  // not be moved above the stores of row group i -- same arrays, no alias information -- and a workgroup made four dependent round
+  // trips instead of one)
+  const int tb = b - nsmall, layer = tile ? tb / 64 : 0, tl = tb % 64;
+  const int r0 = (tl >> 3) * 64, c0 = (tl & 7) * 64, cc = (t & 15) * 4;
+  const int64_t woff = a.w_off[layer];
+  float4 p4[4], g4[4], m4[4], v4[4];
+  if (tile) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rr = (t >> 4) + 16 * i;
@@ -1443,6 +1494,25 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
       v4[i] = *reinterpret_cast<const float4*>(a.v + o);
       g4[i] = *reinterpret_cast<const float4*>((a.slabs ? a.slabs : a.grad) + o);
     }
+  }
+  float lossv;
+  if (a.slabs) {   // fused step: the statistics are still partials; every wave sums the loss for itself
+    if (*a.fault) return;   // a hand-off poll of rowseq_kernel expired in this step: its gradients are garbage, nothing is updated
+    int64_t d;
+    lossv = tail_output(a.tail, (int64_t)a.n_layers * 512 + a.n_fc3, threadIdx.x & 63, d);
+  } else {
+    lossv = a.grad[a.n_params];
+    if (a.grad[a.n_params + 3] != 0.f) {   // some rank's fault word, summed by the all-reduce: every rank skips the step and
+      if (b == 0 && threadIdx.x == 0) {               // falls back at its next state read
+        *a.fault = 1;
+        const_cast<TrainState*>(st)->active = 0;
+      }
+      return;
+    }
+  }
+  if (lossv != lossv) return;  // NaN loss: the reference aborts before the optimiser step (ace_trainer.py:615-617)
+  const AdamScalars s = st->adam;
+  if (tile) {
     if (a.slabs) {   // same additions, in the same order, as grad_reduce_kernel's wide part
       for (int sl = 1; sl < a.nslabs; ++sl) {
         float4 q4[4];
@@ -1486,27 +1556,39 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
     }
   } else {
     // small parameters: biases of the wide layers, fc3 weight + bias
-    const int sb = b - a.n_layers * tiles_per_layer;
     const int64_t n_bias = (int64_t)a.n_layers * 512;
     if (a.slabs) {
-      // fused step: one wavefront per output reduces the partials (exactly grad_reduce_kernel's tail), stores the
-      // gradient / statistic and applies the optimiser to it
+      // fused step: a wavefront reduces the partials of eight consecutive outputs (exactly grad_reduce_kernel's tail, output by
+      // output), stores the gradients / statistics and applies the optimiser: lane j < 8 owns output k0 + j, and its p, m, v are
+      // requested before the reduction
       const int lane = t & 63;
-      const int64_t k = ((int64_t)sb * 256 + t) >> 6;
-      if (k >= n_bias + a.n_fc3 + 4) return;
-      int64_t o;
-      const float g = tail_output(a.tail, k, lane, o);
-      if (lane != 0) return;
+      const int64_t k0 = (((int64_t)b * 256 + t) >> 6) * 8;
+      const int64_t n_out = n_bias + a.n_fc3 + 4;
+      if (k0 >= n_out) return;
+      const int64_t kme = k0 + (lane & 7);
+      int64_t ome = -1;
+      if (kme < n_bias) ome = a.b_off[kme >> 9] + (kme & 511);
+      else if (kme < n_bias + a.n_fc3) ome = a.fc3_off + (kme - n_bias);
+      float p = 0.f, m = 0.f, v = 0.f;
+      if (lane < 8 && ome >= 0) { p = a.params[ome]; m = a.m[ome]; v = a.v[ome]; }
+      float acc[8];
+      int64_t dst[8];
+      tail_output8(a.tail, k0, lane, acc, dst);
+      float g = 0.f;
+      int64_t o = -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if ((lane & 7) == j) { g = acc[j]; o = dst[j]; }
+      if (lane >= 8 || o < 0) return;
       a.tail.grad[o] = g;
-      if (k < n_bias + a.n_fc3) {
-        float p = a.params[o], m = a.m[o], v = a.v[o];
+      if (ome >= 0) {
         p = adamw_one(p, g, m, v, s);
-        a.params[o] = p; a.m[o] = m; a.v[o] = v;
-        if (k >= n_bias && (k - n_bias) < (int64_t)a.no * 512) a.W3b[k - n_bias] = f2bf(p);
+        a.params[ome] = p; a.m[ome] = m; a.v[ome] = v;
+        if (kme >= n_bias && (kme - n_bias) < (int64_t)a.no * 512) a.W3b[kme - n_bias] = f2bf(p);
       }
       return;
     }
-    const int64_t k = (int64_t)sb * 256 + t;
+    const int64_t k = (int64_t)b * 256 + t;
     int64_t o = -1;
     if (k < n_bias) o = a.b_off[k >> 9] + (k & 511);
     else if (k < n_bias + a.n_fc3) o = a.fc3_off + (k - n_bias);
@@ -1679,6 +1761,11 @@ __device__ void sched_prepare(TrainState* st, const SchedConfig& c, float crit_m
   SchedHot h = load_hot(st);
   sched_prepare_hot(h, c, crit_min);
   store_hot(st, h);
+}
+
+// after a rowseq fall-back (head_api.hip seq_fault_check): the fault handler had cleared `active`; restore what sched_prepare would set
+__global__ void sched_reactivate_kernel(TrainState* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) st->active = (st->iteration < st->max_iterations && !st->nan_flag) ? 1 : 0;
 }
 
 // initial state: lr as left by the torch scheduler constructors (ace_schedule.py:12-70)

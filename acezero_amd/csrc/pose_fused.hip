@@ -14,17 +14,27 @@
 // long pole). Only launches whose own workgroups are small qualify -- the gather (no LDS) and the optimiser (8 KiB, HBM-bound): a
 // kernel's LDS and register allocation is the same for all of its workgroups, so the GEMM launches (112-154 KiB) cannot host them.
 // The pose workgroups are unchanged bodies of pose_kernels.hip; the per-image results are the same sums in the same order.
-#include "pose_kernels.hip"
+#include "pose_small.hip"
 
 namespace acez {
+
+// T = images per pose workgroup: 16 = the v_mfma_f32_16x16x4_f32 bodies of pose_kernels.hip, 8 / 4 = the small tiles of
+// pose_small.hip (T / 16 of the matrix time per layer, 16 / T times as many CUs; the default is 8).
+template <int T>
+constexpr int pose_fwd_smem_floats() { return T == 16 ? 4 : pose4_fwd_smem_floats<(T == 16 ? 8 : T)>(); }
+template <int T>
+constexpr int pose_s1_smem_bytes() { return T == 16 ? PS1_SMEM_BYTES : pose4_s1_smem_bytes<(T == 16 ? 8 : T)>(); }
 
 // step_begin + S3: blocks [0, np) = pose forward tiles; then the gather blocks; the last block = the schedule bookkeeping that
 // closes the previous iteration (do_post) -- exactly step_begin_kernel. The pose forward does not look at st->active (the schedule
 // block of this very launch is rewriting it): refined poses computed for a step that turns out to be inactive are never used.
+template <int T>
 __global__ __launch_bounds__(256, 2) void step_begin_pose_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
                                                                  uint16_t* __restrict__ out, int n, PostArgs p, int do_post, PoseNetArgs a, int np) {
+  __shared__ __attribute__((aligned(16))) float smem[pose_fwd_smem_floats<T>()];
   if ((int)blockIdx.x < np) {
-    pose_mlp_fwd_body(a, blockIdx.x);
+    if constexpr (T == 16) pose_mlp_fwd_body(a, blockIdx.x);
+    else pose4_fwd_body<T>(a, blockIdx.x, smem);
     return;
   }
   const int gb = (int)blockIdx.x - np, ngb = (int)gridDim.x - np - 1;
@@ -42,13 +52,35 @@ __global__ __launch_bounds__(256, 2) void step_begin_pose_kernel(const uint16_t*
   }
 }
 
-// AdamW of the head + S1: blocks [0, np) = reduce + backward chain of one 16-image tile each, the rest = adamw_kernel's blocks.
-constexpr int ADAMW_POSE_SMEM = PS1_SMEM_BYTES > 64 * 66 * 2 ? PS1_SMEM_BYTES : 64 * 66 * 2;
+// S1 of one tile (reduction of the per-row pose gradients + compose backward + input-gradient chain)
+template <int T>
+__device__ __forceinline__ void pose_s1_tile(const PoseNetArgs& pn, const float* row_dT, const int* row_image, int n, int tile, char* smem) {
+  if constexpr (T == 16) pose_s1_body(pn, row_dT, row_image, n, tile, smem);
+  else pose4_s1_body<T>(pn, row_dT, row_image, n, tile, smem);
+}
+template <int T>
+__global__ __launch_bounds__(256) void pose_s1t_kernel(PoseNetArgs a, const float* row_dT, const int* row_image, int n) {
+  if (a.active && !*a.active) return;
+  __shared__ __attribute__((aligned(16))) char smem[pose_s1_smem_bytes<T>()];
+  pose_s1_tile<T>(a, row_dT, row_image, n, blockIdx.x, smem);
+}
+// stand-alone forward on small tiles (acez_trainer_get_poses, the split flow)
+template <int T>
+__global__ __launch_bounds__(256) void pose_fwd_t_kernel(PoseNetArgs a) {
+  if (a.active && !*a.active) return;
+  __shared__ __attribute__((aligned(16))) float smem[pose_fwd_smem_floats<T>()];
+  if constexpr (T == 16) pose_mlp_fwd_body(a, blockIdx.x);
+  else pose4_fwd_body<T>(a, blockIdx.x, smem);
+}
+
+// AdamW of the head + S1: blocks [0, np) = reduce + backward chain of one image tile each, the rest = adamw_kernel's blocks.
+template <int T>
 __global__ __launch_bounds__(256, 2) void adamw_pose_kernel(AdamArgs a, PoseNetArgs pn, const float* row_dT, const int* row_image, int n, int np) {
-  __shared__ __attribute__((aligned(16))) char smem[ADAMW_POSE_SMEM];
+  constexpr int SMEM = pose_s1_smem_bytes<T>() > 64 * 66 * 2 ? pose_s1_smem_bytes<T>() : 64 * 66 * 2;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
   if ((int)blockIdx.x < np) {
     if (pn.active && !*pn.active) return;
-    pose_s1_body(pn, row_dT, row_image, n, blockIdx.x, smem);
+    pose_s1_tile<T>(pn, row_dT, row_image, n, blockIdx.x, smem);
     return;
   }
   adamw_body(a, (int)blockIdx.x - np, reinterpret_cast<uint16_t (*)[66]>(smem));

@@ -465,9 +465,11 @@ struct PoseWgradArgs {
   const int* enable;      // st->pose_enable (ace_trainer.py:634-636)
   const int* fault;       // rowseq fault word: an abandoned step updates nothing
 };
-__global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
+constexpr int PW_WAVES = 8;   // waves per workgroup: each takes 1 / PW_WAVES of the images (at 1000 images: 32 MFMA steps = ONE batch of loads)
+template <int PW_BATCH>
+__global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? 4 : 2) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {   // (<= 128 registers: two workgroups per CU, the 354 jobs in one round)
   if (a.active && !*a.active) return;
-  __shared__ float sAcc[4][2][16][17];
+  __shared__ float sAcc[PW_WAVES][2][16][17];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = l & 15, lk = l >> 4;
   int layer = 0;
@@ -478,36 +480,58 @@ __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
   const int o0 = (job / kb) * 16, k0 = (job % kb) * 16;
   const float* dY = a.dY[layer];
   const float* X = a.X[layer];
-  const int per = ((a.I + 3) / 4 + 3) / 4 * 4;   // images per wave, multiple of 4
+  const int per = ((a.I + PW_WAVES - 1) / PW_WAVES + 3) / 4 * 4;   // images per wave, multiple of 4
   const int ib = w * per, ie = min(a.I, ib + per);
   const bool vo = o0 + li < O, vk = k0 + li < K;
   const int oc = min(o0 + li, O - 1), kc = min(k0 + li, K - 1);
-  pn_f4 acc = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+  pn_f4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f}, accb2 = {0.f, 0.f, 0.f, 0.f};
   const bool want_bias = k0 == 0;
   // full groups of 4 images: plain pointer walks (the address arithmetic, not the MFMA, was the cost of this loop)
   const int nfull = (ie > ib) ? (ie - ib) / 4 : 0;
   const float* pa = dY + (size_t)(ib + lk) * O + oc;
   const float* pb = X + (size_t)(ib + lk) * xp + kc;
   const size_t sa = (size_t)4 * O, sb = (size_t)4 * xp;
-  // 16 steps of operands are requested together (the compiler keeps a runtime-trip-count loop at one step per L2 round trip)
-  for (int g0 = 0; g0 < nfull; g0 += 16) {
-    float av[16], bv[16], on[16];
+  // the optimiser's operands (fused epilogue) do not depend on anything computed here: requested first
+  const bool upd = a.fuse && *a.enable && !*a.fault;
+  float pw[4], mw[4], vw[4], pb4[4], mb4[4], vb4[4];
+  if (upd && w == 0) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int r = 0; r < 4; ++r) {
+      const int o = min(o0 + 4 * lk + r, O - 1), kk = min(k0 + li, K - 1);
+      const size_t iw = a.offW[layer] + (size_t)o * K + kk, ib = a.offB[layer] + o;
+      pw[r] = a.p[iw]; mw[r] = a.m[iw]; vw[r] = a.v[iw];
+      pb4[r] = a.p[ib]; mb4[r] = a.m[ib]; vb4[r] = a.v[ib];
+    }
+  }
+  // PW_BATCH steps of operands are requested together (the compiler keeps a runtime-trip-count loop at one step per L2 round trip;
+  // with 16 per batch a wave's 63 steps at 1000 images were four dependent round trips, with 64 they are one)
+  for (int g0 = 0; g0 < nfull; g0 += PW_BATCH) {
+    float av[PW_BATCH], bv[PW_BATCH];
+#pragma unroll
+    for (int j = 0; j < PW_BATCH; ++j) {
       const bool ok = g0 + j < nfull;
       const int g = min(g0 + j, nfull - 1);
       const float x = pa[g * sa], y = pb[g * sb];
       av[j] = (ok && vo) ? x : 0.f;
       bv[j] = (ok && vk) ? y : 0.f;
-      on[j] = ok ? 1.f : 0.f;
     }
+    // two accumulator chains (even / odd steps), summed at the end: a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles, two
+    // independent ones every 32
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+    for (int j = 0; j < PW_BATCH; j += 2) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j + 1], bv[j + 1], acc2, 0, 0, 0);
+    }
     if (want_bias) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], on[j], accb, 0, 0, 0);
+      for (int j = 0; j < PW_BATCH; j += 2) {
+        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], (g0 + j < nfull) ? 1.f : 0.f, accb, 0, 0, 0);
+        accb2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j + 1], (g0 + j + 1 < nfull) ? 1.f : 0.f, accb2, 0, 0, 0);
+      }
     }
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc[r] += acc2[r]; accb[r] += accb2[r]; }
   if (ie > ib && ib + 4 * nfull < ie) {   // ragged last group
     const int img = ib + 4 * nfull + lk;
     const bool vi = img < ie;
@@ -526,24 +550,14 @@ __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
   }
   __syncthreads();
   if (w == 0) {
-    const bool upd = a.fuse && *a.enable && !*a.fault;
-    // every operand of the optimiser first (one round trip), then the arithmetic
-    float pw[4], mw[4], vw[4], pb[4], mb[4], vb[4];
     AdamScalars s{};
-    if (upd) {
-      s = *a.sc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = min(o0 + 4 * lk + r, O - 1), kk = min(k0 + li, K - 1);
-        const size_t iw = a.offW[layer] + (size_t)o * K + kk, ib = a.offB[layer] + o;
-        pw[r] = a.p[iw]; mw[r] = a.m[iw]; vw[r] = a.v[iw];
-        pb[r] = a.p[ib]; mb[r] = a.m[ib]; vb[r] = a.v[ib];
-      }
-    }
+    if (upd) s = *a.sc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int oo = 4 * lk + r, o = o0 + oo, kk = k0 + li;
-      const float g = ((sAcc[0][0][oo][li] + sAcc[1][0][oo][li]) + sAcc[2][0][oo][li]) + sAcc[3][0][oo][li];
+      float g = sAcc[0][0][oo][li];
+#pragma unroll
+      for (int wv = 1; wv < PW_WAVES; ++wv) g += sAcc[wv][0][oo][li];   // wave order: fixed
       if (o < O && kk < K) {
         const size_t iw = a.offW[layer] + (size_t)o * K + kk;
         a.grad[iw] = g;
@@ -554,12 +568,14 @@ __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
         }
       }
       if (want_bias && li == 0 && o < O) {
-        const float gb = ((sAcc[0][1][oo][0] + sAcc[1][1][oo][0]) + sAcc[2][1][oo][0]) + sAcc[3][1][oo][0];
+        float gb = sAcc[0][1][oo][0];
+#pragma unroll
+        for (int wv = 1; wv < PW_WAVES; ++wv) gb += sAcc[wv][1][oo][0];
         const size_t ib = a.offB[layer] + o;
         a.grad[ib] = gb;
         if (upd) {
-          a.p[ib] = adamw_small_one(pb[r], gb, mb[r], vb[r], s);
-          a.m[ib] = mb[r]; a.v[ib] = vb[r];
+          a.p[ib] = adamw_small_one(pb4[r], gb, mb4[r], vb4[r], s);
+          a.m[ib] = mb4[r]; a.v[ib] = vb4[r];
         }
       }
     }
@@ -574,19 +590,23 @@ __global__ __launch_bounds__(256) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {
 // The three phases as a body over caller-provided LDS (MAX_HITS: list capacity per workgroup and pass, a multiple of 256):
 //   sRow int[MAX_HITS], sRel u8[MAX_HITS], sVal float[MAX_HITS][12], sCnt int[4];  out192: [16][12] sums (LDS or global), written by
 // threads 0..191. Every thread of the 256-thread workgroup must call it.
-template <int MAX_HITS>
+template <int MAX_HITS, int TILE = 16>
 __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ row_dT, const int* __restrict__ row_image, const int n, const int i0,
                                                       int* sRow, unsigned char* sRel, float (*sVal)[12], int* sCnt, float* out192) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   constexpr int cap = MAX_HITS / 4;            // list capacity per wave
-  // One pass over all rows when the lists fit (many images: ~5 rows per image); otherwise (few images) passes of MAX_HITS rows, which
-  // cannot overflow. Row order is preserved either way.
+  // One pass over all rows when the lists fit (many images: ~5 rows per image). Otherwise (few images) the rows are taken in several
+  // passes: first of a size chosen from the number of hits the failed pass counted (half-full lists on average), and if a list still
+  // overflows, of MAX_HITS rows, which cannot. Row order is preserved in every case.
   int chunk = n;
   float result = 0.f;
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  for (int attempt = 0; attempt < 3; ++attempt) {
     float acc = 0.f;                               // thread (image t / 12, component t % 12)
     bool overflow = false;
     for (int cb = 0; cb < n; cb += chunk) {
+      // the lists are rewritten below: every reader of the pass before must be done with them (without this barrier a fast wave's
+      // appends overwrote entries other waves were still summing -- wrong pose gradients whenever a tile needed more than one pass)
+      if (cb > 0) __syncthreads();
       const int ce = min(n, cb + chunk);
       const int q = ((ce - cb + 3) / 4 + 63) / 64 * 64;      // rows per wave in this pass
       const int rb = cb + w * q, re = min(ce, rb + q);
@@ -601,7 +621,7 @@ __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ 
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          const bool hit = rel[j] >= 0 && rel[j] < 16;
+          const bool hit = rel[j] >= 0 && rel[j] < TILE;
           const unsigned long long m = __ballot(hit);
           if (hit) {
             const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
@@ -613,7 +633,14 @@ __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ 
       __syncthreads();                             // previous pass' readers of the lists are done
       if (lane == 0) sCnt[w] = cnt;
       __syncthreads();
-      if (sCnt[0] > cap || sCnt[1] > cap || sCnt[2] > cap || sCnt[3] > cap) { overflow = true; break; }
+      if (sCnt[0] > cap || sCnt[1] > cap || sCnt[2] > cap || sCnt[3] > cap) {
+        overflow = true;
+        // hits per row seen in this pass -> rows per pass that would leave the lists half full (a multiple of 256, at least MAX_HITS)
+        const int hits = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
+        const long rows = (long)(ce - cb) * (MAX_HITS / 2) / hits;
+        chunk = attempt == 0 ? (int)max((long)MAX_HITS, rows / 256 * 256) : MAX_HITS;   // MAX_HITS / 4 rows per wave: the lists cannot overflow
+        break;
+      }
       {   // fetch all hit rows: 8 independent loads per thread and round trip
         const int b1 = sCnt[0], b2 = b1 + sCnt[1], b3 = b2 + sCnt[2], H = b3 + sCnt[3];
         for (int f0 = 0; f0 < H * 12; f0 += 256 * 8) {
@@ -634,7 +661,7 @@ __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ 
         }
       }
       __syncthreads();
-      if (t < 16 * 12) {
+      if (t < TILE * 12) {
         const int im = t / 12, c = t % 12;
         for (int wv = 0; wv < 4; ++wv)
           for (int h = 0; h < sCnt[wv]; ++h)
@@ -642,10 +669,9 @@ __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ 
       }
     }
     if (!overflow) { result = acc; break; }
-    chunk = MAX_HITS;                              // MAX_HITS / 4 rows per wave: the lists cannot overflow
     __syncthreads();
   }
-  if (t < 16 * 12) out192[t] = result;
+  if (t < TILE * 12) out192[t] = result;
 }
 
 constexpr int PGR_MAX_HITS = 1024;   // per workgroup (16 images) and pass

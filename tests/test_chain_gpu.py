@@ -20,10 +20,12 @@ def _pair(prob, flat0, cfg, max_batch, num_head_blocks=1):
     out = []
     for chain in ("0", "1"):
         os.environ["ACEZ_CHAIN"] = chain
+        os.environ["ACEZ_POSE_TILE"] = "16"   # the chain kernel keeps round 2's pose launches (16-image tiles): same arithmetic on both sides
         try:
             out.append(_trainer(prob, flat0, cfg, max_batch=max_batch))
         finally:
             os.environ.pop("ACEZ_CHAIN", None)
+            os.environ.pop("ACEZ_POSE_TILE", None)
     return out
 
 

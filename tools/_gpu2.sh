@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_pose_fused_gpu.py tests/test_chain_gpu.py tests/test_dp_gpu.py -m gpu -x -q 2>&1 | tail -15 > gpurun_out/t1.log; cat gpurun_out/t1.log
+for rep in 1 2; do
+for v in "none $PWD/tools/libacez_r02.so" "none " "mlp $PWD/tools/libacez_r02.so" "mlp "; do set -- $v
+  ACEZ_LIB=$2 timeout 200 python bench.py --headline-only --steps 200 --warmup 30 --buffer-patches 2000000 --pose-refinement $1 2>&1 | grep metric | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('pose=$1 lib=$2', round(d['ms_per_step']*1e3,1),'us median; windows', [round(x*1e3,1) for x in d['window_ms_per_step']], {k: round(v,1) for k,v in d['per_class_us_per_step'].items()})
+"
+done; done 2>&1 | tee gpurun_out/ab2.log
+bash tools/prof_r03.sh quick 2>&1 | tail -40 | tee gpurun_out/prof_quick.log

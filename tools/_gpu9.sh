@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_seq_gpu.py -m gpu -x -q 2>&1 | tail -6 > gpurun_out/t1.log; cat gpurun_out/t1.log
+for rep in 1 2; do
+for v in "none $PWD/tools/libacez_r02.so" "none " "none $PWD/tools/libacez_exp_ALL.so" "mlp "; do set -- $v
+  ACEZ_LIB=$2 timeout 200 python bench.py --headline-only --steps 200 --warmup 30 --buffer-patches 2000000 --pose-refinement $1 2>&1 | grep metric | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('pose=$1 lib=$2'[-40:], round(d['ms_per_step']*1e3,1),'us median;', {k: round(v,1) for k,v in d['per_class_us_per_step'].items()})
+"
+done; done 2>&1 | tee gpurun_out/ab9.log
+rocprofv3 --output-format csv --kernel-trace --stats -d /tmp/trm -o trace -- python bench.py --headline-only --steps 200 --warmup 30 --buffer-patches 2000000 --pose-refinement mlp > /dev/null 2>&1
+cut -c1-120 $(find /tmp/trm -name "*kernel_stats.csv" | head -1) | grep acez | head -9 | tee gpurun_out/prof9.log
