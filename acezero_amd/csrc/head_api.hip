@@ -591,10 +591,12 @@ static void launch_pose_wgrad(acez_trainer* tr, const int* active, bool fuse, hi
   w.I = I; w.grad = tr->pb.d_grad + tr->n_params + 4; w.active = active;
   w.fuse = fuse ? 1 : 0; w.p = tr->pb.d_pose_params; w.m = tr->pb.d_pose_m; w.v = tr->pb.d_pose_v; w.Wt = tr->pose_wt;
   w.sc = &tr->st->pose_adam; w.enable = &tr->st->pose_enable; w.fault = tr->seq_err;
-  static const int wb = getenv("ACEZ_POSE_WB") ? atoi(getenv("ACEZ_POSE_WB")) : 32;   // operand steps requested per round trip
-  if (wb == 16) hipLaunchKernelGGL(pose_mlp_wgrad_kernel<16>, dim3(jobs), dim3(64 * PW_WAVES), 0, s, w);
-  else if (wb == 64) hipLaunchKernelGGL(pose_mlp_wgrad_kernel<64>, dim3(jobs), dim3(64 * PW_WAVES), 0, s, w);
-  else hipLaunchKernelGGL(pose_mlp_wgrad_kernel<32>, dim3(jobs), dim3(64 * PW_WAVES), 0, s, w);
+  static const int wb = getenv("ACEZ_POSE_WB") ? atoi(getenv("ACEZ_POSE_WB")) : 16;   // operand steps requested per round trip
+  static const int ww = getenv("ACEZ_POSE_WW") ? atoi(getenv("ACEZ_POSE_WW")) : 8;    // waves per workgroup
+  if (wb == 16 && ww == 4) hipLaunchKernelGGL((pose_mlp_wgrad_kernel<16, 4>), dim3(jobs), dim3(256), 0, s, w);
+  else if (wb == 16) hipLaunchKernelGGL((pose_mlp_wgrad_kernel<16, 8>), dim3(jobs), dim3(512), 0, s, w);
+  else if (ww == 4) hipLaunchKernelGGL((pose_mlp_wgrad_kernel<32, 4>), dim3(jobs), dim3(256), 0, s, w);
+  else hipLaunchKernelGGL((pose_mlp_wgrad_kernel<32, 8>), dim3(jobs), dim3(512), 0, s, w);
 }
 
 static void launch_pose_grad_reduce(acez_trainer* tr, int n, const int* active, hipStream_t s) {

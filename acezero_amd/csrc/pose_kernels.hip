@@ -465,9 +465,9 @@ struct PoseWgradArgs {
   const int* enable;      // st->pose_enable (ace_trainer.py:634-636)
   const int* fault;       // rowseq fault word: an abandoned step updates nothing
 };
-constexpr int PW_WAVES = 8;   // waves per workgroup: each takes 1 / PW_WAVES of the images (at 1000 images: 32 MFMA steps = ONE batch of loads)
-template <int PW_BATCH>
-__global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? 4 : 2) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {   // (<= 128 registers: two workgroups per CU, the 354 jobs in one round)
+// PW_WAVES waves per workgroup: each takes 1 / PW_WAVES of the images (8 waves at 1000 images: 32 MFMA steps = ONE batch of loads)
+template <int PW_BATCH, int PW_WAVES>
+__global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? PW_WAVES / 2 : 2) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {   // (<= 128 registers: two workgroups per CU, the 354 jobs in one round)
   if (a.active && !*a.active) return;
   __shared__ float sAcc[PW_WAVES][2][16][17];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
