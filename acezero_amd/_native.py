@@ -41,7 +41,8 @@ class TrainConfig(C.Structure):
                 ("cooldown_iterations", C.c_int32), ("cooldown_trigger_percent", C.c_double), ("beta1", C.c_double),
                 ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("refine_calibration", C.c_int32),
                 ("focal_init", C.c_float), ("calib_lr", C.c_double), ("pose_refinement", C.c_int32), ("pose_refinement_wait", C.c_int32),
-                ("pose_refinement_lr", C.c_double), ("pose_refinement_weight", C.c_float), ("pose_refinement_ortho", C.c_int32)]
+                ("pose_refinement_lr", C.c_double), ("pose_refinement_weight", C.c_float), ("pose_refinement_ortho", C.c_int32),
+                ("compute_dtype", C.c_int32)]
 
 
 class ParamBuffers(C.Structure):

@@ -10,6 +10,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
@@ -42,7 +43,6 @@ __device__ __forceinline__ void unpack4(uint2 v, float* o) {
   o[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // [row][64] bf16 K-stage tiles: 16-byte chunk index XOR (row >> 1) & 7 -> the ds_read_b128 fragment reads of 32
 // consecutive rows are conflict-free. Applied to the per-lane SOURCE chunk of the LDS-DMA and, identically, to the reads.
@@ -68,6 +68,45 @@ __device__ __forceinline__ float wave_sum63(float v) {
   v = ACEZ_DPP_ADD(v, 0x143, 0xC);   // row_bcast:31 -> rows 2 and 3 add the sum of rows 0..1
   return v;
 }
+
+// ---- the two 16-bit operand formats of the head (acez_train_config.compute_dtype): bf16 (default; BASELINE.json north_star) and fp16
+// (what the reference's autocast uses, ace_trainer.py:517-518; three more mantissa bits, a narrower exponent: gradients are
+// propagated scaled, head_api.hip grad_scale). Same MFMA rate on gfx950 (v_mfma_f32_16x16x32_{bf16,f16}), fp32 accumulation in both.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {   // v_cvt_pk_f16_f32: round to nearest even
+  f16x2_t v;
+  v[0] = (_Float16)a;
+  v[1] = (_Float16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+struct EltBf16 {
+  typedef bf16x8 frag;
+  static constexpr bool is_f16 = false;
+  static __device__ __forceinline__ float to_f(uint16_t h) { return bf2f(h); }
+  static __device__ __forceinline__ uint16_t from_f(float f) { return f2bf(f); }
+  static __device__ __forceinline__ uint32_t pk2(float a, float b) { return pack2(a, b); }
+  static __device__ __forceinline__ uint2 pk4(float a, float b, float c, float d) { return pack4(a, b, c, d); }
+  static __device__ __forceinline__ void un2(uint32_t v, float& a, float& b) { a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u); }
+  static __device__ __forceinline__ void un4(uint2 v, float* o) { unpack4(v, o); }
+  static __device__ __forceinline__ f32x4 mfma16(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mfma32(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+struct EltF16 {
+  typedef f16x8 frag;
+  static constexpr bool is_f16 = true;
+  static __device__ __forceinline__ float to_f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+  static __device__ __forceinline__ uint16_t from_f(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+  static __device__ __forceinline__ uint32_t pk2(float a, float b) { return pack2h(a, b); }
+  static __device__ __forceinline__ uint2 pk4(float a, float b, float c, float d) { uint2 r; r.x = pack2h(a, b); r.y = pack2h(c, d); return r; }
+  static __device__ __forceinline__ void un2(uint32_t v, float& a, float& b) {
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, v);
+    a = (float)h[0]; b = (float)h[1];
+  }
+  static __device__ __forceinline__ void un4(uint2 v, float* o) { un2(v.x, o[0], o[1]); un2(v.y, o[2], o[3]); }
+  static __device__ __forceinline__ f32x4 mfma16(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mfma32(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;

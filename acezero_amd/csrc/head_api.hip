@@ -86,6 +86,10 @@ struct acez_trainer {
   // rowseq_kernel: the forward layers / the input-gradient layers as ONE launch each, kernel boundaries replaced by a same-XCD
   // hand-off (head_kernels.hip). Default when every workgroup can be resident (grid <= CUs); ACEZ_SEQ=0 = per-layer launches.
   bool seq = true;
+  // 16-bit operand format of the GEMM chains (acez_train_config.compute_dtype): bf16, or fp16 with the gradient chain scaled by
+  // grad_scale (fp16's smallest normal is 6e-5; the reference uses a GradScaler for the same reason, ace_schedule.py:70,107-113)
+  bool f16 = false;
+  int last_nblk = 0;   // loss workgroups of the last backward (the schedule wave scans their |ds| maxima in fp16 mode)
   int n_cus = 0;
   uint32_t* seq_flags = nullptr;  // [64 row tiles][32] hand-off counters, monotonically increasing
   uint32_t seq_base[64] = {};     // seams completed so far, per row tile
@@ -213,6 +217,8 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_REQUIRE(cfg->pose_refinement == 0 || (params->d_pose_params && params->d_pose_m && params->d_pose_v), "pose refinement needs the pose parameter buffers");
   ACEZ_REQUIRE(cfg->pose_refinement != 2 || params->n_pose_params == ACEZ_POSE_MLP_PARAMS, "mlp: n_pose_params must be ACEZ_POSE_MLP_PARAMS");
   ACEZ_REQUIRE(cfg->pose_refinement != 1 || (params->n_pose_params > 0 && params->n_pose_params % 12 == 0), "naive: n_pose_params must be 12 * n_images");
+  ACEZ_REQUIRE(cfg->compute_dtype != ACEZ_DTYPE_FP32, "compute_dtype fp32 (train_ace.py --use_half False) is not implemented: choose ACEZ_DTYPE_BF16 or ACEZ_DTYPE_FP16");
+  ACEZ_REQUIRE(cfg->compute_dtype == ACEZ_DTYPE_BF16 || cfg->compute_dtype == ACEZ_DTYPE_FP16, "unknown compute_dtype");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     (void)hipGetLastError();
@@ -227,6 +233,8 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   if (const char* e = getenv("ACEZ_FUSED_FWD")) tr->fused_fwd = atoi(e) != 0;
   if (const char* e = getenv("ACEZ_CHAIN")) tr->chain = atoi(e) != 0;
   if (tr->fused_fwd) tr->chain = false;
+  tr->f16 = cfg->compute_dtype == ACEZ_DTYPE_FP16;
+  if (tr->f16) { tr->fused_fwd = false; tr->chain = false; }   // the opt-in row-persistent kernels exist in bf16 only
   if (const char* e = getenv("ACEZ_POSE_FUSED")) tr->pose_fused = atoi(e) != 0;
   if (const char* e = getenv("ACEZ_POSE_TILE")) { const int v = atoi(e); tr->pose_tile = tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
   if (const char* e = getenv("ACEZ_POSE_TILE_FWD")) { const int v = atoi(e); tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
@@ -245,6 +253,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->fc3_stride = ((int64_t)tr->no * 513 + 3) & ~3LL;
   tr->max_batch = cfg->max_batch;
   if (const char* e = getenv("ACEZ_GEMM_TILE")) tr->gemm_tile = atoi(e) == 128 ? 128 : 80;
+  if (tr->f16) tr->gemm_tile = 80;
   if (const char* e = getenv("ACEZ_SEQ")) tr->seq = atoi(e) != 0;
   {
     hipDeviceProp_t prop;
@@ -254,6 +263,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   // wgrad_kernel: 16 tiles per layer; wgrad256_kernel (ACEZ_WGRAD_TILE=256, measured alternative: -2.8 us of wgrad, +2.4 us of
   // adamw for the two extra slabs): 8; as many row slabs as fill the 256 CUs
   if (const char* e = getenv("ACEZ_WGRAD_TILE")) tr->wgrad_tile = atoi(e) == 256 ? 256 : 128;
+  if (tr->f16) tr->wgrad_tile = 128;
   tr->nslabs = 256 / ((tr->wgrad_tile == 128 ? 16 : 8) * tr->L);
   if (tr->nslabs < 1) tr->nslabs = 1;
 
@@ -313,6 +323,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   sc.beta1 = cfg->beta1; sc.beta2 = cfg->beta2; sc.eps = cfg->eps; sc.weight_decay = cfg->weight_decay;
   sc.calib_lr = cfg->calib_lr;
   sc.pose_refinement = cfg->pose_refinement; sc.pose_wait = cfg->pose_refinement_wait; sc.pose_lr = cfg->pose_refinement_lr;
+  sc.f16 = tr->f16 ? 1 : 0;
   hipLaunchKernelGGL(sched_init_kernel, dim3(1), dim3(64), 0, 0, tr->st, sc);
   ACEZ_HIP_CHECK(hipGetLastError());
   ACEZ_HIP_CHECK(hipMemset(tr->zeros, 0, 1024));
@@ -383,7 +394,7 @@ static void fill_adam_args(acez_trainer* tr, AdamArgs& a) {
   a.fc3_off = tr->fc3_off; a.n_fc3 = (int64_t)tr->no * 513; a.n_params = tr->n_params;
   a.n_layers = tr->L; a.no = tr->no; a.st = tr->st;
   a.slabs = nullptr; a.nslabs = 0; a.slab_stride = 0;
-  a.fault = tr->seq_err;
+  a.fault = tr->seq_err; a.f16 = tr->f16 ? 1 : 0;
 }
 
 extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
@@ -438,7 +449,8 @@ static void launch_rowseq(acez_trainer* tr, const std::vector<SeqLayer>& layers,
     if (cnt > 1 && tr->seq_launches == tr->seq_fault_at)
       for (int mt = 0; mt < 64; ++mt) a.base[mt] += 1u << 20;
     ++tr->seq_launches;
-    hipLaunchKernelGGL(rowseq_kernel<BWD>, dim3(32 * ((mtiles + 7) / 8)), dim3(512), 0, s, a);
+    if (tr->f16) hipLaunchKernelGGL((rowseq_kernel<BWD, EltF16>), dim3(32 * ((mtiles + 7) / 8)), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(rowseq_kernel<BWD>, dim3(32 * ((mtiles + 7) / 8)), dim3(512), 0, s, a);
     for (int mt = 0; mt < mtiles; ++mt) tr->seq_base[mt] += (uint32_t)(cnt - 1);
     tr->prof_launches += cnt;   // accounted as layer GEMMs so that the per-layer average stays comparable
   }
@@ -461,7 +473,7 @@ static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, co
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144;
     g.add = nullptr; g.mask = nullptr; g.res = res; g.out_main = out_main; g.out_aux = out_aux;
     g.M = n; g.N = 512; g.K = 512; g.relu = 1; g.aux_mode = res ? AUX_RESIDUAL : AUX_NONE; g.st = st; g.dbg = 0; g.bias_partials = nullptr;
-    launch_rowgemm(g, tr->gemm_tile, s);
+    launch_rowgemm(g, tr->gemm_tile, s, tr->f16);
     ++tr->prof_launches;
   };
   const uint16_t* r = in0;
@@ -502,6 +514,7 @@ static void fill_loss_train(acez_trainer* tr, LossArgs& a, const uint16_t* act, 
   a.st = tr->st; a.out_xyz = tr->xyz; a.dZ = tr->dZ[f2];
   a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
   a.bias_partials = tr->bias_partials + (size_t)f2 * tr->bias_layer_stride; a.dbg = 0;
+  a.absmax = tr->f16 ? &tr->st->dz_absmax_bits : nullptr;
   if (const char* e = getenv("ACEZ_LOSS_DBG")) a.dbg = atoi(e);   // ablation: 1 = stop after phase A, 2 = after phase B (timing only)
 }
 
@@ -618,7 +631,7 @@ static PostArgs post_args(acez_trainer* tr) {
   PostArgs p;
   p.st = tr->st; p.c = tr->sc; p.grad_stats = (const float*)(tr->pb.d_grad + tr->n_params);
   p.inv_global_batch = 1.0f / (float)tr->cfg.global_batch; p.log_loss = tr->log_loss; p.log_inl = tr->log_inl; p.log_cap = tr->log_cap;
-  p.fault = tr->seq_err;
+  p.fault = tr->seq_err; p.stat_partials = tr->stat_partials; p.n_loss_blocks = tr->last_nblk;
   return p;
 }
 
@@ -629,7 +642,8 @@ static void flush_post(acez_trainer* tr, hipStream_t s) {
   tr->post_pending = false;
   ProfScope ps(tr, s, KC_SCHED);
   const PostArgs p = post_args(tr);
-  hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault);
+  hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault,
+                     p.stat_partials, p.n_loss_blocks);
 }
 
 static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n, void* stream, bool fused) {
@@ -728,8 +742,10 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   {
     LossArgs a{};
     fill_loss_train(tr, a, act, d_indices, n, pose_mlp);
+    tr->last_nblk = nblk;   // (after this step's step_begin, whose schedule wave closed the step BEFORE with that step's count)
     ProfScope ps(tr, s, KC_LOSS);
-    hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, s, a);
+    if (tr->f16) hipLaunchKernelGGL(loss_kernel<EltF16>, dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(loss_kernel<EltBf16>, dim3(nblk), dim3(256), 0, s, a);
   }
 
   if (ps != s) {   // the pose gradients start from the per-row pose gradients the loss kernel has just written
@@ -756,7 +772,8 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     g.In = tr->dZ[l]; g.W = tr->WbT + (size_t)l * 262144; g.bias = nullptr; g.add = add; g.mask = mask; g.res = nullptr;
     g.out_main = out_main; g.out_aux = out_aux; g.M = n; g.N = 512; g.K = 512; g.relu = 0;
     g.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE; g.st = st; g.dbg = 0;
-    launch_rowgemm(g, tr->gemm_tile, s);
+    g.absmax = tr->f16 ? &tr->st->dz_absmax_bits : nullptr;
+    launch_rowgemm(g, tr->gemm_tile, s, tr->f16);
     ++tr->prof_launches;
   };
   ProfScope* dchain = new ProfScope(tr, s, KC_GEMM_DGRAD);
@@ -789,7 +806,8 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.n_layers = tr->L; a.st = st; a.zeros = tr->zeros; a.dbg = 0;
     ProfScope ps(tr, s, KC_WGRAD);
     const int groups = tr->L * tr->nslabs;
-    if (tr->wgrad_tile == 128) hipLaunchKernelGGL(wgrad_kernel, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
+    if (tr->f16) hipLaunchKernelGGL(wgrad_kernel<EltF16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
+    else if (tr->wgrad_tile == 128) hipLaunchKernelGGL(wgrad_kernel<EltBf16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
     else hipLaunchKernelGGL(wgrad256_kernel, dim3(64 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
   }
   {
@@ -952,14 +970,15 @@ static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, fl
   for (int done = 0; done < n; done += tr->max_batch) {
     const int cnt = (n - done < tr->max_batch) ? n - done : tr->max_batch;
     uint16_t* act = tr->fused_fwd      ? launch_forward_fused(tr, f + (size_t)done * 512, nullptr, cnt, false, nullptr, s)
-                    : cnt >= 256 * 128 ? launch_forward_conv(tr, f + (size_t)done * 512, cnt, s)
+                    : (cnt >= 256 * 128 && !tr->f16) ? launch_forward_conv(tr, f + (size_t)done * 512, cnt, s)   // (the large-tile conv kernels are bf16)
                                        : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
     LossArgs a{};
     fill_loss_head(tr, a);
     a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr;
     if (planar_hw > 0) { a.out_xyz = d_out; a.planar_hw = planar_hw; a.row_offset = done; }
     else a.out_xyz = d_out + (size_t)done * 3;
-    hipLaunchKernelGGL(loss_kernel, dim3((cnt + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS)), dim3(256), 0, s, a);
+    if (tr->f16) hipLaunchKernelGGL(loss_kernel<EltF16>, dim3((cnt + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(loss_kernel<EltBf16>, dim3((cnt + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS)), dim3(256), 0, s, a);
   }
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;

@@ -38,6 +38,11 @@ struct TrainState {
   int pose_enable, pose_opt_steps;
   double pose_b1pow, pose_b2pow;
   AdamScalars pose_adam;
+  // fp16 operands: the gradient chain is propagated scaled by grad_scale (a power of two, so that scaling commutes with fp16 rounding
+  // wherever nothing under- or overflows) and un-scaled where it meets the fp32 optimiser. Chosen by the schedule wave from the largest
+  // |d loss / d fc3 output| of the step before (what torch.cuda.amp.GradScaler does with inf checks, ace_schedule.py:70,107-113). bf16: 1.
+  float grad_scale, inv_grad_scale;
+  uint32_t dz_absmax_bits;   // bit pattern of the largest propagated gradient magnitude of the running step, scaled units (absmax_publish)
 };
 
 struct SchedConfig {
@@ -48,6 +53,7 @@ struct SchedConfig {
   double beta1, beta2, eps, weight_decay, calib_lr;
   int pose_refinement, pose_wait;
   double pose_lr;
+  int f16;   // fp16 operands (dynamic gradient scale) instead of bf16
 };
 
 struct RowGemmArgs {
@@ -63,6 +69,7 @@ struct RowGemmArgs {
   int M, N, K, relu, aux_mode;
   const TrainState* st;
   int dbg;  // ablation switches for tools/ablate_rowgemm.hip (0 in production): 1 = no epilogue, 2 = no MFMA, 4 = no loads
+  uint32_t* absmax;  // fp16 gradient launches: &TrainState::dz_absmax_bits (else null)
 };
 
 struct WgradArgs {
@@ -107,6 +114,7 @@ struct LossArgs {
   float* stat_partials;  // [blocks][4]
   float* bias_partials;  // [blocks][512] column sums of dZ
   int dbg;               // ablation (tools/ablate_rowgemm.hip): 1 = stop after phase A, 2 = stop after phase B
+  uint32_t* absmax;      // fp16 training: &TrainState::dz_absmax_bits (else null)
 };
 
 struct GradReduceArgs {
@@ -147,6 +155,7 @@ struct AdamArgs {
   int64_t slab_stride;
   GradReduceArgs tail;   // with slabs != null: the partials of the small parameters and statistics (reduced here as well)
   int* fault;            // the trainer's rowseq fault word: a faulted step updates nothing
+  int f16;               // the compute copies W / W^T / W3 are fp16 (else bf16)
 };
 
 }  // namespace acez

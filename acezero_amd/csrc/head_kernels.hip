@@ -251,6 +251,15 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
 // free both for the accumulator layout and for the row-wise copy), so every global access is a full 256-byte row.
 // ---------------------------------------------------------------------------------------------------
 
+// fp16 gradient-scale control: every kernel that stores propagated gradients folds the largest magnitude it produced (before the
+// conversion, in scaled units) into ONE word per trainer -- a wavefront maximum, then an atomic max on the bit pattern (non-negative
+// floats order like unsigned integers; +inf = 0x7f800000 is the overflow signal). Read and reset by sched_post_wave.
+__device__ __forceinline__ void absmax_publish(uint32_t* word, float amax) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(word, __float_as_uint(amax));
+}
+
 // One layer of one workgroup. SEQ = false: the whole of rowgemm80_kernel. SEQ = true: one link of rowseq_kernel (below), where
 // the layers of a dependent chain run in ONE launch and the kernel boundary is replaced by a same-XCD hand-off (SeqLink).
 struct SeqLink {
@@ -267,7 +276,7 @@ constexpr int RG80_STAGE = (128 + 96) * 64;                        // elements p
 constexpr int RG80_SMEM = 4 * RG80_STAGE + 2 * 80 * 128;           // ring + two staging tiles
 constexpr int RG80_SMEM_SEQ = RG80_SMEM + 1024;                    // + the bias-partial combine buffer (the ring is busy in SEQ mode)
 
-template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX, bool SEQ>
+template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX, bool SEQ, class E = EltBf16>
 __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* smem, const int active, const int mt, const int n0,
                                                const SeqLink& q) {
   constexpr int STAGE = RG80_STAGE;
@@ -279,7 +288,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
   const int M = a.M, N = a.N;
   constexpr int K = 512, KT = 8;
   constexpr bool HAS_IN2 = HAS_MASK || AUX == AUX_RESIDUAL;
-  constexpr int E = 5 * ((HAS_ADD ? 1 : 0) + (HAS_IN2 ? 1 : 0));  // epilogue-input DMA instructions per loader
+  constexpr int EPI = 5 * ((HAS_ADD ? 1 : 0) + (HAS_IN2 ? 1 : 0));  // epilogue-input DMA instructions per loader
 
   if (w >= 4) {
     // ------------------------------------------------------------------ loader waves
@@ -362,9 +371,9 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         else if (SEQ && kt == 2) ACEZ_VMCNT(10);
         else if (kt == 0) ACEZ_VMCNT(21);
         else if (kt <= 4) ACEZ_VMCNT(14);
-        else if (kt == 5) ACEZ_VMCNT_C(14 + E);
-        else if (kt == 6) ACEZ_VMCNT_C(7 + E);
-        else ACEZ_VMCNT_C(E);
+        else if (kt == 5) ACEZ_VMCNT_C(14 + EPI);
+        else if (kt == 6) ACEZ_VMCNT_C(7 + EPI);
+        else ACEZ_VMCNT_C(EPI);
         __builtin_amdgcn_s_barrier();   // stage kt has landed; the multipliers are done with stage kt - 1
         if (kt >= 1 && kt + 3 < KT) issue(kt + 3);
         if (kt == 4) {
@@ -417,19 +426,20 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int c = kk * 4 + fq;
-        bf16x8 fa[2], fb[5];
+        typename E::frag fa[2], fb[5];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz(w * 32 + i * 16 + fr, c)]);
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const typename E::frag*>(&sW[swz(w * 32 + i * 16 + fr, c)]);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz(j * 16 + fr, c)]);
+        for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const typename E::frag*>(&sI[swz(j * 16 + fr, c)]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 5; ++j) acc[i][j] = E::mfma16(fa[i], fb[j], acc[i][j]);
       }
     }
     stage_barrier();                    // epilogue inputs have landed
     if (!SEQ && ((a.dbg & 1) || !active)) return;
+    float amax = 0.f;                   // fp16 gradient layers: largest |value| before the conversion (absmax_publish)
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int ml = j * 16 + fr;
@@ -444,18 +454,19 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         }
         if (HAS_ADD) {
           float ad[4];
-          unpack4(*reinterpret_cast<const uint2*>(pa), ad);
+          E::un4(*reinterpret_cast<const uint2*>(pa), ad);
           v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
         }
         if (BIAS_RELU) {
           v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
         }
-        uint2 y = pack4(v[0], v[1], v[2], v[3]);
+        if (E::is_f16 && HAS_MASK) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        uint2 y = E::pk4(v[0], v[1], v[2], v[3]);
         if (AUX == AUX_RESIDUAL) {
           float yf[4], rf[4];
-          unpack4(y, yf);
-          unpack4(*reinterpret_cast<const uint2*>(pb), rf);
-          *reinterpret_cast<uint2*>(pa) = pack4(yf[0] + rf[0], yf[1] + rf[1], yf[2] + rf[2], yf[3] + rf[3]);
+          E::un4(y, yf);
+          E::un4(*reinterpret_cast<const uint2*>(pb), rf);
+          *reinterpret_cast<uint2*>(pa) = E::pk4(yf[0] + rf[0], yf[1] + rf[1], yf[2] + rf[2], yf[3] + rf[3]);
         } else if (AUX == AUX_UNMASKED) {
           *reinterpret_cast<uint2*>(pa) = y;
         }
@@ -472,6 +483,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         *reinterpret_cast<uint2*>(pb) = y;
       }
     }
+    if (E::is_f16 && HAS_MASK && a.absmax) absmax_publish(a.absmax, amax);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // output tiles complete
   }
@@ -518,7 +530,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
 #pragma unroll
     for (int r = 0; r < 20; ++r) {
       const int row = g * 20 + r;
-      const float v = bf2f(stB[st_off(row, col)]);
+      const float v = E::to_f(stB[st_off(row, col)]);
       sacc += (row < rows) ? v : 0.f;
     }
     float* red = reinterpret_cast<float*>(SEQ ? smem + RG80_SMEM : smem);
@@ -540,7 +552,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
   }
 }
 
-template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX>
+template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX, class E = EltBf16>
 __global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
   const int active = a.st ? a.st->active : 1;
   __shared__ __attribute__((aligned(16))) uint16_t smem[RG80_SMEM];
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
   const int jx = blockIdx.x >> 3;
   const int mt = (blockIdx.x & 7) * per_xcd + (jx >> 2);
   if (mt >= mtiles) return;
-  rowgemm80_body<BIAS_RELU, HAS_ADD, HAS_MASK, AUX, false>(a, smem, active, mt, (jx & 3) * 128, SeqLink{});
+  rowgemm80_body<BIAS_RELU, HAS_ADD, HAS_MASK, AUX, false, E>(a, smem, active, mt, (jx & 3) * 128, SeqLink{});
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -586,7 +598,7 @@ struct RowSeqArgs {
                        // once), flags[64 * 32 + 1] = the poll budget
 };
 
-template <bool BWD>
+template <bool BWD, class E = EltBf16>
 __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[RG80_SMEM_SEQ];
   const int mtiles = (a.M + 79) / 80;
@@ -613,18 +625,19 @@ __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
     RowGemmArgs g;
     g.In = y.In; g.W = y.W; g.bias = y.bias; g.add = y.add; g.mask = y.mask; g.res = y.res; g.out_main = y.out_main; g.out_aux = y.out_aux;
     g.bias_partials = y.bias_partials; g.M = a.M; g.N = 512; g.K = 512; g.relu = BWD ? 0 : 1; g.aux_mode = y.aux_mode; g.st = a.st; g.dbg = 0;
+    g.absmax = (BWD && a.st) ? const_cast<uint32_t*>(&a.st->dz_absmax_bits) : nullptr;
     SeqLink q;
     q.flag = a.flags + mt * 32; q.target = (a.base[mt] + (uint32_t)layer) * 32u;   // 4 workgroups x 8 waves per seam
     q.first = layer == 0; q.wait = layer > 0; q.signal = layer + 1 < a.n_layers;
     q.next_W = q.signal ? a.layer[layer + 1].W : nullptr;
     q.flag_index = (uint32_t)(mt * 32);
     if (!BWD) {
-      if (y.aux_mode == AUX_RESIDUAL) rowgemm80_body<true, false, false, AUX_RESIDUAL, true>(g, smem, 1, mt, n0, q);
-      else rowgemm80_body<true, false, false, AUX_NONE, true>(g, smem, 1, mt, n0, q);
+      if (y.aux_mode == AUX_RESIDUAL) rowgemm80_body<true, false, false, AUX_RESIDUAL, true, E>(g, smem, 1, mt, n0, q);
+      else rowgemm80_body<true, false, false, AUX_NONE, true, E>(g, smem, 1, mt, n0, q);
     } else {
-      if (y.add) rowgemm80_body<false, true, true, AUX_UNMASKED, true>(g, smem, 1, mt, n0, q);
-      else if (y.aux_mode == AUX_UNMASKED) rowgemm80_body<false, false, true, AUX_UNMASKED, true>(g, smem, 1, mt, n0, q);
-      else rowgemm80_body<false, false, true, AUX_NONE, true>(g, smem, 1, mt, n0, q);
+      if (y.add) rowgemm80_body<false, true, true, AUX_UNMASKED, true, E>(g, smem, 1, mt, n0, q);
+      else if (y.aux_mode == AUX_UNMASKED) rowgemm80_body<false, false, true, AUX_UNMASKED, true, E>(g, smem, 1, mt, n0, q);
+      else rowgemm80_body<false, false, true, AUX_NONE, true, E>(g, smem, 1, mt, n0, q);
     }
   }
 }
@@ -647,15 +660,16 @@ __global__ __launch_bounds__(512) void seq_probe_kernel(uint32_t* rec /*[256]*/,
 }
 
 // host-side dispatch on the epilogue shape (the flags of RowGemmArgs select the instantiation)
-static inline void launch_rowgemm(const RowGemmArgs& g, int tile, hipStream_t s) {
+static inline void launch_rowgemm(const RowGemmArgs& g, int tile, hipStream_t s, bool f16 = false) {
   const dim3 blk(256);
   const bool br = g.bias != nullptr;
   const int mtiles = (g.M + tile - 1) / tile;
   const dim3 grid(8 * 4 * ((mtiles + 7) / 8));  // N = 512 -> 4 column tiles; XCD-aware decode inside the kernels
-#define ACEZ_RG(...)                                                                               \
-  do {                                                                                             \
-    if (tile == 80) hipLaunchKernelGGL((rowgemm80_kernel<__VA_ARGS__>), grid, dim3(512), 0, s, g); \
-    else hipLaunchKernelGGL((rowgemm_kernel<__VA_ARGS__>), grid, blk, 0, s, g);                    \
+#define ACEZ_RG(...)                                                                                               \
+  do {                                                                                                             \
+    if (f16) hipLaunchKernelGGL((rowgemm80_kernel<__VA_ARGS__, EltF16>), grid, dim3(512), 0, s, g); /* 80-row tiles only */ \
+    else if (tile == 80) hipLaunchKernelGGL((rowgemm80_kernel<__VA_ARGS__>), grid, dim3(512), 0, s, g);            \
+    else hipLaunchKernelGGL((rowgemm_kernel<__VA_ARGS__>), grid, blk, 0, s, g);                                    \
   } while (0)
   if (br && g.aux_mode == AUX_NONE) ACEZ_RG(true, false, false, AUX_NONE);
   else if (br && g.aux_mode == AUX_RESIDUAL) ACEZ_RG(true, false, false, AUX_RESIDUAL);
@@ -686,17 +700,19 @@ __device__ __forceinline__ int tr_base(int col0, int l) {
   const int phys = ((((colb >> 5) ^ ((i16 >> 2) << 1)) << 5) | (colb & 31)) >> 1;
   return row * 128 + phys;
 }
-__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* p) {
+template <class E = EltBf16>
+__device__ __forceinline__ typename E::frag tr_frag(const uint16_t* p) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 128));
   s16x8 r;
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-  return __builtin_bit_cast(bf16x8, r);
+  return __builtin_bit_cast(typename E::frag, r);
 }
 
 constexpr int WGRAD_LOADERS = 8;                    // loader waves per workgroup (beside the 4 multiplier waves)
 constexpr int WGRAD_THREADS = 256 + 64 * WGRAD_LOADERS;
+template <class E = EltBf16>
 __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
   const int active = a.st ? a.st->active : 1;  // tested before the stores only (see rowgemm_kernel)
   __shared__ __attribute__((aligned(16))) uint16_t smem[4][2][64 * 128];  // 4-slot ring of [dZ | In] stages, 128 KiB
@@ -784,15 +800,15 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
     const int slot = kt & 3;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fa[2], fb[2];
+      typename E::frag fa[2], fb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = tr_frag(&smem[slot][0][offA[i] + kk * 16 * 128]);
+      for (int i = 0; i < 2; ++i) fa[i] = tr_frag<E>(&smem[slot][0][offA[i] + kk * 16 * 128]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = tr_frag(&smem[slot][1][offB[j] + kk * 16 * 128]);
+      for (int j = 0; j < 2; ++j) fb[j] = tr_frag<E>(&smem[slot][1][offB[j] + kk * 16 * 128]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma32(fa[i], fb[j], acc[i][j]);
     }
   }
 
@@ -975,7 +991,7 @@ constexpr int LOSS_SCRATCH_FLOATS = 3 * 4 * LOSS_ROWS * 4;
 // meet once, through `sync` (loss_kernel: __syncthreads; the chain kernel: its flag barrier).
 // PRE_INSIDE (loss_kernel): the per-row index chain of phase B (idx -> view -> image) is started here, BEHIND the loads of phase A:
 // vmcnt completes in order, so a dependent chain issued first holds every later load behind its three round trips.
-template <bool LDSACT, bool PRE_INSIDE, class Sync>
+template <bool LDSACT, bool PRE_INSIDE, class E = EltBf16, class Sync>
 __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, const int wv, const int t, uint16_t* Xt, float* scratch,
                                           LossPre pre, Sync sync) {
   float (*s_s)[4] = reinterpret_cast<float (*)[4]>(scratch + wv * LOSS_ROWS * 4);
@@ -1016,8 +1032,8 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
     float w3[4][8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      unpack4(make_uint2(w3raw[j].x, w3raw[j].y), &w3[j][0]);
-      unpack4(make_uint2(w3raw[j].z, w3raw[j].w), &w3[j][4]);
+      E::un4(make_uint2(w3raw[j].x, w3raw[j].y), &w3[j][0]);
+      E::un4(make_uint2(w3raw[j].z, w3raw[j].w), &w3[j][4]);
       if (j >= no) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) w3[j][e] = 0.f;
@@ -1031,8 +1047,8 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
       const int r = rr, m = m0 + r;
       float x[8];
       const uint4 xr = LDSACT ? *reinterpret_cast<const uint4*>(&Xt[act_off(wv * LOSS_ROWS + r, l * 8)]) : xraw[LDSACT ? 0 : rr];
-      unpack4(make_uint2(xr.x, xr.y), &x[0]);
-      unpack4(make_uint2(xr.z, xr.w), &x[4]);
+      E::un4(make_uint2(xr.x, xr.y), &x[0]);
+      E::un4(make_uint2(xr.z, xr.w), &x[4]);
       if (!(m < n)) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = 0.f;
@@ -1058,6 +1074,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
   if (a.dbg == 1) return;
 
   // ---- phase B
+  const float gscale = (a.idx && a.st) ? a.st->grad_scale : 1.f;
   if (t < LOSS_ROWS) {
     const int r = t, m = m0 + r;
     float loss = 0.f, inl = 0.f, fgrad = 0.f, ds[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1232,8 +1249,10 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
         }
       }
     }
+    // (fp16 operands: the gradient is propagated scaled by grad_scale and un-scaled where it meets the fp32 optimiser; 1 for bf16)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s_ds[r][j] = ds[j];
+    for (int j = 0; j < 4; ++j) s_ds[r][j] = E::is_f16 ? ds[j] * gscale : ds[j];   // (bf16: no multiply at all -- even an exact one changes how
+                                                                                 // the compiler contracts the divisions above: last bits of ds)
     s_red[r][0] = loss; s_red[r][1] = inl; s_red[r][2] = fgrad; s_red[r][3] = 0.f;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1252,6 +1271,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
     const int ch = wv * 128 + 2 * t;
     const int mb = block * 4 * LOSS_ROWS;
     float w3[4][2], gw[4][2], bsum[2] = {0.f, 0.f};
+    float amax = 0.f;   // fp16: largest |dZ| this lane produces (scaled units) -> the gradient-scale control of the schedule wave
     // every load of the phase first (row by row, a load was followed by a full wait: 32 serial round trips)
     uint32_t w3c[4], xv[LDSACT ? 1 : 4 * LOSS_ROWS];
 #pragma unroll
@@ -1264,8 +1284,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t v = (j < no) ? w3c[j] : 0u;
-      w3[j][0] = __uint_as_float(v << 16);
-      w3[j][1] = __uint_as_float(v & 0xffff0000u);
+      E::un2(v, w3[j][0], w3[j][1]);
       gw[j][0] = gw[j][1] = 0.f;
     }
     const float (*ds_all)[4] = reinterpret_cast<const float (*)[4]>(scratch + 4 * LOSS_ROWS * 4);
@@ -1274,7 +1293,8 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
     for (int r = 0; r < 4 * LOSS_ROWS; ++r) {
       const int m = min(mb + r, n - 1);
       const uint32_t v = LDSACT ? *reinterpret_cast<const uint32_t*>(&Xt[act_off(r, ch)]) : xv[LDSACT ? 0 : r];
-      const float x[2] = {__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+      float x[2];
+      E::un2(v, x[0], x[1]);
       float d[2] = {0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1288,16 +1308,20 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
 #pragma unroll
       for (int e = 0; e < 2; ++e)
         if (!(x[e] > 0.f)) d[e] = 0.f;  // relu mask of the fc2 output
-      const uint32_t pk = pack2(d[0], d[1]);
+      if (E::is_f16) amax = fmaxf(amax, fmaxf(fabsf(d[0]), fabsf(d[1])));
+      const uint32_t pk = E::pk2(d[0], d[1]);
       // chain kernel: the gradient replaces the activations in the LDS tile (rows past the end become zero rows); the tile is
       // copied to a.dZ by the caller
       if (LDSACT) *reinterpret_cast<uint32_t*>(&Xt[act_off(r, ch)]) = pk;
       else if (mb + r < n) *reinterpret_cast<uint32_t*>(a.dZ + (size_t)m * 512 + ch) = pk;
       if (mb + r < n) {
-        bsum[0] += __uint_as_float(pk << 16);   // bias gradient of fc2: the bf16-rounded values, in row order
-        bsum[1] += __uint_as_float(pk & 0xffff0000u);
+        float r0, r1;
+        E::un2(pk, r0, r1);
+        bsum[0] += r0;   // bias gradient of fc2: the rounded values, in row order
+        bsum[1] += r1;
       }
     }
+    if (E::is_f16 && a.absmax) absmax_publish(a.absmax, amax);
     *reinterpret_cast<float2*>(a.bias_partials + (size_t)block * 512 + ch) = make_float2(bsum[0], bsum[1]);
     float* gp = a.fc3_partials + (size_t)block * a.fc3_stride;
 #pragma unroll
@@ -1320,11 +1344,12 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
   }
 }
 
+template <class E = EltBf16>
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   if (a.st && !a.st->active) return;
   __shared__ float scratch[LOSS_SCRATCH_FLOATS];
   const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
-  loss_body<false, true>(a, blockIdx.x, wv, t, nullptr, scratch, LossPre{0, 0, 0, 0.f, 0.f}, [] { __syncthreads(); });
+  loss_body<false, true, E>(a, blockIdx.x, wv, t, nullptr, scratch, LossPre{0, 0, 0, 0.f, 0.f}, [] { __syncthreads(); });
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1355,12 +1380,12 @@ __device__ __forceinline__ float tail_output(const GradReduceArgs& a, int64_t k,
       for (int b = lane; b < a.n_loss_blocks; b += 64) acc += a.stat_partials[(size_t)b * 4 + kk];
     // slot 3: this rank's rowseq fault word. It rides in the all-reduced bucket, so that a fault on ONE rank makes EVERY rank skip
     // the optimiser step (adamw_kernel) and the replicas stay identical
-    else if (lane == 0 && a.fault) acc = *a.fault ? 1.f : 0.f;
+    else if (lane == 0 && a.fault) acc = (*a.fault ? 1.f : 0.f) + (a.st->dz_absmax_bits >= 0x7f800000u ? 1024.f : 0.f);   // (+ fp16 overflow)
     dst = a.n_params + kk;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  return acc;
+  return k < n_bias + n_fc3 ? acc * a.st->inv_grad_scale : acc;   // (fp16: gradients arrive scaled; 1 for bf16, an exact product)
 }
 
 // Eight consecutive tail outputs k0 .. k0 + 7 by ONE wavefront: the partial-row loads of all eight are issued before anything is
@@ -1407,10 +1432,11 @@ __device__ __forceinline__ void tail_output8(const GradReduceArgs& a, int64_t k0
       if (lane + 64 * u < cnt[j]) s += v[j][u];          // the additions tail_output performs, in its order (b = lane, lane + 64, ...)
     for (int b = lane + 192; b < cnt[j]; b += 64) s += base[j][(size_t)b * stride[j]];
     const int64_t k = k0 + j;
-    if (k == n_out - 1 && lane == 0 && a.fault) s = *a.fault ? 1.f : 0.f;   // statistics slot 3: the fault word (see tail_output)
+    if (k == n_out - 1 && lane == 0 && a.fault)   // statistics slot 3: the fault word + the fp16 overflow flag (see tail_output)
+      s = (*a.fault ? 1.f : 0.f) + (a.st->dz_absmax_bits >= 0x7f800000u ? 1024.f : 0.f);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    acc[j] = s;
+    acc[j] = k < n_bias + n_fc3 ? s * a.st->inv_grad_scale : s;
   }
 }
 
@@ -1432,6 +1458,8 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
       const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)s * a.slab_stride + i4);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+    const float inv = a.st->inv_grad_scale;
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
     *reinterpret_cast<float4*>(a.grad + i4) = acc;
     return;
   }
@@ -1502,7 +1530,7 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
     lossv = tail_output(a.tail, (int64_t)a.n_layers * 512 + a.n_fc3, threadIdx.x & 63, d);
   } else {
     lossv = a.grad[a.n_params];
-    if (a.grad[a.n_params + 3] != 0.f) {   // some rank's fault word, summed by the all-reduce: every rank skips the step and
+    if (fmodf(a.grad[a.n_params + 3], 1024.f) != 0.f) {   // some rank's fault word, summed by the all-reduce: every rank skips the step and
       if (b == 0 && threadIdx.x == 0) {               // falls back at its next state read
         *a.fault = 1;
         const_cast<TrainState*>(st)->active = 0;
@@ -1511,6 +1539,9 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
     }
   }
   if (lossv != lossv) return;  // NaN loss: the reference aborts before the optimiser step (ace_trainer.py:615-617)
+  // fp16: an infinity was stored somewhere in the gradient chain of this step -> no update (GradScaler.step, ace_schedule.py:112); the
+  // schedule wave lowers the scale. In the split flow the flag arrives all-reduced in statistics slot 3 (+1024 per overflowing rank).
+  if (a.f16 && (a.slabs ? st->dz_absmax_bits >= 0x7f800000u : a.grad[a.n_params + 3] >= 1024.f)) return;
   const AdamScalars s = st->adam;
   if (tile) {
     if (a.slabs) {   // same additions, in the same order, as grad_reduce_kernel's wide part
@@ -1524,6 +1555,8 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
 #pragma unroll
         for (int i = 0; i < 4; ++i) { g4[i].x += q4[i].x; g4[i].y += q4[i].y; g4[i].z += q4[i].z; g4[i].w += q4[i].w; }
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { g4[i].x *= st->inv_grad_scale; g4[i].y *= st->inv_grad_scale; g4[i].z *= st->inv_grad_scale; g4[i].w *= st->inv_grad_scale; }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1538,7 +1571,7 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
       *reinterpret_cast<float4*>(a.params + o) = p;
       *reinterpret_cast<float4*>(a.m + o) = m;
       *reinterpret_cast<float4*>(a.v + o) = v;
-      const uint2 pk = pack4(p.x, p.y, p.z, p.w);
+      const uint2 pk = a.f16 ? EltF16::pk4(p.x, p.y, p.z, p.w) : pack4(p.x, p.y, p.z, p.w);
       *reinterpret_cast<uint2*>(a.Wb + (size_t)layer * 262144 + (size_t)(r0 + rr) * 512 + c0 + cc) = pk;
       tileT[cc + 0][rr] = (uint16_t)(pk.x & 0xffff);
       tileT[cc + 1][rr] = (uint16_t)(pk.x >> 16);
@@ -1584,7 +1617,7 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
       if (ome >= 0) {
         p = adamw_one(p, g, m, v, s);
         a.params[ome] = p; a.m[ome] = m; a.v[ome] = v;
-        if (kme >= n_bias && (kme - n_bias) < (int64_t)a.no * 512) a.W3b[kme - n_bias] = f2bf(p);
+        if (kme >= n_bias && (kme - n_bias) < (int64_t)a.no * 512) a.W3b[kme - n_bias] = a.f16 ? EltF16::from_f(p) : f2bf(p);
       }
       return;
     }
@@ -1596,7 +1629,7 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
       float p = a.params[o], m = a.m[o], v = a.v[o];
       p = adamw_one(p, a.grad[o], m, v, s);
       a.params[o] = p; a.m[o] = m; a.v[o] = v;
-      if (k >= n_bias && (k - n_bias) < (int64_t)a.no * 512) a.W3b[k - n_bias] = f2bf(p);
+      if (k >= n_bias && (k - n_bias) < (int64_t)a.no * 512) a.W3b[k - n_bias] = a.f16 ? EltF16::from_f(p) : f2bf(p);
     }
   }
 }
@@ -1619,7 +1652,7 @@ __global__ __launch_bounds__(256) void recast_kernel(AdamArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int rr = (t >> 4) + 16 * i;
       const float4 p = *reinterpret_cast<const float4*>(a.params + woff + (int64_t)(r0 + rr) * 512 + c0 + cc);
-      const uint2 pk = pack4(p.x, p.y, p.z, p.w);
+      const uint2 pk = a.f16 ? EltF16::pk4(p.x, p.y, p.z, p.w) : pack4(p.x, p.y, p.z, p.w);
       *reinterpret_cast<uint2*>(a.Wb + (size_t)layer * 262144 + (size_t)(r0 + rr) * 512 + c0 + cc) = pk;
       tileT[cc + 0][rr] = (uint16_t)(pk.x & 0xffff);
       tileT[cc + 1][rr] = (uint16_t)(pk.x >> 16);
@@ -1637,7 +1670,7 @@ __global__ __launch_bounds__(256) void recast_kernel(AdamArgs a) {
     }
   } else {
     const int64_t k = (int64_t)(b - a.n_layers * 64) * 256 + t;
-    if (k < (int64_t)a.no * 512) a.W3b[k] = f2bf(a.params[a.fc3_off + k]);
+    if (k < (int64_t)a.no * 512) a.W3b[k] = a.f16 ? EltF16::from_f(a.params[a.fc3_off + k]) : f2bf(a.params[a.fc3_off + k]);
   }
 }
 
@@ -1678,6 +1711,7 @@ struct SchedHot {
   int pose_enable, pose_opt_steps;
   double pose_b1pow, pose_b2pow;
   AdamScalars pose_adam;
+  float grad_scale, inv_grad_scale;
 };
 __device__ __forceinline__ SchedHot load_hot(const TrainState* st) {
   SchedHot h;
@@ -1689,6 +1723,7 @@ __device__ __forceinline__ SchedHot load_hot(const TrainState* st) {
   h.adam = st->adam;
   h.pose_enable = st->pose_enable; h.pose_opt_steps = st->pose_opt_steps; h.pose_b1pow = st->pose_b1pow; h.pose_b2pow = st->pose_b2pow;
   h.pose_adam = st->pose_adam;
+  h.grad_scale = st->grad_scale; h.inv_grad_scale = st->inv_grad_scale;
   return h;
 }
 __device__ __forceinline__ void store_hot(TrainState* st, const SchedHot& h) {
@@ -1700,6 +1735,7 @@ __device__ __forceinline__ void store_hot(TrainState* st, const SchedHot& h) {
   st->adam = h.adam;
   st->pose_enable = h.pose_enable; st->pose_opt_steps = h.pose_opt_steps; st->pose_b1pow = h.pose_b1pow; st->pose_b2pow = h.pose_b2pow;
   st->pose_adam = h.pose_adam;
+  st->grad_scale = h.grad_scale; st->inv_grad_scale = h.inv_grad_scale;
 }
 
 __device__ __forceinline__ void sched_prepare_hot(SchedHot& h, const SchedConfig& c, float crit_min) {
@@ -1776,6 +1812,8 @@ __global__ void sched_init_kernel(TrainState* st, SchedConfig c) {
   st->calib_steps = 0; st->loss_weight = c.soft_clamp; st->last_loss = 0.f; st->last_inliers = 0.f;
   st->calib_g = 0.0; st->calib_m = 0.0; st->calib_v = 0.0; st->beta1_pow = 1.0; st->beta2_pow = 1.0;
   st->pose_enable = 0; st->pose_opt_steps = 0; st->pose_b1pow = 1.0; st->pose_b2pow = 1.0;
+  st->grad_scale = c.f16 ? 64.f : 1.f; st->inv_grad_scale = 1.f / st->grad_scale;   // (fp16: adapted after every step, sched_post_wave)
+  st->dz_absmax_bits = 0u;
   if (c.schedule == SCHED_CONSTANT) st->lr = c.lr_min;
   else if (c.schedule == SCHED_1CYCLEPOLY) st->lr = c.lr_max * (c.warmup_lr / c.lr_max);  // LinearLR._initial_step
   else st->lr = onecycle_lr(c, 0);
@@ -1785,9 +1823,10 @@ __global__ void sched_init_kernel(TrainState* st, SchedConfig c) {
 // Executed by ONE full wavefront (all 64 lanes must call it): the lanes cooperate on the minimum of the cool-down
 // criterion ring, lane 0 does the scalar bookkeeping.
 __device__ void sched_post_wave(TrainState* st, const SchedConfig& c, const float* grad_stats, float inv_global_batch,
-                                float* log_loss, float* log_inl, int log_cap, const int* fault) {
+                                float* log_loss, float* log_inl, int log_cap, const int* fault, const float* stat_partials, int n_loss_blocks) {
   if (fault && *fault) return;   // the step was abandoned (rowseq fault): no iteration is counted, nothing is logged
   const int lane = threadIdx.x & 63;
+  const uint32_t amax_bits = c.f16 ? st->dz_absmax_bits : 0u;   // fp16: largest propagated gradient of the step (scaled units)
   // every load of the wave first: the scalar state (used by lane 0), the statistics, this lane's two ring entries
   SchedHot h = load_hot(st);
   const float g0 = grad_stats[0], g1 = grad_stats[1], g2 = grad_stats[2];
@@ -1863,14 +1902,28 @@ __device__ void sched_post_wave(TrainState* st, const SchedConfig& c, const floa
     const int e = ++h.warmup_epoch;
     h.lr = onecycle_lr(c, e);
   }
+  if (c.f16) {
+    // Gradient scale of the NEXT step (the role of torch.cuda.amp.GradScaler.update, ace_schedule.py:107-113): the power of two that
+    // would have put this step's largest propagated gradient near 4096 -- fp16 tops out at 65504: a factor of 16 for the change from
+    // one step to the next. After an overflow (an inf was stored: this step's update was skipped by adamw_body, as GradScaler.step
+    // skips it) the scale drops by 2^8. Powers of two only: scaling then commutes with fp16 rounding for every value in range.
+    int e = ilogbf(h.grad_scale);
+    if (amax_bits >= 0x7f800000u) e -= 8;
+    else if (amax_bits != 0u) e = ilogbf(4096.f / (__uint_as_float(amax_bits) * h.inv_grad_scale));
+    e = min(16, max(-8, e));
+    h.grad_scale = ldexpf(1.f, e);
+    h.inv_grad_scale = ldexpf(1.f, -e);
+    st->dz_absmax_bits = 0u;
+  }
   h.iteration = it + 1;   // ace_trainer.py:495
   sched_prepare_hot(h, c, crit_min);   // bookkeeping of the NEXT iteration, so that a step needs a single schedule launch
   store_hot(st, h);
 }
 
 __global__ __launch_bounds__(64) void sched_post_kernel(TrainState* st, SchedConfig c, const float* grad_stats, float inv_global_batch,
-                                                        float* log_loss, float* log_inl, int log_cap, const int* fault) {
-  sched_post_wave(st, c, grad_stats, inv_global_batch, log_loss, log_inl, log_cap, fault);
+                                                        float* log_loss, float* log_inl, int log_cap, const int* fault, const float* stat_partials,
+                                                        int n_loss_blocks) {
+  sched_post_wave(st, c, grad_stats, inv_global_batch, log_loss, log_inl, log_cap, fault, stat_partials, n_loss_blocks);
 }
 
 // step_begin: the batch gather of iteration i + 1 and, in ONE extra single-wave workgroup, the schedule bookkeeping that
@@ -1885,11 +1938,13 @@ struct PostArgs {
   float* log_inl;
   int log_cap;
   const int* fault;
+  const float* stat_partials;   // the loss kernel's per-workgroup statistics of the step being closed (slot 3: largest |ds|) and their count
+  int n_loss_blocks;
 };
 __global__ __launch_bounds__(256) void step_begin_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
                                                          uint16_t* __restrict__ out, int n, PostArgs p) {
   if (blockIdx.x == gridDim.x - 1) {
-    if (threadIdx.x < 64) sched_post_wave(p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault);
+    if (threadIdx.x < 64) sched_post_wave(p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault, p.stat_partials, p.n_loss_blocks);
     return;
   }
   const int lane = threadIdx.x & 63;

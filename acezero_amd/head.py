@@ -15,6 +15,7 @@ from . import _native as N
 
 LOSS_TYPES = {"tanh": 0, "dyntanh": 1, "l1": 2, "l1+sqrt": 3, "l1+logl1": 4, "l1+log": 4}
 SCHEDULES = {"constant": 0, "1cyclepoly": 1, "circle": 2}
+DTYPES = {"bf16": 0, "fp16": 1}   # acez_train_config.compute_dtype
 
 
 def layer_names(num_head_blocks):
@@ -71,10 +72,22 @@ class HeadTrainer:
                  cooldown_iterations=5000, cooldown_trigger_percent=0.7, refine_calibration=False, focal_init=0.0,
                  calib_lr=0.001, pose_refinement="none", pose_refinement_wait=0, pose_refinement_lr=0.001,
                  pose_refinement_weight=0.1, refinement_ortho="gram-schmidt", pose_seed=0, initial_poses=None, homogeneous_min_scale=0.01, homogeneous_max_scale=4.0,
-                 device=None):
+                 device=None, dtype=None):
+        """dtype: 16-bit operand format of the head's GEMMs, "bf16" (default) or "fp16" (the reference's autocast format,
+        ace_trainer.py:517-518); None reads ACEZ_DTYPE. "fp32" (train_ace.py --use_half False) is rejected: it is not implemented
+        and must not silently run in another precision."""
         if not torch.cuda.is_available():
             raise RuntimeError("HeadTrainer needs a GPU: the head kernels are HIP only (no CPU fallback)")
         self.lib = N.lib()
+        import os
+        dtype = (dtype or os.environ.get("ACEZ_DTYPE") or "bf16").lower()
+        if dtype in ("fp32", "float32"):
+            raise NotImplementedError("fp32 head arithmetic (--use_half False) is not implemented; choose dtype='fp16' (the reference's "
+                                      "autocast format) or 'bf16'")
+        if dtype not in DTYPES:
+            raise ValueError("dtype must be 'bf16' or 'fp16'")
+        self.dtype = dtype
+        self.feature_dtype = torch.float16 if dtype == "fp16" else torch.bfloat16
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.nb, self.homog = int(num_head_blocks), bool(use_homogeneous)
         self.L = 3 + 3 * self.nb + 2
@@ -129,6 +142,7 @@ class HeadTrainer:
         if refinement_ortho not in ("gram-schmidt", "procrustes"):
             raise ValueError("refinement_ortho must be 'gram-schmidt' or 'procrustes'")
         cfg.pose_refinement_ortho = 1 if refinement_ortho == "procrustes" else 0
+        cfg.compute_dtype = DTYPES[self.dtype]
         pb = N.ParamBuffers(_ptr(self.params), _ptr(self.adam_m), _ptr(self.adam_v), _ptr(self.grad), self.n_params,
                             _ptr(self.pose_params), _ptr(self.pose_m), _ptr(self.pose_v), self.n_pose)
         h = C.c_void_p()
@@ -188,7 +202,7 @@ class HeadTrainer:
         dev = self.device
         t = lambda x, dt: torch.as_tensor(x).to(device=dev, dtype=dt).contiguous()
         self._buf = {
-            "features": t(features, torch.bfloat16), "target_px": t(target_px, torch.float32), "view_idx": t(view_idx, torch.int32),
+            "features": t(features, self.feature_dtype), "target_px": t(target_px, torch.float32), "view_idx": t(view_idx, torch.int32),
             "view_aug_inv": t(view_aug_inv, torch.float32), "view_K": t(view_K, torch.float32),
             "view_Kinv": t(view_Kinv, torch.float32), "view_image": t(view_image, torch.int32),
             "image_pose_inv": t(image_pose_inv, torch.float32),
@@ -283,7 +297,7 @@ class HeadTrainer:
     # ---------------------------------------------------------------- inference
     def get_scene_coordinates(self, features):
         """features: [n,512] CUDA tensor (any float dtype) -> [n,3] float32 CUDA tensor."""
-        f = features.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        f = features.to(device=self.device, dtype=self.feature_dtype).contiguous()
         out = torch.empty(f.shape[0], 3, dtype=torch.float32, device=self.device)
         N.check(self.lib.acez_head_forward(self._h, _ptr(f), int(f.shape[0]), _ptr(out), _stream()))
         return out

@@ -164,7 +164,16 @@ typedef struct acez_train_config {
   double pose_refinement_lr;      /* train_ace.py:223, 1e-3                                               */
   float pose_refinement_weight;   /* train_ace.py:216, 0.1                                                */
   int32_t pose_refinement_ortho;  /* --refinement_ortho (train_ace.py:226): 0 = gram-schmidt, 1 = procrustes */
+  /* 16-bit operand format of the head's GEMMs (features, activations, propagated gradients, weight copies; fp32 accumulation,
+   * fp32 geometry / loss / optimiser either way). The reference runs the head under fp16 autocast (train_ace.py --use_half True,
+   * ace_trainer.py:330,517-518): ACEZ_DTYPE_FP16 mirrors that (the gradient chain carries a power-of-two scale that the device-side
+   * schedule adapts every step, the role torch.cuda.amp.GradScaler plays in ace_schedule.py:70,107-113); ACEZ_DTYPE_BF16 is BASELINE.json's north_star and the default. --use_half False (fp32) is
+   * rejected, never silently replaced. d_features of acez_train_buffer / acez_head_forward are in this format. */
+  int32_t compute_dtype;
 } acez_train_config;
+#define ACEZ_DTYPE_BF16 0
+#define ACEZ_DTYPE_FP16 1
+#define ACEZ_DTYPE_FP32 2
 
 /* Caller-owned parameter storage, so the host side can expose the same state_dict keys as
  * ace_network.Head (ace_trainer.py:690-693) as views of one flat tensor.
@@ -191,7 +200,7 @@ typedef struct acez_param_buffers {
 /* The training buffer of ace_trainer.py:330-340, with the per-image data stored once per view
  * (image x augmentation pass) instead of once per patch. */
 typedef struct acez_train_buffer {
-  const void* d_features;      /* bf16 [n_patches][512]                                                */
+  const void* d_features;      /* bf16 (fp16 with ACEZ_DTYPE_FP16) [n_patches][512]                    */
   const float* d_target_px;    /* f32  [n_patches][2]                                                  */
   const int32_t* d_view_idx;   /* i32  [n_patches]  -> view                                            */
   int64_t n_patches;

@@ -10,10 +10,12 @@ what the reference computes in
     ace_schedule.py:12-126   ScheduleACE (AdamW + LR schedules + cool-down trigger)
     refine_calibration.py:34-59
 
-Two arithmetic modes:
+Three arithmetic modes:
   * "fp32": no rounding anywhere.  PINNED against the reference itself: tests/golden/head_*.npz were produced by
     running the reference's own TrainerACE.training_step (tests/golden/make_head_golden.py) and
     tests/test_head_oracle.py checks this oracle against them.
+  * "fp16": the same rounding points in IEEE half precision (the reference's autocast format, ace_trainer.py:517-518), propagated
+    gradients rounded after scaling by a power of two (the kernels' fp16 mode, acez_train_config.compute_dtype = ACEZ_DTYPE_FP16).
   * "bf16": operands of every 512-wide matmul (activations, weights, propagated gradients) are rounded to
     bfloat16 at the points where the HIP kernels store them; accumulation stays fp32.  This is what the GPU
     results are compared with (tolerance 1e-3 relative, BASELINE.json north_star).
@@ -28,6 +30,15 @@ LOSS_TYPES = {"tanh": 0, "dyntanh": 1, "l1": 2, "l1+sqrt": 3, "l1+logl1": 4}
 
 def bf16_round(x):
     return x.to(torch.bfloat16).to(torch.float32)
+
+
+def fp16_round(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
+GRAD_SCALE_FP16 = 64.0     # a factor the HIP kernels put on the gradient chain in fp16 mode: a power of two chosen per step from the
+                           # largest |d loss / d fc3 output| (head_kernels.hip sched_post_wave); scaling by a power of two commutes with fp16
+                           # rounding wherever nothing under- or overflows, so ANY in-range power of two gives the same result
 
 
 def head_layer_names(num_head_blocks):
@@ -76,9 +87,11 @@ def init_params(seed, num_head_blocks=1, use_homogeneous=True, scale=1.0):
 class HeadOracle:
     def __init__(self, flat_params, mean, num_head_blocks=1, use_homogeneous=True, mode="fp32",
                  homogeneous_min_scale=0.01, homogeneous_max_scale=4.0):
-        assert mode in ("fp32", "bf16")
+        assert mode in ("fp32", "bf16", "fp16")
         self.mode = mode
-        self.r = bf16_round if mode == "bf16" else (lambda x: x)
+        self.r = bf16_round if mode == "bf16" else (fp16_round if mode == "fp16" else (lambda x: x))
+        self.gs = GRAD_SCALE_FP16 if mode == "fp16" else 1.0
+        self.absmax = 0.0     # largest scaled magnitude the last backward rounded (fp16: drives the next step's scale, as on the device)
         self.p = HeadParams(flat_params, num_head_blocks, use_homogeneous)
         self.nb = num_head_blocks
         self.homog = use_homogeneous
@@ -226,9 +239,22 @@ class HeadOracle:
                 "X": X, "e": e, "valid": valid}
 
     # ------------------------------------------------------------------ backward through the MLP
+    def rg(self, g):
+        """rounding of a propagated gradient (stored scaled by self.gs in fp16 mode)"""
+        if self.mode == "fp16":
+            self.absmax = max(self.absmax, float((g * self.gs).abs().max()))
+        return self.r(g * self.gs) / self.gs
+
+    def next_grad_scale(self):
+        """head_kernels.hip sched_post_wave: the power of two that would have put the step's largest propagated gradient near 4096"""
+        if self.mode == "fp16" and self.absmax > 0:
+            e = math.floor(math.log2(4096.0 / (self.absmax / self.gs)))
+            self.gs = 2.0 ** min(16, max(-8, e))
+        self.absmax = 0.0
+
     def backward(self, tape, ds):
         """Returns the flat gradient (same layout as the parameters)."""
-        r, p = self.r, self.p
+        r, rg, p = self.r, self.rg, self.p
         g = torch.zeros_like(p.flat)
         G = HeadParams(g, self.nb, self.homog)
         f1i = 3 * (self.nb + 1)
@@ -236,17 +262,17 @@ class HeadOracle:
         G.W3.copy_(ds.t() @ f2)
         G.b3.copy_(ds.sum(dim=0))
         dZ = [None] * p.L
-        dZ[f1i + 1] = r((ds @ r(p.W3)) * (f2 > 0))
-        dZ[f1i] = r(dZ[f1i + 1] @ r(p.W[f1i + 1])) * (tape["out"][f1i] > 0)
-        t = r(dZ[f1i] @ r(p.W[f1i]))
+        dZ[f1i + 1] = rg((ds @ r(p.W3)) * (f2 > 0))
+        dZ[f1i] = rg(dZ[f1i + 1] @ r(p.W[f1i + 1])) * (tape["out"][f1i] > 0)
+        t = rg(dZ[f1i] @ r(p.W[f1i]))
         dR = t
         dZ[3 * self.nb + 2] = t * (tape["out"][3 * self.nb + 2] > 0)
         for b in range(self.nb, -1, -1):
             l = 3 * b
-            dZ[l + 1] = r(dZ[l + 2] @ r(p.W[l + 2])) * (tape["out"][l + 1] > 0)
-            dZ[l] = r(dZ[l + 1] @ r(p.W[l + 1])) * (tape["out"][l] > 0)
+            dZ[l + 1] = rg(dZ[l + 2] @ r(p.W[l + 2])) * (tape["out"][l + 1] > 0)
+            dZ[l] = rg(dZ[l + 1] @ r(p.W[l + 1])) * (tape["out"][l] > 0)
             if b > 0:
-                t = r(dZ[l] @ r(p.W[l]) + dR)
+                t = rg(dZ[l] @ r(p.W[l]) + dR)
                 dR = t
                 dZ[l - 1] = t * (tape["out"][l - 1] > 0)
         ins = [None] * p.L
@@ -511,6 +537,7 @@ class TrainerOracle:
                 X = self.head.dehomogenise(sl)[0]
             out = {"loss_sum": float(loss_sum), "inliers": inl, "ds": sl.grad.detach(), "focal_grad": 0.0, "X": X.detach()}
         grad = self.head.backward(tape, out["ds"])
+        self.head.next_grad_scale()   # (fp16 mode: the device adapts its gradient scale after every step; no-op otherwise)
         loss = out["loss_sum"] / cfg["global_batch"]
         inl = out["inliers"] / cfg["global_batch"]
         lr_used = sch.lr

@@ -19,9 +19,9 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
-def _trainer(prob, flat0, cfg, max_batch=helpers.B, global_batch=None):
+def _trainer(prob, flat0, cfg, max_batch=helpers.B, global_batch=None, dtype=None):
     from acezero_amd.head import HeadTrainer
-    tr = HeadTrainer(prob["mean"], num_head_blocks=cfg.get("num_head_blocks", 1), use_homogeneous=cfg.get("use_homogeneous", True),
+    tr = HeadTrainer(prob["mean"], dtype=dtype, num_head_blocks=cfg.get("num_head_blocks", 1), use_homogeneous=cfg.get("use_homogeneous", True),
                      max_batch=max_batch, global_batch=global_batch or cfg["global_batch"], loss_type=cfg["loss_type"],
                      schedule=cfg["schedule"], iterations=cfg["iterations"], lr_min=cfg["lr_min"], lr_max=cfg["lr_max"],
                      warmup_iterations=cfg["warmup_iterations"], warmup_lr=cfg["warmup_lr"], cooldown_iterations=cfg["cooldown_iterations"],
