@@ -49,7 +49,8 @@ TRAIN_FLAGS = [
     (("--encoder_path",), Path, "<path>", None, "pre-trained encoder weights"),
     (("--load_weights",), Path, None, None, "head weights to start from"),
     (("--num_head_blocks",), int, 1, None, "residual blocks of the head"),
-    (("--use_half",), _strtobool, True, None, "16-bit matrix arithmetic (bf16 on MI355X)"),
+    (("--use_half",), _strtobool, True, None, "16-bit matrix arithmetic (True: bf16, or fp16 with --compute_dtype fp16; False = fp32 is NOT "
+                                                "implemented and is rejected, never replaced by another precision)"),
     (("--use_homogeneous",), _strtobool, True, None, "homogeneous scene-coordinate output"),
     (("--learning_rate_min",), float, 0.0005, None, ""),
     (("--learning_rate_max",), float, 0.005, None, ""),
@@ -181,6 +182,9 @@ def train_parser():
     p.add_argument("output_map_file", type=Path, help="target file for the trained head")
     _add(p, TRAIN_FLAGS)
     p.add_argument("--feature_buffer", type=Path, default=None, help="[additive] .npz training buffer (acez_train_buffer layout)")
+    p.add_argument("--compute_dtype", default=None, choices=["bf16", "fp16"],
+                   help="[additive] 16-bit operand format of the head: bf16 (default) or fp16, the reference's autocast format "
+                        "(ace_trainer.py:517-518); default: $ACEZ_DTYPE or bf16")
     p.add_argument("--num_gpus", type=int, default=1, help="[additive] informational; multi-GPU reconstructions are launched as "
                    "`torchrun --nproc-per-node G ace_zero.py ...` (the mapping rounds inside are data parallel)")
     return p
@@ -260,7 +264,14 @@ def train_with_options(opt):
     from .head import HeadTrainer
     if opt.batch_size % 512 != 0:
         raise SystemExit("batch_size must be a multiple of 512 (train_ace.py:138)")
+    if not opt.use_half:
+        raise SystemExit("--use_half False (fp32 head arithmetic, ace_trainer.py:330) is not implemented on this path; it is refused rather "
+                         "than silently run in 16 bits. Use --use_half True [--compute_dtype fp16 for the reference's autocast precision].")
+    dtype = getattr(opt, "compute_dtype", None)
     if opt.feature_buffer is None:
+        if (dtype or os.environ.get("ACEZ_DTYPE", "bf16")).lower() == "fp16":
+            raise SystemExit("--compute_dtype fp16 needs fp16 features: the encoder of this package emits bf16 rows; train from a "
+                             "--feature_buffer of fp16-representable features, or use bf16")
         return _train_from_images(opt)
     buf = np.load(opt.feature_buffer, allow_pickle=False)
     n = min(int(buf["features"].shape[0]), opt.max_training_buffer_size)
@@ -278,7 +289,8 @@ def train_with_options(opt):
                      pose_refinement=opt.pose_refinement, pose_refinement_wait=opt.pose_refinement_wait,
                      pose_refinement_lr=opt.pose_refinement_lr, pose_refinement_weight=opt.pose_refinement_weight,
                      refinement_ortho=opt.refinement_ortho,
-                     pose_seed=opt.base_seed + 511, initial_poses=buf["image_pose_inv"][:, :3] if opt.pose_refinement == "naive" else None)
+                     pose_seed=opt.base_seed + 511, initial_poses=buf["image_pose_inv"][:, :3] if opt.pose_refinement == "naive" else None,
+                     dtype=dtype)
     if opt.load_weights is not None:
         tr.load_state_dict(torch.load(opt.load_weights, map_location="cpu"))
         _logger.info(f"Loaded weights from: {opt.load_weights}")

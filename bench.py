@@ -89,7 +89,7 @@ def make_buffer(n_patches, device, seed, n_images=1000, grid=(80, 60)):
 
 
 def bench_training(args, rank, world, device, pose_refinement=None, steps=None, buffer_patches=None, strong=False, windows=WINDOWS,
-                   n_images=1000, grid=(80, 60)):
+                   n_images=1000, grid=(80, 60), dtype="bf16"):
     """pose_refinement None -> args.pose_refinement (the headline leg); 'mlp' -> ace_zero's non-seed mapping iterations
     (--pose_refinement mlp --refine_calibration True, ace_zero.py:86,97,262-264).
     strong=True: the REFERENCE's step on N GPUs -- the global batch stays 5120, every rank draws the same permutation of the global
@@ -105,7 +105,7 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
     total_iters = windows * steps + args.warmup + 64
     tr = HeadTrainer(prob["mean"], max_batch=BATCH, global_batch=BATCH if strong else BATCH * world, loss_type="tanh", schedule="1cyclepoly",
                      iterations=max(total_iters, 25000), lr_min=0.0005, lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005,
-                     cooldown_iterations=5000, pose_refinement=pose_refinement,
+                     cooldown_iterations=5000, pose_refinement=pose_refinement, dtype=dtype,
                      refine_calibration=pose_refinement != "none", focal_init=float(prob["focal"]))   # ace_zero.py:105-123 mapping settings
     tr.load_flat(torch.from_numpy(synth.init_head_params(1)))
     tr.set_buffer(feats, target_px, view_idx, prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"], prob["view_image"],
@@ -440,6 +440,8 @@ def main():
     dt_gar, st_gar, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000),
                                        n_images=185, grid=(93, 60))
     ngar, dt_gar_reg, gar_ok = bench_registration(args, rank, world, device, h=60, w=93, frames=1024)
+    # the headline step with fp16 operands (the reference's autocast precision; HeadTrainer(dtype="fp16")): same kernels, same rate
+    dt_f16, st_f16, _ = bench_training(args, rank, world, device, steps=100, buffer_patches=min(args.buffer_patches, 2_000_000), dtype="fp16")
     dt_strong = None
     if world > 1:   # the reference's step (global batch 5120) split over the ranks
         dt_strong, st_strong, _ = bench_training(args, rank, world, device, steps=args.steps, buffer_patches=min(args.buffer_patches, 2_000_000), strong=True)
@@ -447,10 +449,10 @@ def main():
     pipe = bench_pipeline(args, rank, world, device)
     sess = bench_session(args, device) if world == 1 and args.session_frames > 0 else None
     if world > 1:
-        t = torch.tensor([dt, dt_reg, dt_ref, dt_strong, dt_gar, dt_gar_reg] + st["window_ms_per_step"], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, dt_reg, dt_ref, dt_strong, dt_gar, dt_gar_reg, dt_f16] + st["window_ms_per_step"], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt, dt_reg, dt_ref, dt_strong, dt_gar, dt_gar_reg = (float(x) for x in t[:6])
-        st["window_ms_per_step"] = [float(x) for x in t[6:]]
+        dt, dt_reg, dt_ref, dt_strong, dt_gar, dt_gar_reg, dt_f16 = (float(x) for x in t[:7])
+        st["window_ms_per_step"] = [float(x) for x in t[7:]]
     if rank == 0:
         patches_per_s = BATCH * world * args.steps / dt
         gemm_ms, gemm_n = 0.0, 0
@@ -507,6 +509,9 @@ def main():
                                 "value": BATCH * world * 100 / dt_ref, "unit": "patches/s", "ms_per_step": dt_ref / 100 * 1e3, "steps": 100,
                                 "ms_per_step_median": float(np.median(st_ref["window_ms_per_step"])), "window_ms_per_step": st_ref["window_ms_per_step"],
                                 "n_images": 1000, "final_loss": st_ref["loss"]},
+            "dtype_fp16": {"metric": "ACE patches/sec, the headline step with fp16 operands (the reference's autocast precision, compute_dtype fp16)",
+                           "value": BATCH * world * 100 / dt_f16, "unit": "patches/s", "ms_per_step": dt_f16 / 100 * 1e3,
+                           "ms_per_step_median": float(np.median(st_f16["window_ms_per_step"])), "final_loss": st_f16["loss"]},
             "garden_like": {"metric": "BASELINE configs[2] shape: 185 frames of 480x741 (60x93 feature maps), --pose_refinement mlp --refine_calibration True",
                             "training": {"value": BATCH * world * 100 / dt_gar, "unit": "patches/s", "ms_per_step": dt_gar / 100 * 1e3,
                                          "ms_per_step_median": float(np.median(st_gar["window_ms_per_step"])), "n_images": 185,

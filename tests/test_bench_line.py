@@ -37,7 +37,7 @@ def test_bench_json_line_contract(monkeypatch, seq):
     assert abs(d["value"] - 5120 / (sum(wins) / 5 * 1e-3)) < 1 and abs(d["ms_per_step"] - 0.1550) < 1e-9 and "workload" in d["config"]
     assert d["windows"] == 5 and d["window_ms_per_step"] == wins and abs(d["ms_per_step_mean"] - sum(wins) / 5) < 1e-9
     assert d["garden_like"]["training"]["n_images"] == 185 and d["garden_like"]["registration"]["map"] == "60x93"
-    assert d["refinement_step"]["ms_per_step"] > 0 and "mfma_busy_frac" in d["roofline"]
+    assert d["refinement_step"]["ms_per_step"] > 0 and "mfma_busy_frac" in d["roofline"] and d["dtype_fp16"]["ms_per_step"] > 0
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert ("rowseq_kernel" in r["kernel"]) == (seq == "1") and r["launches_timed"] == 300

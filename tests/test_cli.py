@@ -28,7 +28,7 @@ def _surface(parser):
     return out
 
 
-@pytest.mark.parametrize("name,parser,extra", [("train_ace", cli.train_parser, {"feature_buffer", "num_gpus"}),
+@pytest.mark.parametrize("name,parser,extra", [("train_ace", cli.train_parser, {"feature_buffer", "num_gpus", "compute_dtype"}),
                                                ("register_mapping", cli.register_parser, {"feature_file"}),
                                                ("ace_zero", cli.ace_zero_parser, {"encoder_path"}),
                                                ("export_point_cloud", cli.export_point_cloud_parser, set())])
@@ -161,3 +161,12 @@ def test_reference_module_names_are_importable():
     opt.batch_size = 5000
     with pytest.raises(ValueError):
         TrainerACE(opt)
+
+
+def test_use_half_false_is_refused_not_silently_ignored(tmp_path):
+    """train_ace.py --use_half False selects fp32 arithmetic in the reference (ace_trainer.py:330); this package has no fp32 head path
+    and must say so instead of running in 16 bits (missing 2)."""
+    opt = cli.train_parser().parse_args(["scene/*.png", str(tmp_path / "out.pt"), "--use_half", "False"])
+    with pytest.raises(SystemExit) as e:
+        cli.train_with_options(opt)
+    assert "not implemented" in str(e.value) and "use_half" in str(e.value)
