@@ -435,13 +435,13 @@ def main():
                               "pose_refinement": args.pose_refinement,
                               "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()}, "final_loss": st["loss"]}))
         return
+    # the headline step with fp16 operands (the reference's autocast precision; HeadTrainer(dtype="fp16")): same kernels, same rate
+    dt_f16, st_f16, _ = bench_training(args, rank, world, device, steps=100, buffer_patches=min(args.buffer_patches, 2_000_000), dtype="fp16")
     dt_ref, st_ref, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000))
     # BASELINE configs[2] (Mip-NeRF 360 garden-like): 185 frames of 480x741 -> 60x93 maps, focal refinement in the loop
     dt_gar, st_gar, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000),
                                        n_images=185, grid=(93, 60))
     ngar, dt_gar_reg, gar_ok = bench_registration(args, rank, world, device, h=60, w=93, frames=1024)
-    # the headline step with fp16 operands (the reference's autocast precision; HeadTrainer(dtype="fp16")): same kernels, same rate
-    dt_f16, st_f16, _ = bench_training(args, rank, world, device, steps=100, buffer_patches=min(args.buffer_patches, 2_000_000), dtype="fp16")
     dt_strong = None
     if world > 1:   # the reference's step (global batch 5120) split over the ranks
         dt_strong, st_strong, _ = bench_training(args, rank, world, device, steps=args.steps, buffer_patches=min(args.buffer_patches, 2_000_000), strong=True)
