@@ -395,6 +395,7 @@ static void fill_adam_args(acez_trainer* tr, AdamArgs& a) {
   a.n_layers = tr->L; a.no = tr->no; a.st = tr->st;
   a.slabs = nullptr; a.nslabs = 0; a.slab_stride = 0;
   a.fault = tr->seq_err; a.f16 = tr->f16 ? 1 : 0;
+  a.layer_lo = 0; a.layer_hi = tr->L;
 }
 
 extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
@@ -847,8 +848,11 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
   return train_backward_impl(tr, d_indices, n, stream, false);
 }
 
-static int train_update_impl(acez_trainer* tr, void* stream, bool fused) {
+static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int layer_lo = 0, int layer_hi = -1) {
   ACEZ_REQUIRE(tr, "null trainer");
+  if (layer_hi < 0) layer_hi = tr->L;
+  ACEZ_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= tr->L, "layer range out of bounds");
+  ACEZ_REQUIRE(!fused || (layer_lo == 0 && layer_hi == tr->L), "the fused step updates every layer");
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   hipStream_t s = (hipStream_t)stream;
   // two updates without a backward in between (a data-parallel rank whose shard holds no row of a batch zeroes its gradient and
@@ -874,7 +878,8 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused) {
     ACEZ_HIP_CHECK(hipGetLastError());
     return ACEZ_OK;
   }
-  { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3(tr->L * 64 + nsmall), dim3(256), 0, s, a); }
+  a.layer_lo = layer_lo; a.layer_hi = layer_hi;
+  { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3((layer_hi - layer_lo) * 64 + nsmall), dim3(256), 0, s, a); }
   if (tr->cfg.pose_refinement != 0) tr->pose_wt_valid = false;   // adamw_small_kernel does not refresh the transposed copies
   if (tr->cfg.pose_refinement != 0)
     hipLaunchKernelGGL(adamw_small_kernel, dim3((unsigned)((tr->pb.n_pose_params + 255) / 256)), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,
@@ -886,6 +891,35 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused) {
 }
 
 extern "C" int acez_train_update(acez_trainer* tr, void* stream) { return train_update_impl(tr, stream, false); }
+
+// Sharded data-parallel update (ZeRO-1 by layer): this rank applies AdamW to the weight matrices of wide layers [layer_lo, layer_hi)
+// only -- d_grad must hold their reduced gradients -- and to ALL small parameters (biases, fc3; their gradients are all-reduced and
+// the update is replicated), then closes the step's schedule bookkeeping like acez_train_update. The fp32 masters / AdamW moments of
+// the other layers' weights go stale on this rank until the owners' values are copied in (host: HeadTrainer.gather_masters).
+extern "C" int acez_train_update_layers(acez_trainer* tr, int layer_lo, int layer_hi, void* stream) {
+  return train_update_impl(tr, stream, false, layer_lo, layer_hi);
+}
+
+// 16-bit compute copies W[out][in] of wide layers [layer_lo, layer_hi), 512 x 512 each, to / from a caller buffer (the all-gather
+// of the sharded update). Import also rebuilds the transposed copies of those layers.
+extern "C" int acez_trainer_export_weights16(acez_trainer* tr, int layer_lo, int layer_hi, void* d_dst, void* stream) {
+  ACEZ_REQUIRE(tr && d_dst, "null pointer");
+  ACEZ_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= tr->L, "layer range out of bounds");
+  if (layer_hi == layer_lo) return ACEZ_OK;
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  ACEZ_HIP_CHECK(hipMemcpyAsync(d_dst, tr->Wb + (size_t)layer_lo * 262144, (size_t)(layer_hi - layer_lo) * 262144 * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return ACEZ_OK;
+}
+extern "C" int acez_trainer_import_weights16(acez_trainer* tr, int layer_lo, int layer_hi, const void* d_src, void* stream) {
+  ACEZ_REQUIRE(tr && d_src, "null pointer");
+  ACEZ_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= tr->L, "layer range out of bounds");
+  if (layer_hi == layer_lo) return ACEZ_OK;
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  ACEZ_HIP_CHECK(hipMemcpyAsync(tr->Wb + (size_t)layer_lo * 262144, d_src, (size_t)(layer_hi - layer_lo) * 262144 * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  hipLaunchKernelGGL(transpose16_kernel, dim3((layer_hi - layer_lo) * 64), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)tr->Wb, tr->WbT, layer_lo);
+  ACEZ_HIP_CHECK(hipGetLastError());
+  return ACEZ_OK;
+}
 
 // Single-GPU step: backward + update with the wide-layer gradients handed from the weight-gradient slabs straight to the
 // optimiser (no flat-gradient round trip through HBM). Bitwise the same parameters as acez_train_backward + acez_train_update;

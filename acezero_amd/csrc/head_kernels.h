@@ -156,6 +156,8 @@ struct AdamArgs {
   GradReduceArgs tail;   // with slabs != null: the partials of the small parameters and statistics (reduced here as well)
   int* fault;            // the trainer's rowseq fault word: a faulted step updates nothing
   int f16;               // the compute copies W / W^T / W3 are fp16 (else bf16)
+  int layer_lo, layer_hi;   // wide layers whose WEIGHT tiles this launch updates (sharded data-parallel update: the rank's own
+                            // layers); biases, fc3 and the statistics are always handled. 0 .. n_layers = everything
 };
 
 }  // namespace acez

@@ -1508,7 +1508,7 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
   // of its own, and before any store: written as one load / compute / store loop per row group, the loads of row group i + 1 could
   // not be moved above the stores of row group i -- same arrays, no alias information -- and a workgroup made four dependent round
   // trips instead of one)
-  const int tb = b - nsmall, layer = tile ? tb / 64 : 0, tl = tb % 64;
+  const int tb = b - nsmall, layer = tile ? a.layer_lo + tb / 64 : 0, tl = tb % 64;   // (tile blocks cover layers layer_lo .. layer_hi - 1)
   const int r0 = (tl >> 3) * 64, c0 = (tl & 7) * 64, cc = (t & 15) * 4;
   const int64_t woff = a.w_off[layer];
   float4 p4[4], g4[4], m4[4], v4[4];
@@ -1637,6 +1637,33 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   __shared__ uint16_t tileT[64][66];
   adamw_body(a, blockIdx.x, tileT);
+}
+
+// W^T of wide layers layer_lo .. from their 16-bit W (acez_trainer_import_weights16: the sharded data-parallel update receives the
+// other ranks' layers as 16-bit copies and derives the transposed operand of the input-gradient GEMM locally). One 64 x 64 tile per block.
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ Wb, uint16_t* __restrict__ WbT, int layer_lo) {
+  __shared__ uint16_t tileT[64][66];
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int layer = layer_lo + b / 64, tl = b % 64;
+  const int r0 = (tl >> 3) * 64, c0 = (tl & 7) * 64, cc = (t & 15) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = (t >> 4) + 16 * i;
+    const uint2 pk = *reinterpret_cast<const uint2*>(Wb + (size_t)layer * 262144 + (size_t)(r0 + rr) * 512 + c0 + cc);
+    tileT[cc + 0][rr] = (uint16_t)(pk.x & 0xffff);
+    tileT[cc + 1][rr] = (uint16_t)(pk.x >> 16);
+    tileT[cc + 2][rr] = (uint16_t)(pk.y & 0xffff);
+    tileT[cc + 3][rr] = (uint16_t)(pk.y >> 16);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = (t >> 4) + 16 * i;
+    uint2 pk;
+    pk.x = (uint32_t)tileT[rr][cc + 0] | ((uint32_t)tileT[rr][cc + 1] << 16);
+    pk.y = (uint32_t)tileT[rr][cc + 2] | ((uint32_t)tileT[rr][cc + 3] << 16);
+    *reinterpret_cast<uint2*>(WbT + (size_t)layer * 262144 + (size_t)(c0 + rr) * 512 + r0 + cc) = pk;
+  }
 }
 
 // recast only (no optimiser step): used after loading weights

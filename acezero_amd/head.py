@@ -228,6 +228,32 @@ class HeadTrainer:
     def update(self):
         N.check(self.lib.acez_train_update(self._h, _stream()))
 
+    # ---- sharded data-parallel update (parallel.ShardedDataParallel)
+    LAYER_STRIDE = 262144 + 512          # floats of one wide layer (weight + bias) in the flat parameter / gradient vectors
+
+    def update_layers(self, layer_lo, layer_hi):
+        """AdamW on the weight matrices of wide layers [layer_lo, layer_hi) + all small parameters + the schedule bookkeeping."""
+        N.check(self.lib.acez_train_update_layers(self._h, int(layer_lo), int(layer_hi), _stream()))
+
+    def new_weights16_buffer(self):
+        """[L, 512 * 512 / 2] device tensor of int32 words (two 16-bit weights each; a dtype every torch.distributed backend moves): the
+        all-gather buffer of the compute copies."""
+        return torch.empty((self.L, 131072), dtype=torch.int32, device=self.device)
+
+    def export_weights16(self, layer_lo, layer_hi, dst):
+        assert dst.is_cuda and dst.is_contiguous() and dst.numel() * dst.element_size() == (layer_hi - layer_lo) * 524288
+        if layer_hi > layer_lo:
+            N.check(self.lib.acez_trainer_export_weights16(self._h, int(layer_lo), int(layer_hi), _ptr(dst), _stream()))
+
+    def import_weights16(self, layer_lo, layer_hi, src):
+        assert src.is_cuda and src.is_contiguous() and src.numel() * src.element_size() == (layer_hi - layer_lo) * 524288
+        if layer_hi > layer_lo:
+            N.check(self.lib.acez_trainer_import_weights16(self._h, int(layer_lo), int(layer_hi), _ptr(src), _stream()))
+
+    def master_tensors(self):
+        """The flat fp32 vectors whose wide-layer ranges an owner rank keeps current under the sharded update."""
+        return [self.params, self.adam_m, self.adam_v]
+
     def step(self, indices):
         assert indices.dtype == torch.int64 and indices.is_cuda and indices.is_contiguous()
         N.check(self.lib.acez_train_step(self._h, _ptr(indices), int(indices.numel()), _stream()))

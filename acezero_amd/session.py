@@ -34,7 +34,7 @@ from .encoder import Encoder, output_size
 import torch.distributed as dist
 
 from .head import HeadTrainer, _ptr, _stream, epoch_permutations
-from .parallel import epoch_local_batches, gather_registrations, rank_world
+from .parallel import epoch_local_batches, gather_registrations, make_data_parallel, rank_world
 
 _logger = logging.getLogger("acezero_amd.session")
 
@@ -393,19 +393,14 @@ class ReconstructionSession:
         t_loop0 = time.time()
         launched, done = 0, False
         perms = epoch_permutations(n, o.base_seed + 8191, self.dev)       # ace_trainer.py:79-80 seed of the training generator
+        dpt = make_data_parallel(tr, self.group) if dp else None          # reduce-scatter / sharded AdamW / all-gather (parallel.py)
         while not done:                                                  # TrainerACE.train / run_epoch (ace_trainer.py:454-497)
             perm = next(perms)
             if dp:
                 local, offs = epoch_local_batches(perm, o.batch_size, shard_lo, shard_lo + n_local)
             for b in range(n // o.batch_size):
                 if dp:
-                    rows = local[offs[b]:offs[b + 1]]
-                    if rows.numel() > 0:
-                        tr.backward(rows)
-                    else:
-                        tr.grad.zero_()
-                    dist.all_reduce(tr.grad, op=dist.ReduceOp.SUM, group=self.group)   # RCCL: head + pose gradients, loss / inlier / focal statistics
-                    tr.update()
+                    dpt.step(local[offs[b]:offs[b + 1]])   # RCCL: head + pose gradients, loss / inlier / focal statistics
                 else:
                     tr.step(perm[b * o.batch_size:(b + 1) * o.batch_size])
                 launched += 1
@@ -417,6 +412,8 @@ class ReconstructionSession:
                         done = True
                         break
         st = tr.state()
+        if dpt is not None:
+            dpt.gather_masters()                                         # the fp32 masters of the other ranks' layers, for the checkpoint
         dt = time.time() - t0
         t_loop = time.time() - t_loop0
         out = {"head": {k: v.detach().cpu().half() for k, v in tr.state_dict().items()},      # save_model (ace_trainer.py:681-694)

@@ -9,7 +9,8 @@ mapping on one MI355X, default head).  `value` = patches/s of the whole job.  Th
 half of the metric, DSAC* registration (images/s, scene coordinates resident in HBM, ace_zero's 32 hypotheses /
 16 tries), and reports it under "registration".  With N > 1 the feature buffer is sharded across ranks
 (each rank owns buffer_patches/N rows... here: its own 8M/N-row shard), every rank runs 5120 rows per step and the
-flat gradient bucket is summed with one RCCL all-reduce per step (weak scaling: global batch = 5120 N);
+gradient bucket is exchanged over RCCL once per step (reduce-scatter by layer, sharded AdamW, all-gather of the 16-bit copies; weak
+scaling: global batch = 5120 N);
 registration frames are sharded across ranks with no collective.
 
 Extra objects on the JSON line: "roofline" for the dominant kernel (rowgemm_kernel, bf16 MFMA), measured live
@@ -124,14 +125,20 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
         nb = per_rank // BATCH
         batches = [perm[i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(nb, total_iters))]
 
+    dp = None
+    if dist is not None:
+        # the step's exchange over RCCL (acezero_amd/parallel.py): reduce-scatter of the weight gradients by layer, AdamW on the rank's
+        # own layers, all-gather of the 16-bit compute copies, one small all-reduce for biases / fc3 / statistics / pose gradient
+        # (ACEZ_DP_MODE=allreduce: round 2's single all-reduce of the whole bucket + replicated update)
+        from acezero_amd.parallel import make_data_parallel
+        dp = make_data_parallel(tr)
+
     def step(i):
         idx = batches[i % len(batches)]
-        if dist is None:
+        if dp is None:
             tr.step(idx)
         else:
-            tr.backward(idx)
-            dist.all_reduce(tr.grad)          # RCCL sum of the flat gradient bucket (+ loss / inlier statistics)
-            tr.update()
+            dp.step(idx)
 
     for i in range(args.warmup):
         step(i)

@@ -245,6 +245,18 @@ int acez_trainer_sync_weights(acez_trainer* tr, void* stream);
  * (iteration >= max_iterations, ace_trainer.py:509-510) is a device-side no-op. */
 int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, int n, void* stream);
 int acez_train_update(acez_trainer* tr, void* stream);
+/* Sharded data-parallel update (reduce-scatter of the weight gradients, each rank updates its own layers, all-gather
+ * of the 16-bit compute copies; no reference counterpart -- the reference is single-GPU):
+ *   acez_train_update_layers        AdamW on the weight matrices of wide layers [layer_lo, layer_hi) only (d_grad holds their reduced
+ *                                   gradients) and on ALL small parameters (biases, fc3: their gradients are all-reduced, the update is
+ *                                   replicated); closes the step's schedule bookkeeping like acez_train_update
+ *   acez_trainer_export_weights16   16-bit W[out][in] of layers [layer_lo, layer_hi) -> d_dst  ((hi - lo) x 512 x 512 elements)
+ *   acez_trainer_import_weights16   d_src -> the 16-bit W of those layers, and rebuilds their transposed copies
+ * The fp32 masters / moments of layers a rank does not own go stale on it; the host copies the owners' values in before it reads them. */
+int acez_train_update_layers(acez_trainer* tr, int layer_lo, int layer_hi, void* stream);
+int acez_trainer_export_weights16(acez_trainer* tr, int layer_lo, int layer_hi, void* d_dst, void* stream);
+int acez_trainer_import_weights16(acez_trainer* tr, int layer_lo, int layer_hi, const void* d_src, void* stream);
+
 /* Single-GPU step = backward + update, with the wide-layer weight gradients handed from the split-K slabs straight to the
  * optimiser: bitwise the same parameters as the two calls above; afterwards d_grad holds the bias / fc3 gradients and the
  * statistics only (its wide-layer weight part is not written). Use backward / all-reduce / update when ranks exchange d_grad. */

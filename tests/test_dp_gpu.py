@@ -28,6 +28,24 @@ def _free_port():
     return p
 
 
+def _collect(procs, q, timeout):
+    """One result per worker; fails at once when a worker has died (a crashed rank must not cost the GPU box the full timeout)."""
+    import queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < len(procs):
+        try:
+            out.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError(f"worker exit codes {[p.exitcode for p in procs]} after {time.time() - t0:.0f}s")
+    return out
+
+
 def _problem():
     from acezero_amd import synth
     prob = synth.make_training_problem(seed=helpers.SEED + 7, n_images=24, views_per_image=2, patches_per_view=512)
@@ -77,7 +95,7 @@ def test_two_rank_data_parallel_step_equals_single_rank():
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    res = sorted(_collect(procs, q, 300), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -131,7 +149,7 @@ def test_two_rank_session_maps_and_registers_like_one():
     procs = [ctx.Process(target=_session_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    res = sorted(_collect(procs, q, 400), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -143,3 +161,58 @@ def test_two_rank_session_maps_and_registers_like_one():
     poses, inl, gt = a[4], a[5], a[8]
     dt = np.linalg.norm(poses[:, :3, 3] - gt[:, :3, 3], axis=1)
     assert (inl > 500).mean() >= 0.95 and np.median(dt) < 0.02, ((inl > 500).mean(), np.median(dt))
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from acezero_amd import parallel
+    prob, flat0 = _problem()
+    n = prob["features"].shape[0]
+    lo, hi = parallel.shard_range(n, rank, world)
+    gen = torch.Generator(device="cuda").manual_seed(8191)
+    perm = torch.randperm(n, generator=gen, device="cuda")
+    local, offs = parallel.epoch_local_batches(perm, B, lo, hi)
+    out = {}
+    for mode in ("allreduce", "sharded"):
+        tr = _make_trainer(prob, flat0, lo, hi)
+        dp = parallel.make_data_parallel(tr, mode=mode)
+        for b in range(4):
+            dp.step(local[offs[b]:offs[b + 1]])
+        torch.cuda.synchronize()
+        stale = tr.params.clone()
+        dp.gather_masters()
+        f = torch.from_numpy(prob["features"][:777]).cuda()
+        out[mode] = (tr.params.cpu().numpy(), tr.adam_m.cpu().numpy(), tr.adam_v.cpu().numpy(), tr.state(), tr.get_scene_coordinates(f).cpu().numpy(),
+                     bool((stale != tr.params).any()))
+        tr.close()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_update_equals_the_all_reduce_path_bitwise():
+    """parallel.ShardedDataParallel through the real kernels (acez_train_update_layers, export / import of the 16-bit copies with the
+    local transpose): two ranks, four steps. A two-term sum has one order, so the reduced gradients -- and with them every
+    parameter, both AdamW moments, the schedule state and the scene coordinates computed from the received compute copies --
+    must be BIT-identical to the all-reduce + replicated-update path, on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(_collect(procs, q, 300))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = res[0]["allreduce"]
+    for r in (0, 1):
+        for mode in ("allreduce", "sharded"):
+            got = res[r][mode]
+            for k in range(3):
+                assert np.array_equal(got[k], ref[k]), (r, mode, k)
+            assert got[3] == ref[3] and np.array_equal(got[4], ref[4]), (r, mode)
+        assert res[r]["sharded"][5] and not res[r]["allreduce"][5]      # masters of the other rank's layers were stale until gathered
+    assert ref[3]["iteration"] == 4

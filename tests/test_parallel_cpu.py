@@ -43,6 +43,36 @@ class OracleTrainer:
         sch.sched_step(float(self.grad[-3]) / self.cfg["global_batch"])
         self.orc.iteration += 1
 
+    # ---- the contract of parallel.ShardedDataParallel (HeadTrainer's methods of the same names)
+    L, LAYER_STRIDE = 8, 262144 + 512
+
+    def _foreign_weights(self, lo, hi):
+        m = torch.ones(self.L * self.LAYER_STRIDE, dtype=torch.bool).view(self.L, self.LAYER_STRIDE)
+        m[:, 262144:] = False            # biases are updated by every rank
+        m[lo:hi] = False                 # ... and so are the owned layers' weights
+        return m.view(-1)
+
+    def update_layers(self, lo, hi):
+        sch, flat = self.orc.sched, self.orc.head.p.flat
+        keep = self._foreign_weights(lo, hi)
+        n = keep.numel()
+        saved = [x[:n][keep].clone() for x in (flat, sch.m, sch.v)]
+        self.update()
+        for x, sv in zip((flat, sch.m, sch.v), saved):
+            x[:n][keep] = sv              # the weight matrices of the other ranks' layers were not touched
+
+    def new_weights16_buffer(self):
+        return torch.zeros(self.L, 262144)   # (fp32 stand-in for the 16-bit compute copies)
+
+    def export_weights16(self, lo, hi, dst):
+        dst.copy_(self.orc.head.p.flat[:self.L * self.LAYER_STRIDE].view(self.L, self.LAYER_STRIDE)[lo:hi, :262144])
+
+    def import_weights16(self, lo, hi, src):
+        self.orc.head.p.flat[:self.L * self.LAYER_STRIDE].view(self.L, self.LAYER_STRIDE)[lo:hi, :262144] = src
+
+    def master_tensors(self):
+        return [self.orc.head.p.flat, self.orc.sched.m, self.orc.sched.v]
+
 
 def _free_port():
     s = socket.socket()
@@ -129,3 +159,62 @@ def test_shard_helpers():
     assert parallel.frames_of_rank(7, 1, 3) == [1, 4]
     idx = torch.tensor([5, 0, 9, 3, 7])
     assert parallel.split_batch_by_owner(idx, 3, 8).tolist() == [2, 0, 4]
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    prob, flat0 = helpers.golden_problem()
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
+    n = prob["features"].shape[0]
+    lo, hi = parallel.shard_range(n, rank, world)
+    gen = torch.Generator().manual_seed(8191)
+    perm = torch.randperm(n, generator=gen)
+    out = {}
+    for mode in ("allreduce", "sharded"):
+        tr = OracleTrainer(prob, flat0, cfg, np.arange(lo, hi))
+        dp = parallel.make_data_parallel(tr, mode=mode)
+        for it in range(3):
+            batch = perm[it * helpers.B:(it + 1) * helpers.B]
+            dp.step(parallel.split_batch_by_owner(batch, lo, hi))
+        before = tr.orc.sched.m.clone()
+        dp.gather_masters()
+        out[mode] = (tr.orc.head.p.flat.numpy().copy(), tr.orc.sched.m.numpy().copy(), tr.orc.sched.lr, tr.orc.iteration,
+                     bool((before != tr.orc.sched.m).any()), (dp.lo, dp.hi) if mode == "sharded" else None)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_update_world_gloo(world):
+    """reduce(-scatter) by layer -> every rank updates its own layers' weight matrices -> broadcast / all-gather of the compute copies:
+    replicas end identical, each rank really updated only its share (the gather of the masters changes the moments of the others'
+    layers), and the result equals the all-reduce + replicated-update path -- bit for bit with two ranks (a two-term sum has one
+    order), to rounding with three (8 layers over 3 ranks: unequal shards, the per-owner reduce / broadcast fall-back)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ranges = [res[r]["sharded"][5] for r in range(world)]
+    assert ranges == [parallel.shard_range(8, r, world) for r in range(world)]
+    for r in range(1, world):
+        for mode in ("allreduce", "sharded"):
+            assert np.array_equal(res[0][mode][0], res[r][mode][0]) and np.array_equal(res[0][mode][1], res[r][mode][1]), (mode, r)
+            assert res[0][mode][2] == res[r][mode][2] and res[r][mode][3] == 3
+    assert all(res[r]["sharded"][4] for r in range(world))          # the masters of foreign layers were stale before the gather
+    assert not any(res[r]["allreduce"][4] for r in range(world))
+    a, b = res[0]["allreduce"][0], res[0]["sharded"][0]
+    if world == 2:
+        assert np.array_equal(a, b)
+    else:
+        assert np.abs(a - b).max() < 2e-4 and np.linalg.norm(a - b) < 1e-3 * np.linalg.norm(a - helpers.golden_problem()[1].numpy())
