@@ -335,6 +335,20 @@ class ReconstructionSession:
         t0 = time.time()
         image_ids = [int(i) for i in image_ids]
         m = len(image_ids)
+        if data_parallel is None and self.world > 1 and m < self.world:
+            # Fewer images than ranks: nothing to shard. ONE rank trains and hands its result to the others -- if every rank trained its
+            # own copy, their augmentation / sampling streams (advanced by different amounts in earlier calls) would give different
+            # heads, and the next warm-started data-parallel round would all-reduce gradients taken at different weights.
+            owners = sorted({i % self.world for i in image_ids})
+            if not o.use_aug and len(owners) != 1:
+                raise RuntimeError("mapping fewer images than ranks without augmentation needs all of them on one rank (cached features "
+                                   "live on the frame's owner): use --use_aug True or fewer GPUs")      # (the same decision on every rank)
+            src = 0 if o.use_aug else owners[0]
+            box = [self.map(image_ids, poses_c2w, focal, iterations=iterations, loss_type=loss_type, schedule=schedule, lr_max=lr_max,
+                            refinement=refinement, pose_wait=pose_wait, refine_calibration=refine_calibration, load_weights=load_weights,
+                            with_depth=with_depth, tag=tag, data_parallel=False) if self.rank == src else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+            return box[0]
         poses_c2w = torch.as_tensor(poses_c2w, dtype=torch.float32).reshape(-1, 4, 4)
         dp = (self.world > 1 and m >= self.world) if data_parallel is None else bool(data_parallel and self.world > 1)
         fill = self._fill_buffer_augmented if o.use_aug else self._fill_buffer
@@ -515,10 +529,13 @@ class ReconstructionSession:
             else:
                 # a seed trial maps ONE image (nothing to shard): trial i runs on rank i % world, side by side with the others; its
                 # head is then handed to every rank and scored by all of them together (sharded registration)
-                maps = [self.map_seed(i, sd_) if i % self.world == self.rank else None for i, sd_ in enumerate(seeds)]
+                # (without augmentation the buffer is filled from the cached feature maps, which only the frame's owner holds)
+                runner = [(i if o.use_aug else int(sd_ * self.n)) % self.world for i, sd_ in enumerate(seeds)]
+                maps = [self.map_seed(i, sd_) if runner[i] == self.rank else None for i, sd_ in enumerate(seeds)]
                 for i in range(len(maps)):
                     box = [maps[i]]
-                    dist.broadcast_object_list(box, src=i % self.world, group=self.group)
+                    dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, runner[i]) if self.group is not None else runner[i],
+                                               group=self.group)
                     maps[i] = box[0]
                 trials = [(mp_, self.score_seed(i, mp_)) for i, mp_ in enumerate(maps)]
             best = int(np.argmax([r for _, r in trials]))

@@ -136,8 +136,10 @@ def _session_worker(rank, world, port, q):
     m = ses.map(even, seq["poses"][even].cpu(), seq["focal"], iterations=2000, loss_type="tanh", schedule="1cyclepoly", lr_max=0.003)
     poses, inl = ses.register(m["head"], seq["focal"])
     sub_p, sub_i = ses.register(m["head"], seq["focal"], max_estimates=10)
+    # fewer images than ranks: ONE rank trains, every rank gets its head (the ranks used to train diverging copies)
+    one = ses.map([2], seq["poses"][[2]].cpu(), seq["focal"], iterations=300, loss_type="tanh", schedule="constant", lr_max=0.003, with_depth=True)
     q.put((rank, m["data_parallel"], m["buffer"], m["iterations"], poses, inl, sub_p, sub_i, seq["poses"].cpu().numpy(),
-           {k: v.numpy() for k, v in m["head"].items()}))
+           {k: v.numpy() for k, v in m["head"].items()}, {k: v.numpy() for k, v in one["head"].items()}, one["data_parallel"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -158,6 +160,7 @@ def test_two_rank_session_maps_and_registers_like_one():
     assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]), "both ranks hold every frame's pose after the gather"
     assert all(np.array_equal(a[9][k], b[9][k]) for k in a[9]), "replicated heads are bit-identical"
     assert len(a[6]) == 10 and np.array_equal(a[6], b[6])                # --max_estimates: the same random subset on both ranks
+    assert not a[11] and not b[11] and all(np.array_equal(a[10][k], b[10][k]) for k in a[10]), "one image on two ranks: one head, handed over"
     poses, inl, gt = a[4], a[5], a[8]
     dt = np.linalg.norm(poses[:, :3, 3] - gt[:, :3, 3], axis=1)
     assert (inl > 500).mean() >= 0.95 and np.median(dt) < 0.02, ((inl > 500).mean(), np.median(dt))
