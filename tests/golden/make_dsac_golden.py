@@ -4,9 +4,13 @@
 This cannot run in the build container (no OpenCV, dsacstar cannot be compiled: oracle/dsac_oracle.cpp header). Run it once
 inside the reference's conda env (environment.yml: libopencv 4.4.0, py-opencv 4.4.0), after `python dsacstar/setup.py install`:
 
-    cd /path/to/acezero            # the reference checkout (for `import dsacstar`)
-    OMP_NUM_THREADS=1 python /path/to/this/repo/tests/golden/make_dsac_golden.py --out /path/to/this/repo/tests/golden/dsac_ref.npz
-    OMP_NUM_THREADS=12 python ... --out .../dsac_ref_t12.npz          # register_mapping.py:8 runs with 12 threads
+    OMP_NUM_THREADS=1 python tests/golden/make_dsac_golden.py --reference /path/to/acezero --out tests/golden/dsac_ref.npz
+    OMP_NUM_THREADS=12 python tests/golden/make_dsac_golden.py --reference /path/to/acezero --out tests/golden/dsac_ref_t12.npz
+                                                                       # (register_mapping.py:8 runs with 12 threads)
+
+(--reference: the reference checkout, put on sys.path for `import dsacstar` -- the extension built in place by `python setup.py
+build_ext --inplace` inside dsacstar/ works as well as an installed one. Nothing else of this repository is imported: the script needs
+numpy, torch, cv2 and the reference's dsacstar only.)
 
 and commit the .npz. tests/test_dsac_reference_golden.py then pins the oracle (and through the bit-exact GPU test the kernels) on
   * cv2.solvePnP(SOLVEPNP_P3P) on seeded minimal sets                         (dsacstar_util.h:104-112 via :185-193)
@@ -75,8 +79,11 @@ def room_frames(rng, n_frames, h=60, w=80, sub=8, noise=0.02, outliers=0.3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
-    ap.add_argument("--frames", type=int, default=6)
+    ap.add_argument("--frames", type=int, default=50, help="whole-frame forward_rgb calls per case")
+    ap.add_argument("--reference", default=None, help="path of the reference checkout (and its dsacstar/ build directory) for `import dsacstar`")
     args = ap.parse_args()
+    if args.reference:
+        sys.path[:0] = [args.reference, os.path.join(args.reference, "dsacstar")]
     import cv2
     import torch
     import dsacstar
@@ -147,8 +154,18 @@ def main():
             pose = torch.zeros(4, 4)
             inl[ci, i] = dsacstar.forward_rgb(torch.from_numpy(sc[i:i + 1]), pose, hyp, 10.0, F, ppx, ppy, 100.0, 100.0, 8, 1305, tries)
             poses4[ci, i] = pose.numpy()
+    # case 2: the Mip-NeRF-360-garden map size (480 x 741 frames -> 60 x 93 coordinates), ace_zero's 32 hypotheses / 16 tries
+    sc93, ppx93, ppy93 = room_frames(rng, args.frames, h=60, w=93)
+    pose93 = np.zeros((args.frames, 4, 4), np.float32); inl93 = np.zeros(args.frames, np.int64)
+    for i in range(args.frames):
+        pose = torch.zeros(4, 4)
+        inl93[i] = dsacstar.forward_rgb(torch.from_numpy(sc93[i:i + 1]), pose, 32, 10.0, F, ppx93, ppy93, 100.0, 100.0, 8, 1305, 16)
+        pose93[i] = pose.numpy()
     out.update(fr_sc=sc, fr_ppx=np.array(ppx), fr_ppy=np.array(ppy), fr_cases=np.array(cases), fr_pose=poses4, fr_inliers=inl,
-               fr_note=np.array("calls were made in this order within ONE process: case 0 frames 0..n-1, then case 1 frames 0..n-1, seed 1305"))
+               fr93_sc=sc93, fr93_ppx=np.array(ppx93), fr93_ppy=np.array(ppy93), fr93_pose=pose93, fr93_inliers=inl93,
+               fr_note=np.array("calls were made in this order within ONE process (the generators are seeded once and continue): case 0 "
+                                "(32 hyp / 16 tries) frames 0..n-1, case 1 (64 / 1e6) frames 0..n-1, then the 60x93 frames 0..n-1 with "
+                                "32 / 16; seed 1305"))
     np.savez_compressed(args.out, **out)
     print("wrote", args.out, "OpenCV", cv2.__version__, "OMP threads", os.environ.get("OMP_NUM_THREADS"))
 

@@ -12,8 +12,9 @@ import pytest
 from oracle import dsac_oracle
 
 FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dsac_ref*.npz")))
-pytestmark = pytest.mark.skipif(not FILES, reason="R PARITY UNPINNED: no tests/golden/dsac_ref*.npz (run tests/golden/make_dsac_golden.py in the "
-                                                  "reference's OpenCV 4.4.0 environment and commit its output)")
+pytestmark = pytest.mark.skipif(not FILES, reason="R PARITY UNPINNED: no tests/golden/dsac_ref*.npz. One command in the reference's conda environment "
+                                                  "(OpenCV 4.4.0, dsacstar built) pins it: OMP_NUM_THREADS=1 python tests/golden/make_dsac_golden.py "
+                                                  "--reference /path/to/acezero --out tests/golden/dsac_ref.npz  (then commit the .npz)")
 
 
 @pytest.fixture(params=FILES or [None])
@@ -65,5 +66,10 @@ def test_whole_forward_rgb_calls_match_the_reference_binary(ref):
                                             int(tries))
                 assert r["inliers"] == int(ref["fr_inliers"][ci, i]), (ci, i)
                 np.testing.assert_allclose(r["pose"], ref["fr_pose"][ci, i], rtol=0, atol=1e-4)
+        if "fr93_sc" in ref.files:   # the 60 x 93 maps (garden-sized frames) came last in the generating process
+            for i, sc in enumerate(ref["fr93_sc"]):
+                r = dsac_oracle.forward_rgb(sc, 32, 10.0, f, float(ref["fr93_ppx"]), float(ref["fr93_ppy"]), 100.0, 100.0, 8, 1305, i, 16)
+                assert r["inliers"] == int(ref["fr93_inliers"][i]), ("60x93", i)
+                np.testing.assert_allclose(r["pose"], ref["fr93_pose"][i], rtol=0, atol=1e-4)
     finally:
         dsac_oracle.set_options()

@@ -94,3 +94,13 @@ def test_rodrigues_project_solve_bitexact(probe):
         Ad[np.diag_indices(6)] *= 1 + 10.0 ** rng.integers(-16, 3)        # the damped system of an LM step
         probe.probe_solve_normal6(_p(np.ascontiguousarray(Ad)), _p(b), _p(x))
         assert np.array_equal(x.view(np.uint64), O.solve_normal6(Ad, b).view(np.uint64))
+
+
+def test_both_det_math_copies_are_generator_output():
+    """oracle/det_math.h and acezero_amd/csrc/det_math.h are not shared by copy-and-hope: both must be byte-for-byte what
+    tools/gen_det_header.py emits from the mpmath fits of tools/gen_det_math.py."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_det_header.py"), "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
