@@ -313,7 +313,8 @@ def train_with_options(opt):
         while not done:
             perm = next(perms)
             for b0 in range(0, n - opt.batch_size + 1, opt.batch_size):
-                tr.step(perm[b0:b0 + opt.batch_size])
+                b1 = b0 + opt.batch_size
+                tr.step(perm[b0:b1], perm[b1:b1 + opt.batch_size] if b1 + opt.batch_size <= n else None)   # next slice: gathered ahead
                 launched += 1
                 if launched % opt.iterations_output == 0 or launched % 64 == 0:
                     st = tr.state()                                  # the only host synchronisation of the loop

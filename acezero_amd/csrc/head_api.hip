@@ -42,13 +42,18 @@ struct acez_trainer {
   uint16_t* zeros = nullptr;
   float *log_loss = nullptr, *log_inl = nullptr;
   int log_cap = 0;
-  TrainState* st = nullptr;
+  TrainState* st = nullptr;         // = st_slot[st_cur]: the slot every launch made from now on reads
+  TrainState* st_slot[2] = {nullptr, nullptr};   // sched_post_wave reads one slot and writes the other; the host flips after launching it
+  int st_cur = 0;
   TrainState* st_infer = nullptr;   // schedule-free launches (inference) get this always-active state, so that a rowseq fault can switch them off too
   // pose refinement runs on its own stream, beside the head's GEMM chains (6 launches, ~65 us if serialised at 1000 images)
   hipStream_t pose_stream = nullptr;
   hipEvent_t ev_begin = nullptr, ev_pose_fwd = nullptr, ev_loss = nullptr, ev_pose_bwd = nullptr;
   GradReduceArgs last_reduce{};   // partial buffers of the last backward (input of the fused update)
   bool post_pending = false;   // acez_train_update has run; its schedule bookkeeping rides with the next step's gather (flush_post)
+  // acez_train_step_next: the batch of the NEXT step was gathered (and this step's bookkeeping done) inside the optimiser's launch
+  const int64_t* pre_idx = nullptr;
+  int pre_n = 0;
   SchedConfig sc;
   std::vector<void*> allocs;
   // pose refinement (mlp): per-image activations and gradients, allocated by set_buffer (needs n_images)
@@ -309,7 +314,9 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->log_cap = cfg->iterations + 8;
   A((void**)&tr->log_loss, (size_t)tr->log_cap * sizeof(float));
   A((void**)&tr->log_inl, (size_t)tr->log_cap * sizeof(float));
-  A((void**)&tr->st, sizeof(TrainState));
+  A((void**)&tr->st_slot[0], sizeof(TrainState));
+  A((void**)&tr->st_slot[1], sizeof(TrainState));
+  tr->st = tr->st_slot[0];
   A((void**)&tr->st_infer, sizeof(TrainState));
   if (rc != ACEZ_OK) { acez_trainer_destroy(tr); return rc; }
 
@@ -628,9 +635,15 @@ static void pose_backward(acez_trainer* tr, int n, const int* active, hipStream_
   launch_pose_wgrad(tr, active, false, s);
 }
 
+// after a launch that ran the schedule bookkeeping (it wrote the other slot): every later launch reads that slot
+static void st_flip(acez_trainer* tr) {
+  tr->st_cur ^= 1;
+  tr->st = tr->st_slot[tr->st_cur];
+}
+
 static PostArgs post_args(acez_trainer* tr) {
   PostArgs p;
-  p.st = tr->st; p.c = tr->sc; p.grad_stats = (const float*)(tr->pb.d_grad + tr->n_params);
+  p.src = tr->st; p.st = tr->st_slot[tr->st_cur ^ 1]; p.c = tr->sc; p.grad_stats = (const float*)(tr->pb.d_grad + tr->n_params);
   p.inv_global_batch = 1.0f / (float)tr->cfg.global_batch; p.log_loss = tr->log_loss; p.log_inl = tr->log_inl; p.log_cap = tr->log_cap;
   p.fault = tr->seq_err; p.stat_partials = tr->stat_partials; p.n_loss_blocks = tr->last_nblk;
   return p;
@@ -643,8 +656,9 @@ static void flush_post(acez_trainer* tr, hipStream_t s) {
   tr->post_pending = false;
   ProfScope ps(tr, s, KC_SCHED);
   const PostArgs p = post_args(tr);
-  hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault,
+  hipLaunchKernelGGL(sched_post_kernel, dim3(1), dim3(64), 0, s, p.src, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault,
                      p.stat_partials, p.n_loss_blocks);
+  st_flip(tr);
 }
 
 static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n, void* stream, bool fused) {
@@ -653,7 +667,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   ACEZ_REQUIRE(n > 0 && n <= tr->max_batch, "n must be in [1, max_batch]");
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   hipStream_t s = (hipStream_t)stream;
-  const TrainState* st = tr->st;
+  const TrainState* st = tr->st;   // (re-read below: the launch that closes the previous step moves the state to the other slot)
   tr->last_n = n;
 
   const bool pose_naive = tr->cfg.pose_refinement == 1;
@@ -685,6 +699,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     // ---- one launch for gather + forward + loss + input gradients (head_chain.hip). The schedule bookkeeping that closes the
     // previous step must be complete before it starts (its workgroups read the state), so it is its own small launch here.
     flush_post(tr, s);
+    st = tr->st;
     if (ps != s) {
       ACEZ_HIP_CHECK(hipEventRecord(tr->ev_begin, s));
       ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_begin, 0));
@@ -706,7 +721,13 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   uint16_t* act = nullptr;
   if (tr->fused_fwd) {
     flush_post(tr, s);
+    st = tr->st;
     act = launch_forward_fused(tr, (const uint16_t*)tr->buf.d_features, d_indices, n, true, st, s);
+  } else {
+  const bool pregathered = !pf && tr->pre_idx == d_indices && tr->pre_n == n && !tr->post_pending;
+  tr->pre_idx = nullptr; tr->pre_n = 0;
+  if (pregathered) {
+    // acez_train_step_next of the step before has gathered exactly this batch into R[0] and closed that step's bookkeeping
   } else {
   if (pf && !tr->pose_wt_valid) {   // first step / after acez_trainer_sync_weights / after a split (backward + update) step
     hipLaunchKernelGGL(pose_transpose_kernel, dim3(4, 4, 4), dim3(256), 0, s, (const float*)tr->pb.d_pose_params, tr->pose_wt, (const int*)nullptr);
@@ -722,15 +743,19 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
                                         d_indices, tr->R[0], n, post_args(tr), do_post, pose_net_args(tr, nullptr), np)
     if (T == 16) ACEZ_SBP(16); else if (T == 4) ACEZ_SBP(4); else ACEZ_SBP(8);
 #undef ACEZ_SBP
+    if (do_post) st_flip(tr);
   } else if (tr->post_pending) {   // gather of this step + the schedule bookkeeping of the previous one, in one launch
     tr->post_pending = false;
     hipLaunchKernelGGL(step_begin_kernel, dim3(gblocks + 1), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n,
                        post_args(tr));
+    st_flip(tr);
   } else {
     hipLaunchKernelGGL(gather_kernel, dim3(gblocks), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n, st);
   }
   delete psg;
   }
+  }
+  st = tr->st;   // the slot the bookkeeping (if any rode with the gather) has just written
   if (ps != s) {   // after the schedule bookkeeping of step_begin (the pose kernels read st->active / pose_enable)
     ACEZ_HIP_CHECK(hipEventRecord(tr->ev_begin, s));
     ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_begin, 0));
@@ -848,7 +873,8 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
   return train_backward_impl(tr, d_indices, n, stream, false);
 }
 
-static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int layer_lo = 0, int layer_hi = -1) {
+static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int layer_lo = 0, int layer_hi = -1, const int64_t* d_next = nullptr,
+                             int n_next = 0) {
   ACEZ_REQUIRE(tr, "null trainer");
   if (layer_hi < 0) layer_hi = tr->L;
   ACEZ_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= tr->L, "layer range out of bounds");
@@ -879,6 +905,19 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     return ACEZ_OK;
   }
   a.layer_lo = layer_lo; a.layer_hi = layer_hi;
+  if (fused && d_next && n_next > 0 && tr->cfg.pose_refinement == 0 && !tr->chain && !tr->fused_fwd && tr->have_buf) {
+    // the next batch is known: its gather and this step's schedule bookkeeping ride in the optimiser's launch (adamw_next_kernel)
+    const int n_adam = tr->L * 64 + nsmall;
+    const int gblocks = (n_next + 3) / 4 < 1024 ? (n_next + 3) / 4 : 1024;
+    { ProfScope ps(tr, s, KC_ADAMW);
+      hipLaunchKernelGGL(adamw_next_kernel, dim3(n_adam + gblocks), dim3(256), 0, s, a, n_adam, (const uint16_t*)tr->buf.d_features, d_next, tr->R[0], n_next,
+                         post_args(tr)); }
+    st_flip(tr);
+    tr->pre_idx = d_next; tr->pre_n = n_next;
+    tr->post_pending = false;
+    ACEZ_HIP_CHECK(hipGetLastError());
+    return ACEZ_OK;
+  }
   { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3((layer_hi - layer_lo) * 64 + nsmall), dim3(256), 0, s, a); }
   if (tr->cfg.pose_refinement != 0) tr->pose_wt_valid = false;   // adamw_small_kernel does not refresh the transposed copies
   if (tr->cfg.pose_refinement != 0)
@@ -928,6 +967,17 @@ extern "C" int acez_train_step(acez_trainer* tr, const int64_t* d_indices, int n
   int rc = train_backward_impl(tr, d_indices, n, stream, true);
   if (rc != ACEZ_OK) return rc;
   return train_update_impl(tr, stream, true);
+}
+
+// acez_train_step with the NEXT step's batch announced: when the following call is acez_train_step / acez_train_step_next with exactly
+// these indices (same device pointer, same count), its gather has already happened -- inside this step's optimiser launch, together
+// with this step's schedule bookkeeping -- and that call starts with the forward GEMM chain. Any other next call (other indices, a
+// split backward, a state read) is still correct: it simply gathers again. d_indices_next may be NULL (= acez_train_step).
+extern "C" int acez_train_step_next(acez_trainer* tr, const int64_t* d_indices, int n, const int64_t* d_indices_next, int n_next, void* stream) {
+  ACEZ_REQUIRE(n_next >= 0 && n_next <= (tr ? tr->max_batch : 0), "n_next must be in [0, max_batch]");
+  int rc = train_backward_impl(tr, d_indices, n, stream, true);
+  if (rc != ACEZ_OK) return rc;
+  return train_update_impl(tr, stream, true, 0, -1, d_indices_next, n_next);
 }
 
 extern "C" int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out, void* stream) {

@@ -1849,16 +1849,37 @@ __global__ void sched_init_kernel(TrainState* st, SchedConfig c) {
 
 // Executed by ONE full wavefront (all 64 lanes must call it): the lanes cooperate on the minimum of the cool-down
 // criterion ring, lane 0 does the scalar bookkeeping.
-__device__ void sched_post_wave(TrainState* st, const SchedConfig& c, const float* grad_stats, float inv_global_batch,
-                                float* log_loss, float* log_inl, int log_cap, const int* fault, const float* stat_partials, int n_loss_blocks) {
-  if (fault && *fault) return;   // the step was abandoned (rowseq fault): no iteration is counted, nothing is logged
+// The schedule state lives in TWO slots (acez_trainer::st_slot): the kernels of a step read the slot the host passes them, the
+// bookkeeping that closes the step reads that slot (`src`) and writes the OTHER one (`st`), which the host hands to every later
+// launch. So the bookkeeping may run beside kernels that still read the old slot -- the optimiser's own launch (adamw_next_kernel) --
+// without any ordering between them. Every path through this function leaves `st` a complete state (src == st: in place).
+__device__ void sched_post_wave(const TrainState* src, TrainState* st, const SchedConfig& c, const float* grad_stats, float inv_global_batch,
+                                float* log_loss, float* log_inl, int log_cap, const int* fault, const float* stat_partials, int n_loss_blocks,
+                                const GradReduceArgs* tail = nullptr) {
   const int lane = threadIdx.x & 63;
-  const uint32_t amax_bits = c.f16 ? st->dz_absmax_bits : 0u;   // fp16: largest propagated gradient of the step (scaled units)
+  const uint32_t amax_bits = src->dz_absmax_bits;   // fp16: largest propagated gradient of the step (scaled units)
   // every load of the wave first: the scalar state (used by lane 0), the statistics, this lane's two ring entries
-  SchedHot h = load_hot(st);
-  const float g0 = grad_stats[0], g1 = grad_stats[1], g2 = grad_stats[2];
-  const float ring0 = st->crit_buf[lane], ring1 = (lane + 64 < 100) ? st->crit_buf[lane + 64] : 0.f;
-  if (!h.active) return;  // the schedule has ended: state is frozen (ace_trainer.py:509-510)
+  SchedHot h = load_hot(src);
+  const float ring0 = src->crit_buf[lane], ring1 = (lane + 64 < 100) ? src->crit_buf[lane + 64] : 0.f;
+  if ((fault && *fault) || !h.active) {
+    // the step was abandoned (rowseq fault: no iteration is counted, nothing is logged) or the schedule has ended (state frozen,
+    // ace_trainer.py:509-510): the other slot becomes a copy
+    if (src != st) {
+      st->crit_buf[lane] = ring0;
+      if (lane + 64 < 100) st->crit_buf[lane + 64] = ring1;
+      if (lane == 0) { store_hot(st, h); st->dz_absmax_bits = amax_bits; }
+    }
+    return;
+  }
+  float g0, g1, g2;
+  if (tail) {   // inside the optimiser's own launch (adamw_next_kernel): the reduced statistics are being written by sibling workgroups of
+                // this launch, so the wave reduces the loss kernel's partials itself -- tail_output's arithmetic: the same bits
+    int64_t d;
+    const int64_t k0 = (int64_t)tail->n_layers * 512 + (tail->n_params - tail->n_wide);
+    g0 = tail_output(*tail, k0, lane, d); g1 = tail_output(*tail, k0 + 1, lane, d); g2 = tail_output(*tail, k0 + 2, lane, d);
+  } else {
+    g0 = grad_stats[0]; g1 = grad_stats[1]; g2 = grad_stats[2];
+  }
   const float loss = g0 * inv_global_batch;
   const float inl = g1 * inv_global_batch;
   // minimum of the ring as it will be after this step's push: the entries that stay, and the new value
@@ -1873,6 +1894,12 @@ __device__ void sched_post_wave(TrainState* st, const SchedConfig& c, const floa
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) crit_min = fminf(crit_min, __shfl_xor(crit_min, off));
+  }
+  {   // the ring as it is after this step's push (1cyclepoly: the new value replaces entry crit_pos), written by all lanes
+    const bool push = c.schedule == SCHED_1CYCLEPOLY;
+    const int pos = h.crit_pos;
+    st->crit_buf[lane] = (push && lane == pos) ? inl : ring0;
+    if (lane + 64 < 100) st->crit_buf[lane + 64] = (push && lane + 64 == pos) ? inl : ring1;
   }
   if (lane != 0) return;
   h.last_loss = loss;
@@ -1920,9 +1947,8 @@ __device__ void sched_post_wave(TrainState* st, const SchedConfig& c, const floa
       if (e <= c.warmup_iterations)
         h.lr = h.lr * (1.0 + (ef - sf) / ((double)c.warmup_iterations * sf + (double)(e - 1) * (ef - sf)));
     }
-    // rolling buffer of the last 100 batch_inliers
+    // rolling buffer of the last 100 batch_inliers (the entry itself was written above)
     const int pos = h.crit_pos;
-    st->crit_buf[pos] = inl;
     h.crit_pos = (pos + 1 == 100) ? 0 : pos + 1;
     if (h.crit_count < 100) h.crit_count += 1;
   } else if (c.schedule == SCHED_CIRCLE) {
@@ -1940,24 +1966,25 @@ __device__ void sched_post_wave(TrainState* st, const SchedConfig& c, const floa
     e = min(16, max(-8, e));
     h.grad_scale = ldexpf(1.f, e);
     h.inv_grad_scale = ldexpf(1.f, -e);
-    st->dz_absmax_bits = 0u;
   }
+  st->dz_absmax_bits = 0u;
   h.iteration = it + 1;   // ace_trainer.py:495
   sched_prepare_hot(h, c, crit_min);   // bookkeeping of the NEXT iteration, so that a step needs a single schedule launch
   store_hot(st, h);
 }
 
-__global__ __launch_bounds__(64) void sched_post_kernel(TrainState* st, SchedConfig c, const float* grad_stats, float inv_global_batch,
+__global__ __launch_bounds__(64) void sched_post_kernel(const TrainState* src, TrainState* st, SchedConfig c, const float* grad_stats, float inv_global_batch,
                                                         float* log_loss, float* log_inl, int log_cap, const int* fault, const float* stat_partials,
                                                         int n_loss_blocks) {
-  sched_post_wave(st, c, grad_stats, inv_global_batch, log_loss, log_inl, log_cap, fault, stat_partials, n_loss_blocks);
+  sched_post_wave(src, st, c, grad_stats, inv_global_batch, log_loss, log_inl, log_cap, fault, stat_partials, n_loss_blocks);
 }
 
 // step_begin: the batch gather of iteration i + 1 and, in ONE extra single-wave workgroup, the schedule bookkeeping that
 // closes iteration i (the two are independent: the gather does not look at the schedule state; a gather into the scratch
 // rows of an inactive step is harmless). Saves a dependent single-thread launch per step.
 struct PostArgs {
-  TrainState* st;
+  const TrainState* src;   // the slot the closing step's kernels read
+  TrainState* st;          // the slot the bookkeeping writes (the other one; == src: in place)
   SchedConfig c;
   const float* grad_stats;
   float inv_global_batch;
@@ -1971,7 +1998,7 @@ struct PostArgs {
 __global__ __launch_bounds__(256) void step_begin_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
                                                          uint16_t* __restrict__ out, int n, PostArgs p) {
   if (blockIdx.x == gridDim.x - 1) {
-    if (threadIdx.x < 64) sched_post_wave(p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault, p.stat_partials, p.n_loss_blocks);
+    if (threadIdx.x < 64) sched_post_wave(p.src, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault, p.stat_partials, p.n_loss_blocks);
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -1979,6 +2006,35 @@ __global__ __launch_bounds__(256) void step_begin_kernel(const uint16_t* __restr
   const int nwaves = ((gridDim.x - 1) * blockDim.x) >> 6;
   for (int r = wave; r < n; r += nwaves) {
     const int64_t src = idx[r];
+    const uint4 v = *reinterpret_cast<const uint4*>(feat + src * 512 + lane * 8);
+    *reinterpret_cast<uint4*>(out + (size_t)r * 512 + lane * 8) = v;
+  }
+}
+
+// The optimiser of step k, the batch gather of step k + 1 and the schedule bookkeeping that closes step k in ONE launch (single-GPU
+// step with the next batch's indices known: acez_train_step_next). The three do not depend on each other: the bookkeeping reads the
+// loss kernel's statistic partials and the state slot of step k and writes the OTHER slot (sched_post_wave), which only later launches
+// read. Saves the step_begin launch (5 us + a kernel boundary) of every step: the gather hides under the HBM-bound optimiser.
+// (First version: one slot, bookkeeping in the workgroup that finished last, found with a ticket counter -- 1700 atomics on one word
+// cost 20 us.)   blocks [0, n_adam) = adamw_kernel's; then the gather blocks; the last block = the schedule wave
+__global__ __launch_bounds__(256) void adamw_next_kernel(AdamArgs a, int n_adam, const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx_next,
+                                                         uint16_t* __restrict__ out, int n_next, PostArgs p) {
+  __shared__ uint16_t tileT[64][66];
+  const int b = (int)blockIdx.x;
+  if (b < n_adam) {
+    adamw_body(a, b, tileT);
+    return;
+  }
+  if (b == (int)gridDim.x - 1) {
+    if (threadIdx.x < 64)
+      sched_post_wave(p.src, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault, p.stat_partials, p.n_loss_blocks, &a.tail);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = ((b - n_adam) * (int)blockDim.x + (int)threadIdx.x) >> 6;
+  const int nwaves = (((int)gridDim.x - 1 - n_adam) * (int)blockDim.x) >> 6;
+  for (int r = wave; r < n_next; r += nwaves) {
+    const int64_t src = idx_next[r];
     const uint4 v = *reinterpret_cast<const uint4*>(feat + src * 512 + lane * 8);
     *reinterpret_cast<uint4*>(out + (size_t)r * 512 + lane * 8) = v;
   }

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256, 2) void step_begin_pose_kernel(const uint16_t*
   }
   const int gb = (int)blockIdx.x - np, ngb = (int)gridDim.x - np - 1;
   if (gb == ngb) {
-    if (do_post && threadIdx.x < 64) sched_post_wave(p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault, p.stat_partials, p.n_loss_blocks);
+    if (do_post && threadIdx.x < 64) sched_post_wave(p.src, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault, p.stat_partials, p.n_loss_blocks);
     return;
   }
   const int lane = threadIdx.x & 63;

@@ -254,9 +254,17 @@ class HeadTrainer:
         """The flat fp32 vectors whose wide-layer ranges an owner rank keeps current under the sharded update."""
         return [self.params, self.adam_m, self.adam_v]
 
-    def step(self, indices):
+    def step(self, indices, next_indices=None):
+        """One fused training step. next_indices: the batch of the FOLLOWING step() call, if known (run_epoch walks one permutation):
+        it is gathered inside this step's optimiser launch; pass the very same tensor to the next call."""
         assert indices.dtype == torch.int64 and indices.is_cuda and indices.is_contiguous()
-        N.check(self.lib.acez_train_step(self._h, _ptr(indices), int(indices.numel()), _stream()))
+        if next_indices is None:
+            N.check(self.lib.acez_train_step(self._h, _ptr(indices), int(indices.numel()), _stream()))
+        else:
+            assert next_indices.dtype == torch.int64 and next_indices.is_cuda and next_indices.is_contiguous()
+            self._next_keepalive = next_indices     # the device pointer must stay valid until the next call has consumed it
+            N.check(self.lib.acez_train_step_next(self._h, _ptr(indices), int(indices.numel()), _ptr(next_indices), int(next_indices.numel()),
+                                                  _stream()))
 
     def state(self):
         st = N.TrainState()

@@ -416,7 +416,8 @@ class ReconstructionSession:
                 if dp:
                     dpt.step(local[offs[b]:offs[b + 1]])   # RCCL: head + pose gradients, loss / inlier / focal statistics
                 else:
-                    tr.step(perm[b * o.batch_size:(b + 1) * o.batch_size])
+                    nxt = perm[(b + 1) * o.batch_size:(b + 2) * o.batch_size] if b + 1 < n // o.batch_size else None
+                    tr.step(perm[b * o.batch_size:(b + 1) * o.batch_size], nxt)   # (the next slice of the permutation is gathered ahead)
                 launched += 1
                 if launched % 64 == 0:                                   # the only host synchronisation of the loop
                     st = tr.state()

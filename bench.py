@@ -136,7 +136,7 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
     def step(i):
         idx = batches[i % len(batches)]
         if dp is None:
-            tr.step(idx)
+            tr.step(idx, batches[(i + 1) % len(batches)])   # the next batch is known (run_epoch): gathered inside this step's optimiser launch
         else:
             dp.step(idx)
 

@@ -261,6 +261,10 @@ int acez_trainer_import_weights16(acez_trainer* tr, int layer_lo, int layer_hi, 
  * optimiser: bitwise the same parameters as the two calls above; afterwards d_grad holds the bias / fc3 gradients and the
  * statistics only (its wide-layer weight part is not written). Use backward / all-reduce / update when ranks exchange d_grad. */
 int acez_train_step(acez_trainer* tr, const int64_t* d_indices, int n, void* stream);
+/* acez_train_step with the NEXT step's indices announced (run_epoch walks consecutive slices of one permutation, ace_trainer.py:466-494,
+ * so the caller knows them): the next batch is gathered, and this step's schedule bookkeeping done, inside this step's optimiser
+ * launch. The next call must pass the same device pointer and count to profit; anything else is still correct. NULL = acez_train_step. */
+int acez_train_step_next(acez_trainer* tr, const int64_t* d_indices, int n, const int64_t* d_indices_next, int n_next, void* stream);
 /* Synchronises `stream` and copies the schedule state. */
 int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out, void* stream);
 /* Per-iteration log kept on the device: loss and batch_inliers of iterations [first, first+count). */

@@ -307,3 +307,38 @@ def test_ten_free_running_steps_stay_close_to_the_oracle(regime):
     cosine = float(np.dot(d_gpu.astype(np.float64), d_orc.astype(np.float64)) / (np.linalg.norm(d_gpu.astype(np.float64)) * np.linalg.norm(d_orc.astype(np.float64))))
     assert cosine > 0.95, cosine
     assert tr.state()["iteration"] == 10 and abs(tr.state()["lr"] - orc.sched.lr) < 1e-15
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_step_with_the_next_batch_announced_equals_plain_steps_bitwise(dtype):
+    """acez_train_step_next gathers the following batch, and closes the step's schedule bookkeeping (in the workgroup that finishes
+    last), inside the optimiser's launch. Parameters, optimiser state, schedule state and the per-iteration log must equal plain
+    acez_train_step calls bit for bit -- also when the announcement is wrong (another batch follows), when a state read or a split
+    step comes in between, with ragged batch sizes, and across the cool-down trigger of 1cyclepoly."""
+    from tests.test_chain_gpu import _big_problem
+    prob = _big_problem(n_images=8, patches_per_view=512)
+    flat0 = head_oracle.init_params(helpers.SEED + 1)
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
+    cfg.update(global_batch=2048, iterations=60, warmup_iterations=5, cooldown_iterations=10, cooldown_trigger_percent=-1.0)
+    plain, piped = (_trainer(prob, flat0, cfg, max_batch=2048, dtype=dtype) for _ in range(2))
+    rng = np.random.default_rng(17)
+    N = prob["features"].shape[0]
+    batches = [torch.from_numpy(rng.permutation(N)[:(2048 if i % 5 else 1111)].astype(np.int64)).cuda() for i in range(40)]
+    other = torch.from_numpy(rng.permutation(N)[:2048].astype(np.int64)).cuda()
+    for i, b in enumerate(batches):
+        plain.step(b)
+        nxt = batches[i + 1] if i + 1 < len(batches) else None
+        if i % 7 == 3:
+            nxt = other                       # a wrong announcement: the next call must notice and gather its own batch
+        if i % 11 == 5:
+            piped.backward(b); piped.update()   # a split step in between (its bookkeeping rides with the next gather as before)
+        else:
+            piped.step(b, nxt)
+        if i % 9 == 4:
+            assert plain.state() == piped.state()
+    torch.cuda.synchronize()
+    assert torch.equal(plain.params, piped.params) and torch.equal(plain.adam_m, piped.adam_m) and torch.equal(plain.adam_v, piped.adam_v)
+    sp, sq = plain.state(), piped.state()
+    assert sp == sq and sp["iteration"] == sp["max_iterations"] < 60      # the cool-down ended the schedule early, on both
+    lp, lq = plain.log(0, sp["iteration"]), piped.log(0, sp["iteration"])
+    assert np.array_equal(lp[0], lq[0]) and np.array_equal(lp[1], lq[1])
