@@ -427,10 +427,65 @@ def _train_from_images(opt):
     return 0
 
 
+def frame_size_classes(rgb_glob):
+    """The sorted file list grouped by image size (header reads only): {(W, H): [positions in the sorted list]}. One size means
+    one resize factor and one resized shape for load_frames. The reference's batch-size-1 loaders take any mix (dataset.py:278-417)."""
+    import glob
+    from PIL import Image
+    files = sorted(glob.glob(rgb_glob))
+    if not files:
+        raise SystemExit(f"no files match {rgb_glob!r}")
+    classes = {}
+    for i, f in enumerate(files):
+        with Image.open(f) as im:
+            classes.setdefault(im.size, []).append(i)
+    return files, classes
+
+
+def _register_mixed_sizes(opt, files, classes):
+    """register_mapping.py on a folder whose frames have several sizes: registration is independent per frame, so every size class
+    gets its own encoder / RANSAC context (one ReconstructionSession each); --max_estimates draws its seeded subset over the whole
+    list, the random streams are keyed by the position in the whole list, the pose file keeps the list's order."""
+    import torch
+    from .session import ReconstructionSession
+    n = len(files)
+    if opt.max_estimates <= 0 or opt.max_estimates >= n:
+        chosen = np.arange(n)
+    else:
+        chosen = np.sort(torch.randperm(n, generator=torch.Generator().manual_seed(int(opt.base_seed)))[:opt.max_estimates].numpy())
+    keep = set(int(i) for i in chosen)
+    enc_sd = torch.load(_default_encoder_path(opt.encoder_path), map_location="cpu")
+    head_sd = torch.load(opt.network, map_location="cpu")
+    rows = {}
+    for (w, h), pos in sorted(classes.items()):
+        pos = [i for i in pos if i in keep]
+        if not pos:
+            continue
+        sub_files, frames, fscale = load_frames(None, opt.image_resolution, files=[files[i] for i in pos])
+        so = _session_options(opt, use_external_focal_length=opt.use_external_focal_length * fscale if opt.use_external_focal_length > 0 else -1.0,
+                              ransac_iterations=opt.hypotheses, ransac_threshold=opt.threshold, register_seed=opt.base_seed, use_aug=False,
+                              registration_confidence=opt.confidence_threshold)
+        ses = ReconstructionSession(enc_sd, frames, opt=so)
+        poses, inl = ses.register(head_sd, ses.focal0, max_tries=opt.hypotheses_max_tries, rng_ids=pos, tag=f"register {w}x{h}")
+        for k, i in enumerate(pos):
+            rows[i] = (poses[k], int(inl[k]), ses.focal0 / fscale)
+        del ses
+    out = Path(opt.network).parent / f"poses_{opt.session}.txt"
+    with open(out, "w") as f:
+        for i in sorted(rows):
+            p, c, focal = rows[i]
+            write_pose_line(f, files[i], np.linalg.inv(np.asarray(p, np.float64)), c, float(focal))
+    _logger.info(f"Registered {len(rows)} images of {len(classes)} sizes -> {out}")
+    return 0
+
+
 def _register_from_images(opt):
     """register_mapping.py on image files: encoder -> head -> RANSAC for every frame (register_mapping.py:201-276)."""
     import torch
     from .session import ReconstructionSession, write_pose_file
+    all_files, classes = frame_size_classes(opt.rgb_files)
+    if len(classes) > 1:
+        return _register_mixed_sizes(opt, all_files, classes)
     files, frames, fscale = load_frames(opt.rgb_files, opt.image_resolution)
     so = _session_options(opt, use_external_focal_length=opt.use_external_focal_length * fscale if opt.use_external_focal_length > 0 else -1.0,
                           ransac_iterations=opt.hypotheses, ransac_threshold=opt.threshold, register_seed=opt.base_seed, use_aug=False,
@@ -438,7 +493,7 @@ def _register_from_images(opt):
     ses = ReconstructionSession(torch.load(_default_encoder_path(opt.encoder_path), map_location="cpu"), frames, opt=so)
     poses, inl = ses.register(torch.load(opt.network, map_location="cpu"), ses.focal0, max_estimates=opt.max_estimates, max_tries=opt.hypotheses_max_tries)
     out = Path(opt.network).parent / f"poses_{opt.session}.txt"
-    write_pose_file(out, files[:len(poses)], poses, inl, ses.focal0 / fscale)
+    write_pose_file(out, [files[i] for i in ses.registered_ids], poses, inl, ses.focal0 / fscale)
     _logger.info(f"Registered {len(poses)} images -> {out}")
     return 0
 
@@ -524,9 +579,9 @@ def load_frames(rgb_glob, image_resolution=480, files=None, return_rgb=False):
             except RuntimeError as e:
                 raise SystemExit(str(e))
         elif g.shape != size:
-            raise SystemExit(f"{f}: resized frame is {g.shape}, the first one {size}: the in-process session batches frames of ONE size "
-                             "(the reference's batch-size-1 loaders accept mixed sizes); crop or pad the images to a common aspect ratio, "
-                             "or run the differently sized images as separate scenes")
+            raise SystemExit(f"{f}: resized frame is {g.shape}, the first one {size}: the in-process mapping session batches frames of ONE "
+                             "size (register_mapping.py handles folders of mixed sizes, one context per size class; the reference's "
+                             "batch-size-1 loaders accept them everywhere): crop or pad the images to a common aspect ratio for mapping")
         frames.append((g - 0.4) / 0.25)
         factor = sc
     if return_rgb:

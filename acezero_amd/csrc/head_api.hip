@@ -94,6 +94,7 @@ struct acez_trainer {
   // 16-bit operand format of the GEMM chains (acez_train_config.compute_dtype): bf16, or fp16 with the gradient chain scaled by
   // grad_scale (fp16's smallest normal is 6e-5; the reference uses a GradScaler for the same reason, ace_schedule.py:70,107-113)
   bool f16 = false;
+  int loss_rows = 4;   // rows per wavefront of loss_kernel (4 waves per workgroup): 4 = 16-row workgroups; 8 with the chain kernel / ACEZ_LOSS_ROWS=8
   int last_nblk = 0;   // loss workgroups of the last backward (the schedule wave scans their |ds| maxima in fp16 mode)
   int n_cus = 0;
   uint32_t* seq_flags = nullptr;  // [64 row tiles][32] hand-off counters, monotonically increasing
@@ -240,6 +241,8 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   if (tr->fused_fwd) tr->chain = false;
   tr->f16 = cfg->compute_dtype == ACEZ_DTYPE_FP16;
   if (tr->f16) { tr->fused_fwd = false; tr->chain = false; }   // the opt-in row-persistent kernels exist in bf16 only
+  if (const char* e = getenv("ACEZ_LOSS_ROWS")) tr->loss_rows = (atoi(e) == 8) ? 8 : 4;
+  if (tr->chain) tr->loss_rows = 8;   // the chain kernel's loss phase owns 32-row tiles; partial counts follow it
   if (const char* e = getenv("ACEZ_POSE_FUSED")) tr->pose_fused = atoi(e) != 0;
   if (const char* e = getenv("ACEZ_POSE_TILE")) { const int v = atoi(e); tr->pose_tile = tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
   if (const char* e = getenv("ACEZ_POSE_TILE_FWD")) { const int v = atoi(e); tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
@@ -286,10 +289,11 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->dR[0], act_bytes);
   A((void**)&tr->dR[1], act_bytes);
   A((void**)&tr->slabs, (size_t)tr->nslabs * tr->n_wide * sizeof(float));
-  const int max_blocks = (tr->max_batch + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS);
-  A((void**)&tr->fc3_partials, (size_t)max_blocks * tr->fc3_stride * sizeof(float));
-  A((void**)&tr->stat_partials, (size_t)max_blocks * 4 * sizeof(float));
-  tr->bias_layer_stride = (int64_t)max_blocks * 512;
+  const int max_blocks = (tr->max_batch + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS);   // 32-row tiles of the chain kernel
+  const int max_loss_blocks = (tr->max_batch + 4 * tr->loss_rows - 1) / (4 * tr->loss_rows);
+  A((void**)&tr->fc3_partials, (size_t)max_loss_blocks * tr->fc3_stride * sizeof(float));
+  A((void**)&tr->stat_partials, (size_t)max_loss_blocks * 4 * sizeof(float));
+  tr->bias_layer_stride = (int64_t)max_loss_blocks * 512;
   A((void**)&tr->bias_partials, (size_t)tr->L * tr->bias_layer_stride * sizeof(float));
   A((void**)&tr->xyz, (size_t)tr->max_batch * 3 * sizeof(float));
   A((void**)&tr->maskbits, (size_t)tr->L * max_blocks * 512 * sizeof(uint32_t));
@@ -506,6 +510,16 @@ static void fill_loss_head(acez_trainer* tr, LossArgs& a) {
 }
 
 
+static void launch_loss(acez_trainer* tr, int nblk, hipStream_t s, const LossArgs& a) {
+  if (tr->loss_rows == 4) {
+    if (tr->f16) hipLaunchKernelGGL((loss_kernel<EltF16, 4>), dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((loss_kernel<EltBf16, 4>), dim3(nblk), dim3(256), 0, s, a);
+  } else {
+    if (tr->f16) hipLaunchKernelGGL((loss_kernel<EltF16, 8>), dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((loss_kernel<EltBf16, 8>), dim3(nblk), dim3(256), 0, s, a);
+  }
+}
+
 // training-mode arguments of the loss phases (loss_kernel / the chain kernel's loss phase)
 static void fill_loss_train(acez_trainer* tr, LossArgs& a, const uint16_t* act, const int64_t* d_indices, int n, bool pose_tables) {
   const int f2 = 3 * (tr->nb + 1) + 1;
@@ -678,7 +692,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   // mlp refinement folded into the step's own launches (pose_fused.hip): forward beside the gather, backward beside / behind the optimiser
   const bool pf = tr->pose_fused && !tr->chain && !tr->fused_fwd;
   const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
-  const int nblk = (n + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS);
+  const int nblk = (n + 4 * tr->loss_rows - 1) / (4 * tr->loss_rows);
   auto pose_fwd_launches = [&](hipStream_t q) {
     if (tr->cfg.pose_refinement == 2) pose_forward(tr, &tr->st->active, q);
     if (pose_naive)   // refine_poses.py:224-234: the poses themselves are the parameters; P = 0 + 1 * params, then Gram-Schmidt
@@ -770,8 +784,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     fill_loss_train(tr, a, act, d_indices, n, pose_mlp);
     tr->last_nblk = nblk;   // (after this step's step_begin, whose schedule wave closed the step BEFORE with that step's count)
     ProfScope ps(tr, s, KC_LOSS);
-    if (tr->f16) hipLaunchKernelGGL(loss_kernel<EltF16>, dim3(nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(loss_kernel<EltBf16>, dim3(nblk), dim3(256), 0, s, a);
+    launch_loss(tr, nblk, s, a);
   }
 
   if (ps != s) {   // the pose gradients start from the per-row pose gradients the loss kernel has just written
@@ -1061,8 +1074,7 @@ static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, fl
     a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr;
     if (planar_hw > 0) { a.out_xyz = d_out; a.planar_hw = planar_hw; a.row_offset = done; }
     else a.out_xyz = d_out + (size_t)done * 3;
-    if (tr->f16) hipLaunchKernelGGL(loss_kernel<EltF16>, dim3((cnt + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(loss_kernel<EltBf16>, dim3((cnt + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS)), dim3(256), 0, s, a);
+    launch_loss(tr, (cnt + 4 * tr->loss_rows - 1) / (4 * tr->loss_rows), s, a);
   }
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;

@@ -970,9 +970,9 @@ struct LossPre {
   int view, img;
   float tu, tv;
 };
-__device__ __forceinline__ LossPre loss_prefetch(const LossArgs& a, int m0, int t) {
+__device__ __forceinline__ LossPre loss_prefetch(const LossArgs& a, int m0, int t, int rows = LOSS_ROWS) {
   LossPre q{0, 0, 0, 0.f, 0.f};
-  if (a.idx && t < LOSS_ROWS && m0 + t < a.n) {
+  if (a.idx && t < rows && m0 + t < a.n) {
     q.p = a.idx[m0 + t];
     q.view = a.view_idx[q.p];
     q.img = a.view_image[q.view];
@@ -991,9 +991,13 @@ constexpr int LOSS_SCRATCH_FLOATS = 3 * 4 * LOSS_ROWS * 4;
 // meet once, through `sync` (loss_kernel: __syncthreads; the chain kernel: its flag barrier).
 // PRE_INSIDE (loss_kernel): the per-row index chain of phase B (idx -> view -> image) is started here, BEHIND the loads of phase A:
 // vmcnt completes in order, so a dependent chain issued first holds every later load behind its three round trips.
-template <bool LDSACT, bool PRE_INSIDE, class E = EltBf16, class Sync>
+// LR rows per wavefront (4 LR per workgroup). The chain kernel's tile is 32 rows (LR = 8); loss_kernel runs LR = 4 by default: 320
+// workgroups for a 5120-row batch instead of 160 on 256 CUs, half the serial row loop per wave (the summation order of the
+// fc3 / bias partials follows the workgroup size, so the two sizes agree to rounding, not bitwise).
+template <bool LDSACT, bool PRE_INSIDE, class E = EltBf16, int LR = 8, class Sync>
 __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, const int wv, const int t, uint16_t* Xt, float* scratch,
                                           LossPre pre, Sync sync) {
+  constexpr int LOSS_ROWS = LR;
   float (*s_s)[4] = reinterpret_cast<float (*)[4]>(scratch + wv * LOSS_ROWS * 4);
   float (*s_ds)[4] = reinterpret_cast<float (*)[4]>(scratch + (4 + wv) * LOSS_ROWS * 4);
   float (*s_red)[4] = reinterpret_cast<float (*)[4]>(scratch + (8 + wv) * LOSS_ROWS * 4);
@@ -1012,7 +1016,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
 #pragma unroll
     for (int rr = 0; rr < LOSS_ROWS; ++rr) xraw[LDSACT ? 0 : rr] = *reinterpret_cast<const uint4*>(a.act + (size_t)min(m0 + rr, n - 1) * 512 + l * 8);
   }
-  if (PRE_INSIDE) pre = loss_prefetch(a, m0, t);
+  if (PRE_INSIDE) pre = loss_prefetch(a, m0, t, LOSS_ROWS);
   const int64_t pre_p = pre.p;
   const int pre_view = pre.view, pre_img = pre.img;
   const float pre_tu = pre.tu, pre_tv = pre.tv;
@@ -1344,12 +1348,12 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
   }
 }
 
-template <class E = EltBf16>
+template <class E = EltBf16, int LR = 8>
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   if (a.st && !a.st->active) return;
   __shared__ float scratch[LOSS_SCRATCH_FLOATS];
   const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
-  loss_body<false, true, E>(a, blockIdx.x, wv, t, nullptr, scratch, LossPre{0, 0, 0, 0.f, 0.f}, [] { __syncthreads(); });
+  loss_body<false, true, E, LR>(a, blockIdx.x, wv, t, nullptr, scratch, LossPre{0, 0, 0, 0.f, 0.f}, [] { __syncthreads(); });
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1376,8 +1380,21 @@ __device__ __forceinline__ float tail_output(const GradReduceArgs& a, int64_t k,
     dst = a.n_wide + kk;
   } else {
     const int64_t kk = k - n_bias - n_fc3;
-    if (kk < 3)
-      for (int b = lane; b < a.n_loss_blocks; b += 64) acc += a.stat_partials[(size_t)b * 4 + kk];
+    if (kk < 3) {
+      // every wave of the fused optimiser sums the loss for itself (NaN check) before it may store: the first 320 partial rows in ONE
+      // memory round trip (a loop of dependent load -> add rounds cost the optimiser 1 us per 64 rows); same additions, same order
+      float v[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int b = lane + 64 * u;
+        const float x = a.stat_partials[(size_t)min(b, max(a.n_loss_blocks - 1, 0)) * 4 + kk];
+        v[u] = b < a.n_loss_blocks ? x : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 5; ++u)
+        if (lane + 64 * u < a.n_loss_blocks) acc += v[u];
+      for (int b = lane + 320; b < a.n_loss_blocks; b += 64) acc += a.stat_partials[(size_t)b * 4 + kk];
+    }
     // slot 3: this rank's rowseq fault word. It rides in the all-reduced bucket, so that a fault on ONE rank makes EVERY rank skip
     // the optimiser step (adamw_kernel) and the replicas stay identical
     else if (lane == 0 && a.fault) acc = (*a.fault ? 1.f : 0.f) + (a.st->dz_absmax_bits >= 0x7f800000u ? 1024.f : 0.f);   // (+ fp16 overflow)
@@ -1395,7 +1412,8 @@ __device__ __forceinline__ void tail_output8(const GradReduceArgs& a, int64_t k0
   const int64_t n_bias = (int64_t)a.n_layers * 512;
   const int64_t n_fc3 = a.n_params - a.n_wide;
   const int64_t n_out = n_bias + n_fc3 + 4;
-  float v[8][3];   // up to 192 partial rows per output (rowseq: 64 row tiles, loss: 160 workgroups at batch 5120); more are looped below
+  constexpr int TD = 5;   // up to 320 partial rows per output in one round trip (rowseq: 64 row tiles, loss: 320 workgroups at batch 5120); more are looped below
+  float v[8][TD];
   const float* base[8];
   int cnt[8];
   int64_t stride[8];
@@ -1419,7 +1437,7 @@ __device__ __forceinline__ void tail_output8(const GradReduceArgs& a, int64_t k0
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < TD; ++u) {
       const int b = lane + 64 * u;
       const float x = base[j][(size_t)min(b, max(cnt[j] - 1, 0)) * stride[j]];   // unconditional load, masked afterwards
       v[j][u] = b < cnt[j] ? x : 0.f;
@@ -1428,9 +1446,9 @@ __device__ __forceinline__ void tail_output8(const GradReduceArgs& a, int64_t k0
   for (int j = 0; j < 8; ++j) {
     float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < TD; ++u)
       if (lane + 64 * u < cnt[j]) s += v[j][u];          // the additions tail_output performs, in its order (b = lane, lane + 64, ...)
-    for (int b = lane + 192; b < cnt[j]; b += 64) s += base[j][(size_t)b * stride[j]];
+    for (int b = lane + 64 * TD; b < cnt[j]; b += 64) s += base[j][(size_t)b * stride[j]];
     const int64_t k = k0 + j;
     if (k == n_out - 1 && lane == 0 && a.fault)   // statistics slot 3: the fault word + the fp16 overflow flag (see tail_output)
       s = (*a.fault ? 1.f : 0.f) + (a.st->dz_absmax_bits >= 0x7f800000u ? 1024.f : 0.f);

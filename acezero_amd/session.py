@@ -464,26 +464,31 @@ class ReconstructionSession:
         head.close()
         return out
 
-    def register(self, head_sd, focal, max_estimates=-1, tag="register", max_tries=16):
-        """register_mapping.py:201-276: (poses cam->world [k,4,4] float32, inlier counts [k] int32, frame ids [k]).
+    def register(self, head_sd, focal, max_estimates=-1, tag="register", max_tries=16, rng_ids=None):
+        """register_mapping.py:201-276: (poses cam->world [k,4,4] float32, inlier counts [k] int32); the k frame ids they belong to
+        are left in self.registered_ids (all frames in order unless max_estimates draws a subset).
 
         max_estimates > 0 scores a random subset like the reference does: register_mapping.py iterates a DataLoader(shuffle=True)
         under torch.manual_seed(base_seed) and stops after max_estimates frames (:122-147,256) -- a seeded permutation of the frame
         ids here (a different stream, the same law), NOT the first k frames of the sequence. Frames are sharded over the ranks
         (frame i -> rank i % world); the random stream of a frame is keyed by its id, so the result does not depend on the
-        partition, and one gather returns every frame's result to every rank."""
+        partition, and one gather returns every frame's result to every rank. rng_ids: the ids that key the random streams, if
+        they are not the positions in this session (register_mapping.py on a folder of mixed frame sizes: one session per size
+        class, streams keyed by the position in the whole file list)."""
         o = self.opt
         if max_estimates <= 0 or max_estimates >= self.n:
             ids = np.arange(self.n)
         else:
             g = torch.Generator().manual_seed(int(o.register_seed))
             ids = np.sort(torch.randperm(self.n, generator=g)[:max_estimates].numpy())
+        self.registered_ids = ids
         t0 = time.time()
         mine = ids[ids % self.world == self.rank]
         sc = self.scene_coordinates(head_sd, mine)
         prm = dict(hyps=o.ransac_iterations, thr=o.ransac_threshold, alpha=float(o.inlieralpha), max_reproj=float(o.maxpixelerror), sub=8, max_tries=max_tries)
         if len(mine):
-            poses, inl, _ = dsacstar.register_batch(sc, [(focal, self.ppx, self.ppy)] * len(mine), prm, o.register_seed, [int(i) for i in mine], want_masks=False)
+            keys = [int(i) for i in mine] if rng_ids is None else [int(rng_ids[i]) for i in mine]
+            poses, inl, _ = dsacstar.register_batch(sc, [(focal, self.ppx, self.ppy)] * len(mine), prm, o.register_seed, keys, want_masks=False)
             poses, inl = poses.cpu(), inl.cpu().to(torch.int32)
         else:
             poses, inl = torch.zeros(0, 4, 4), torch.zeros(0, dtype=torch.int32)

@@ -16,6 +16,13 @@ from tests.test_head_gpu import _trainer
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _loss_tiles_of_32_rows(monkeypatch):
+    """The chain kernel's loss phase sums its fc3 / bias partials over 32-row tiles; the per-layer side of these bitwise comparisons runs
+    loss_kernel with the same tile (its default is 16 rows per workgroup: same values to rounding, another summation order)."""
+    monkeypatch.setenv("ACEZ_LOSS_ROWS", "8")
+
+
 def _pair(prob, flat0, cfg, max_batch, num_head_blocks=1):
     out = []
     for chain in ("0", "1"):

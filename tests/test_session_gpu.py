@@ -181,6 +181,42 @@ def test_train_ace_and_register_mapping_scripts_on_image_files(tmp_path):
     idx = [files.index(f) for f in fl]
     dt, ang = _pose_err(poses, gt[idx])
     assert np.median(dt) < 0.01 and np.median(ang) < 0.5
+    # a folder of two frame sizes (dataset.py:278-417 loads any mix): every odd frame centre-cropped to 576 columns. One context per
+    # size class, random streams keyed by the position in the whole list: the uncropped frames come out exactly as above.
+    mixed = tmp_path / "mixed"
+    mixed.mkdir()
+    w = img.shape[2]
+    for i in range(len(img)):
+        g = img[i] if i % 2 == 0 else img[i][:, (w - 576) // 2:(w - 576) // 2 + 576]
+        Image.fromarray(np.stack([g] * 3, -1)).save(str(mixed / f"rgb_{i:04d}.png"))
+    rc = cli.register_main([str(mixed / "rgb_*.png"), str(out), "--encoder_path", str(tmp_path / "encoder.pt"), "--session", "mixed",
+                            "--use_external_focal_length", str(seq["focal"]), "--hypotheses", "32", "--hypotheses_max_tries", "16"])
+    assert rc == 0
+    rows = [l.split() for l in open(tmp_path / "map" / "poses_mixed.txt").read().splitlines()]
+    ref_rows = {os.path.basename(l.split()[0]): l.split()[1:] for l in open(tmp_path / "map" / "poses_query.txt").read().splitlines()}
+    assert [os.path.basename(r[0]) for r in rows] == [f"rgb_{i:04d}.png" for i in range(len(img))]
+    same = 0
+    for i, r in enumerate(rows):                       # (the encoder picks its tiling by chunk size: the last, shorter chunk may round differently)
+        if i % 2 == 0:
+            want = ref_rows[os.path.basename(r[0])]
+            same += r[1:] == want
+            assert np.allclose([float(x) for x in r[1:8]], [float(x) for x in want[:7]], atol=2e-3), i
+    assert same >= 16
+    fl, poses, _ = cli.read_ace_pose_file(tmp_path / "map" / "poses_mixed.txt", 500)
+    idx = [int(os.path.basename(f)[4:8]) for f in fl]
+    assert sum(1 for i in idx if i % 2) >= 17
+    dt, ang = _pose_err(poses, gt[idx])
+    assert np.median(dt) < 0.015 and np.median(ang) < 0.6
+    # --max_estimates: the seeded subset is drawn over the whole list and written under the right names
+    rc = cli.register_main([str(mixed / "rgb_*.png"), str(out), "--encoder_path", str(tmp_path / "encoder.pt"), "--session", "few",
+                            "--use_external_focal_length", str(seq["focal"]), "--hypotheses", "32", "--hypotheses_max_tries", "16",
+                            "--max_estimates", "10"])
+    few = [l.split() for l in open(tmp_path / "map" / "poses_few.txt").read().splitlines()]
+    want = np.sort(torch.randperm(len(img), generator=torch.Generator().manual_seed(1305))[:10].numpy())
+    assert [os.path.basename(r[0]) for r in few] == [f"rgb_{i:04d}.png" for i in want]
+    fl, poses, _ = cli.read_ace_pose_file(tmp_path / "map" / "poses_few.txt", 500)
+    dt, ang = _pose_err(poses, gt[[int(os.path.basename(f)[4:8]) for f in fl]])
+    assert len(fl) >= 9 and np.median(dt) < 0.015 and np.median(ang) < 0.6
 
 
 def test_seed_without_usable_depth_raises_instead_of_hanging():

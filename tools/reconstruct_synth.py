@@ -1,5 +1,10 @@
 """Scale check of the in-process ACE0 loop: N synthetic frames, the reference's default iteration budgets (ace_zero.py:41-177),
-mild augmentation (the stand-in encoder has no learned invariances).  python tools/reconstruct_synth.py [frames] [arc_deg]"""
+mild augmentation (the stand-in encoder has no learned invariances).  python tools/reconstruct_synth.py [frames] [arc_deg]
+
+Focal study: every round is printed with its focal NEXT TO the pose error after a similarity alignment of the
+camera centres to the generator's poses (scale, median centre error relative to the trajectory extent, median rotation error), so
+that a drifting focal can be read against what it does to the geometry. ACEZ_STUDY_FIXED_FOCAL=1 repeats the run with
+refine_calibration off (focal pinned at the generator's) for the comparison."""
 import json
 import logging
 import sys
@@ -13,6 +18,11 @@ from acezero_amd import synth
 from acezero_amd.session import ReconstructionSession, default_options
 
 logging.basicConfig(level=logging.INFO)
+
+
+from tools.pose_geometry import geometry
+
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 arc = float(sys.argv[2]) if len(sys.argv) > 2 else 0.36 * n
 t0 = time.time()
@@ -20,7 +30,9 @@ seq = synth.render_room_sequence(seed=2089, n_frames=n, arc_deg=arc, device="cud
 torch.cuda.synchronize()
 t_render = time.time() - t0
 esd = {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights_bandpass(seed=4099).items()}
-opt = default_options(use_external_focal_length=seq["focal"], aug_rotation=2, aug_scale=1.06, aug_black_white=0.02)
+import os
+fixed = os.environ.get("ACEZ_STUDY_FIXED_FOCAL", "0") == "1"
+opt = default_options(use_external_focal_length=seq["focal"], aug_rotation=2, aug_scale=1.06, aug_black_white=0.02, refine_calibration=not fixed)
 t0 = time.time()
 ses = ReconstructionSession(esd, seq["images"], opt=opt, depth=seq["depth"])
 res = ses.reconstruct()
@@ -28,8 +40,17 @@ torch.cuda.synchronize()
 dt = time.time() - t0
 gt = seq["poses"].cpu().numpy().astype(np.float64)
 ok = res["confidence"] > opt.registration_confidence
+rounds = []
+for h in res["history"]:
+    r = {k: v for k, v in h.items() if k in ("id", "registration_rate", "focal", "mapped_images", "iterations", "map_seconds", "refit", "seed_rates")}
+    okh = h["confidence"] > opt.registration_confidence
+    a = r["aligned"] = geometry(h["poses"][okh], gt[okh]) if okh.sum() >= 3 else None
+    rounds.append(r)
+    if a:
+        print(f"# {r['id']:>18}: focal {r['focal']:7.1f} ({r['focal'] / seq['focal']:.3f} x generator), registered {r['registration_rate'] * 100:5.1f}%, "
+              f"alignment scale {a['scale']:.3f}, centre error {a['centre_rel_median'] * 100:.2f}% of the extent (p90 {a['centre_rel_p90'] * 100:.2f}%), "
+              f"rotation {a['rot_abs_deg_median']:.2f} deg (rotation-only alignment), consecutive frames {a['rot_rel_deg_median']:.3f} deg")
 out = {"frames": n, "arc_deg": arc, "render_s": t_render, "reconstruction_s": dt, "registered": float(ok.mean()), "focal": res["focal"],
-       "rounds": [{k: v for k, v in h.items() if k in ("id", "registration_rate", "focal", "mapped_images", "iterations", "map_seconds", "refit", "seed_rates")}
-                  for h in res["history"]],
+       "refine_calibration": not fixed, "rounds": rounds,
        "gpu_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}
 print(json.dumps(out))
