@@ -239,10 +239,14 @@ def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     only = sys.argv[1:]   # optional: names of the configurations to (re)generate
     from tests import helpers   # the "trained regime" configurations and their problem live next to the tests that consume them
-    for name, c in list(CONFIGS.items()) + list(helpers.TRAINED_CONFIGS.items()) + [("head_focal_drift", helpers.FOCAL_DRIFT)]:
+    global B
+    for name, c in list(CONFIGS.items()) + list(helpers.TRAINED_CONFIGS.items()) + [("head_focal_drift", helpers.FOCAL_DRIFT)] + list(helpers.BIG_CONFIGS.items()):
         if only and name not in only:
             continue
-        if name in helpers.TRAINED_CONFIGS or name == "head_focal_drift":
+        B = helpers.BIG_B if name in helpers.BIG_CONFIGS else 512
+        if name in helpers.BIG_CONFIGS:
+            prob, flat0, cfg = helpers.problem_for(name)
+        elif name in helpers.TRAINED_CONFIGS or name == "head_focal_drift":
             prob, flat0, cfg = helpers.problem_for(name)
         else:
             cfg = full_cfg(c)
@@ -252,7 +256,7 @@ def main():
             flat0 = head_oracle.init_params(SEED + 1)
         rng = np.random.default_rng(SEED + 2)
         n = prob["features"].shape[0]
-        batches = [rng.permutation(n)[:B] for _ in range(cfg["steps"])]
+        batches = helpers.big_batches(prob, cfg["steps"]) if name in helpers.BIG_CONFIGS else [rng.permutation(n)[:B] for _ in range(cfg["steps"])]
         rec, snaps, coords0 = run_reference(cfg, prob, flat0, batches)
         first = snaps[0]
         last_it = max(snaps)

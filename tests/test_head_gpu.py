@@ -342,3 +342,35 @@ def test_step_with_the_next_batch_announced_equals_plain_steps_bitwise(dtype):
     assert sp == sq and sp["iteration"] == sp["max_iterations"] < 60      # the cool-down ended the schedule early, on both
     lp, lq = plain.log(0, sp["iteration"]), piped.log(0, sp["iteration"])
     assert np.array_equal(lp[0], lq[0]) and np.array_equal(lp[1], lq[1])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", list(helpers.BIG_CONFIGS))
+def test_baseline_batch_against_the_reference_golden(name, dtype):
+    """BASELINE's batch (5120 rows) against three steps of the REFERENCE's fp32 training_step (tests/golden/head_b5120_*.npz), in both
+    operand types: scene coordinates, the first loss (same weights), then the free-running losses, inlier fractions and focal."""
+    prob, flat0, cfg = helpers.problem_for(name)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    tr = _trainer(prob, flat0, cfg, max_batch=helpers.BIG_B, dtype=dtype)
+    trained = bool(helpers.BIG_CONFIGS[name].get("trained"))
+    batches = helpers.big_batches(prob, cfg["steps"])
+    di = [torch.from_numpy(b.astype(np.int64)).cuda() for b in batches]
+    tr.backward(di[0])
+    torch.cuda.synchronize()
+    X = tr.last_scene_coords(helpers.BIG_B)[:64]
+    rel = _rel(X - prob["mean"], g["coords0"] - prob["mean"])
+    assert rel < (2e-3 if dtype == "fp16" else 3e-2), rel
+    loss0 = float(tr.grad[tr.n_params]) / helpers.BIG_B
+    tol0 = {("fp16", False): 1e-3, ("fp16", True): 1.5e-2, ("bf16", False): 3e-2, ("bf16", True): 0.12}[(dtype, trained)]
+    assert abs(loss0 - g["loss"][0]) < tol0 * abs(g["loss"][0]), (loss0, g["loss"][0])
+    assert abs(float(tr.grad[tr.n_params + 1]) / helpers.BIG_B - g["inliers"][0]) < (0.03 if trained else 2.0 / helpers.BIG_B)
+    tr.update()
+    for d in di[1:]:
+        tr.step(d)
+    st = tr.state()
+    assert not st["nan"] and st["iteration"] == cfg["steps"]
+    loss, inl = tr.log(0, cfg["steps"])
+    np.testing.assert_allclose(loss, g["loss"], rtol=0.12 if trained else (5e-3 if dtype == "fp16" else 3e-2))
+    np.testing.assert_allclose(inl, g["inliers"], atol=0.03 if trained else 2.0 / helpers.BIG_B)
+    if cfg["refine_calibration"]:
+        assert abs(st["focal_scale"] - float(g["focal_scale"][-1])) < 2e-3

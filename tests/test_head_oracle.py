@@ -73,3 +73,26 @@ def test_bf16_mode_close_to_fp32():
     X32, X16 = h32.scene_coordinates(b["features"]), h16.scene_coordinates(b["features"])
     rel = (X32 - X16).norm() / (X32 - torch.from_numpy(prob["mean"])).norm()
     assert rel < 0.05
+
+
+@pytest.mark.parametrize("name", list(helpers.BIG_CONFIGS))
+def test_oracle_fp32_matches_reference_golden_at_the_baseline_batch(name, golden_dir):
+    """BASELINE's batch of 5120 rows: three steps of the reference's own training_step (tests/golden/make_head_golden.py)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    prob, flat0, cfg = helpers.problem_for(name)
+    tr = head_oracle.TrainerOracle(flat0.clone(), prob["mean"], cfg, mode="fp32", image_pose_inv=prob["image_pose_inv"])
+    losses, inl, lrs, focal = [], [], [], []
+    for it, idx in enumerate(helpers.big_batches(prob, cfg["steps"])):
+        assert len(idx) == helpers.BIG_B
+        b = helpers.torch_batch(prob, idx)
+        if it == 0:
+            np.testing.assert_allclose(tr.head.scene_coordinates(b["features"])[:64].numpy(), g["coords0"], rtol=1e-4, atol=1e-4)
+        rec = tr.step(b["features"], b)
+        losses.append(rec["loss"]); inl.append(rec["inliers"]); lrs.append(rec["lr"]); focal.append(1.0 + tr.sched.calib_g)
+        if it == 0:
+            np.testing.assert_allclose(tr.head.p.flat.numpy()[g["param_sel"]], g["params_after_first"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(lrs, g["lr"], rtol=1e-12)
+    np.testing.assert_allclose(inl, g["inliers"], atol=1.5 / helpers.BIG_B)
+    np.testing.assert_allclose(losses[:1], g["loss"][:1], rtol=2e-5)
+    np.testing.assert_allclose(losses, g["loss"], rtol=3e-4)
+    np.testing.assert_allclose(focal, g["focal_scale"], atol=2e-6)
