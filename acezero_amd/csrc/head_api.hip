@@ -454,7 +454,7 @@ static void launch_rowseq(acez_trainer* tr, const std::vector<SeqLayer>& layers,
     RowSeqArgs a{};
     const int cnt = (int)std::min<size_t>(SEQ_MAX_LAYERS, layers.size() - i0);
     for (int i = 0; i < cnt; ++i) a.layer[i] = layers[i0 + i];
-    a.n_layers = cnt; a.M = n; a.st = st ? st : tr->st_infer; a.flags = tr->seq_flags; a.xcc_dbg = tr->seq_xcc;
+    a.n_layers = cnt; a.M = n; a.st = st ? st : tr->st_infer; a.flags = tr->seq_flags; a.xcc_dbg = tr->seq_xcc; a.spin_limit = tr->seq_spin_limit;
     for (int mt = 0; mt < 64; ++mt) a.base[mt] = tr->seq_base[mt];
     // tests (ACEZ_SEQ_FAULT_AT): this launch is told that a million seams have completed before it -- every hand-off then waits
     // for a count that never comes, which is what a sibling on a foreign XCD looks like

@@ -269,8 +269,8 @@ struct SeqLink {
   bool signal;           // another layer follows: bump *flag after the stores
   const uint16_t* next_W;  // weights of the layer after (null: none): its first four W stages are requested before the epilogue
   uint32_t flag_index;   // flag = flags + flag_index; the trainer's sticky fault word is flags[64 * 32]: set when the bounded poll
-                         // below expires (the host then falls back to per-layer launches, head_api.hip seq_fault_check); the poll budget
-                         // (a number of polls) is flags[64 * 32 + 1]
+                         // below expires (the host then falls back to per-layer launches, head_api.hip seq_fault_check)
+  uint32_t limit;        // the poll budget (a number of polls), a kernel argument
 };
 constexpr int RG80_STAGE = (128 + 96) * 64;                        // elements per ring slot
 constexpr int RG80_SMEM = 4 * RG80_STAGE + 2 * 80 * 128;           // ring + two staging tiles
@@ -344,22 +344,37 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
           // stream. When the budget expires the wave raises the sticky fault word and goes on with whatever is in memory: the
           // results of this launch are garbage, the optimiser and schedule kernels of the step see the word and do nothing, and
           // the host switches the trainer to per-layer launches at its next state read (head_api.hip).
-          uint32_t seen, spins = 0;
-          for (;;) {   // sc1: past this CU's L1; the counter and the tiles live in the L2 all four workgroups share, no L2 invalidate
-            asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(q.flag) : "memory");
-            seen = __builtin_amdgcn_readfirstlane(seen);   // every lane loaded the same word: a scalar loop condition
-            if ((int32_t)(seen - q.target) >= 0) break;
-            __builtin_amdgcn_s_sleep(1);
-            // the budget is counted in polls (>= ~0.5 us each: an L2 round trip + the sleep) and looked up every 256th poll only --
-            // flags[64 * 32 + 1], next to the fault word flags[64 * 32] -- so that the hand-off carries no state but the counter
-            if ((++spins & 255u) == 0 && spins > __builtin_nontemporal_load(q.flag - q.flag_index + 64 * 32 + 1)) {
-              if (l == 0) {   // the fault word, and the step is switched off: every later kernel of this trainer starts with `if (!st->active) return`
-                __hip_atomic_store(q.flag - q.flag_index + 64 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a.st) __hip_atomic_store(const_cast<int*>(&a.st->active), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-              break;
-            }
+          // The whole poll is ONE asm statement: written as a C loop with a second exit, the compiler re-scheduled the K loops and
+          // epilogues of the input-gradient instantiation (+3 us per chain, same instruction mix; found by diffing the ISA of a
+          // build without the bound). sc1: past this CU's L1; the counter and the tiles live in the L2 all four workgroups share,
+          // no L2 invalidate. Every lane loads the same word: the loop condition is scalar. The budget is counted in polls
+          // (>= ~0.5 us each: an L2 round trip + the sleep).
+          uint32_t vseen, sseen, spins, timed;
+          asm volatile(
+              "s_mov_b32 %[spins], 0\n\t"
+              "s_mov_b32 %[timed], 0\n"
+              "1:\n\t"
+              "global_load_dword %[vseen], %[flag], off sc1\n\t"
+              "s_waitcnt vmcnt(0)\n\t"
+              "v_readfirstlane_b32 %[sseen], %[vseen]\n\t"
+              "s_sub_i32 %[sseen], %[sseen], %[target]\n\t"
+              "s_cmp_ge_i32 %[sseen], 0\n\t"
+              "s_cbranch_scc1 2f\n\t"
+              "s_sleep 1\n\t"
+              "s_add_u32 %[spins], %[spins], 1\n\t"
+              "s_cmp_lt_u32 %[spins], %[limit]\n\t"
+              "s_cbranch_scc1 1b\n\t"
+              "s_mov_b32 %[timed], 1\n"
+              "2:"
+              : [vseen] "=&v"(vseen), [sseen] "=&s"(sseen), [spins] "=&s"(spins), [timed] "=&s"(timed)
+              : [flag] "v"(q.flag), [target] "s"(q.target), [limit] "s"(q.limit)
+              : "memory", "scc");
+#ifndef ACEZ_SEQ_UNBOUNDED   // (timing experiments only, tools/lib_variant.sh: what the fault path costs)
+          if (timed && l == 0) {   // the fault word, and the step is switched off: every later kernel of this trainer starts with `if (!st->active) return`
+            __hip_atomic_store(q.flag - q.flag_index + 64 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.st) __hip_atomic_store(const_cast<int*>(&a.st->active), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+#endif
         }
         issueI(0); issueI(1); issueI(2); issueI(3);
       }
@@ -591,11 +606,12 @@ struct RowSeqArgs {
   const TrainState* st;
   uint32_t* flags;     // [64 row tiles][32] hand-off counters + [64 * 32] the fault word
   uint32_t base[64];   // per row tile: seams completed by earlier launches (a launch only touches the row tiles of ITS batch)
+  uint32_t spin_limit; // poll budget of a hand-off (polls of >= ~0.5 us); expired: fault word + st->active = 0
   uint32_t* xcc_dbg;   // null, or [8 + 256]: words 0..7 |= 1 << XCC_ID of the workgroups with blockIdx & 7 = word (sticky); word
                        // 8 + 4 mt + nt = XCC_ID of the workgroup that owned tile (mt, nt) in the last launch (tests: the four column
                        // tiles of a row tile must report the same XCD)
                        // flags[64 * 32] = the sticky fault word (non-zero: a poll of this trainer has expired, every launch returns at
-                       // once), flags[64 * 32 + 1] = the poll budget
+                       // once), flags[64 * 32 + 1] = a copy of the poll budget (diagnostics)
 };
 
 template <bool BWD, class E = EltBf16>
@@ -630,7 +646,7 @@ __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
     q.flag = a.flags + mt * 32; q.target = (a.base[mt] + (uint32_t)layer) * 32u;   // 4 workgroups x 8 waves per seam
     q.first = layer == 0; q.wait = layer > 0; q.signal = layer + 1 < a.n_layers;
     q.next_W = q.signal ? a.layer[layer + 1].W : nullptr;
-    q.flag_index = (uint32_t)(mt * 32);
+    q.flag_index = (uint32_t)(mt * 32); q.limit = a.spin_limit;
     if (!BWD) {
       if (y.aux_mode == AUX_RESIDUAL) rowgemm80_body<true, false, false, AUX_RESIDUAL, true, E>(g, smem, 1, mt, n0, q);
       else rowgemm80_body<true, false, false, AUX_NONE, true, E>(g, smem, 1, mt, n0, q);
