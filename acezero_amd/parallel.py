@@ -63,7 +63,7 @@ def rank_world(group=None):
 class DataParallelTrainer:
     """Wraps a trainer exposing backward(indices), grad (flat tensor incl. statistics) and update()."""
 
-    def __init__(self, trainer, group=None):
+    def __init__(self, trainer, group=None, one_shot=None):
         self.trainer = trainer
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -101,7 +101,7 @@ class ShardedDataParallel:
     ranks -- one reduce / broadcast per owner. The trainer object needs: L, LAYER_STRIDE, grad, backward(rows), update_layers(lo, hi),
     new_weights16_buffer(), export_weights16 / import_weights16(lo, hi, tensor), master_tensors()."""
 
-    def __init__(self, trainer, group=None):
+    def __init__(self, trainer, group=None, one_shot=None):
         self.trainer = trainer
         self.group = group
         self.rank, self.world = rank_world(group)
@@ -109,7 +109,9 @@ class ShardedDataParallel:
         self.ranges = [shard_range(self.L, r, self.world) for r in range(self.world)]
         self.lo, self.hi = self.ranges[self.rank]
         backend = dist.get_backend(group) if self.world > 1 else ""
-        self.one_shot = backend == "nccl" and self.L % self.world == 0
+        # (one_shot=True under gloo: the CPU test of this branch, with reduce_scatter_tensor emulated -- gloo has none)
+        self.one_shot = (backend == "nccl" and self.L % self.world == 0) if one_shot is None else bool(one_shot)
+        assert not self.one_shot or self.L % self.world == 0
         self.wbuf = trainer.new_weights16_buffer() if self.world > 1 else None
         # separate send / receive staging for the one-shot collectives (1 MB + 0.5 MB per owned layer; no aliasing of a collective's
         # input and output)
@@ -178,7 +180,9 @@ def make_data_parallel(trainer, group=None, mode=None):
     """ACEZ_DP_MODE = "sharded" (default) | "allreduce" (round 2's single all-reduce + replicated update)."""
     import os
     mode = (mode or os.environ.get("ACEZ_DP_MODE", "sharded")).lower()
-    return DataParallelTrainer(trainer, group) if mode == "allreduce" else ShardedDataParallel(trainer, group)
+    if mode == "allreduce":
+        return DataParallelTrainer(trainer, group)
+    return ShardedDataParallel(trainer, group, one_shot=True if mode == "sharded_oneshot" else None)
 
 
 def gather_registrations(local_frame_ids, local_poses, local_inliers, n_frames, group=None, expect=None):

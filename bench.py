@@ -505,10 +505,10 @@ def main():
             "config": {"workload": "7-Scenes-chess-like ace_zero mapping step: 8M-patch bf16 feature buffer in HBM, batch 5120 per GPU, "
                                    "default head (1 block, 2 103 300 params), tanh loss, 1cyclepoly AdamW, pose_refinement " + args.pose_refinement,
                        "buffer_patches": args.buffer_patches, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}" + ("" if world == 1 else " (" + ("one all-reduce of the gradient bucket, replicated AdamW" if os.environ.get("ACEZ_DP_MODE", "sharded").lower() == "allreduce" else "reduce-scatter of the weight gradients by layer, AdamW on the owned layers, all-gather of the 16-bit weights") + ")")},
             "whole_step_flop_frac_of_mfma_peak": patches_per_s / world * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS * 1e12),
             "strong_scaling": None if dt_strong is None else {
-                "metric": "ACE patches/sec, the reference's step: global batch 5120 split over the ranks by buffer shard, one gradient all-reduce per step",
+                "metric": "ACE patches/sec, the reference's step: global batch 5120 split over the ranks by buffer shard, one gradient exchange per step (see `collective`)",
                 "value": BATCH * args.steps / dt_strong, "unit": "patches/s", "ms_per_step": dt_strong / args.steps * 1e3, "scaling": "strong",
                 "collective": os.environ.get("ACEZ_DP_MODE", "sharded"),
                 "global_batch": BATCH, "rows_per_gpu": BATCH / world},

@@ -178,7 +178,30 @@ def _sharded_worker(rank, world, port, q):
     perm = torch.randperm(n, generator=gen, device="cuda")
     local, offs = parallel.epoch_local_batches(perm, B, lo, hi)
     out = {}
-    for mode in ("allreduce", "sharded"):
+    # the RCCL branch of ShardedDataParallel (one reduce_scatter_tensor, one all_gather_into_tensor on staging buffers) under gloo:
+    # gloo has no reduce-scatter, so that one collective is emulated; the slicing, the staging and the kernels around it are real
+    def _rs(output, input, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        full = input.clone()
+        dist.all_reduce(full, op=op, group=group)
+        k = output.numel()
+        output.copy_(full[dist.get_rank(group) * k:(dist.get_rank(group) + 1) * k])
+
+        class _Done:
+            def wait(self):
+                return True
+        return _Done()
+    dist.reduce_scatter_tensor = _rs
+    try:
+        probe_out, probe_in = torch.zeros(2 * world, dtype=torch.int32, device="cuda"), torch.full((2,), rank, dtype=torch.int32, device="cuda")
+        dist.all_gather_into_tensor(probe_out, probe_in)
+        assert probe_out.cpu().tolist() == [r for r in range(world) for _ in range(2)]
+    except (RuntimeError, NotImplementedError):
+        def _ag(output, input, group=None, async_op=False):
+            parts = [torch.empty_like(input) for _ in range(dist.get_world_size(group))]
+            dist.all_gather(parts, input, group=group)
+            output.copy_(torch.cat(parts))
+        dist.all_gather_into_tensor = _ag
+    for mode in ("allreduce", "sharded", "sharded_oneshot"):
         tr = _make_trainer(prob, flat0, lo, hi)
         dp = parallel.make_data_parallel(tr, mode=mode)
         for b in range(4):
@@ -212,10 +235,10 @@ def test_sharded_update_equals_the_all_reduce_path_bitwise():
         assert p.exitcode == 0
     ref = res[0]["allreduce"]
     for r in (0, 1):
-        for mode in ("allreduce", "sharded"):
+        for mode in ("allreduce", "sharded", "sharded_oneshot"):
             got = res[r][mode]
             for k in range(3):
                 assert np.array_equal(got[k], ref[k]), (r, mode, k)
             assert got[3] == ref[3] and np.array_equal(got[4], ref[4]), (r, mode)
-        assert res[r]["sharded"][5] and not res[r]["allreduce"][5]      # masters of the other rank's layers were stale until gathered
+        assert res[r]["sharded"][5] and res[r]["sharded_oneshot"][5] and not res[r]["allreduce"][5]      # masters of the other rank's layers were stale until gathered
     assert ref[3]["iteration"] == 4

@@ -173,7 +173,22 @@ def _sharded_worker(rank, world, port, q):
     gen = torch.Generator().manual_seed(8191)
     perm = torch.randperm(n, generator=gen)
     out = {}
-    for mode in ("allreduce", "sharded"):
+    modes = ("allreduce", "sharded") + (("sharded_oneshot",) if 8 % world == 0 else ())
+    if "sharded_oneshot" in modes:
+        # the RCCL branch (ONE reduce_scatter_tensor + ONE all_gather_into_tensor on staging buffers) under gloo, which has no
+        # reduce-scatter: emulate that one collective, keep everything else of the branch (slicing, staging, the gather) real
+        def _rs(output, input, op=dist.ReduceOp.SUM, group=None, async_op=False):
+            full = input.clone()
+            dist.all_reduce(full, op=op, group=group)
+            k = output.numel()
+            output.copy_(full[dist.get_rank(group) * k:(dist.get_rank(group) + 1) * k])
+
+            class _Done:
+                def wait(self):
+                    return True
+            return _Done()
+        dist.reduce_scatter_tensor = _rs
+    for mode in modes:
         tr = OracleTrainer(prob, flat0, cfg, np.arange(lo, hi))
         dp = parallel.make_data_parallel(tr, mode=mode)
         for it in range(3):
@@ -182,7 +197,7 @@ def _sharded_worker(rank, world, port, q):
         before = tr.orc.sched.m.clone()
         dp.gather_masters()
         out[mode] = (tr.orc.head.p.flat.numpy().copy(), tr.orc.sched.m.numpy().copy(), tr.orc.sched.lr, tr.orc.iteration,
-                     bool((before != tr.orc.sched.m).any()), (dp.lo, dp.hi) if mode == "sharded" else None)
+                     bool((before != tr.orc.sched.m).any()), (dp.lo, dp.hi) if mode != "allreduce" else None)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -213,6 +228,10 @@ def test_sharded_update_world_gloo(world):
             assert res[0][mode][2] == res[r][mode][2] and res[r][mode][3] == 3
     assert all(res[r]["sharded"][4] for r in range(world))          # the masters of foreign layers were stale before the gather
     assert not any(res[r]["allreduce"][4] for r in range(world))
+    if 8 % world == 0:   # the one-shot branch gives what the per-owner branch gives
+        for r in range(world):
+            assert np.array_equal(res[r]["sharded_oneshot"][0], res[r]["sharded"][0]) and np.array_equal(res[r]["sharded_oneshot"][1], res[r]["sharded"][1])
+            assert res[r]["sharded_oneshot"][4] and res[r]["sharded_oneshot"][5] == res[r]["sharded"][5]
     a, b = res[0]["allreduce"][0], res[0]["sharded"][0]
     if world == 2:
         assert np.array_equal(a, b)
