@@ -536,7 +536,7 @@ static void fill_loss_train(acez_trainer* tr, LossArgs& a, const uint16_t* act, 
   a.st = tr->st; a.out_xyz = tr->xyz; a.dZ = tr->dZ[f2];
   a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
   a.bias_partials = tr->bias_partials + (size_t)f2 * tr->bias_layer_stride; a.dbg = 0;
-  a.absmax = tr->f16 ? &tr->st->dz_absmax_bits : nullptr;
+  a.absmax = tr->f16 ? tr->st->dz_absmax_slots : nullptr;
   if (const char* e = getenv("ACEZ_LOSS_DBG")) a.dbg = atoi(e);   // ablation: 1 = stop after phase A, 2 = after phase B (timing only)
 }
 
@@ -811,7 +811,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     g.In = tr->dZ[l]; g.W = tr->WbT + (size_t)l * 262144; g.bias = nullptr; g.add = add; g.mask = mask; g.res = nullptr;
     g.out_main = out_main; g.out_aux = out_aux; g.M = n; g.N = 512; g.K = 512; g.relu = 0;
     g.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE; g.st = st; g.dbg = 0;
-    g.absmax = tr->f16 ? &tr->st->dz_absmax_bits : nullptr;
+    g.absmax = tr->f16 ? tr->st->dz_absmax_slots : nullptr;
     launch_rowgemm(g, tr->gemm_tile, s, tr->f16);
     ++tr->prof_launches;
   };
@@ -1002,7 +1002,7 @@ extern "C" int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out,
   seq_fault_check(tr, (hipStream_t)stream);
   TrainState hs;
   int chain_err = 0;
-  ACEZ_HIP_CHECK(hipMemcpyAsync(&hs, tr->st, sizeof(TrainState), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  ACEZ_HIP_CHECK(hipMemcpyAsync(&hs, tr->st, offsetof(TrainState, dz_absmax_slots), hipMemcpyDeviceToHost, (hipStream_t)stream));
   ACEZ_HIP_CHECK(hipMemcpyAsync(&chain_err, tr->chain_err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   if (chain_err) {

@@ -42,7 +42,11 @@ struct TrainState {
   // wherever nothing under- or overflows) and un-scaled where it meets the fp32 optimiser. Chosen by the schedule wave from the largest
   // |d loss / d fc3 output| of the step before (what torch.cuda.amp.GradScaler does with inf checks, ace_schedule.py:70,107-113). bf16: 1.
   float grad_scale, inv_grad_scale;
-  uint32_t dz_absmax_bits;   // bit pattern of the largest propagated gradient magnitude of the running step, scaled units (absmax_publish)
+  // bit patterns of the largest propagated gradient magnitudes of the running step, scaled units (absmax_publish): 64 words on 64
+  // different 128-byte lines, workgroup b folds into word (b & 63) * 32. ONE word would serialise every wavefront's atomic of a launch
+  // on one L2 line (11-13 ns each: measured +51 us on the input-gradient chain, +13 us on the loss kernel); readers take the maximum of
+  // the 64 (absmax_all). Last member: the host's state read stops before it.
+  uint32_t dz_absmax_slots[64 * 32];
 };
 
 struct SchedConfig {
@@ -69,7 +73,7 @@ struct RowGemmArgs {
   int M, N, K, relu, aux_mode;
   const TrainState* st;
   int dbg;  // ablation switches for tools/ablate_rowgemm.hip (0 in production): 1 = no epilogue, 2 = no MFMA, 4 = no loads
-  uint32_t* absmax;  // fp16 gradient launches: &TrainState::dz_absmax_bits (else null)
+  uint32_t* absmax;  // fp16 gradient launches: TrainState::dz_absmax_slots (else null)
 };
 
 struct WgradArgs {
@@ -114,7 +118,7 @@ struct LossArgs {
   float* stat_partials;  // [blocks][4]
   float* bias_partials;  // [blocks][512] column sums of dZ
   int dbg;               // ablation (tools/ablate_rowgemm.hip): 1 = stop after phase A, 2 = stop after phase B
-  uint32_t* absmax;      // fp16 training: &TrainState::dz_absmax_bits (else null)
+  uint32_t* absmax;      // fp16 training: TrainState::dz_absmax_slots (else null)
 };
 
 struct GradReduceArgs {

@@ -252,12 +252,20 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
 // ---------------------------------------------------------------------------------------------------
 
 // fp16 gradient-scale control: every kernel that stores propagated gradients folds the largest magnitude it produced (before the
-// conversion, in scaled units) into ONE word per trainer -- a wavefront maximum, then an atomic max on the bit pattern (non-negative
-// floats order like unsigned integers; +inf = 0x7f800000 is the overflow signal). Read and reset by sched_post_wave.
-__device__ __forceinline__ void absmax_publish(uint32_t* word, float amax) {
+// conversion, in scaled units) into the trainer's 64 striped words (TrainState::dz_absmax_slots) -- a wavefront maximum, then an atomic
+// max on the bit pattern (non-negative floats order like unsigned integers; +inf = 0x7f800000 is the overflow signal) of the word of
+// this workgroup's stripe. Read (absmax_all) and reset by sched_post_wave.
+__device__ __forceinline__ void absmax_publish(uint32_t* slots, float amax) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-  if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(word, __float_as_uint(amax));
+  if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(slots + (blockIdx.x & 63) * 32, __float_as_uint(amax));
+}
+// the maximum over the 64 stripes; all 64 lanes of the wavefront must call it, every lane returns the result
+__device__ __forceinline__ uint32_t absmax_all(const TrainState* st, int lane) {
+  uint32_t m = __builtin_nontemporal_load(&st->dz_absmax_slots[lane * 32]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+  return m;
 }
 
 // One layer of one workgroup. SEQ = false: the whole of rowgemm80_kernel. SEQ = true: one link of rowseq_kernel (below), where
@@ -641,7 +649,7 @@ __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
     RowGemmArgs g;
     g.In = y.In; g.W = y.W; g.bias = y.bias; g.add = y.add; g.mask = y.mask; g.res = y.res; g.out_main = y.out_main; g.out_aux = y.out_aux;
     g.bias_partials = y.bias_partials; g.M = a.M; g.N = 512; g.K = 512; g.relu = BWD ? 0 : 1; g.aux_mode = y.aux_mode; g.st = a.st; g.dbg = 0;
-    g.absmax = (BWD && a.st) ? const_cast<uint32_t*>(&a.st->dz_absmax_bits) : nullptr;
+    g.absmax = (BWD && a.st) ? const_cast<uint32_t*>(a.st->dz_absmax_slots) : nullptr;
     SeqLink q;
     q.flag = a.flags + mt * 32; q.target = (a.base[mt] + (uint32_t)layer) * 32u;   // 4 workgroups x 8 waves per seam
     q.first = layer == 0; q.wait = layer > 0; q.signal = layer + 1 < a.n_layers;
@@ -1413,7 +1421,10 @@ __device__ __forceinline__ float tail_output(const GradReduceArgs& a, int64_t k,
     }
     // slot 3: this rank's rowseq fault word. It rides in the all-reduced bucket, so that a fault on ONE rank makes EVERY rank skip
     // the optimiser step (adamw_kernel) and the replicas stay identical
-    else if (lane == 0 && a.fault) acc = (*a.fault ? 1.f : 0.f) + (a.st->dz_absmax_bits >= 0x7f800000u ? 1024.f : 0.f);   // (+ fp16 overflow)
+    else if (a.fault) {
+      const uint32_t amax_bits = absmax_all(a.st, lane);
+      if (lane == 0) acc = (*a.fault ? 1.f : 0.f) + (amax_bits >= 0x7f800000u ? 1024.f : 0.f);   // (+ fp16 overflow)
+    }
     dst = a.n_params + kk;
   }
 #pragma unroll
@@ -1466,8 +1477,10 @@ __device__ __forceinline__ void tail_output8(const GradReduceArgs& a, int64_t k0
       if (lane + 64 * u < cnt[j]) s += v[j][u];          // the additions tail_output performs, in its order (b = lane, lane + 64, ...)
     for (int b = lane + 64 * TD; b < cnt[j]; b += 64) s += base[j][(size_t)b * stride[j]];
     const int64_t k = k0 + j;
-    if (k == n_out - 1 && lane == 0 && a.fault)   // statistics slot 3: the fault word + the fp16 overflow flag (see tail_output)
-      s = (*a.fault ? 1.f : 0.f) + (a.st->dz_absmax_bits >= 0x7f800000u ? 1024.f : 0.f);
+    if (k == n_out - 1 && a.fault) {   // statistics slot 3: the fault word + the fp16 overflow flag (see tail_output)
+      const uint32_t amax_bits = absmax_all(a.st, lane);
+      if (lane == 0) s = (*a.fault ? 1.f : 0.f) + (amax_bits >= 0x7f800000u ? 1024.f : 0.f);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     acc[j] = k < n_bias + n_fc3 ? s * a.st->inv_grad_scale : s;
@@ -1575,7 +1588,7 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
   if (lossv != lossv) return;  // NaN loss: the reference aborts before the optimiser step (ace_trainer.py:615-617)
   // fp16: an infinity was stored somewhere in the gradient chain of this step -> no update (GradScaler.step, ace_schedule.py:112); the
   // schedule wave lowers the scale. In the split flow the flag arrives all-reduced in statistics slot 3 (+1024 per overflowing rank).
-  if (a.f16 && (a.slabs ? st->dz_absmax_bits >= 0x7f800000u : a.grad[a.n_params + 3] >= 1024.f)) return;
+  if (a.f16 && (a.slabs ? absmax_all(st, threadIdx.x & 63) >= 0x7f800000u : a.grad[a.n_params + 3] >= 1024.f)) return;
   const AdamScalars s = st->adam;
   if (tile) {
     if (a.slabs) {   // same additions, in the same order, as grad_reduce_kernel's wide part
@@ -1874,7 +1887,7 @@ __global__ void sched_init_kernel(TrainState* st, SchedConfig c) {
   st->calib_g = 0.0; st->calib_m = 0.0; st->calib_v = 0.0; st->beta1_pow = 1.0; st->beta2_pow = 1.0;
   st->pose_enable = 0; st->pose_opt_steps = 0; st->pose_b1pow = 1.0; st->pose_b2pow = 1.0;
   st->grad_scale = c.f16 ? 64.f : 1.f; st->inv_grad_scale = 1.f / st->grad_scale;   // (fp16: adapted after every step, sched_post_wave)
-  st->dz_absmax_bits = 0u;
+  for (int i = 0; i < 64; ++i) st->dz_absmax_slots[i * 32] = 0u;
   if (c.schedule == SCHED_CONSTANT) st->lr = c.lr_min;
   else if (c.schedule == SCHED_1CYCLEPOLY) st->lr = c.lr_max * (c.warmup_lr / c.lr_max);  // LinearLR._initial_step
   else st->lr = onecycle_lr(c, 0);
@@ -1891,7 +1904,10 @@ __device__ void sched_post_wave(const TrainState* src, TrainState* st, const Sch
                                 float* log_loss, float* log_inl, int log_cap, const int* fault, const float* stat_partials, int n_loss_blocks,
                                 const GradReduceArgs* tail = nullptr) {
   const int lane = threadIdx.x & 63;
-  const uint32_t amax_bits = src->dz_absmax_bits;   // fp16: largest propagated gradient of the step (scaled units)
+  const uint32_t my_stripe = __builtin_nontemporal_load(&src->dz_absmax_slots[lane * 32]);
+  uint32_t amax_bits = my_stripe;   // fp16: largest propagated gradient of the step (scaled units), over the 64 stripes
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) amax_bits = max(amax_bits, (uint32_t)__shfl_xor((int)amax_bits, off));
   // every load of the wave first: the scalar state (used by lane 0), the statistics, this lane's two ring entries
   SchedHot h = load_hot(src);
   const float ring0 = src->crit_buf[lane], ring1 = (lane + 64 < 100) ? src->crit_buf[lane + 64] : 0.f;
@@ -1901,7 +1917,8 @@ __device__ void sched_post_wave(const TrainState* src, TrainState* st, const Sch
     if (src != st) {
       st->crit_buf[lane] = ring0;
       if (lane + 64 < 100) st->crit_buf[lane + 64] = ring1;
-      if (lane == 0) { store_hot(st, h); st->dz_absmax_bits = amax_bits; }
+      st->dz_absmax_slots[lane * 32] = my_stripe;
+      if (lane == 0) store_hot(st, h);
     }
     return;
   }
@@ -1935,6 +1952,7 @@ __device__ void sched_post_wave(const TrainState* src, TrainState* st, const Sch
     st->crit_buf[lane] = (push && lane == pos) ? inl : ring0;
     if (lane + 64 < 100) st->crit_buf[lane + 64] = (push && lane + 64 == pos) ? inl : ring1;
   }
+  st->dz_absmax_slots[lane * 32] = 0u;   // the stripes of the state the NEXT step's kernels fold into
   if (lane != 0) return;
   h.last_loss = loss;
   h.last_inliers = inl;
@@ -2001,7 +2019,6 @@ __device__ void sched_post_wave(const TrainState* src, TrainState* st, const Sch
     h.grad_scale = ldexpf(1.f, e);
     h.inv_grad_scale = ldexpf(1.f, -e);
   }
-  st->dz_absmax_bits = 0u;
   h.iteration = it + 1;   // ace_trainer.py:495
   sched_prepare_hot(h, c, crit_min);   // bookkeeping of the NEXT iteration, so that a step needs a single schedule launch
   store_hot(st, h);

@@ -150,6 +150,8 @@ class ReconstructionSession:
         self.hw = self.oh * self.ow
         self.group = group
         self.rank, self.world = rank_world(group)
+        if self.rank:   # data-parallel fills draw their augmentations / sample positions from per-rank streams (rank 0: the single-process one),
+            self._aug_rng = np.random.default_rng([self.opt.base_seed + 77, self.rank])   # so the shards' views are not copies of one sequence
         self.owned = np.arange(self.rank, self.n, self.world)            # parallel.frames_of_rank; local slot of frame g: g // world
         self.features = torch.empty((len(self.owned), self.hw, self.enc.out_channels), dtype=torch.bfloat16, device=self.dev)
         t0 = time.time()
@@ -206,7 +208,7 @@ class ReconstructionSession:
             else:
                 of, op, ov, ox = (t[filled:filled + take] for t in (feats, px, vidx, pix))
             N.check(N.lib().acez_buffer_sample_views(_ptr(src), _ptr(mask) if mask is not None else None, v, self.oh, self.ow, C,
-                                                     o.samples_per_image, o.base_seed + 4095, self._views_sampled, n_views, _ptr(of), _ptr(op),
+                                                     o.samples_per_image, o.base_seed + 4095 + 7919 * self.rank, self._views_sampled, n_views, _ptr(of), _ptr(op),
                                                      _ptr(ov), _ptr(ox), _stream()))
             if take < v * o.samples_per_image:
                 feats[filled:], px[filled:], vidx[filled:], pix[filled:] = of[:take], op[:take], ov[:take], ox[:take]
@@ -260,7 +262,7 @@ class ReconstructionSession:
         ids = torch.as_tensor([int(i) for i in image_ids], dtype=torch.long)
         m = len(ids)
         total = total if total is not None else min(o.max_training_buffer_size, o.max_dataset_passes * m * o.samples_per_image)
-        bld = BufferBuilder(self.enc, capacity=total, samples_per_image=o.samples_per_image, seed=o.base_seed + 4095 + self._views_sampled)
+        bld = BufferBuilder(self.enc, capacity=total, samples_per_image=o.samples_per_image, seed=o.base_seed + 4095 + 7919 * self.rank + self._views_sampled)
         poses_c2w = torch.as_tensor(poses_c2w, dtype=torch.float64).reshape(m, 4, 4)
         pose_inv = torch.linalg.inv(poses_c2w).to(torch.float32)
         # views per warp / encoder / sampling batch (<= the encoder's max_frames). 32 instead of 16: the 3x3 patch kernel gets a full

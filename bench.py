@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--pose-refinement", default="none", choices=["none", "mlp"])   # ace_zero.py:86 maps every non-seed iteration with mlp
     ap.add_argument("--session-frames", type=int, default=120, help="frames of the in-process ACE0 reconstruction leg (N = 1 only; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp16"), help="with --headline-only: operand type of the timed step (diagnostics; the default line is bf16 + a dtype_fp16 leg)")
     ap.add_argument("--headline-only", action="store_true", help="only the timed training steps (the leg rocprofv3 is pointed at: tools/prof_r02.sh)")
     # control-flow smoke of the N > 1 path on a ONE-GPU box: every rank on cuda:0, gloo instead of RCCL (not a measurement)
     ap.add_argument("--smoke-same-device", action="store_true")
@@ -326,6 +327,33 @@ def bench_session(args, device):
             "note": "synthetic textured room, stand-in encoder (zero-mean smoothed random filters), augmentation +-2 deg / x1.06, 2 seed trials"}
 
 
+def device_state(device):
+    """Clocks / power / partition mode of the GPU while it is busy (rocm-smi beside a ~1.5 s matrix-multiply loop; outside every timed
+    region). The pool's boxes differ by 25 % on the same binary (headline step 152-156 us on most, 190-200 us on some): this records
+    which kind of box a line came from. Best effort: {} when rocm-smi is missing or its output is not understood."""
+    import subprocess
+    out = {}
+    try:
+        a = torch.randn(4096, 4096, device=device, dtype=torch.bfloat16)
+        p = subprocess.Popen(["rocm-smi", "-d", str(device.index or 0), "--showclocks", "--showpower", "--showperflevel", "--showcomputepartition",
+                              "--showmemorypartition", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 1.5 and p.poll() is None:
+            for _ in range(20):
+                a = (a @ a).clamp_(-1, 1)
+            torch.cuda.synchronize()
+        txt, _ = p.communicate(timeout=20)
+        js = json.loads(txt[txt.index("{"):])
+        card = next(iter(js.values()))
+        for k, v in card.items():
+            kl = k.lower()
+            if any(w in kl for w in ("sclk", "mclk", "fclk", "socclk", "power", "performance level", "partition")):
+                out[k] = v
+    except Exception as e:   # noqa: BLE001 (diagnostics only)
+        out["error"] = repr(e)[:200]
+    return out
+
+
 def cpu_baseline():
     """Oracle timed on the host cores (kind "port": the reference itself is not on the GPU box)."""
     from acezero_amd import synth
@@ -427,7 +455,8 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=device)
     assert world == args.gpus or world == 1, (world, args.gpus)
 
-    dt, st, prof = bench_training(args, rank, world, device)
+    dt, st, prof = bench_training(args, rank, world, device, dtype=args.dtype if args.headline_only else "bf16")
+    dev_state = device_state(device) if rank == 0 else None
     if args.headline_only:
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -439,8 +468,8 @@ def main():
             print(json.dumps({"metric": "ACE patches/sec", "value": BATCH * world * args.steps / dt, "unit": "patches/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(np.median(st["window_ms_per_step"])),
                               "ms_per_step_mean": dt / args.steps * 1e3, "window_ms_per_step": st["window_ms_per_step"], "headline_only": True,
-                              "pose_refinement": args.pose_refinement,
-                              "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()}, "final_loss": st["loss"]}))
+                              "pose_refinement": args.pose_refinement, "dtype": args.dtype,
+                              "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()}, "final_loss": st["loss"], "device_state": dev_state}))
         return
     # the headline step with fp16 operands (the reference's autocast precision; HeadTrainer(dtype="fp16")): same kernels, same rate
     dt_f16, st_f16, _ = bench_training(args, rank, world, device, steps=100, buffer_patches=min(args.buffer_patches, 2_000_000), dtype="fp16")
@@ -553,7 +582,7 @@ def main():
                                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_tflops / MFMA_PEAK_TFLOPS, "traffic": None,
                                "avg_launch_us": wg_s * 1e6},
             "roofline_ransac": ransac_roofline(nreg * world / dt_reg),
-            "final_loss": st["loss"],
+            "final_loss": st["loss"], "device_state": dev_state,
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()

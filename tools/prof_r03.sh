@@ -73,9 +73,9 @@ for name, c in summary.items():
     if e:
         step["kernels"][name] = e
 for k in list(step["kernels"]):
-    if "rowseq_kernel<false>" in k and "bytes_per_launch" in step["kernels"][k]:
+    if "rowseq_kernel<false" in k and "F16" not in k and "bytes_per_launch" in step["kernels"][k]:
         step["kernels"][k].update(layers_per_launch=8, bytes_per_layer=step["kernels"][k]["bytes_per_launch"] / 8)
-    if "rowseq_kernel<true>" in k and "bytes_per_launch" in step["kernels"][k]:
+    if "rowseq_kernel<true" in k and "F16" not in k and "bytes_per_launch" in step["kernels"][k]:
         step["kernels"][k].update(layers_per_launch=7, bytes_per_layer=step["kernels"][k]["bytes_per_launch"] / 7)
 json.dump(step, open(keep + "/r03_step_hbm_traffic.json", "w"), indent=1, sort_keys=True)
 for k, e in sorted(step["kernels"].items()):
