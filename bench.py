@@ -376,7 +376,7 @@ def cpu_baseline():
     orc.step(b["features"], b)
     t0 = time.perf_counter()
     steps = 0
-    while time.perf_counter() - t0 < 12.0 and steps < 40:
+    while time.perf_counter() - t0 < 12.0 and steps < 120:
         orc.step(b["features"], b)
         steps += 1
     t_train = (time.perf_counter() - t0) / max(steps, 1)
