@@ -213,6 +213,17 @@ def ransac_roofline(images_per_s):
     peak = 256 * 4 * 16 * 2.4e9 / 1e12
     out = {"bound": "valu_fp64", "kernel": "ransac_kernel<false> (one 256-thread workgroup per 60x80 frame)", "peak": peak,
            "unit": "T lane-ops/s", "achieved": None, "frac": None, "traffic": None}
+    # SURVEY section 8(d)'s algorithmic figures beside the counter-based one: scoring = hypotheses x cells x ~32 flop (3x3 mat-vec + t,
+    # divide, 2 FMA, norm, clamp, sigmoid) = 4.9 MFLOP per 60x80 frame at 32 hypotheses (the kernel evaluates it in fp64: determinism);
+    # the refinement rounds are data dependent and not counted. Bytes: 57.6 KB of coordinates in, 64 B pose + 4.8 KB mask out per frame.
+    score_flop = 32 * 4800 * 32
+    out["algorithmic"] = {"scoring_flop_per_frame": score_flop, "scoring_tflops": images_per_s * score_flop / 1e12,
+                          "scoring_frac_of_fp64_valu_peak": images_per_s * score_flop / 1e12 / (2 * peak),
+                          "hbm_bytes_per_frame": 57600 + 64 + 4800, "hbm_GBps": images_per_s * (57600 + 64 + 4800) / 1e9,
+                          "hbm_frac_of_8TBps": images_per_s * (57600 + 64 + 4800) / 8e12,
+                          "note": "the algorithmic scoring flops are ~9 % of the lane operations the kernel issues: sampling (P3P per hypothesis and try), the "
+                                  "soft-inlier refinement rounds (Gauss-Newton on up to 4800 inliers) and the reductions are the rest; hence the "
+                                  "counter-based `frac` above is the utilisation figure"}
     try:
         side = json.load(open(path.replace(".json", ".digest.json")))
         if side.get("source_digest") != src_digest(RANSAC_SOURCES):   # the kernel has changed since the counter pass: nothing stale is quoted
