@@ -170,3 +170,43 @@ def test_use_half_false_is_refused_not_silently_ignored(tmp_path):
     with pytest.raises(SystemExit) as e:
         cli.train_with_options(opt)
     assert "not implemented" in str(e.value) and "use_half" in str(e.value)
+
+
+def test_frame_size_classes_group_the_sorted_file_list(tmp_path):
+    """register_mapping.py on a folder of mixed frame sizes: one class per image size, positions in the sorted list (headers only)."""
+    from PIL import Image
+    from acezero_amd import cli
+    sizes = [(64, 48), (80, 48), (64, 48), (48, 64), (80, 48)]
+    for i, wh in enumerate(sizes):
+        Image.new("RGB", wh).save(tmp_path / f"im_{i:02d}.png")
+    files, classes = cli.frame_size_classes(str(tmp_path / "im_*.png"))
+    assert [os.path.basename(f) for f in files] == [f"im_{i:02d}.png" for i in range(5)]
+    assert classes == {(64, 48): [0, 2], (80, 48): [1, 4], (48, 64): [3]}
+    with pytest.raises(SystemExit):
+        cli.frame_size_classes(str(tmp_path / "nothing_*.png"))
+
+
+def test_gauge_aware_pose_comparison_is_invariant_to_a_similarity():
+    """tools/pose_geometry.py (the session studies of DESIGN.md section 4c): a similarity transform of the whole reconstruction gives
+    zero error and the inverse scale; a distortion of the centres shows up in the centre error, not in the relative rotations."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.pose_geometry import geometry
+    rng = np.random.default_rng(5)
+
+    def rot(r):
+        th = np.linalg.norm(r); k = r / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    gt = np.tile(np.eye(4), (40, 1, 1))
+    for i in range(40):
+        gt[i, :3, :3] = rot(rng.normal(size=3)); gt[i, :3, 3] = rng.normal(size=3)
+    Q, s, t = rot(np.array([0.3, -0.2, 0.5])), 2.5, np.array([1.0, -2.0, 3.0])
+    est = gt.copy()
+    est[:, :3, :3] = Q @ gt[:, :3, :3]
+    est[:, :3, 3] = s * (gt[:, :3, 3] @ Q.T) + t
+    g = geometry(est, gt)
+    assert abs(g["scale"] - 1 / s) < 1e-3 and g["centre_rel_median"] < 1e-6 and g["rot_abs_deg_median"] < 1e-3 and g["rot_rel_deg_median"] < 1e-3
+    est[:, :3, 3] += rng.normal(size=(40, 3)) * 0.5
+    g = geometry(est, gt)
+    assert g["centre_rel_median"] > 0.01 and g["rot_rel_deg_median"] < 1e-3
