@@ -406,8 +406,8 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
       }
       ACEZ_VMCNT(0);
       __builtin_amdgcn_s_barrier();     // epilogue inputs have landed; the ring is free
-      if (SEQ && q.next_W) {            // overlaps the epilogue: 64 KiB of the next layer's 208 KiB
-#pragma unroll
+      if (SEQ && q.next_W) {            // overlaps the epilogue: 64 KiB of the next layer's 208 KiB (requested behind the hand-off
+#pragma unroll                          // instead, so that the loader waves' vmcnt(0) there covers stores only: measured +3 us per chain)
         for (int j = 0; j < 4; ++j) gW[j] += q.next_W - a.W;
         issueW(0); issueW(1); issueW(2); issueW(3);
       }
@@ -531,17 +531,28 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (also keeps the reads above this point)
     const int r0 = m0 + (q0 >> 4), r1 = m0 + (q1 >> 4), r2 = m0 + (q2 >> 4);
     const size_t o0 = (size_t)r0 * N + n0 + (q0 & 15) * 8, o1 = (size_t)r1 * N + n0 + (q1 & 15) * 8, o2 = (size_t)r2 * N + n0 + (q2 & 15) * 8;
-    if (r0 < M) {
-      *reinterpret_cast<uint4*>(a.out_main + o0) = m0v;
-      if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o0) = a0v;
+    // SEQ: the tile the NEXT layer reads goes first -- the main tile, or after a residual add the aux tile (the residual stream is the next
+    // block's input) -- and the hand-off follows its acknowledgement; the other tile (pre-residual activation kept for the backward pass /
+    // unmasked gradient with its tile-local consumer) and the bias column sums come after the signal
+    constexpr bool AUX_FIRST = AUX == AUX_RESIDUAL;
+    uint16_t* const first = AUX_FIRST ? a.out_aux : a.out_main;
+    uint16_t* const second = AUX_FIRST ? a.out_main : a.out_aux;
+    const uint4 f0 = AUX_FIRST ? a0v : m0v, f1v = AUX_FIRST ? a1v : m1v, f2v = AUX_FIRST ? a2v : m2v;
+    const uint4 s0 = AUX_FIRST ? m0v : a0v, s1 = AUX_FIRST ? m1v : a1v, s2 = AUX_FIRST ? m2v : a2v;
+    if (r0 < M) *reinterpret_cast<uint4*>(first + o0) = f0;
+    if (r1 < M) *reinterpret_cast<uint4*>(first + o1) = f1v;
+    if (q2 < 1280 && r2 < M) *reinterpret_cast<uint4*>(first + o2) = f2v;
+    if (SEQ && q.signal) {
+      ACEZ_VMCNT(0);   // this wave's stores are acknowledged by the L2 = visible to the three sibling workgroups (same XCD)
+      if (l == 0) {
+        const uint32_t one = 1;
+        asm volatile("global_atomic_add %0, %1, off" ::"v"(q.flag), "v"(one) : "memory");
+      }
     }
-    if (r1 < M) {
-      *reinterpret_cast<uint4*>(a.out_main + o1) = m1v;
-      if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o1) = a1v;
-    }
-    if (q2 < 1280 && r2 < M) {
-      *reinterpret_cast<uint4*>(a.out_main + o2) = m2v;
-      if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o2) = a2v;
+    if (AUX != AUX_NONE) {
+      if (r0 < M) *reinterpret_cast<uint4*>(second + o0) = s0;
+      if (r1 < M) *reinterpret_cast<uint4*>(second + o1) = s1;
+      if (q2 < 1280 && r2 < M) *reinterpret_cast<uint4*>(second + o2) = s2;
     }
   }
   if (HAS_MASK && a.bias_partials) {
@@ -565,13 +576,6 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
       __syncthreads();
     }
     if (t < 128) a.bias_partials[(size_t)mt * 512 + n0 + t] = ((red[t] + red[128 + t]) + red[256 + t]) + red[384 + t];
-  }
-  if (SEQ && q.signal) {
-    ACEZ_VMCNT(0);   // this wave's stores are acknowledged by the L2 = visible to the three sibling workgroups (same XCD)
-    if (l == 0) {
-      const uint32_t one = 1;
-      asm volatile("global_atomic_add %0, %1, off" ::"v"(q.flag), "v"(one) : "memory");
-    }
   }
 }
 
