@@ -270,6 +270,9 @@ __device__ __forceinline__ uint32_t absmax_all(const TrainState* st, int lane) {
 
 // One layer of one workgroup. SEQ = false: the whole of rowgemm80_kernel. SEQ = true: one link of rowseq_kernel (below), where
 // the layers of a dependent chain run in ONE launch and the kernel boundary is replaced by a same-XCD hand-off (SeqLink).
+#ifndef ACEZ_SEQ_SLEEP
+#define ACEZ_SEQ_SLEEP "1"   // s_sleep argument between two polls of a hand-off counter (64 clocks each)
+#endif
 struct SeqLink {
   uint32_t* flag;        // per-row-tile counter in this XCD's L2 (one 128-byte line each), monotonically increasing
   uint32_t target;       // value of *flag when the four column tiles of the layer before have stored their outputs
@@ -368,7 +371,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
               "s_sub_i32 %[sseen], %[sseen], %[target]\n\t"
               "s_cmp_ge_i32 %[sseen], 0\n\t"
               "s_cbranch_scc1 2f\n\t"
-              "s_sleep 1\n\t"
+              "s_sleep " ACEZ_SEQ_SLEEP "\n\t"
               "s_add_u32 %[spins], %[spins], 1\n\t"
               "s_cmp_lt_u32 %[spins], %[limit]\n\t"
               "s_cbranch_scc1 1b\n\t"
