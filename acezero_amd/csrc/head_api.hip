@@ -34,6 +34,7 @@ struct acez_trainer {
   std::vector<uint16_t*> dZ;    // gradient wrt each wide layer's pre-activation
   uint16_t* dR[2] = {nullptr, nullptr};
   float* slabs = nullptr;
+  int4* batch_meta = nullptr;   // [max_batch] GatherMeta of the batch in R[0]
   float* fc3_partials = nullptr;
   float* stat_partials = nullptr;
   float* bias_partials = nullptr;
@@ -296,6 +297,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->bias_layer_stride = (int64_t)max_loss_blocks * 512;
   A((void**)&tr->bias_partials, (size_t)tr->L * tr->bias_layer_stride * sizeof(float));
   A((void**)&tr->xyz, (size_t)tr->max_batch * 3 * sizeof(float));
+  A((void**)&tr->batch_meta, (size_t)tr->max_batch * sizeof(int4));
   A((void**)&tr->maskbits, (size_t)tr->L * max_blocks * 512 * sizeof(uint32_t));
   A((void**)&tr->chain_err, sizeof(int));
   A((void**)&tr->seq_flags, (64 * 32 + 32) * sizeof(uint32_t));
@@ -521,11 +523,19 @@ static void launch_loss(acez_trainer* tr, int nblk, hipStream_t s, const LossArg
 }
 
 // training-mode arguments of the loss phases (loss_kernel / the chain kernel's loss phase)
+// where the gather launches of a batch leave the per-row metadata for the loss kernel (not with the chain kernel, which gathers itself)
+static GatherMeta gather_meta(acez_trainer* tr) {
+  GatherMeta m{};
+  if (tr->chain || tr->fused_fwd) return m;
+  m.dst = tr->batch_meta; m.view_idx = tr->buf.d_view_idx; m.view_image = tr->buf.d_view_image; m.target_px = tr->buf.d_target_px;
+  return m;
+}
+
 static void fill_loss_train(acez_trainer* tr, LossArgs& a, const uint16_t* act, const int64_t* d_indices, int n, bool pose_tables) {
   const int f2 = 3 * (tr->nb + 1) + 1;
   fill_loss_head(tr, a);
   a.act = act; a.n = n;
-  a.idx = d_indices; a.target_px = tr->buf.d_target_px; a.target_crds = tr->buf.d_target_crds; a.view_idx = tr->buf.d_view_idx;
+  a.idx = d_indices; a.meta = (tr->chain || tr->fused_fwd) ? nullptr : tr->batch_meta; a.target_px = tr->buf.d_target_px; a.target_crds = tr->buf.d_target_crds; a.view_idx = tr->buf.d_view_idx;
   a.view_aug_inv = tr->buf.d_view_aug_inv; a.view_K = tr->buf.d_view_K; a.view_Kinv = tr->buf.d_view_Kinv;
   a.view_image = tr->buf.d_view_image; a.image_pose_inv = pose_tables ? tr->pose_cur : tr->buf.d_image_pose_inv;
   a.row_dT = pose_tables ? tr->row_dT : nullptr; a.row_image = pose_tables ? tr->row_image : nullptr;
@@ -754,17 +764,17 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     const int do_post = tr->post_pending ? 1 : 0;
     tr->post_pending = false;
 #define ACEZ_SBP(TT) hipLaunchKernelGGL(step_begin_pose_kernel<TT>, dim3(np + gblocks + 1), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, \
-                                        d_indices, tr->R[0], n, post_args(tr), do_post, pose_net_args(tr, nullptr), np)
+                                        d_indices, tr->R[0], n, post_args(tr), do_post, pose_net_args(tr, nullptr), np, gather_meta(tr))
     if (T == 16) ACEZ_SBP(16); else if (T == 4) ACEZ_SBP(4); else ACEZ_SBP(8);
 #undef ACEZ_SBP
     if (do_post) st_flip(tr);
   } else if (tr->post_pending) {   // gather of this step + the schedule bookkeeping of the previous one, in one launch
     tr->post_pending = false;
     hipLaunchKernelGGL(step_begin_kernel, dim3(gblocks + 1), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n,
-                       post_args(tr));
+                       post_args(tr), gather_meta(tr));
     st_flip(tr);
   } else {
-    hipLaunchKernelGGL(gather_kernel, dim3(gblocks), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n, st);
+    hipLaunchKernelGGL(gather_kernel, dim3(gblocks), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, d_indices, tr->R[0], n, st, gather_meta(tr));
   }
   delete psg;
   }
@@ -924,7 +934,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     const int gblocks = (n_next + 3) / 4 < 1024 ? (n_next + 3) / 4 : 1024;
     { ProfScope ps(tr, s, KC_ADAMW);
       hipLaunchKernelGGL(adamw_next_kernel, dim3(n_adam + gblocks), dim3(256), 0, s, a, n_adam, (const uint16_t*)tr->buf.d_features, d_next, tr->R[0], n_next,
-                         post_args(tr)); }
+                         post_args(tr), gather_meta(tr)); }
     st_flip(tr);
     tr->pre_idx = d_next; tr->pre_n = n_next;
     tr->post_pending = false;

@@ -49,6 +49,16 @@ struct TrainState {
   uint32_t dz_absmax_slots[64 * 32];
 };
 
+// Per-row metadata of the gathered batch, written where the batch is gathered and read by the loss kernel: without it the loss kernel
+// starts with a chain of three dependent loads (idx -> view_idx -> view_image) in front of its first computation, because vmcnt
+// completes in order. {view, image, target u, target v (float bits)} of row r; dst == null: not written.
+struct GatherMeta {
+  int4* dst;
+  const int32_t* view_idx;
+  const int32_t* view_image;
+  const float* target_px;
+};
+
 struct SchedConfig {
   int schedule, iterations, warmup_iterations, cooldown_iterations;
   int loss_type, circle_schedule, refine_calibration;
@@ -96,6 +106,7 @@ struct LossArgs {
   float mean[3], max_inv_scale, min_inv_scale, h_beta;
   // training only (idx == null -> inference)
   const int64_t* idx;
+  const int4* meta;   // GatherMeta::dst of the batch `idx` (null: the chain idx -> view_idx -> view_image is followed here)
   const float* target_px;
   const float* target_crds;      // [patches][3] ground-truth scene coordinates (zeros = none) or null: use_depth mode
   const int32_t* view_idx;

@@ -27,17 +27,43 @@ namespace acez {
 // ---------------------------------------------------------------------------------------------------
 // gather: out[r][:] = features[idx[r]][:]   (one wave copies one 1 KiB row per instruction)
 // ---------------------------------------------------------------------------------------------------
+// Rows wave, wave + nwaves, ... of a batch, two at a time: the loads of a level are issued for both rows before anything of the next
+// level (one row after the other, every row paid its own idx -> row round trips). With meta.dst the per-row metadata the loss kernel
+// needs (GatherMeta) is looked up beside the copy: a third level for the image index, overlapped with the row stores.
+__device__ __forceinline__ void gather_rows(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx, uint16_t* __restrict__ out, int n,
+                                            int wave, int nwaves, int lane, const GatherMeta& meta) {
+  for (int r0 = wave; r0 < n; r0 += 2 * nwaves) {
+    const int r1 = r0 + nwaves;
+    const bool two = r1 < n;
+    const int64_t s0 = idx[r0], s1 = idx[two ? r1 : r0];
+    const uint4 v0 = *reinterpret_cast<const uint4*>(feat + s0 * 512 + lane * 8);
+    const uint4 v1 = *reinterpret_cast<const uint4*>(feat + s1 * 512 + lane * 8);
+    int view0 = 0, view1 = 0;
+    float2 t0 = make_float2(0.f, 0.f), t1 = t0;
+    if (meta.dst) {
+      view0 = meta.view_idx[s0]; view1 = meta.view_idx[s1];
+      t0 = *reinterpret_cast<const float2*>(meta.target_px + s0 * 2);
+      t1 = *reinterpret_cast<const float2*>(meta.target_px + s1 * 2);
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)r0 * 512 + lane * 8) = v0;
+    if (two) *reinterpret_cast<uint4*>(out + (size_t)r1 * 512 + lane * 8) = v1;
+    if (meta.dst) {
+      const int img0 = meta.view_image[view0], img1 = meta.view_image[view1];
+      if (lane == 0) {
+        meta.dst[r0] = make_int4(view0, img0, __float_as_int(t0.x), __float_as_int(t0.y));
+        if (two) meta.dst[r1] = make_int4(view1, img1, __float_as_int(t1.x), __float_as_int(t1.y));
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gather_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
-                                                     uint16_t* __restrict__ out, int n, const TrainState* st) {
+                                                     uint16_t* __restrict__ out, int n, const TrainState* st, GatherMeta meta) {
   if (st && !st->active) return;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (int r = wave; r < n; r += nwaves) {
-    const int64_t src = idx[r];
-    const uint4 v = *reinterpret_cast<const uint4*>(feat + src * 512 + lane * 8);
-    *reinterpret_cast<uint4*>(out + (size_t)r * 512 + lane * 8) = v;
-  }
+  gather_rows(feat, idx, out, n, wave, nwaves, lane, meta);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1005,10 +1031,15 @@ __device__ __forceinline__ LossPre loss_prefetch(const LossArgs& a, int m0, int 
   LossPre q{0, 0, 0, 0.f, 0.f};
   if (a.idx && t < rows && m0 + t < a.n) {
     q.p = a.idx[m0 + t];
-    q.view = a.view_idx[q.p];
-    q.img = a.view_image[q.view];
-    q.tu = a.target_px[q.p * 2 + 0];
-    q.tv = a.target_px[q.p * 2 + 1];
+    if (a.meta) {   // looked up where the batch was gathered (GatherMeta): one load level instead of three
+      const int4 m = a.meta[m0 + t];
+      q.view = m.x; q.img = m.y; q.tu = __int_as_float(m.z); q.tv = __int_as_float(m.w);
+    } else {
+      q.view = a.view_idx[q.p];
+      q.img = a.view_image[q.view];
+      q.tu = a.target_px[q.p * 2 + 0];
+      q.tv = a.target_px[q.p * 2 + 1];
+    }
   }
   return q;
 }
@@ -2054,7 +2085,7 @@ struct PostArgs {
   int n_loss_blocks;
 };
 __global__ __launch_bounds__(256) void step_begin_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
-                                                         uint16_t* __restrict__ out, int n, PostArgs p) {
+                                                         uint16_t* __restrict__ out, int n, PostArgs p, GatherMeta meta) {
   if (blockIdx.x == gridDim.x - 1) {
     if (threadIdx.x < 64) sched_post_wave(p.src, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault, p.stat_partials, p.n_loss_blocks);
     return;
@@ -2062,11 +2093,7 @@ __global__ __launch_bounds__(256) void step_begin_kernel(const uint16_t* __restr
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = ((gridDim.x - 1) * blockDim.x) >> 6;
-  for (int r = wave; r < n; r += nwaves) {
-    const int64_t src = idx[r];
-    const uint4 v = *reinterpret_cast<const uint4*>(feat + src * 512 + lane * 8);
-    *reinterpret_cast<uint4*>(out + (size_t)r * 512 + lane * 8) = v;
-  }
+  gather_rows(feat, idx, out, n, wave, nwaves, lane, meta);
 }
 
 // The optimiser of step k, the batch gather of step k + 1 and the schedule bookkeeping that closes step k in ONE launch (single-GPU
@@ -2076,7 +2103,7 @@ __global__ __launch_bounds__(256) void step_begin_kernel(const uint16_t* __restr
 // (First version: one slot, bookkeeping in the workgroup that finished last, found with a ticket counter -- 1700 atomics on one word
 // cost 20 us.)   blocks [0, n_adam) = adamw_kernel's; then the gather blocks; the last block = the schedule wave
 __global__ __launch_bounds__(256) void adamw_next_kernel(AdamArgs a, int n_adam, const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx_next,
-                                                         uint16_t* __restrict__ out, int n_next, PostArgs p) {
+                                                         uint16_t* __restrict__ out, int n_next, PostArgs p, GatherMeta meta) {
   __shared__ uint16_t tileT[64][66];
   const int b = (int)blockIdx.x;
   if (b < n_adam) {
@@ -2091,11 +2118,7 @@ __global__ __launch_bounds__(256) void adamw_next_kernel(AdamArgs a, int n_adam,
   const int lane = threadIdx.x & 63;
   const int wave = ((b - n_adam) * (int)blockDim.x + (int)threadIdx.x) >> 6;
   const int nwaves = (((int)gridDim.x - 1 - n_adam) * (int)blockDim.x) >> 6;
-  for (int r = wave; r < n_next; r += nwaves) {
-    const int64_t src = idx_next[r];
-    const uint4 v = *reinterpret_cast<const uint4*>(feat + src * 512 + lane * 8);
-    *reinterpret_cast<uint4*>(out + (size_t)r * 512 + lane * 8) = v;
-  }
+  gather_rows(feat, idx_next, out, n_next, wave, nwaves, lane, meta);
 }
 
 // cos(pi x) for x in [0,1] with basic operations only (Taylor around the nearest multiple of 1/2).

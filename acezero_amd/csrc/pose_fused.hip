@@ -30,7 +30,8 @@ constexpr int pose_s1_smem_bytes() { return T == 16 ? PS1_SMEM_BYTES : pose4_s1_
 // block of this very launch is rewriting it): refined poses computed for a step that turns out to be inactive are never used.
 template <int T>
 __global__ __launch_bounds__(256, 2) void step_begin_pose_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
-                                                                 uint16_t* __restrict__ out, int n, PostArgs p, int do_post, PoseNetArgs a, int np) {
+                                                                 uint16_t* __restrict__ out, int n, PostArgs p, int do_post, PoseNetArgs a, int np,
+                                                                 GatherMeta meta) {
   __shared__ __attribute__((aligned(16))) float smem[pose_fwd_smem_floats<T>()];
   if ((int)blockIdx.x < np) {
     if constexpr (T == 16) pose_mlp_fwd_body(a, blockIdx.x);
@@ -45,11 +46,7 @@ __global__ __launch_bounds__(256, 2) void step_begin_pose_kernel(const uint16_t*
   const int lane = threadIdx.x & 63;
   const int wave = (gb * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (ngb * blockDim.x) >> 6;
-  for (int r = wave; r < n; r += nwaves) {
-    const int64_t src = idx[r];
-    const uint4 v = *reinterpret_cast<const uint4*>(feat + src * 512 + lane * 8);
-    *reinterpret_cast<uint4*>(out + (size_t)r * 512 + lane * 8) = v;
-  }
+  gather_rows(feat, idx, out, n, wave, nwaves, lane, meta);
 }
 
 // S1 of one tile (reduction of the per-row pose gradients + compose backward + input-gradient chain)
