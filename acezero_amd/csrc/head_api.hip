@@ -931,7 +931,14 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
   if (fused && d_next && n_next > 0 && tr->cfg.pose_refinement == 0 && !tr->chain && !tr->fused_fwd && tr->have_buf) {
     // the next batch is known: its gather and this step's schedule bookkeeping ride in the optimiser's launch (adamw_next_kernel)
     const int n_adam = tr->L * 64 + nsmall;
-    const int gblocks = (n_next + 3) / 4 < 1024 ? (n_next + 3) / 4 : 1024;
+    // every workgroup of the launch resident at once (4 of these 256-thread workgroups per CU): gather workgroups that had to wait for a
+    // free slot started when the optimiser's tiles were done and ran their three load levels as the launch's tail. ACEZ_NEXT_GBLOCKS
+    // overrides the count (timing experiments).
+    int gcap = 4 * tr->n_cus - n_adam - 1;
+    if (gcap < 64) gcap = 64;
+    if (const char* e = getenv("ACEZ_NEXT_GBLOCKS")) gcap = std::max(1, atoi(e));
+    const int gwant = (n_next + 3) / 4 < 1024 ? (n_next + 3) / 4 : 1024;
+    const int gblocks = gwant < gcap ? gwant : gcap;
     { ProfScope ps(tr, s, KC_ADAMW);
       hipLaunchKernelGGL(adamw_next_kernel, dim3(n_adam + gblocks), dim3(256), 0, s, a, n_adam, (const uint16_t*)tr->buf.d_features, d_next, tr->R[0], n_next,
                          post_args(tr), gather_meta(tr)); }
