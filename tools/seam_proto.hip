@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
           __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)(slot + 128 * 64 + (lw * 3 + j) * 8 * 64), 16, 0, 0);
       };
       if (layer == 0) { issueW(0); issueW(1); issueW(2); issueW(3); }   // later layers: requested at the end of the layer before
-      if (layer > 0) {
+      if (layer > 0 && !(a.mode & 4)) {   // mode bit 2 (4): NO wait at all -- timing only (results are wrong): the ceiling of what hiding the seam can give
         const uint32_t target = (a.base + (uint32_t)layer) * 32u;       // 4 workgroups x 8 waves per seam
         if (a.mode & 1) {
           while ((int32_t)(__hip_atomic_load(&a.flags[mt * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (l == 0) __hip_atomic_fetch_add(&a.flags[mt * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        ACEZ_VMCNT(0);                     // stores acknowledged by this XCD's L2 = visible to the three sibling workgroups
+        if (!(a.mode & 8)) ACEZ_VMCNT(0);  // stores acknowledged by this XCD's L2 = visible to the three sibling workgroups (mode bit 3 (8): not waited for -- timing only)
         if (l == 0) {
           const uint32_t one = 1;
           asm volatile("global_atomic_add %0, %1, off" ::"v"(a.flags + mt * 32), "v"(one) : "memory");
@@ -252,6 +252,14 @@ int main() {
       CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_seq(L, 1); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms1, e0, e1));
       for (int i = 0; i < 10; ++i) run_seq(L, 2);
       CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_seq(L, 2); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms2, e0, e1));
+      if (rep) {
+        for (int mode : {4, 8, 12}) {   // timing only: no consumer wait / no store-acknowledgement wait / neither
+          float ms;
+          for (int i = 0; i < 10; ++i) run_seq(L, mode);
+          CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_seq(L, mode); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+          printf("L=%d  one launch, timing only, mode %2d (4: consumers do not wait, 8: producers do not wait for store acknowledgements): %7.2f us (%.2f per layer)\n", L, mode, ms * 1e3 / n, ms * 1e3 / n / L);
+        }
+      }
       if (rep) printf("L=%d  per-layer launches %7.2f us | one launch: no fences %7.2f us, acquire fence only %7.2f us, release+acquire fences %7.2f us   (per layer %.2f | %.2f / %.2f / %.2f)\n",
                       L, ms_ref * 1e3 / n, ms0 * 1e3 / n, ms2 * 1e3 / n, ms1 * 1e3 / n, ms_ref * 1e3 / n / L, ms0 * 1e3 / n / L, ms2 * 1e3 / n / L, ms1 * 1e3 / n / L);
     }
