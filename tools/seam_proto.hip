@@ -16,6 +16,11 @@
 #include <cstring>
 using namespace acez;
 
+// s_waitcnt vmcnt(n) for a value known after unrolling (the K loop is fully unrolled: n folds to a constant and one case survives)
+#define ACEZ_VMCNT_DYN(n) do { switch (n) { case 0: ACEZ_VMCNT(0); break; case 3: ACEZ_VMCNT(3); break; case 6: ACEZ_VMCNT(6); break; case 7: ACEZ_VMCNT(7); break; \
+  case 9: ACEZ_VMCNT(9); break; case 10: ACEZ_VMCNT(10); break; case 12: ACEZ_VMCNT(12); break; case 13: ACEZ_VMCNT(13); break; case 14: ACEZ_VMCNT(14); break; \
+  case 17: ACEZ_VMCNT(17); break; case 21: ACEZ_VMCNT(21); break; default: ACEZ_VMCNT(0); break; } } while (0)
+
 struct SeqArgs {
   const uint16_t* In;       // layer 0 input
   const uint16_t* W;        // [L][512][512]
@@ -26,10 +31,11 @@ struct SeqArgs {
   int M, L, mode;
 };
 
+template <int R>   // ring depth: 4 = the product's; 5 = one more 28 KiB stage in flight (fits beside ONE staging tile: 160 KiB exactly)
 __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
   constexpr int STAGE = (128 + 96) * 64;
-  __shared__ __attribute__((aligned(16))) uint16_t smem[4 * STAGE + 80 * 128];
-  uint16_t* const stB = smem + 4 * STAGE;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[R * STAGE + 80 * 128];
+  uint16_t* const stB = smem + R * STAGE;
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int mtiles = (a.M + 79) / 80;
@@ -59,18 +65,21 @@ __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
         gI[j] = In + (size_t)min(m0 + row, M - 1) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8;
       }
       auto issueW = [&](int kt) {
-        uint16_t* slot = smem + (kt & 3) * STAGE;
+        uint16_t* slot = smem + (kt % R) * STAGE;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + kt * 64), (lvoid_t*)(slot + (lw * 4 + j) * 8 * 64), 16, 0, 0);
       };
       auto issueI = [&](int kt) {
-        uint16_t* slot = smem + (kt & 3) * STAGE;
+        uint16_t* slot = smem + (kt % R) * STAGE;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)(slot + 128 * 64 + (lw * 3 + j) * 8 * 64), 16, 0, 0);
       };
-      if (layer == 0) { issueW(0); issueW(1); issueW(2); issueW(3); }   // later layers: requested at the end of the layer before
+      if (layer == 0) {   // later layers: requested at the end of the layer before
+#pragma unroll
+        for (int k = 0; k < R; ++k) issueW(k);
+      }
       if (layer > 0 && !(a.mode & 4)) {   // mode bit 2 (4): NO wait at all -- timing only (results are wrong): the ceiling of what hiding the seam can give
         const uint32_t target = (a.base + (uint32_t)layer) * 32u;       // 4 workgroups x 8 waves per seam
         if (a.mode & 1) {
@@ -86,24 +95,26 @@ __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
           if (a.mode & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
       }
-      issueI(0); issueI(1); issueI(2); issueI(3);
+#pragma unroll
+      for (int k = 0; k < R; ++k) issueI(k);
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
-        if (kt == 0) ACEZ_VMCNT(9);
-        else if (kt == 1) ACEZ_VMCNT(6);
-        else if (kt == 2) ACEZ_VMCNT(10);
-        else if (kt <= 4) ACEZ_VMCNT(14);
-        else if (kt == 5) ACEZ_VMCNT(14);
-        else if (kt == 6) ACEZ_VMCNT(7);
-        else ACEZ_VMCNT(0);
+        // in-order completion: what may still be in flight when stage kt must have landed = the In instructions of the initial stages
+        // after kt (3 each) + the refills requested so far (7 each: stage s >= R is requested at kt = s - R + 1, after that kt's wait)
+        constexpr int dummy = 0; (void)dummy;
+        const int init_after = (kt < R) ? 3 * (R - 1 - kt) : 0;
+        const int last_refill = (kt - 1 + R - 1 < KT - 1) ? kt - 1 + R - 1 : KT - 1;   // highest stage requested before this wait
+        const int refills = (last_refill >= R && last_refill > kt) ? (last_refill - (kt > R - 1 ? kt : R - 1)) : 0;
+        ACEZ_VMCNT_DYN(init_after + 7 * refills);
         __builtin_amdgcn_s_barrier();
-        if (kt >= 1 && kt + 3 < KT) { issueW(kt + 3); issueI(kt + 3); }
+        if (kt >= 1 && kt + R - 1 < KT) { issueW(kt + R - 1); issueI(kt + R - 1); }
       }
       __builtin_amdgcn_s_barrier();       // K loop over: the ring is free
       if (layer + 1 < a.L) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) gW[j] += 512 * 512;
-        issueW(0); issueW(1); issueW(2); issueW(3);
+#pragma unroll
+        for (int k = 0; k < R; ++k) issueW(k);
       }
       __builtin_amdgcn_s_barrier();       // output tile complete
     } else {
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const uint16_t* sW = smem + (kt & 3) * STAGE;
+        const uint16_t* sW = smem + (kt % R) * STAGE;
         const uint16_t* sI = sW + 128 * 64;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -216,7 +227,8 @@ int main() {
     SeqArgs a{};
     a.In = In; a.W = W; a.bias = bias; a.flags = flags; a.base = base; a.M = M; a.L = L; a.mode = mode;
     for (int i = 0; i < LMAX; ++i) a.out[i] = outB[i];
-    hipLaunchKernelGGL(rowseq_kernel, dim3(256), dim3(512), 0, 0, a);
+    if (a.mode & 16) hipLaunchKernelGGL(rowseq_kernel<5>, dim3(256), dim3(512), 0, 0, a);   // mode bit 4 (16): five ring slots
+    else hipLaunchKernelGGL(rowseq_kernel<4>, dim3(256), dim3(512), 0, 0, a);
     base += (uint32_t)(L - 1);
   };
   auto run_ref = [&](int L) {
@@ -230,7 +242,7 @@ int main() {
   // bit equality of the last layer's output
   std::vector<uint16_t> ra((size_t)M * 512), rb((size_t)M * 512);
   for (int L : {2, 4, 8}) {
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode : {0, 1, 2, 16}) {
       for (int i = 0; i < LMAX; ++i) CK(hipMemset(outB[i], 0xff, (size_t)M * 512 * 2));
       run_ref(L); run_seq(L, mode);
       CK(hipDeviceSynchronize());
@@ -253,7 +265,7 @@ int main() {
       for (int i = 0; i < 10; ++i) run_seq(L, 2);
       CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_seq(L, 2); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms2, e0, e1));
       if (rep) {
-        for (int mode : {4, 8, 12}) {   // timing only: no consumer wait / no store-acknowledgement wait / neither
+        for (int mode : {16, 4, 8, 12, 28}) {   // 16: five ring slots (valid results); timing only: no consumer wait / no store-acknowledgement wait / neither
           float ms;
           for (int i = 0; i < 10; ++i) run_seq(L, mode);
           CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_seq(L, mode); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
