@@ -31,7 +31,11 @@ struct SeqArgs {
   int M, L, mode;
 };
 
-template <int R>   // ring depth: 4 = the product's; 5 = one more 28 KiB stage in flight (fits beside ONE staging tile: 160 KiB exactly)
+// R: ring depth: 4 = the product's; 5 = one more 28 KiB stage in flight (fits beside ONE staging tile: 160 KiB exactly).
+// AH: the stage barrier of iteration kt certifies stage kt + 1 (one AHEAD): the multiplier waves request the fragments of stage kt + 1
+// before they run the MFMAs of stage kt (two fragment sets in registers), so that neither the LDS latency nor the barrier skew sits
+// between a stage's barrier and its first MFMA. Same MFMAs in the same order: bit-identical.
+template <int R, bool AH>
 __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
   constexpr int STAGE = (128 + 96) * 64;
   __shared__ __attribute__((aligned(16))) uint16_t smem[R * STAGE + 80 * 128];
@@ -97,17 +101,32 @@ __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
       }
 #pragma unroll
       for (int k = 0; k < R; ++k) issueI(k);
+      if (AH) {
+        ACEZ_VMCNT_DYN(3 * (R - 1));          // stage 0 has landed
+        __builtin_amdgcn_s_barrier();         // #P
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          if (kt + 1 < KT) {
+            // stage kt + 1 must have landed. Issued so far, in order: In 0 .. R-1 (3 instructions each), then the refills R, R+1, ... (7 each),
+            // one after each of the barriers #1 .. #(kt-1) while stages remain
+            const int issued = (kt - 1 < KT - R) ? (kt - 1 > 0 ? kt - 1 : 0) : KT - R;
+            const int s1 = kt + 1;
+            const int allowed = (s1 < R) ? 3 * (R - 1 - s1) + 7 * issued : 7 * (issued - (s1 - R + 1));
+            ACEZ_VMCNT_DYN(allowed);
+          }
+          __builtin_amdgcn_s_barrier();       // #kt: stage kt + 1 has landed; the multipliers have read stage kt - 1
+          if (kt >= 1 && kt + R - 1 < KT) { issueW(kt + R - 1); issueI(kt + R - 1); }
+        }
+      } else {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
-        // in-order completion: what may still be in flight when stage kt must have landed = the In instructions of the initial stages
-        // after kt (3 each) + the refills requested so far (7 each: stage s >= R is requested at kt = s - R + 1, after that kt's wait)
-        constexpr int dummy = 0; (void)dummy;
         const int init_after = (kt < R) ? 3 * (R - 1 - kt) : 0;
         const int last_refill = (kt - 1 + R - 1 < KT - 1) ? kt - 1 + R - 1 : KT - 1;   // highest stage requested before this wait
         const int refills = (last_refill >= R && last_refill > kt) ? (last_refill - (kt > R - 1 ? kt : R - 1)) : 0;
         ACEZ_VMCNT_DYN(init_after + 7 * refills);
         __builtin_amdgcn_s_barrier();
         if (kt >= 1 && kt + R - 1 < KT) { issueW(kt + R - 1); issueI(kt + R - 1); }
+      }
       }
       __builtin_amdgcn_s_barrier();       // K loop over: the ring is free
       if (layer + 1 < a.L) {
@@ -129,6 +148,40 @@ __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
       float4 bias[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) bias[i] = *reinterpret_cast<const float4*>(a.bias + layer * 512 + n0 + w * 32 + i * 16 + 4 * fq);
+      if (AH) {
+        bf16x8 fa[2][2][2], fb[2][2][5];   // [set][kk][fragment]
+        auto fetch = [&](int kt, int set) {
+          const uint16_t* sW = smem + (kt % R) * STAGE;
+          const uint16_t* sI = sW + 128 * 64;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int c = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[set][kk][i] = *reinterpret_cast<const bf16x8*>(&sW[swz(w * 32 + i * 16 + fr, c)]);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) fb[set][kk][j] = *reinterpret_cast<const bf16x8*>(&sI[swz(j * 16 + fr, c)]);
+          }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();         // #P: stage 0 has landed
+        fetch(0, 0);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          // the fragments of stage kt (requested one iteration ago) must be in registers before this wave lets the loaders refill
+          // that slot (after barrier #kt + 1); they are: the MFMAs below consume them, and the wait here keeps the scheduler honest
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();       // #kt: stage kt + 1 has landed
+          if (kt + 1 < KT) fetch(kt + 1, (kt + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kt & 1][kk][i], fb[kt & 1][kk][j], acc[i][j], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         // (straight-line code: without this the scheduler leaves the previous stage's last ds_reads in flight across the barrier
@@ -151,6 +204,7 @@ __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -227,8 +281,11 @@ int main() {
     SeqArgs a{};
     a.In = In; a.W = W; a.bias = bias; a.flags = flags; a.base = base; a.M = M; a.L = L; a.mode = mode;
     for (int i = 0; i < LMAX; ++i) a.out[i] = outB[i];
-    if (a.mode & 16) hipLaunchKernelGGL(rowseq_kernel<5>, dim3(256), dim3(512), 0, 0, a);   // mode bit 4 (16): five ring slots
-    else hipLaunchKernelGGL(rowseq_kernel<4>, dim3(256), dim3(512), 0, 0, a);
+    // mode bit 4 (16): five ring slots; bit 5 (32): stage barriers one stage ahead + fragment double buffering
+    if ((a.mode & 48) == 48) hipLaunchKernelGGL((rowseq_kernel<5, true>), dim3(256), dim3(512), 0, 0, a);
+    else if (a.mode & 32) hipLaunchKernelGGL((rowseq_kernel<4, true>), dim3(256), dim3(512), 0, 0, a);
+    else if (a.mode & 16) hipLaunchKernelGGL((rowseq_kernel<5, false>), dim3(256), dim3(512), 0, 0, a);
+    else hipLaunchKernelGGL((rowseq_kernel<4, false>), dim3(256), dim3(512), 0, 0, a);
     base += (uint32_t)(L - 1);
   };
   auto run_ref = [&](int L) {
@@ -242,7 +299,7 @@ int main() {
   // bit equality of the last layer's output
   std::vector<uint16_t> ra((size_t)M * 512), rb((size_t)M * 512);
   for (int L : {2, 4, 8}) {
-    for (int mode : {0, 1, 2, 16}) {
+    for (int mode : {0, 1, 2, 16, 32, 48}) {
       for (int i = 0; i < LMAX; ++i) CK(hipMemset(outB[i], 0xff, (size_t)M * 512 * 2));
       run_ref(L); run_seq(L, mode);
       CK(hipDeviceSynchronize());
@@ -265,7 +322,7 @@ int main() {
       for (int i = 0; i < 10; ++i) run_seq(L, 2);
       CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_seq(L, 2); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms2, e0, e1));
       if (rep) {
-        for (int mode : {16, 4, 8, 12, 28}) {   // 16: five ring slots (valid results); timing only: no consumer wait / no store-acknowledgement wait / neither
+        for (int mode : {16, 32, 48, 4, 8, 12, 28, 44}) {   // 16 / 32 / 48: five slots / one stage ahead / both (valid results); timing only: no consumer wait / no store-acknowledgement wait / neither
           float ms;
           for (int i = 0; i < 10; ++i) run_seq(L, mode);
           CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_seq(L, mode); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
