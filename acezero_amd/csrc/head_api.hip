@@ -360,6 +360,7 @@ extern "C" int acez_trainer_set_buffer(acez_trainer* tr, const acez_train_buffer
   ACEZ_REQUIRE(buf->d_image_pose_inv && buf->n_images > 0, "empty pose table");
   tr->buf = *buf;
   tr->have_buf = true;
+  tr->pre_idx = nullptr; tr->pre_n = 0;   // rows gathered ahead (acez_train_step_next) came from the buffer before
   if (tr->cfg.pose_refinement == 1) {
     ACEZ_REQUIRE(tr->pb.n_pose_params == (int64_t)buf->n_images * 12, "naive pose refinement: n_pose_params != 12 * n_images");
     if (tr->pose_images < buf->n_images) {
@@ -420,6 +421,7 @@ extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
   hipLaunchKernelGGL(recast_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
   ACEZ_HIP_CHECK(hipGetLastError());
   tr->pose_wt_valid = false;   // the caller may have rewritten the pose parameters as well
+  tr->pre_idx = nullptr; tr->pre_n = 0;   // a restart point: the next step gathers its own batch
   return ACEZ_OK;
 }
 
@@ -940,7 +942,8 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     const int gwant = (n_next + 3) / 4 < 1024 ? (n_next + 3) / 4 : 1024;
     const int gblocks = gwant < gcap ? gwant : gcap;
     { ProfScope ps(tr, s, KC_ADAMW);
-      hipLaunchKernelGGL(adamw_next_kernel, dim3(n_adam + gblocks), dim3(256), 0, s, a, n_adam, (const uint16_t*)tr->buf.d_features, d_next, tr->R[0], n_next,
+      // (+ 1: the launch's last workgroup is the schedule wave, as in step_begin_kernel -- gblocks gather workgroups remain)
+      hipLaunchKernelGGL(adamw_next_kernel, dim3(n_adam + gblocks + 1), dim3(256), 0, s, a, n_adam, (const uint16_t*)tr->buf.d_features, d_next, tr->R[0], n_next,
                          post_args(tr), gather_meta(tr)); }
     st_flip(tr);
     tr->pre_idx = d_next; tr->pre_n = n_next;
@@ -1081,18 +1084,28 @@ static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, fl
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   hipStream_t s = (hipStream_t)stream;
   const uint16_t* f = (const uint16_t*)d_features;
-  for (int done = 0; done < n; done += tr->max_batch) {
-    const int cnt = (n - done < tr->max_batch) ? n - done : tr->max_batch;
-    uint16_t* act = tr->fused_fwd      ? launch_forward_fused(tr, f + (size_t)done * 512, nullptr, cnt, false, nullptr, s)
-                    : (cnt >= 256 * 128 && !tr->f16) ? launch_forward_conv(tr, f + (size_t)done * 512, cnt, s)   // (the large-tile conv kernels are bf16)
-                                       : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
-    LossArgs a{};
-    fill_loss_head(tr, a);
-    a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr;
-    if (planar_hw > 0) { a.out_xyz = d_out; a.planar_hw = planar_hw; a.row_offset = done; }
-    else a.out_xyz = d_out + (size_t)done * 3;
-    launch_loss(tr, (cnt + 4 * tr->loss_rows - 1) / (4 * tr->loss_rows), s, a);
-  }
+  bool used_seq = false;
+  auto pass = [&]() {
+    for (int done = 0; done < n; done += tr->max_batch) {
+      const int cnt = (n - done < tr->max_batch) ? n - done : tr->max_batch;
+      const bool conv = cnt >= 256 * 128 && !tr->f16;   // (the large-tile conv kernels are bf16)
+      used_seq = used_seq || (!tr->fused_fwd && !conv && seq_usable(tr, cnt));
+      uint16_t* act = tr->fused_fwd ? launch_forward_fused(tr, f + (size_t)done * 512, nullptr, cnt, false, nullptr, s)
+                      : conv        ? launch_forward_conv(tr, f + (size_t)done * 512, cnt, s)
+                                    : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
+      LossArgs a{};
+      fill_loss_head(tr, a);
+      a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr;
+      if (planar_hw > 0) { a.out_xyz = d_out; a.planar_hw = planar_hw; a.row_offset = done; }
+      else a.out_xyz = d_out + (size_t)done * 3;
+      launch_loss(tr, (cnt + 4 * tr->loss_rows - 1) / (4 * tr->loss_rows), s, a);
+    }
+  };
+  pass();
+  // A one-launch chain whose hand-off poll expired has produced garbage (and switched st_infer off): nothing else reads the fault word
+  // on the inference path, so it is read here -- a call that used the chains is synchronous -- and the pass is repeated on per-layer
+  // launches (seq_fault_check has disabled the chains for good).
+  if (used_seq && seq_fault_check(tr, s)) pass();
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
 }

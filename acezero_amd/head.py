@@ -175,8 +175,21 @@ class HeadTrainer:
         out["fc3.bias"] = self.params[o:o + self.no]
         return out
 
+    def _require_whole_masters(self, what):
+        # Under parallel.ShardedDataParallel a rank keeps only ITS layers' fp32 masters / AdamW moments current (update_layers with a
+        # partial range); the others go stale until gather_masters(). Reading or recasting them in that state would silently use stale
+        # weights, so it is an error.
+        if getattr(self, "_masters_partial", False):
+            raise RuntimeError(f"{what}: the fp32 masters of layers this rank does not own are stale (sharded data-parallel update); "
+                               "call ShardedDataParallel.gather_masters() first")
+
+    def masters_synced(self):
+        """Called by whoever has made every layer's masters current again (ShardedDataParallel.gather_masters)."""
+        self._masters_partial = False
+
     def state_dict(self):
         """Same keys / shapes as ace_network.Head.state_dict() (fp32; the trainer saves .half(), ace_trainer.py:690)."""
+        self._require_whole_masters("state_dict()")
         sd = {k: v.clone() for k, v in self.buffers.items() if self.homog or k == "mean"}
         sd.update({k: v.detach().clone() for k, v in self._views().items()})
         return sd
@@ -187,13 +200,17 @@ class HeadTrainer:
             v.copy_(sd[k].to(torch.float32).view_as(v))
         if "mean" in sd and not torch.allclose(sd["mean"].float().view(3).cpu(), self.mean):
             raise ValueError("mean of the checkpoint differs from the mean this trainer was created with")
+        self._masters_partial = False      # every master has just been overwritten
         self.sync_weights()
 
     def load_flat(self, flat):
         self.params.copy_(torch.as_tensor(flat, dtype=torch.float32).to(self.device))
+        self._masters_partial = False
         self.sync_weights()
 
     def sync_weights(self):
+        """Recast the 16-bit compute copies from the fp32 masters (after the caller rewrote them)."""
+        self._require_whole_masters("sync_weights()")   # would clobber the imported 16-bit copies of foreign layers with stale masters
         N.check(self.lib.acez_trainer_sync_weights(self._h, _stream()))
 
     # ---------------------------------------------------------------- training buffer
@@ -234,6 +251,8 @@ class HeadTrainer:
     def update_layers(self, layer_lo, layer_hi):
         """AdamW on the weight matrices of wide layers [layer_lo, layer_hi) + all small parameters + the schedule bookkeeping."""
         N.check(self.lib.acez_train_update_layers(self._h, int(layer_lo), int(layer_hi), _stream()))
+        if (int(layer_lo), int(layer_hi)) != (0, self.L):
+            self._masters_partial = True
 
     def new_weights16_buffer(self):
         """[L, 512 * 512 / 2] device tensor of int32 words (two 16-bit weights each; a dtype every torch.distributed backend moves): the

@@ -39,8 +39,10 @@ class Regressor:
             raise ValueError("the head kernels are built for 512 encoder features (ace_network.py:22 default)")
         # an inference-only context: max_batch rows per internal pass of the head (whole chunks of frames: with >= 32768 rows the
         # layers run on the encoder's large-tile kernels)
+        # dtype is pinned: the encoder emits bf16 rows and they reach the head by raw pointer (acez_head_forward_maps), so the head's
+        # operand format must not follow $ACEZ_DTYPE here
         self.heads = HeadTrainer(mean, num_head_blocks=num_head_blocks, use_homogeneous=use_homogeneous, max_batch=max(4, max_frames) * oh * ow,
-                                 device=device, **kw)
+                                 device=device, dtype="bf16", **kw)
         self.heads.load_state_dict(hs)
         self.device = self.heads.device
 

@@ -174,6 +174,8 @@ class ShardedDataParallel:
             if hi > lo:
                 for x in self.trainer.master_tensors():
                     dist.broadcast(x[lo * self.stride:hi * self.stride], src=self._global(r), group=self.group)
+        if hasattr(self.trainer, "masters_synced"):
+            self.trainer.masters_synced()
 
 
 def make_data_parallel(trainer, group=None, mode=None):

@@ -455,7 +455,8 @@ class ReconstructionSession:
         slots = self._slots(ids)
         nb = sum(1 for k in head_sd if k.endswith("c0.weight"))
         head = HeadTrainer(head_sd["mean"].float().view(3), num_head_blocks=nb, use_homogeneous=head_sd["fc3.weight"].shape[0] == 4,
-                           max_batch=min(count, 64) * self.hw, iterations=1, device=self.dev.index)
+                           max_batch=min(count, 64) * self.hw, iterations=1, device=self.dev.index,
+                           dtype="bf16")   # self.features holds the encoder's bf16 rows, handed over by raw pointer below
         head.load_state_dict(head_sd)
         contiguous = bool(np.all(np.diff(slots.cpu().numpy()) == 1)) if count > 1 else True
         for c0 in range(0, count, 64):

@@ -263,7 +263,10 @@ int acez_trainer_import_weights16(acez_trainer* tr, int layer_lo, int layer_hi, 
 int acez_train_step(acez_trainer* tr, const int64_t* d_indices, int n, void* stream);
 /* acez_train_step with the NEXT step's indices announced (run_epoch walks consecutive slices of one permutation, ace_trainer.py:466-494,
  * so the caller knows them): the next batch is gathered, and this step's schedule bookkeeping done, inside this step's optimiser
- * launch. The next call must pass the same device pointer and count to profit; anything else is still correct. NULL = acez_train_step. */
+ * launch. The next call must pass the same device pointer and count to profit; a different pointer or count is still correct (the batch
+ * is then gathered again). The rows gathered ahead are recognised by (pointer, count) only: the n_next indices at d_indices_next must
+ * not be rewritten, nor their memory freed and reused, between this call and the next step call -- acez_trainer_set_buffer and
+ * acez_trainer_sync_weights drop the rows gathered ahead. NULL = acez_train_step. */
 int acez_train_step_next(acez_trainer* tr, const int64_t* d_indices, int n, const int64_t* d_indices_next, int n_next, void* stream);
 /* Synchronises `stream` and copies the schedule state. */
 int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out, void* stream);
