@@ -1,6 +1,7 @@
 """ctypes binding of libacez.so (include/acez.h).  No compute happens in Python: every call below enqueues HIP
 kernels through the C ABI.  There is deliberately NO fallback: if the library is missing it is built with hipcc,
 and if that fails the import error propagates."""
+import contextlib
 import ctypes as C
 import os
 
@@ -112,23 +113,46 @@ SYMBOLS = {
 }
 
 
+def _load(path, lenient=False):
+    if not os.path.exists(path):
+        raise RuntimeError("libacez.so is missing and could not be built: the HIP extension is mandatory")
+    L = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        if lenient and not hasattr(L, name):
+            continue
+        fn = getattr(L, name)  # AttributeError here means the library does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
 def lib():
     """Load (building first if needed) libacez.so and declare every prototype."""
     global _lib
     if _lib is None:
-        other = os.environ.get("ACEZ_LIB")   # diagnostics only (tools/lib_ab.sh): time an older build of the library on the same box
-        path = other or _build.build()
-        if not os.path.exists(path):
-            raise RuntimeError("libacez.so is missing and could not be built: the HIP extension is mandatory")
-        L = C.CDLL(path)
-        for name, (res, args) in SYMBOLS.items():
-            if other and not hasattr(L, name):
-                continue
-            fn = getattr(L, name)  # AttributeError here means the library does not export the ABI
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        other = os.environ.get("ACEZ_LIB")   # diagnostics only (tools/lib_variant.sh): time another build of the library on the same box
+        if other == "diag":
+            other = _build.build(diag=True)
+        _lib = _load(other or _build.build(), lenient=bool(other))
     return _lib
+
+
+_diag = None
+
+
+@contextlib.contextmanager
+def diag_library():
+    """tests/ and tools/ only: inside the block lib() is the diagnostics build (libacez_diag.so = the same sources with -DACEZ_DIAG), the
+    only build in which the ACEZ_* ablation switches, the measured-and-rejected kernels and the fault-injection hooks exist. Objects
+    created inside keep that library (HeadTrainer.lib) and must be used and closed inside the block."""
+    global _lib, _diag
+    if _diag is None:
+        _diag = _load(_build.build(diag=True))
+    saved, _lib = _lib, _diag
+    try:
+        yield _diag
+    finally:
+        _lib = saved
 
 
 class AcezError(RuntimeError):

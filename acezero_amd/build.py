@@ -13,6 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacez.so")
 STAMP = os.path.join(HERE, ".libacez.stamp")
+# the diagnostics build (-DACEZ_DIAG): ablation switches, measured-and-rejected kernels, fault-injection hooks. tests/ and tools/ only
+# (acezero_amd._native.diag_library()); nothing in the product loads it.
+LIB_DIAG = os.path.join(HERE, "libacez_diag.so")
+STAMP_DIAG = os.path.join(HERE, ".libacez_diag.stamp")
 
 # translation unit -> extra flags.  The RANSAC and point-cloud units must not contract a*b+c into fma: their arithmetic
 # is compared bit-for-bit with the CPU oracle (DESIGN.md "Determinism").
@@ -47,15 +51,17 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP unit for gfx950 and link libacez.so. Returns the library path."""
-    digest = _digest()
+def build(force=False, verbose=False, diag=False):
+    """Compile every HIP unit for gfx950 and link libacez.so (diag=True: libacez_diag.so, the same sources with -DACEZ_DIAG).
+    Returns the library path."""
+    LIB, STAMP = (LIB_DIAG, STAMP_DIAG) if diag else (globals()["LIB"], globals()["STAMP"])
+    digest = _digest() + ("-diag" if diag else "")
     if not force and os.path.exists(LIB) and os.path.exists(STAMP):
         with open(STAMP) as f:
             if f.read().strip() == digest:
                 return LIB
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_diag" if diag else "build")
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
@@ -65,7 +71,7 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"missing source {src}")
         obj = os.path.join(objdir, unit.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + COMMON + extra + ["-c", src, "-o", obj]
+        cmd = [hipcc] + COMMON + extra + (["-DACEZ_DIAG"] if diag else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -85,4 +91,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

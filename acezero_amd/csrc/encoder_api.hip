@@ -477,7 +477,7 @@ __global__ __launch_bounds__(1024) void convgemm256_kernel(ConvGemmArgs a) {
         __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(slot + 128 * 64 + (lw * 4 + j) * 8 * 64), 16, 0, 0);
       }
     };
-    const bool do_loads = !(a.dbg & 4);
+    const bool do_loads = !(ACEZ_DBG(a.dbg) & 4);
     if (do_loads) for (int kt = 0; kt < 3 && kt < KT; ++kt) issue(kt);
     for (int kt = 0; kt < KT; ++kt) {
       // issued so far: 0..2 at kt = 0, 0..kt+1 afterwards; 6 DMA instructions per stage, in-order completion
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(1024) void convgemm256_kernel(ConvGemmArgs a) {
     const int fr = l & 31, fh = l >> 5;
     for (int kt = 0; kt < KT; ++kt) {
       __builtin_amdgcn_s_barrier();
-      if (a.dbg & 2) continue;
+      if (ACEZ_DBG(a.dbg) & 2) continue;
       const uint16_t* sW = smem + ((kt + rot) % 3) * STAGE;
       const uint16_t* sI = sW + 128 * 64;
 #pragma unroll
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
         __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(slot + 256 * 32 + (lw * 4 + j) * 16 * 32), 16, 0, 0);
       }
     };
-    const bool do_loads = !(a.dbg & 4);
+    const bool do_loads = !(ACEZ_DBG(a.dbg) & 4);
     if (do_loads) for (int kt = 0; kt < 4 && kt < KT; ++kt) issue(kt);
     for (int kt = 0; kt < KT; ++kt) {
       const int later = (kt == 0) ? min(3, KT - 1) : min(2, KT - 1 - kt);
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
     const int fr = l & 31, fh = l >> 5;
     for (int kt = 0; kt < KT; ++kt) {
       __builtin_amdgcn_s_barrier();
-      if (a.dbg & 2) continue;
+      if (ACEZ_DBG(a.dbg) & 2) continue;
       const uint16_t* sW = smem + (kt & 3) * STAGE;
       const uint16_t* sI = sW + 256 * 32;
 #pragma unroll
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
     for (int j = 0; j < 4; ++j) {
       const int row = (lw * 4 + j) * 16 + lrow;
       gW[j] = a.W + (size_t)(n0 + row) * Kp + (lch ^ ((row >> 2) & 3)) * 8;
-      if (a.dbg & 32) gW[j] = a.W + (size_t)(row & 15) * Kp + lch * 8;   // ablation: same bytes into LDS, but from 16 hot rows
+      if (ACEZ_DBG(a.dbg) & 32) gW[j] = a.W + (size_t)(row & 15) * Kp + lch * 8;   // ablation: same bytes into LDS, but from 16 hot rows
     }
     // patch rows (lw * 7 + j) * 16 + lrow, j < 7: global pixel m0 - Wi - 1 + row, clamped (clamped rows are never validly read)
     const uint16_t* gP[7];
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
     int islot = 0;                            // ring slot of the next weight stage to issue
     auto issue_w = [&](int s) {
       const int cc = s / 9, tap = s - cc * 9;
-      const int koff = (a.dbg & 32) ? 0 : tap * a.Ci + cc * 32;
+      const int koff = (ACEZ_DBG(a.dbg) & 32) ? 0 : tap * a.Ci + cc * 32;
       uint16_t* slot = smem + islot * WSTAGE;
       islot = (islot == WRING - 1) ? 0 : islot + 1;
 #pragma unroll
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
         default: ACEZ_VMCNT(27); break;
       }
       __builtin_amdgcn_s_barrier();   // W(s) (and, at a chunk start, its patch) has landed; the multipliers are done with stage s - 1
-      if (s >= 1 && s + WRING - 1 < S && !((a.dbg & 64) && (s & 1))) issue_w(s + WRING - 1);   // ablation 64: every other weight stage is not fetched
+      if (s >= 1 && s + WRING - 1 < S && !((ACEZ_DBG(a.dbg) & 64) && (s & 1))) issue_w(s + WRING - 1);   // ablation 64: every other weight stage is not fetched
       const int cc = s / 9;
       if (s == cc * 9 && cc + 1 < NC) {   // first stage of chunk cc: the other patch buffer (chunk cc - 1) is free now
         issue_patch(cc + 1);
@@ -1232,12 +1232,12 @@ void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s, int tile_m
                         g.Ci % 32 == 0 && g.Co % 256 == 0 && g.K == g.Kp;
   // the patch kernel pays from one tile per CU on (16 frames of 480x640 at Co = 256: 0.0925 -> 0.0775 ms per frame against the
   // 80-row / 256 x 128 kernels; 32 frames: 0.0715 -> 0.067); round 1's conv3x3p needed four waves of tiles to win
-  static const int patch_min_tiles = [] { const char* e = getenv("ACEZ_PATCH_MIN_TILES"); return e ? atoi(e) : 256; }();
+  static const int patch_min_tiles = [] { const char* e = ACEZ_DIAG_ENV("ACEZ_PATCH_MIN_TILES"); return e ? atoi(e) : 256; }();
   if (patch_ok && (tile_mode == 3 || (tile_mode == 0 && (int64_t)((g.M + 255) / 256) * (g.Co / 256) >= patch_min_tiles))) {
     const int ntiles = g.Co / 256, mtiles = (g.M + 255) / 256;
     const dim3 grid(8 * ntiles * ((mtiles + 7) / 8)), blk(768);
-    static const int wring = [] { const char* e = getenv("ACEZ_P3_WRING"); return (e && atoi(e) == 6) ? 6 : 4; }();
-    static const int lean = [] { const char* e = getenv("ACEZ_P3Q"); return e ? atoi(e) : 2; }();   // 2 (default): conv3x3r, 0: conv3x3p
+    static const int wring = [] { const char* e = ACEZ_DIAG_ENV("ACEZ_P3_WRING"); return (e && atoi(e) == 6) ? 6 : 4; }();
+    static const int lean = [] { const char* e = ACEZ_DIAG_ENV("ACEZ_P3Q"); return e ? atoi(e) : 2; }();   // 2 (default): conv3x3r, 0: conv3x3p
     if (!relu) abort();
     if (lean) {
       const dim3 blkq(512);
@@ -1445,8 +1445,8 @@ extern "C" int acez_encoder_create(acez_encoder** out, const float* const* h_wei
   ACEZ_HIP_CHECK(hipSetDevice(device));
   acez_encoder* e = new acez_encoder();
   e->device = device; e->out_channels = out_channels; e->max_frames = max_frames; e->max_h = max_h; e->max_w = max_w;
-  if (const char* tm = getenv("ACEZ_CONV_TILE")) e->tile_mode = atoi(tm);
-  if (const char* f12 = getenv("ACEZ_CONV12")) e->fuse12 = atoi(f12) != 0;
+  if (const char* tm = ACEZ_DIAG_ENV("ACEZ_CONV_TILE")) e->tile_mode = atoi(tm);
+  if (const char* f12 = ACEZ_DIAG_ENV("ACEZ_CONV12")) e->fuse12 = atoi(f12) != 0;
   auto A = [&](void** p, size_t bytes) -> hipError_t {
     hipError_t rc = hipMalloc(p, bytes);
     if (rc == hipSuccess) e->allocs.push_back(*p);
@@ -1546,7 +1546,7 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
       g.In = in; g.W = e->W[li]; g.bias = e->bias[li]; g.add = add; g.out = outp; g.zeros = e->zeros;
       g.Hi = hi; g.Wi = wi; g.Ci = L.ci; g.ci_shift = __builtin_ctz(L.ci); g.Ho = ho; g.Wo = wo; g.Co = e->co[li];
       g.ksize = L.k; g.stride = L.stride; g.pad = L.k / 2; g.K = e->K[li]; g.Kp = e->Kp[li]; g.M = F * ho * wo;
-      if (const char* d = getenv("ACEZ_CONV_DBG")) g.dbg = atoi(d);
+      if (const char* d = ACEZ_DIAG_ENV("ACEZ_CONV_DBG")) g.dbg = atoi(d);
       launch_convgemm(g, relu, s, e->tile_mode);
     };
     if (!e->fuse12) conv(1, e->a1, h, w, e->a2, h2, w2, nullptr, true);

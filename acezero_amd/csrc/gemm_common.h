@@ -4,6 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Ablation bits of the argument structs (`dbg` fields; tools/ablate_rowgemm.hip, tools/loss_ablate.py, tools/enc_ablate.sh) are read only in
+// the diagnostics build: in the product library they are the constant 0 and the branches they guard do not exist.
+#ifdef ACEZ_DIAG
+#define ACEZ_DBG(x) (x)
+#else
+#define ACEZ_DBG(x) 0
+#endif
+
 namespace acez {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -2,8 +2,11 @@
 // Host-side orchestration only: every entry point enqueues kernels of head_kernels.hip on the caller's stream.
 #include "head_kernels.hip"
 #include "pose_fused.hip"
+#include "acez_common.h"
+#ifdef ACEZ_DIAG   // measured-and-rejected row-persistent kernels: diagnostics build only
 #include "head_fused.hip"
 #include "head_chain.hip"
+#endif
 #include "conv_launch.h"
 #include <stdlib.h>
 #include <string.h>
@@ -163,7 +166,7 @@ static int seq_placement_probe(acez_trainer* tr) {
   hipDeviceProp_t prop;
   ACEZ_HIP_CHECK(hipGetDeviceProperties(&prop, tr->device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 || tr->n_cus < 256) { tr->seq = false; tr->seq_probe = 0; return ACEZ_OK; }
-  if (getenv("ACEZ_SEQ_NOPROBE")) return ACEZ_OK;
+  if (ACEZ_DIAG_ENV("ACEZ_SEQ_NOPROBE")) return ACEZ_OK;
   uint32_t* d_rec = nullptr;
   ACEZ_HIP_CHECK(hipMalloc((void**)&d_rec, 256 * sizeof(uint32_t)));
   uint32_t h[256];
@@ -237,18 +240,18 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_REQUIRE(tr, "out of host memory");
   ACEZ_HIP_CHECK(hipGetDevice(&tr->device));
   tr->cfg = *cfg;
-  if (const char* e = getenv("ACEZ_FUSED_FWD")) tr->fused_fwd = atoi(e) != 0;
-  if (const char* e = getenv("ACEZ_CHAIN")) tr->chain = atoi(e) != 0;
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_FUSED_FWD")) tr->fused_fwd = atoi(e) != 0;
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_CHAIN")) tr->chain = atoi(e) != 0;
   if (tr->fused_fwd) tr->chain = false;
   tr->f16 = cfg->compute_dtype == ACEZ_DTYPE_FP16;
   if (tr->f16) { tr->fused_fwd = false; tr->chain = false; }   // the opt-in row-persistent kernels exist in bf16 only
-  if (const char* e = getenv("ACEZ_LOSS_ROWS")) tr->loss_rows = (atoi(e) == 8) ? 8 : 4;
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_LOSS_ROWS")) tr->loss_rows = (atoi(e) == 8) ? 8 : 4;
   if (tr->chain) tr->loss_rows = 8;   // the chain kernel's loss phase owns 32-row tiles; partial counts follow it
-  if (const char* e = getenv("ACEZ_POSE_FUSED")) tr->pose_fused = atoi(e) != 0;
-  if (const char* e = getenv("ACEZ_POSE_TILE")) { const int v = atoi(e); tr->pose_tile = tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
-  if (const char* e = getenv("ACEZ_POSE_TILE_FWD")) { const int v = atoi(e); tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_POSE_FUSED")) tr->pose_fused = atoi(e) != 0;
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_POSE_TILE")) { const int v = atoi(e); tr->pose_tile = tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_POSE_TILE_FWD")) { const int v = atoi(e); tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
   if (cfg->pose_refinement != 2 || tr->chain || tr->fused_fwd) tr->pose_fused = false;   // (the opt-in row-persistent kernels keep round 2's pose launches)
-  if (cfg->pose_refinement != 0 && !tr->pose_fused && !(getenv("ACEZ_POSE_STREAM") && atoi(getenv("ACEZ_POSE_STREAM")) == 0)) {
+  if (cfg->pose_refinement != 0 && !tr->pose_fused && !(ACEZ_DIAG_ENV("ACEZ_POSE_STREAM") && atoi(ACEZ_DIAG_ENV("ACEZ_POSE_STREAM")) == 0)) {
     ACEZ_HIP_CHECK(hipStreamCreateWithFlags(&tr->pose_stream, hipStreamNonBlocking));
     for (hipEvent_t* e : {&tr->ev_begin, &tr->ev_pose_fwd, &tr->ev_loss, &tr->ev_pose_bwd}) ACEZ_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
@@ -261,7 +264,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->n_params = params->n_params;
   tr->fc3_stride = ((int64_t)tr->no * 513 + 3) & ~3LL;
   tr->max_batch = cfg->max_batch;
-  if (const char* e = getenv("ACEZ_GEMM_TILE")) tr->gemm_tile = atoi(e) == 128 ? 128 : 80;
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_GEMM_TILE")) tr->gemm_tile = atoi(e) == 128 ? 128 : 80;
   if (tr->f16) tr->gemm_tile = 80;
   if (const char* e = getenv("ACEZ_SEQ")) tr->seq = atoi(e) != 0;
   {
@@ -271,7 +274,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   }
   // wgrad_kernel: 16 tiles per layer; wgrad256_kernel (ACEZ_WGRAD_TILE=256, measured alternative: -2.8 us of wgrad, +2.4 us of
   // adamw for the two extra slabs): 8; as many row slabs as fill the 256 CUs
-  if (const char* e = getenv("ACEZ_WGRAD_TILE")) tr->wgrad_tile = atoi(e) == 256 ? 256 : 128;
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGRAD_TILE")) tr->wgrad_tile = atoi(e) == 256 ? 256 : 128;
   if (tr->f16) tr->wgrad_tile = 128;
   tr->nslabs = 256 / ((tr->wgrad_tile == 128 ? 16 : 8) * tr->L);
   if (tr->nslabs < 1) tr->nslabs = 1;
@@ -305,12 +308,12 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->seq_err = reinterpret_cast<int*>(tr->seq_flags + 64 * 32);
   if (const char* e = getenv("ACEZ_SEQ_SPIN_US")) tr->seq_spin_limit = (uint32_t)std::max(1L, atol(e)) * 2u;
   if (rc == ACEZ_OK) (void)hipMemcpy(tr->seq_flags + 64 * 32 + 1, &tr->seq_spin_limit, sizeof(uint32_t), hipMemcpyHostToDevice);
-  if (const char* e = getenv("ACEZ_SEQ_FAULT_AT")) tr->seq_fault_at = atol(e);
-  if (getenv("ACEZ_SEQ_XCC")) {
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_SEQ_FAULT_AT")) tr->seq_fault_at = atol(e);
+  if (ACEZ_DIAG_ENV("ACEZ_SEQ_XCC")) {
     A((void**)&tr->seq_xcc, (8 + 256) * sizeof(uint32_t));
     if (rc == ACEZ_OK) (void)hipMemset(tr->seq_xcc, 0, (8 + 256) * sizeof(uint32_t));
   }
-  if (getenv("ACEZ_CHAIN_TRACE")) {
+  if (ACEZ_DIAG_ENV("ACEZ_CHAIN_TRACE")) {
     A((void**)&tr->chain_trace, 512 * sizeof(unsigned long long));
     if (rc == ACEZ_OK) (void)hipMemset(tr->chain_trace, 0, 512 * sizeof(unsigned long long));
   }
@@ -425,6 +428,7 @@ extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
   return ACEZ_OK;
 }
 
+#ifdef ACEZ_DIAG
 // persistent row-tile forward: gather (idx may be null) + all wide layers in one launch; returns the fc2 output buffer
 static uint16_t* launch_forward_fused(acez_trainer* tr, const uint16_t* feat, const int64_t* idx, int n, bool keep, const TrainState* st,
                                       hipStream_t s) {
@@ -443,6 +447,10 @@ static uint16_t* launch_forward_fused(acez_trainer* tr, const uint16_t* feat, co
   tr->prof_launches += tr->L;  // accounted as L layer-GEMMs so that the per-layer average stays comparable
   return tr->out[f2];
 }
+
+#else
+static uint16_t* launch_forward_fused(acez_trainer*, const uint16_t*, const int64_t*, int, bool, const TrainState*, hipStream_t) { abort(); }   // (tr->fused_fwd is never set in the product build)
+#endif
 
 // forward chain on n rows whose input features are in `in0`; returns the fc2 output buffer
 // rowseq_kernel is usable when its workgroups wait for each other safely: all of them resident at once
@@ -549,9 +557,10 @@ static void fill_loss_train(acez_trainer* tr, LossArgs& a, const uint16_t* act, 
   a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
   a.bias_partials = tr->bias_partials + (size_t)f2 * tr->bias_layer_stride; a.dbg = 0;
   a.absmax = tr->f16 ? tr->st->dz_absmax_slots : nullptr;
-  if (const char* e = getenv("ACEZ_LOSS_DBG")) a.dbg = atoi(e);   // ablation: 1 = stop after phase A, 2 = after phase B (timing only)
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_LOSS_DBG")) a.dbg = atoi(e);   // ablation: 1 = stop after phase A, 2 = after phase B (timing only)
 }
 
+#ifdef ACEZ_DIAG
 // The dependent chain of a step as one launch of chain_kernel (head_chain.hip). phases: 1 = gather + forward (the fc2 output
 // is stored for a later phase-2 launch), 2 = loss + input gradients (from the stored fc2 output), 3 = everything.
 static void launch_chain(acez_trainer* tr, const int64_t* d_indices, int n, int phases, bool pose_tables, hipStream_t s) {
@@ -561,7 +570,7 @@ static void launch_chain(acez_trainer* tr, const int64_t* d_indices, int n, int 
   c.idx = d_indices; c.g_in = tr->R[0]; c.g_dz_last = tr->dZ[f2]; c.maskbits = tr->maskbits;
   c.bias_partials = tr->bias_partials; c.bias_layer_stride = tr->bias_layer_stride;
   c.n = n; c.phases = phases; c.st = tr->st; c.err = tr->chain_err; c.trace = tr->chain_trace;
-  if (const char* e = getenv("ACEZ_CHAIN_DBG")) c.dbg = atoi(e);
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_CHAIN_DBG")) c.dbg = atoi(e);
   const float* P = tr->pb.d_params;
   int k = 0;
   auto fwd = [&](int l, uint16_t* g_out, const uint16_t* r_in, int mask_layer) {
@@ -598,6 +607,10 @@ static void launch_chain(acez_trainer* tr, const int64_t* d_indices, int n, int 
   if (c.dbg) hipLaunchKernelGGL(chain_kernel<true>, dim3((n + CHAIN_ROWS - 1) / CHAIN_ROWS), dim3(CHAIN_THREADS), 0, s, c);
   else hipLaunchKernelGGL(chain_kernel<false>, dim3((n + CHAIN_ROWS - 1) / CHAIN_ROWS), dim3(CHAIN_THREADS), 0, s, c);
 }
+
+#else
+static void launch_chain(acez_trainer*, const int64_t*, int, int, bool, hipStream_t) { abort(); }   // (tr->chain is never set in the product build)
+#endif
 
 // ---- pose refinement (the flat parameter offsets in PoseNetwork.named_parameters() order are PN_* in pose_kernels.hip)
 static PoseNetArgs pose_net_args(acez_trainer* tr, const int* active) {
@@ -638,8 +651,8 @@ static void launch_pose_wgrad(acez_trainer* tr, const int* active, bool fuse, hi
   w.I = I; w.grad = tr->pb.d_grad + tr->n_params + 4; w.active = active;
   w.fuse = fuse ? 1 : 0; w.p = tr->pb.d_pose_params; w.m = tr->pb.d_pose_m; w.v = tr->pb.d_pose_v; w.Wt = tr->pose_wt;
   w.sc = &tr->st->pose_adam; w.enable = &tr->st->pose_enable; w.fault = tr->seq_err;
-  static const int wb = getenv("ACEZ_POSE_WB") ? atoi(getenv("ACEZ_POSE_WB")) : 16;   // operand steps requested per round trip
-  static const int ww = getenv("ACEZ_POSE_WW") ? atoi(getenv("ACEZ_POSE_WW")) : 8;    // waves per workgroup
+  static const int wb = ACEZ_DIAG_ENV("ACEZ_POSE_WB") ? atoi(ACEZ_DIAG_ENV("ACEZ_POSE_WB")) : 16;   // operand steps requested per round trip
+  static const int ww = ACEZ_DIAG_ENV("ACEZ_POSE_WW") ? atoi(ACEZ_DIAG_ENV("ACEZ_POSE_WW")) : 8;    // waves per workgroup
   if (wb == 16 && ww == 4) hipLaunchKernelGGL((pose_mlp_wgrad_kernel<16, 4>), dim3(jobs), dim3(256), 0, s, w);
   else if (wb == 16) hipLaunchKernelGGL((pose_mlp_wgrad_kernel<16, 8>), dim3(jobs), dim3(512), 0, s, w);
   else if (ww == 4) hipLaunchKernelGGL((pose_mlp_wgrad_kernel<32, 4>), dim3(jobs), dim3(256), 0, s, w);
@@ -859,7 +872,11 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     const int groups = tr->L * tr->nslabs;
     if (tr->f16) hipLaunchKernelGGL(wgrad_kernel<EltF16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
     else if (tr->wgrad_tile == 128) hipLaunchKernelGGL(wgrad_kernel<EltBf16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
+#ifdef ACEZ_DIAG
     else hipLaunchKernelGGL(wgrad256_kernel, dim3(64 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
+#else
+    else abort();   // (wgrad_tile is 128 in the product build)
+#endif
   }
   {
     GradReduceArgs a{};
@@ -938,7 +955,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     // overrides the count (timing experiments).
     int gcap = 4 * tr->n_cus - n_adam - 1;
     if (gcap < 64) gcap = 64;
-    if (const char* e = getenv("ACEZ_NEXT_GBLOCKS")) gcap = std::max(1, atoi(e));
+    if (const char* e = ACEZ_DIAG_ENV("ACEZ_NEXT_GBLOCKS")) gcap = std::max(1, atoi(e));
     const int gwant = (n_next + 3) / 4 < 1024 ? (n_next + 3) / 4 : 1024;
     const int gblocks = gwant < gcap ? gwant : gcap;
     { ProfScope ps(tr, s, KC_ADAMW);

@@ -2,6 +2,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "gemm_common.h"   // ACEZ_DBG
+
 namespace acez {
 
 constexpr int MAX_LAYERS = 20;

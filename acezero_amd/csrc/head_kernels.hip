@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
       __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)&smem[slot][1][(w * 4 + j) * 8 * 64], 16, 0, 0);
     }
   };
-  if (!(a.dbg & 4)) { issue(0); issue(1); issue(2); issue(3); }
+  if (!(ACEZ_DBG(a.dbg) & 4)) { issue(0); issue(1); issue(2); issue(3); }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
     else if (kt == 6) ACEZ_VMCNT(8);
     else ACEZ_VMCNT(0);
     __builtin_amdgcn_s_barrier();  // every wave's share of stage kt has landed; everyone is done with stage kt-1
-    if (kt >= 1 && kt + 3 < KT && !(a.dbg & 4)) issue(kt + 3);  // refill the slot read in the previous iteration
-    if (a.dbg & 2) continue;
+    if (kt >= 1 && kt + 3 < KT && !(ACEZ_DBG(a.dbg) & 4)) issue(kt + 3);  // refill the slot read in the previous iteration
+    if (ACEZ_DBG(a.dbg) & 2) continue;
     const int slot = kt & 3;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
   // storing that directly touches 32 rows x 16 B per instruction and was measured at 8-12 us per launch
   // (tools/ablate_rowgemm.hip), 2x the rest of the kernel. Each wave owns two [64][72] bf16 regions of the
   // (now idle) ring: A = `add` in / aux out, B = mask|res in / main out.
-  if (a.dbg & 1) { if (acc[0][0][0] == 1.2345e30f) a.out_main[0] = 1; return; }
+  if (ACEZ_DBG(a.dbg) & 1) { if (acc[0][0][0] == 1.2345e30f) a.out_main[0] = 1; return; }
   if (!active) return;  // schedule ended (ace_trainer.py:509-510): nothing is written
   __syncthreads();  // every wave is done reading the ring
   constexpr int EP = 72;
@@ -330,7 +330,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
   if (w >= 4) {
     // ------------------------------------------------------------------ loader waves
     const int lw = w - 4;
-    if (a.dbg & 4) {
+    if (ACEZ_DBG(a.dbg) & 4) {
       for (int kt = 0; kt < KT + 1; ++kt) __builtin_amdgcn_s_barrier();
     } else {
       // W instructions 4lw .. 4lw+3 (8 rows each), In instructions 3lw .. 3lw+2; lane: row + (l>>3), slot l&7
@@ -441,7 +441,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         issueW(0); issueW(1); issueW(2); issueW(3);
       }
     }
-    if (!SEQ && ((a.dbg & 1) || !active)) return;
+    if (!SEQ && ((ACEZ_DBG(a.dbg) & 1) || !active)) return;
     __builtin_amdgcn_s_barrier();       // the multipliers have written the output tiles
   } else {
     // ------------------------------------------------------------------ multiplier waves
@@ -458,21 +458,19 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
 #pragma unroll
       for (int i = 0; i < 2; ++i) bias[i] = *reinterpret_cast<const float4*>(a.bias + n0 + w * 32 + i * 16 + 4 * fq);
     }
-    // SEQ: a.dbg is a compile-time 0 there, the K loop becomes straight-line code and the scheduler sinks the second half's MFMAs
-    // below the next s_barrier -- their ds_reads would still be in flight when the loader waves, released by that barrier,
-    // refill the slot (only the DMA latency protects them: a rare last-bit corruption under two processes on one GPU). Keep the
-    // fragment reads of a stage complete before the wave arrives at the barrier, as the branchy non-SEQ code does by construction.
+    // The K loop is straight-line code (the ablation bits are compile-time 0 in the product build): without this the scheduler sinks
+    // the second half's MFMAs below the next s_barrier -- their ds_reads would still be in flight when the loader waves, released by
+    // that barrier, refill the slot (only the DMA latency protects them: a rare last-bit corruption under two processes on one GPU,
+    // found with tools/seq_stress.py). Keep the fragment reads of a stage complete before the wave arrives at the barrier.
     auto stage_barrier = [&]() {
-      if (SEQ) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       stage_barrier();
-      if (a.dbg & 2) continue;
+      if (ACEZ_DBG(a.dbg) & 2) continue;
       const uint16_t* sW = smem + (kt & 3) * STAGE;
       const uint16_t* sI = sW + 128 * 64;
 #pragma unroll
@@ -490,7 +488,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
       }
     }
     stage_barrier();                    // epilogue inputs have landed
-    if (!SEQ && ((a.dbg & 1) || !active)) return;
+    if (!SEQ && ((ACEZ_DBG(a.dbg) & 1) || !active)) return;
     float amax = 0.f;                   // fp16 gradient layers: largest |value| before the conversion (absmax_publish)
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -719,14 +717,20 @@ __global__ __launch_bounds__(512) void seq_probe_kernel(uint32_t* rec /*[256]*/,
 // host-side dispatch on the epilogue shape (the flags of RowGemmArgs select the instantiation)
 static inline void launch_rowgemm(const RowGemmArgs& g, int tile, hipStream_t s, bool f16 = false) {
   const dim3 blk(256);
+  (void)blk;   // (the 128-row tiling of the diagnostics build)
   const bool br = g.bias != nullptr;
   const int mtiles = (g.M + tile - 1) / tile;
   const dim3 grid(8 * 4 * ((mtiles + 7) / 8));  // N = 512 -> 4 column tiles; XCD-aware decode inside the kernels
+#ifdef ACEZ_DIAG   // the 128 x 128 tiling (rowgemm_kernel) is the tested alternative of the diagnostics build; the product has 80-row tiles only
+#define ACEZ_RG128(...) hipLaunchKernelGGL((rowgemm_kernel<__VA_ARGS__>), grid, blk, 0, s, g)
+#else
+#define ACEZ_RG128(...) abort()
+#endif
 #define ACEZ_RG(...)                                                                                               \
   do {                                                                                                             \
     if (f16) hipLaunchKernelGGL((rowgemm80_kernel<__VA_ARGS__, EltF16>), grid, dim3(512), 0, s, g); /* 80-row tiles only */ \
     else if (tile == 80) hipLaunchKernelGGL((rowgemm80_kernel<__VA_ARGS__>), grid, dim3(512), 0, s, g);            \
-    else hipLaunchKernelGGL((rowgemm_kernel<__VA_ARGS__>), grid, blk, 0, s, g);                                    \
+    else ACEZ_RG128(__VA_ARGS__);                                                                                  \
   } while (0)
   if (br && g.aux_mode == AUX_NONE) ACEZ_RG(true, false, false, AUX_NONE);
   else if (br && g.aux_mode == AUX_RESIDUAL) ACEZ_RG(true, false, false, AUX_RESIDUAL);
@@ -736,6 +740,7 @@ static inline void launch_rowgemm(const RowGemmArgs& g, int tile, hipStream_t s,
   else if (!br && g.mask && g.add && g.aux_mode == AUX_NONE) ACEZ_RG(false, true, true, AUX_NONE);
   else abort();  // no other epilogue shape exists in the head
 #undef ACEZ_RG
+#undef ACEZ_RG128
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
   // Two separate loops (one per role) with the same number of barriers: sharing one loop body makes the compiler
   // carry the 64 accumulator registers through the loader's control flow (moves on every iteration).
   if (loader) {
-    if (a.dbg & 4) {
+    if (ACEZ_DBG(a.dbg) & 4) {
       for (int kt = 0; kt < KT; ++kt) __builtin_amdgcn_s_barrier();
       return;
     }
@@ -853,7 +858,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
   }
   for (int kt = 0; kt < KT; ++kt) {
     __builtin_amdgcn_s_barrier();
-    if (a.dbg & 2) continue;
+    if (ACEZ_DBG(a.dbg) & 2) continue;
     const int slot = kt & 3;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -869,7 +874,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
     }
   }
 
-  if (a.dbg & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
+  if (ACEZ_DBG(a.dbg) & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
   if (!active) return;
   float* __restrict__ G = a.slabs + (size_t)slab * a.slab_stride;
   const int h = l >> 5;
@@ -886,6 +891,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+#ifdef ACEZ_DIAG   // measured alternative tiling (DESIGN.md section 3 "Round 2" (3)): diagnostics build only
 // ---------------------------------------------------------------------------------------------------
 // wgrad256: the same product on 256 (dZ columns) x 128 (In columns) workgroup tiles, four multiplier waves of 128 x 64 each.
 // Why: wgrad_kernel is bound by the LDS, not by MFMA issue -- per 16-row step its four 64 x 64 waves read 4 x 4 KiB of transposed
@@ -937,7 +943,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad256_kernel(WgradArgs a) {
   };
 
   if (loader) {
-    if (a.dbg & 4) {
+    if (ACEZ_DBG(a.dbg) & 4) {
       for (int kt = 0; kt < KT; ++kt) __builtin_amdgcn_s_barrier();
       return;
     }
@@ -970,7 +976,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad256_kernel(WgradArgs a) {
   int slot = 0;
   for (int kt = 0; kt < KT; ++kt) {
     __builtin_amdgcn_s_barrier();
-    if (!(a.dbg & 2)) {
+    if (!(ACEZ_DBG(a.dbg) & 2)) {
       const uint16_t* sz = &smem[slot][wn][0];
       const uint16_t* sx = &smem[slot][2][0];
 #pragma unroll
@@ -989,7 +995,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad256_kernel(WgradArgs a) {
     slot = (slot == 2) ? 0 : slot + 1;
   }
 
-  if (a.dbg & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
+  if (ACEZ_DBG(a.dbg) & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
   if (!active) return;
   float* __restrict__ G = a.slabs + (size_t)slab * a.slab_stride;
   const int h = l >> 5;
@@ -1005,6 +1011,8 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad256_kernel(WgradArgs a) {
       }
     }
 }
+
+#endif  // ACEZ_DIAG
 
 // ---------------------------------------------------------------------------------------------------
 // loss kernel (32 rows per workgroup, four wavefronts):
@@ -1137,7 +1145,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (a.dbg == 1) return;
+  if (ACEZ_DBG(a.dbg) == 1) return;
 
   // ---- phase B
   const float gscale = (a.idx && a.st) ? a.st->grad_scale : 1.f;
@@ -1324,7 +1332,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (!a.idx) return;  // inference: no gradients
-  if (a.dbg == 2) return;
+  if (ACEZ_DBG(a.dbg) == 2) return;
 
   // ---- the four waves meet once: phase C reads every row's ds and, in the chain kernel, overwrites activations that the other
   // waves' phase A has read

@@ -84,3 +84,25 @@ def test_single_hip_runtime_whatever_the_import_order():
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.strip().splitlines()[-1].startswith("1 "), r.stdout
+
+
+def test_product_library_has_no_ablation_surface():
+    """the shipped library reads exactly two environment variables (neither can change a result) and contains none of
+    the measured-and-rejected kernels; everything else lives in the diagnostics build (libacez_diag.so, tests/ and tools/ only)."""
+    import re
+    import subprocess
+    from acezero_amd import build as b
+    prod = open(b.build(), "rb").read()
+    names = set(m.decode() for m in re.findall(rb"ACEZ_[A-Z][A-Z0-9_]{2,}", prod))
+    env_like = {n for n in names if not n.startswith(("ACEZ_ERR", "ACEZ_OK", "ACEZ_DTYPE", "ACEZ_POSE_MLP", "ACEZ_HIP_CHECK", "ACEZ_REQUIRE", "ACEZ_LOSS_"))}
+    assert env_like == {"ACEZ_SEQ", "ACEZ_SEQ_SPIN_US"}, sorted(env_like)
+    for kern in (b"chain_kernel", b"headfwd_kernel", b"wgrad256_kernel", b"14rowgemm_kernelI"):
+        assert kern not in prod, kern
+    diag = open(b.build(diag=True), "rb").read()
+    for kern in (b"chain_kernel", b"headfwd_kernel", b"wgrad256_kernel", b"14rowgemm_kernelI", b"ACEZ_SEQ_FAULT_AT", b"ACEZ_CHAIN"):
+        assert kern in diag, kern
+    # the same C ABI in both builds
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+        return sorted(l.split()[-1] for l in out.splitlines() if " T " in l and "acez_" in l)
+    assert exported(b.LIB) == exported(b.LIB_DIAG)

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def _loss_tiles_of_32_rows(monkeypatch):
+def _loss_tiles_of_32_rows(monkeypatch, diag_lib):   # diag_lib: chain_kernel and the switches below exist in the diagnostics build only
     """The chain kernel's loss phase sums its fc3 / bias partials over 32-row tiles; the per-layer side of these bitwise comparisons runs
     loss_kernel with the same tile (its default is 16 rows per workgroup: same values to rounding, another summation order)."""
     monkeypatch.setenv("ACEZ_LOSS_ROWS", "8")

@@ -15,7 +15,7 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("tile", ["0", "80", "256", "512", "3"])   # 3: the 3x3 patch kernel where the layer allows it
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 120, 200), (3, 41, 77)])
-def test_encoder_matches_bf16_oracle(shape, tile, monkeypatch):
+def test_encoder_matches_bf16_oracle(shape, tile, monkeypatch, diag_lib):   # ACEZ_CONV_TILE / ACEZ_CONV12: diagnostics build
     from acezero_amd.encoder import Encoder, output_size
     monkeypatch.setenv("ACEZ_CONV_TILE", tile)   # 256: the large-M kernel on small inputs (ragged last tiles everywhere)
     n, h, w = shape
@@ -36,7 +36,7 @@ def test_encoder_matches_bf16_oracle(shape, tile, monkeypatch):
     assert _rel(out, ref32) < 2e-2
 
 
-def test_separate_conv1_conv2_path_still_matches(monkeypatch):
+def test_separate_conv1_conv2_path_still_matches(monkeypatch, diag_lib):
     from acezero_amd.encoder import Encoder
     monkeypatch.setenv("ACEZ_CONV12", "0")
     sd = encoder_oracle.init_weights(seed=4099)

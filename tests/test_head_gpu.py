@@ -211,7 +211,7 @@ def test_large_batch_inference_runs_on_conv_kernels_and_matches():
 
 
 @pytest.mark.parametrize("env", [("ACEZ_GEMM_TILE", "128"), ("ACEZ_FUSED_FWD", "1")])
-def test_alternative_kernel_paths_stay_correct(env, monkeypatch):
+def test_alternative_kernel_paths_stay_correct(env, monkeypatch, diag_lib):
     """The 128 x 128 GEMM tiling and the persistent row-tile forward are kept as measured alternatives:
     same rounding points as the default path, so the same checks must hold."""
     monkeypatch.setenv(*env)

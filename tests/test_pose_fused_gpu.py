@@ -17,6 +17,12 @@ from tests.test_head_gpu import _trainer
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _diagnostics_build(diag_lib):
+    """ACEZ_POSE_FUSED / ACEZ_POSE_TILE (the side-stream launches and the other tile sizes) are switches of the diagnostics build."""
+    yield
+
+
 def _problem(n_images, patches_per_view=128):
     from acezero_amd import synth
     return synth.make_training_problem(seed=11, n_images=n_images, views_per_image=2, patches_per_view=patches_per_view)

@@ -128,7 +128,7 @@ def test_counters_keep_step_when_training_has_ended_and_batch_sizes_change():
     assert torch.equal(ref.params, new.params) and ref.state()["iteration"] == 3
 
 
-def test_sibling_workgroups_share_an_xcd():
+def test_sibling_workgroups_share_an_xcd(diag_lib):
     """The hand-off is only valid inside one XCD's L2: the four column tiles of every row tile must have run on the same XCD
     (HW_REG_XCC_ID recorded by the kernel, ACEZ_SEQ_XCC=1; tools/seq_stress.py checks the same with two processes on the GPU)."""
     import ctypes as C
@@ -180,7 +180,7 @@ def test_placement_probe_passes_on_this_gpu_and_gates_the_chains():
 
 
 @pytest.mark.parametrize("fault_at", [2, 3])   # launch 2 = the forward chain of the second step, 3 = its input-gradient chain
-def test_expired_handoff_poll_abandons_the_step_and_falls_back_to_per_layer_launches(fault_at):
+def test_expired_handoff_poll_abandons_the_step_and_falls_back_to_per_layer_launches(fault_at, diag_lib):
     """Fault injection (ACEZ_SEQ_FAULT_AT): one seam of one launch waits for a count that never comes -- what a sibling on a foreign
     XCD looks like. The poll must expire (no hang), the step it happened in must leave parameters, optimiser state and iteration
     count untouched, every later step before the next state read must be a no-op too, state() must switch the trainer to
@@ -220,7 +220,7 @@ def test_expired_handoff_poll_abandons_the_step_and_falls_back_to_per_layer_laun
     assert torch.equal(new.get_scene_coordinates(f), ref.get_scene_coordinates(f))
 
 
-def test_fault_word_travels_in_the_gradient_bucket():
+def test_fault_word_travels_in_the_gradient_bucket(diag_lib):
     """Data-parallel flow (backward / all-reduce / update): statistics slot 3 of the bucket carries the rank's fault word, so that
     after the all-reduce EVERY rank skips the optimiser step and the replicas stay identical. One process plays both ranks here:
     rank A faults, rank B does not; B receives A's slot through the (emulated) sum and must skip its update and fall back too."""

@@ -1,5 +1,6 @@
 // ablate_rowgemm.hip -- on-GPU ablation of rowgemm_kernel (tools; not part of the library).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -I acezero_amd/csrc tools/ablate_rowgemm.hip -o /tmp/ablate && /tmp/ablate
+#define ACEZ_DIAG 1   // the ablation bits (RowGemmArgs::dbg, WgradArgs::dbg, LossArgs::dbg) exist in the diagnostics build only
 #include "head_kernels.hip"
 #include <cstdio>
 #include <vector>

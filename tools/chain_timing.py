@@ -1,5 +1,7 @@
 """Step time of the training step at BASELINE's batch (5120 rows, 8 wide layers) with the one-launch chain kernel and with the
 per-layer launches (ACEZ_CHAIN=0), same process, same buffer.  python tools/chain_timing.py [buffer_patches] [steps]"""
+import os as _os
+_os.environ.setdefault("ACEZ_LIB", "diag")   # the ACEZ_* ablation switches exist in the diagnostics build only (acezero_amd/build.py --diag)
 import os
 import sys
 import time

@@ -1,5 +1,7 @@
 """Timeline of one chain_kernel launch from in-kernel s_memtime stamps (workgroup 0: multiplier wave 0 and loader 0).
 ACEZ_CHAIN_DBG=<flags> python tools/chain_trace.py"""
+import os as _os
+_os.environ.setdefault("ACEZ_LIB", "diag")   # the ACEZ_* ablation switches exist in the diagnostics build only (acezero_amd/build.py --diag)
 import ctypes as C
 import os
 import sys

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Per-kernel durations of the encoder under ablation switches: bash tools/enc_kstats.sh "0 6 2 4"
+export ACEZ_LIB=${ACEZ_LIB:-diag}   # the ablation switches exist in the diagnostics build only (python -m acezero_amd.build --diag)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export PYTHONPATH=$R

@@ -1,3 +1,5 @@
+import os as _os
+_os.environ.setdefault("ACEZ_LIB", "diag")   # the ACEZ_* ablation switches exist in the diagnostics build only (acezero_amd/build.py --diag)
 import os, sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
 import chain_timing

@@ -2,6 +2,8 @@
     ACEZ_POSE_TILE=8 ACEZ_POSE_WB=32 python tools/pose_kernels_timing.py [n_images] [rows]
 Drives the split flow (acez_train_backward / acez_train_update), in which the reduction + backward chain (pose_s1t_kernel) and the
 weight gradients (pose_mlp_wgrad_kernel) are their own launches, and acez_trainer_get_poses (pose_fwd_t_kernel)."""
+import os as _os
+_os.environ.setdefault("ACEZ_LIB", "diag")   # the ACEZ_* ablation switches exist in the diagnostics build only (acezero_amd/build.py --diag)
 import os
 import sys
 

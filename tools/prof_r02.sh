@@ -8,6 +8,7 @@
 #            the default since the end of round 2) -> kernel durations, and FETCH_SIZE / WRITE_SIZE of one rowgemm80 layer launch
 # Summaries land in gpurun_out/prof_keep/ (copied to profiles/ by hand and committed). The RANSAC kernel has its own recipe
 # (tools/prof_ransac.sh).
+export ACEZ_LIB=${ACEZ_LIB:-diag}   # the ablation switches exist in the diagnostics build only (python -m acezero_amd.build --diag)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export PYTHONPATH=$R

@@ -19,7 +19,7 @@ using namespace acez;
 // s_waitcnt vmcnt(n) for a value known after unrolling (the K loop is fully unrolled: n folds to a constant and one case survives)
 #define ACEZ_VMCNT_DYN(n) do { switch (n) { case 0: ACEZ_VMCNT(0); break; case 2: ACEZ_VMCNT(2); break; case 4: ACEZ_VMCNT(4); break; case 8: ACEZ_VMCNT(8); break; case 3: ACEZ_VMCNT(3); break; case 6: ACEZ_VMCNT(6); break; case 7: ACEZ_VMCNT(7); break; \
   case 9: ACEZ_VMCNT(9); break; case 10: ACEZ_VMCNT(10); break; case 12: ACEZ_VMCNT(12); break; case 13: ACEZ_VMCNT(13); break; case 14: ACEZ_VMCNT(14); break; \
-  case 17: ACEZ_VMCNT(17); break; case 21: ACEZ_VMCNT(21); break; default: ACEZ_VMCNT(0); break; } } while (0)
+  case 15: ACEZ_VMCNT(15); break; case 18: ACEZ_VMCNT(18); break; case 17: ACEZ_VMCNT(17); break; case 21: ACEZ_VMCNT(21); break; default: ACEZ_VMCNT(0); break; } } while (0)
 
 struct SeqArgs {
   const uint16_t* In;       // layer 0 input
@@ -258,6 +258,152 @@ __global__ __launch_bounds__(512) void rowseq_kernel(SeqArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the weight stream out of the LDS ring. rowseq_wreg_kernel keeps rowseq's tiling (80 x 128, one workgroup
+// per CU, same K order => bit-identical) but a multiplier wave holds its 32-column x 512 weight panel in REGISTERS (2 x 16 A-fragments
+// = 128 VGPRs), loaded with plain global loads right after the wave has signalled the hand-off of the layer before -- the registers are
+// dead from the end of the K loop, and the ~1.5 us until the next K loop starts (sibling stores, counter, poll, first In stage) hide the
+// 32 KiB per wave. The ring then carries In only: all eight [96 x 64] stages of a layer (96 KiB) are requested at once behind the
+// hand-off, no refills, and a K-step reads 5 fragments from LDS instead of 7.
+// FRAGW: W is read from a fragment-ordered copy (per workgroup column tile and wave: [K-step 16][column fragment 2][lane 64] x 16 B, every
+// load instruction 1 KiB contiguous) instead of row-major (sixteen 64-byte pieces per instruction).
+template <bool FRAGW>
+__global__ __launch_bounds__(512) void rowseq_wreg_kernel(SeqArgs a) {
+  constexpr int STAGE = 96 * 64;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[8 * STAGE + 80 * 128];
+  uint16_t* const stB = smem + 8 * STAGE;
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int mtiles = (a.M + 79) / 80;
+  const int per_xcd = (mtiles + 7) >> 3;
+  const int jx = blockIdx.x >> 3;
+  const int mt = (blockIdx.x & 7) * per_xcd + (jx >> 2);
+  if (mt >= mtiles) return;
+  const int nt = jx & 3, n0 = nt * 128, m0 = mt * 80;
+  const int M = a.M;
+  constexpr int K = 512, KT = 8, N = 512;
+  const int fr = l & 15, fq = l >> 4;
+  bf16x8 fa[2][16];
+  auto load_w = [&](int layer) {
+    if (FRAGW) {
+      const uint16_t* p = a.W + (size_t)layer * 512 * 512 + (size_t)(nt * 4 + w) * (32 * 512) + l * 8;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i][s] = *reinterpret_cast<const bf16x8*>(p + (s * 2 + i) * 512);
+    } else {
+      const uint16_t* p = a.W + (size_t)layer * 512 * 512 + (size_t)(n0 + w * 32) * 512;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i][s] = *reinterpret_cast<const bf16x8*>(p + (i * 16 + fr) * 512 + s * 32 + fq * 8);
+    }
+  };
+  if (w < 4) load_w(0);
+
+  for (int layer = 0; layer < a.L; ++layer) {
+    const uint16_t* In = layer ? a.out[layer - 1] : a.In;
+    if (w >= 4) {
+      const int lw = w - 4;
+      const uint16_t* gI[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int row = (lw * 3 + j) * 8 + (l >> 3);
+        gI[j] = In + (size_t)min(m0 + row, M - 1) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8;
+      }
+      if (layer > 0 && !(a.mode & 4)) {
+        const uint32_t target = (a.base + (uint32_t)layer) * 32u;
+        uint32_t seen;
+        do {
+          asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(a.flags + mt * 32) : "memory");
+          if ((int32_t)(seen - target) < 0) __builtin_amdgcn_s_sleep(1);
+        } while ((int32_t)(seen - target) < 0);
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)(smem + kt * STAGE + (lw * 3 + j) * 8 * 64), 16, 0, 0);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        ACEZ_VMCNT_DYN(3 * (KT - 1 - kt));
+        __builtin_amdgcn_s_barrier();       // stage kt has landed
+      }
+      __builtin_amdgcn_s_barrier();         // K loop over
+      __builtin_amdgcn_s_barrier();         // output tile complete
+    } else {
+      f32x4 acc[2][5];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+      float4 bias[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) bias[i] = *reinterpret_cast<const float4*>(a.bias + layer * 512 + n0 + w * 32 + i * 16 + 4 * fq);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        const uint16_t* sI = smem + kt * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int c = kk * 4 + fq;
+          bf16x8 fb[5];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz(j * 16 + fr, c)]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kt * 2 + kk], fb[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();         // K loop over (no stage is refilled in this kernel: only the staging tile is reused)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int ml = j * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int nl = w * 32 + i * 16 + 4 * fq;
+          float v[4] = {acc[i][j][0] + bias[i].x, acc[i][j][1] + bias[i].y, acc[i][j][2] + bias[i].z, acc[i][j][3] + bias[i].w};
+          *reinterpret_cast<uint2*>(&stB[st_off(ml, nl)]) = pack4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    {
+      uint16_t* out = a.out[layer];
+      const int q0 = t, q1 = t + 512, q2 = t + 1024;
+      const int so0 = (q0 >> 4) * 128 + (((q0 & 15) ^ ((q0 >> 4) & 15)) << 3);
+      const int so1 = (q1 >> 4) * 128 + (((q1 & 15) ^ ((q1 >> 4) & 15)) << 3);
+      const int so2 = (q2 < 1280) ? (q2 >> 4) * 128 + (((q2 & 15) ^ ((q2 >> 4) & 15)) << 3) : 0;
+      const uint4 m0v = *reinterpret_cast<const uint4*>(&stB[so0]);
+      const uint4 m1v = *reinterpret_cast<const uint4*>(&stB[so1]);
+      const uint4 m2v = *reinterpret_cast<const uint4*>(&stB[so2]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int r0 = m0 + (q0 >> 4), r1 = m0 + (q1 >> 4), r2 = m0 + (q2 >> 4);
+      const size_t o0 = (size_t)r0 * N + n0 + (q0 & 15) * 8, o1 = (size_t)r1 * N + n0 + (q1 & 15) * 8, o2 = (size_t)r2 * N + n0 + (q2 & 15) * 8;
+      if (r0 < M) *reinterpret_cast<uint4*>(out + o0) = m0v;
+      if (r1 < M) *reinterpret_cast<uint4*>(out + o1) = m1v;
+      if (q2 < 1280 && r2 < M) *reinterpret_cast<uint4*>(out + o2) = m2v;
+    }
+    if (layer + 1 < a.L) {
+      if (!(a.mode & 8)) ACEZ_VMCNT(0);
+      if (l == 0) {
+        const uint32_t one = 1;
+        asm volatile("global_atomic_add %0, %1, off" ::"v"(a.flags + mt * 32), "v"(one) : "memory");
+      }
+      if (w < 4) load_w(layer + 1);         // behind the signal: the vmcnt(0) above must cover the stores only
+      // the next layer's loaders write stages 0.. while a slow multiplier may still... no: every multiplier passed the "K loop over"
+      // barrier before any wave got here, and the staging tile is rewritten only after the next K loop
+    }
+  }
+}
+
 static uint16_t f2bf_host(float f) {
   uint32_t u; memcpy(&u, &f, 4);
   u += 0x7fffu + ((u >> 16) & 1u);
@@ -280,8 +426,29 @@ int main() {
   for (auto& x : hb) x = rnd() * 0.1f + 0.02f;
   CK(hipMemcpy(In, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  // fragment-ordered copy of W for rowseq_wreg_kernel<true>: element (n, k) of a layer with n = nt*128 + w*32 + i*16 + fr, k = s*32 + fq*8 + e
+  // at ((nt*4 + w) * 32 + s*2 + i) * 512 + (fq*16 + fr) * 8 + e
+  uint16_t* Wf; CK(hipMalloc(&Wf, (size_t)LMAX * 512 * 512 * 2));
+  {
+    std::vector<uint16_t> hf(hw.size());
+    for (int L = 0; L < LMAX; ++L)
+      for (int n = 0; n < 512; ++n)
+        for (int k = 0; k < 512; ++k) {
+          const int nt = n >> 7, w = (n >> 5) & 3, i = (n >> 4) & 1, fr = n & 15, s2 = k >> 5, fq = (k >> 3) & 3, e = k & 7;
+          hf[(size_t)L * 262144 + (size_t)((nt * 4 + w) * 32 + s2 * 2 + i) * 512 + (fq * 16 + fr) * 8 + e] = hw[(size_t)L * 262144 + (size_t)n * 512 + k];
+        }
+    CK(hipMemcpy(Wf, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
+  }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   uint32_t base = 0;
+  auto run_wreg = [&](int L, bool fragw, int mode) {
+    SeqArgs a{};
+    a.In = In; a.W = fragw ? Wf : W; a.bias = bias; a.flags = flags; a.base = base; a.M = M; a.L = L; a.mode = mode;
+    for (int i = 0; i < LMAX; ++i) a.out[i] = outB[i];
+    if (fragw) hipLaunchKernelGGL((rowseq_wreg_kernel<true>), dim3(256), dim3(512), 0, 0, a);
+    else hipLaunchKernelGGL((rowseq_wreg_kernel<false>), dim3(256), dim3(512), 0, 0, a);
+    base += (uint32_t)(L - 1);
+  };
   auto run_seq = [&](int L, int mode) {
     SeqArgs a{};
     a.In = In; a.W = W; a.bias = bias; a.flags = flags; a.base = base; a.M = M; a.L = L; a.mode = mode;
@@ -314,8 +481,28 @@ int main() {
       printf("L=%d mode=%d: %zu mismatching of %zu (non-zero %zu)\n", L, mode, bad, ra.size(), nz);
     }
   }
+  for (int L : {2, 8})
+    for (int fragw = 0; fragw < 2; ++fragw) {
+      for (int i = 0; i < LMAX; ++i) CK(hipMemset(outB[i], 0xff, (size_t)M * 512 * 2));
+      run_ref(L); run_wreg(L, fragw != 0, 0);
+      CK(hipDeviceSynchronize());
+      size_t bad = 0;
+      for (int li = 0; li < L; ++li) {
+        CK(hipMemcpy(ra.data(), outA[li], ra.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(rb.data(), outB[li], rb.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ra.size(); ++i) bad += ra[i] != rb[i];
+      }
+      printf("W in registers L=%d %s: %zu mismatching of %zu (all layers)\n", L, fragw ? "fragment-ordered W" : "row-major W", bad, ra.size() * L);
+    }
   for (int rep = 0; rep < 2; ++rep)
     for (int L : {1, 2, 4, 8}) {
+      for (int fragw = 0; fragw < 2; ++fragw)
+        for (int mode : {0, 4, 12}) {
+          float ms; const int n = 200;
+          for (int i = 0; i < 10; ++i) run_wreg(L, fragw != 0, mode);
+          CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_wreg(L, fragw != 0, mode); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+          if (rep) printf("L=%d  W in registers (%s) mode %2d%s: %7.2f us (%.2f per layer)\n", L, fragw ? "fragment-ordered" : "row-major       ", mode,
+                          mode ? " (timing only)" : "              ", ms * 1e3 / n, ms * 1e3 / n / L);
+        }
       float ms_ref, ms0, ms1, ms2;
       const int n = 200;
       for (int i = 0; i < 10; ++i) run_ref(L);

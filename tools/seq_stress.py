@@ -4,6 +4,8 @@ batches -- `tr` with ACEZ_SEQ=SEQ (and the XCD placement record) and `ref` with 
 gradient vectors differ in any bit; for the first such step it lists the buffers (layer, rows, columns) that differ. This is what
 found the fragment-read race of DESIGN.md section 3 "Round 2" (0): seq vs per-layer 13 and 90 of 90 steps before the fix, 0 of
 2 x 150 after; per-layer vs per-layer 0. Prints (rank, steps with siblings on different XCDs, differing steps, first difference)."""
+import os as _os
+_os.environ.setdefault("ACEZ_LIB", "diag")   # the ACEZ_* ablation switches exist in the diagnostics build only (acezero_amd/build.py --diag)
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
