@@ -88,6 +88,7 @@ SYMBOLS = {
     "acez_train_update_layers": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "acez_trainer_export_weights16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "acez_trainer_import_weights16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "acez_trainer_import_weights16_all": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "acez_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "acez_train_step_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "acez_trainer_get_state": (C.c_int, [C.c_void_p, C.POINTER(TrainState), C.c_void_p]),

@@ -1010,6 +1010,16 @@ extern "C" int acez_trainer_import_weights16(acez_trainer* tr, int layer_lo, int
   return ACEZ_OK;
 }
 
+extern "C" int acez_trainer_import_weights16_all(acez_trainer* tr, int own_lo, int own_hi, const void* d_src_all, void* stream) {
+  ACEZ_REQUIRE(tr && d_src_all, "null pointer");
+  ACEZ_REQUIRE(own_lo >= 0 && own_lo <= own_hi && own_hi <= tr->L, "layer range out of bounds");
+  if (own_hi - own_lo == tr->L) return ACEZ_OK;
+  ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  hipLaunchKernelGGL(import16_kernel, dim3(tr->L * 64), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)d_src_all, tr->Wb, tr->WbT, own_lo, own_hi);
+  ACEZ_HIP_CHECK(hipGetLastError());
+  return ACEZ_OK;
+}
+
 // Single-GPU step: backward + update with the wide-layer gradients handed from the weight-gradient slabs straight to the
 // optimiser (no flat-gradient round trip through HBM). Bitwise the same parameters as acez_train_backward + acez_train_update;
 // afterwards d_grad holds the bias / fc3 gradients and the statistics, its wide-layer weight part is NOT written.

@@ -27,31 +27,39 @@ namespace acez {
 // ---------------------------------------------------------------------------------------------------
 // gather: out[r][:] = features[idx[r]][:]   (one wave copies one 1 KiB row per instruction)
 // ---------------------------------------------------------------------------------------------------
-// Rows wave, wave + nwaves, ... of a batch, two at a time: the loads of a level are issued for both rows before anything of the next
-// level (one row after the other, every row paid its own idx -> row round trips). With meta.dst the per-row metadata the loss kernel
-// needs (GatherMeta) is looked up beside the copy: a third level for the image index, overlapped with the row stores.
+// Rows wave, wave + nwaves, ... of a batch, GR at a time: the loads of a level are issued for all GR rows before anything of the next
+// level (one row after the other, every row paid its own idx -> row round trips; two at a time -- round 3 -- the optimiser launch's 1720
+// gather waves still walked their three rows in two passes of three dependent levels each). With meta.dst the per-row metadata the
+// loss kernel needs (GatherMeta) is looked up beside the copy: a third level for the image index, overlapped with the row stores.
+constexpr int GR = 4;
 __device__ __forceinline__ void gather_rows(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx, uint16_t* __restrict__ out, int n,
                                             int wave, int nwaves, int lane, const GatherMeta& meta) {
-  for (int r0 = wave; r0 < n; r0 += 2 * nwaves) {
-    const int r1 = r0 + nwaves;
-    const bool two = r1 < n;
-    const int64_t s0 = idx[r0], s1 = idx[two ? r1 : r0];
-    const uint4 v0 = *reinterpret_cast<const uint4*>(feat + s0 * 512 + lane * 8);
-    const uint4 v1 = *reinterpret_cast<const uint4*>(feat + s1 * 512 + lane * 8);
-    int view0 = 0, view1 = 0;
-    float2 t0 = make_float2(0.f, 0.f), t1 = t0;
+  for (int r0 = wave; r0 < n; r0 += GR * nwaves) {
+    int r[GR];
+    bool ok[GR];
+    int64_t s[GR];
+#pragma unroll
+    for (int j = 0; j < GR; ++j) { r[j] = r0 + j * nwaves; ok[j] = r[j] < n; s[j] = idx[ok[j] ? r[j] : r0]; }
+    uint4 v[GR];
+#pragma unroll
+    for (int j = 0; j < GR; ++j) v[j] = *reinterpret_cast<const uint4*>(feat + s[j] * 512 + lane * 8);
+    int view[GR];
+    float2 tp[GR];
     if (meta.dst) {
-      view0 = meta.view_idx[s0]; view1 = meta.view_idx[s1];
-      t0 = *reinterpret_cast<const float2*>(meta.target_px + s0 * 2);
-      t1 = *reinterpret_cast<const float2*>(meta.target_px + s1 * 2);
+#pragma unroll
+      for (int j = 0; j < GR; ++j) { view[j] = meta.view_idx[s[j]]; tp[j] = *reinterpret_cast<const float2*>(meta.target_px + s[j] * 2); }
     }
-    *reinterpret_cast<uint4*>(out + (size_t)r0 * 512 + lane * 8) = v0;
-    if (two) *reinterpret_cast<uint4*>(out + (size_t)r1 * 512 + lane * 8) = v1;
+#pragma unroll
+    for (int j = 0; j < GR; ++j)
+      if (ok[j]) *reinterpret_cast<uint4*>(out + (size_t)r[j] * 512 + lane * 8) = v[j];
     if (meta.dst) {
-      const int img0 = meta.view_image[view0], img1 = meta.view_image[view1];
+      int img[GR];
+#pragma unroll
+      for (int j = 0; j < GR; ++j) img[j] = meta.view_image[view[j]];
       if (lane == 0) {
-        meta.dst[r0] = make_int4(view0, img0, __float_as_int(t0.x), __float_as_int(t0.y));
-        if (two) meta.dst[r1] = make_int4(view1, img1, __float_as_int(t1.x), __float_as_int(t1.y));
+#pragma unroll
+        for (int j = 0; j < GR; ++j)
+          if (ok[j]) meta.dst[r[j]] = make_int4(view[j], img[j], __float_as_int(tp[j].x), __float_as_int(tp[j].y));
       }
     }
   }
@@ -1593,7 +1601,6 @@ __host__ __device__ inline int adamw_small_blocks(int n_layers, int64_t n_fc3, b
 // The body of adamw_kernel and of adamw_pose_kernel (pose_fused.hip), where the pose network's backward runs beside it.
 __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint16_t (*tileT)[66]) {
   const TrainState* st = a.st;
-  if (!st->active) return;
   const int t = threadIdx.x;
   const int nsmall = adamw_small_blocks(a.n_layers, a.n_fc3, a.slabs != nullptr);
   const bool tile = b >= nsmall;
@@ -1604,7 +1611,7 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
   const int tb = b - nsmall, layer = tile ? a.layer_lo + tb / 64 : 0, tl = tb % 64;   // (tile blocks cover layers layer_lo .. layer_hi - 1)
   const int r0 = (tl >> 3) * 64, c0 = (tl & 7) * 64, cc = (t & 15) * 4;
   const int64_t woff = a.w_off[layer];
-  float4 p4[4], g4[4], m4[4], v4[4];
+  float4 p4[4], g4[4], m4[4], v4[4], q1[4];
   if (tile) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1614,14 +1621,25 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
       m4[i] = *reinterpret_cast<const float4*>(a.m + o);
       v4[i] = *reinterpret_cast<const float4*>(a.v + o);
       g4[i] = *reinterpret_cast<const float4*>((a.slabs ? a.slabs : a.grad) + o);
+      if (a.slabs && a.nslabs > 1) q1[i] = *reinterpret_cast<const float4*>(a.slabs + (size_t)a.slab_stride + o);   // the second split-K slab, in the same round trip
     }
   }
+  // Everything the guards below need is requested BEHIND the tile loads and before any of it is looked at: the schedule's `active` flag,
+  // the chain fault word, the optimiser scalars (scalar loads) and the loss partials of the NaN check (vector loads) -- one memory round
+  // trip for the whole prologue. (Round 3 read `active` first, then the tile, then the fault word, then the partials: three dependent
+  // round trips in front of the first store of every workgroup of a launch that lives for a single wave of tiles.)
+  const int active = st->active;
+  const AdamScalars s = st->adam;
+  const float inv_scale = st->inv_grad_scale;
   float lossv;
+  int fault_now = 0;
   if (a.slabs) {   // fused step: the statistics are still partials; every wave sums the loss for itself
-    if (*a.fault) return;   // a hand-off poll of rowseq_kernel expired in this step: its gradients are garbage, nothing is updated
+    fault_now = *a.fault;   // a hand-off poll of rowseq_kernel expired in this step: its gradients are garbage, nothing is updated
     int64_t d;
     lossv = tail_output(a.tail, (int64_t)a.n_layers * 512 + a.n_fc3, threadIdx.x & 63, d);
+    if (!active || fault_now) return;
   } else {
+    if (!active) return;
     lossv = a.grad[a.n_params];
     if (fmodf(a.grad[a.n_params + 3], 1024.f) != 0.f) {   // some rank's fault word, summed by the all-reduce: every rank skips the step and
       if (b == 0 && threadIdx.x == 0) {               // falls back at its next state read
@@ -1635,7 +1653,6 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
   // fp16: an infinity was stored somewhere in the gradient chain of this step -> no update (GradScaler.step, ace_schedule.py:112); the
   // schedule wave lowers the scale. In the split flow the flag arrives all-reduced in statistics slot 3 (+1024 per overflowing rank).
   if (a.f16 && (a.slabs ? absmax_all(st, threadIdx.x & 63) >= 0x7f800000u : a.grad[a.n_params + 3] >= 1024.f)) return;
-  const AdamScalars s = st->adam;
   if (tile) {
     if (a.slabs) {   // same additions, in the same order, as grad_reduce_kernel's wide part
       for (int sl = 1; sl < a.nslabs; ++sl) {
@@ -1643,13 +1660,14 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int rr = (t >> 4) + 16 * i;
-          q4[i] = *reinterpret_cast<const float4*>(a.slabs + (size_t)sl * a.slab_stride + woff + (int64_t)(r0 + rr) * 512 + c0 + cc);
+          if (sl == 1) q4[i] = q1[i];
+          else q4[i] = *reinterpret_cast<const float4*>(a.slabs + (size_t)sl * a.slab_stride + woff + (int64_t)(r0 + rr) * 512 + c0 + cc);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { g4[i].x += q4[i].x; g4[i].y += q4[i].y; g4[i].z += q4[i].z; g4[i].w += q4[i].w; }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { g4[i].x *= st->inv_grad_scale; g4[i].y *= st->inv_grad_scale; g4[i].z *= st->inv_grad_scale; g4[i].w *= st->inv_grad_scale; }
+      for (int i = 0; i < 4; ++i) { g4[i].x *= inv_scale; g4[i].y *= inv_scale; g4[i].z *= inv_scale; g4[i].w *= inv_scale; }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1760,6 +1778,38 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
 }
 
 // recast only (no optimiser step): used after loading weights
+// The sharded data-parallel update in ONE launch on the receiving side: every wide layer OUTSIDE [own_lo, own_hi) is taken from the
+// all-gather buffer `src` ([L][512][512] 16-bit, all ranks' layers) into W and, transposed, into W^T (the rank's own layers were written
+// by its optimiser launch). Replaces one copy + one transpose launch per peer (2 (G - 1) small launches per step at G ranks).
+__global__ __launch_bounds__(256) void import16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ Wb, uint16_t* __restrict__ WbT,
+                                                       int own_lo, int own_hi) {
+  __shared__ uint16_t tileT[64][66];
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int layer = b / 64, tl = b % 64;
+  if (layer >= own_lo && layer < own_hi) return;
+  const int r0 = (tl >> 3) * 64, c0 = (tl & 7) * 64, cc = (t & 15) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = (t >> 4) + 16 * i;
+    const size_t o = (size_t)layer * 262144 + (size_t)(r0 + rr) * 512 + c0 + cc;
+    const uint2 pk = *reinterpret_cast<const uint2*>(src + o);
+    *reinterpret_cast<uint2*>(Wb + o) = pk;
+    tileT[cc + 0][rr] = (uint16_t)(pk.x & 0xffff);
+    tileT[cc + 1][rr] = (uint16_t)(pk.x >> 16);
+    tileT[cc + 2][rr] = (uint16_t)(pk.y & 0xffff);
+    tileT[cc + 3][rr] = (uint16_t)(pk.y >> 16);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = (t >> 4) + 16 * i;
+    uint2 pk;
+    pk.x = (uint32_t)tileT[rr][cc + 0] | ((uint32_t)tileT[rr][cc + 1] << 16);
+    pk.y = (uint32_t)tileT[rr][cc + 2] | ((uint32_t)tileT[rr][cc + 3] << 16);
+    *reinterpret_cast<uint2*>(WbT + (size_t)layer * 262144 + (size_t)(c0 + rr) * 512 + r0 + cc) = pk;
+  }
+}
+
 __global__ __launch_bounds__(256) void recast_kernel(AdamArgs a) {
   __shared__ uint16_t tileT[64][66];
   const int t = threadIdx.x, b = blockIdx.x;

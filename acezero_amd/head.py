@@ -269,6 +269,11 @@ class HeadTrainer:
         if layer_hi > layer_lo:
             N.check(self.lib.acez_trainer_import_weights16(self._h, int(layer_lo), int(layer_hi), _ptr(src), _stream()))
 
+    def import_weights16_all(self, own_lo, own_hi, src_all):
+        """One launch for the receiving side of the all-gather: every layer outside [own_lo, own_hi) from `src_all` ([L, 131072] int32)."""
+        assert src_all.is_cuda and src_all.is_contiguous() and src_all.numel() * src_all.element_size() == self.L * 524288
+        N.check(self.lib.acez_trainer_import_weights16_all(self._h, int(own_lo), int(own_hi), _ptr(src_all), _stream()))
+
     def master_tensors(self):
         """The flat fp32 vectors whose wide-layer ranges an owner rank keeps current under the sharded update."""
         return [self.params, self.adam_m, self.adam_v]

@@ -162,9 +162,12 @@ class ShardedDataParallel:
             for r, (lo, hi) in enumerate(self.ranges):
                 if hi > lo:
                     dist.broadcast(self.wbuf[lo:hi], src=self._global(r), group=self.group)
-        for r, (lo, hi) in enumerate(self.ranges):
-            if r != self.rank:
-                t.import_weights16(lo, hi, self.wbuf[lo:hi])
+        if hasattr(t, "import_weights16_all"):      # one launch for all peers' layers (a copy + a transpose launch per peer before)
+            t.import_weights16_all(self.lo, self.hi, self.wbuf)
+        else:
+            for r, (lo, hi) in enumerate(self.ranges):
+                if r != self.rank:
+                    t.import_weights16(lo, hi, self.wbuf[lo:hi])
 
     def gather_masters(self):
         """fp32 masters and AdamW moments of every layer on every rank (before state_dict() / a checkpoint)."""

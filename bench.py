@@ -53,6 +53,38 @@ def src_digest(files):
     return h.hexdigest()
 
 
+PROFILE_TAG = "r04"              # profiles/<tag>_* written by tools/prof_r04.sh: the stored counter / trace pass bench.py may quote
+# algorithmic HBM bytes of one 5120-patch step = what must move at least once. Batch rows in (features bf16 1024 B +
+# target 8 B + view index 4 B = 1036 B per patch in this layout; the reference's per-patch replicated layout is 1230 B) + the optimiser's
+# state traffic: fp32 masters, m, v read and written (24 B / parameter), + two 16-bit compute copies of the wide layers written (4 B).
+ALGO_BYTES_PER_PATCH = 1036
+ALGO_BYTES_OPTIMISER = 2_103_300 * 24 + 8 * 262_144 * 4
+ALGO_BYTES_PER_STEP = ALGO_BYTES_PER_PATCH * BATCH + ALGO_BYTES_OPTIMISER
+
+
+def parity_table():
+    """The tolerances the GPU parity tests assert (tests/golden/parity_tolerances.json: the tests read the same file)."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "parity_tolerances.json")) as f:
+            t = json.load(f)
+        t.pop("_what", None)
+        t["source"] = "tests/golden/parity_tolerances.json (asserted by tests/test_head_gpu.py, tests/test_head_fp16_gpu.py, tests/test_dsac_gpu.py)"
+        return t
+    except (OSError, ValueError):
+        return None
+
+
+def stored_step_profile():
+    """profiles/<tag>_step_hbm_traffic.json if it was measured on the kernel sources of the running build (else (None, reason))."""
+    tf = os.path.join(ROOT, "profiles", PROFILE_TAG + "_step_hbm_traffic.json")
+    if not os.path.exists(tf):
+        return None, f"profiles/{PROFILE_TAG}_step_hbm_traffic.json not found"
+    tj = json.load(open(tf))
+    if tj.get("source_digest") != src_digest(STEP_SOURCES):
+        return None, f"profiles/{PROFILE_TAG}_step_hbm_traffic.json was measured on different kernel sources than this build: not quoted"
+    return tj, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -437,7 +469,17 @@ def cpu_baseline():
     for rep in range(4):
         cloud_oracle.point_cloud(frc["scene_coords"], pinv, [Kc] * 8, 100.0, False, 1000)
     t_cloud = (time.perf_counter() - t0) / 32
-    return {"value": BATCH / t_train, "unit": "patches/s", "cores": tcores, "kind": kind,
+    ref_stored = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_cpu_reference_training_step.json")) as f:
+            rs = json.load(f)
+        ref_stored = {"kind": "reference (stored)", "value": rs["patches_per_s"], "unit": "patches/s", "cores": rs["threads"], "cpu": rs["cpu"],
+                      "seconds_per_step": rs["seconds_per_step_median"], "file": "profiles/r04_cpu_reference_training_step.json",
+                      "what": "the reference's own TrainerACE.training_step timed in the build container (the GPU box has no reference checkout); not this box's "
+                              "cores -- the live figure beside it is"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"value": BATCH / t_train, "unit": "patches/s", "cores": tcores, "kind": kind, "reference_stored": ref_stored,
             "kind_note": "reference = the reference's own training_step (only where /root/reference exists); port = oracle/ restatement "
                          "(the GPU box has no reference checkout). The registration figures are always the oracle port: the reference's "
                          "dsacstar needs OpenCV 4.4.0, which is not available.",
@@ -514,29 +556,49 @@ def main():
         gemm_kernel_name = ("rowseq_kernel (the 8 forward / the 7 input-gradient 5120x512x512 bf16 layers of a step as ONE launch each; figures per layer)"
                             if seq else "rowgemm80_kernel (5120x512x512 bf16, fwd + dgrad launches)")
         gemm_note = ("HIP events on the launch stream around the two chain launches of a step; achieved = 15 layers' FLOPs / their summed durations = one "
-                     "layer's FLOPs / avg_launch_us (launches_timed counts layers); rocprofv3 kernel durations are in profiles/r03_kernel_stats_rocprofv3_headline_only_trace.csv"
+                     "layer's FLOPs / avg_launch_us (launches_timed counts layers); rocprofv3 kernel durations are in profiles/" + PROFILE_TAG + "_kernel_stats_rocprofv3_headline_only_trace.csv"
                      if seq else
                      "HIP events on the launch stream around each chain of dependent rowgemm launches (8 fwd, 7 dgrad per step): average start-to-start "
                      "cadence incl. the ~1-2 us kernel boundary; rocprofv3 kernel durations are in profiles/")
         # Counter figures cannot be collected inside this run (they need rocprofv3 around the process: tools/prof_r03.sh); the stored
         # pass is quoted only if it was taken on the sources this build was compiled from, and it names the kernel it belongs to.
         traffic, traffic_source, mfma_busy, stored = None, None, None, None
-        tf = os.path.join(ROOT, "profiles", "r03_step_hbm_traffic.json")
-        if seq and os.path.exists(tf):
-            tj = json.load(open(tf))
-            if tj.get("source_digest") == src_digest(STEP_SOURCES):
-                ks = {k: v for k, v in tj["kernels"].items() if "rowseq_kernel" in k and "bytes_per_layer" in v}
-                if len(ks) == 2:
-                    layers = sum(v["layers_per_launch"] for v in ks.values())
-                    traffic = sum(v["bytes_per_launch"] for v in ks.values()) / layers       # per unit (one layer), like `achieved`
-                    if all("mfma_busy_frac" in v for v in ks.values()):
-                        mfma_busy = sum(v["mfma_busy_frac"] * v["avg_ns"] for v in ks.values()) / sum(v["avg_ns"] for v in ks.values())
-                    traffic_source = ("profiles/r03_step_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE (separate passes) of "
-                                      "rowseq_kernel<false> (8 layers) and rowseq_kernel<true> (7 layers), the kernels timed here, per layer; a STORED "
-                                      "measurement taken on the same kernel sources as this build (source_digest matches)")
-                    stored = {"file": "profiles/r03_step_hbm_traffic.json", "source_digest": tj["source_digest"], "kernels": sorted(ks)}
-            else:
-                traffic_source = "profiles/r03_step_hbm_traffic.json was measured on different kernel sources than this build: not quoted"
+        step_prof = None
+        tj, why_not = stored_step_profile()
+        if seq and tj is not None:
+            ks = {k: v for k, v in tj["kernels"].items() if "rowseq_kernel" in k and "bytes_per_layer" in v}
+            if len(ks) == 2:
+                layers = sum(v["layers_per_launch"] for v in ks.values())
+                traffic = sum(v["bytes_per_launch"] for v in ks.values()) / layers       # per unit (one layer), like `achieved`
+                if all("mfma_busy_frac" in v for v in ks.values()):
+                    mfma_busy = sum(v["mfma_busy_frac"] * v["avg_ns"] for v in ks.values()) / sum(v["avg_ns"] for v in ks.values())
+                traffic_source = (f"profiles/{PROFILE_TAG}_step_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE x fetch_factor + WRITE_SIZE x write_factor (separate "
+                                  "passes; the factors are calibrated on this kernel's access pattern with tools/pmc_calib.hip and stored in the file) of "
+                                  "rowseq_kernel<false> (8 layers) and rowseq_kernel<true> (7 layers), the kernels timed here, per layer; a STORED "
+                                  "measurement taken on the same kernel sources as this build (source_digest matches)")
+                stored = {"file": f"profiles/{PROFILE_TAG}_step_hbm_traffic.json", "source_digest": tj["source_digest"], "kernels": sorted(ks),
+                          "calibration": tj.get("calibration")}
+            # the whole step from the same stored pass: every kernel's duration and counter bytes, so that each `frac` on this line can be
+            # recomputed from profiles/ alone
+            rows = {k: {"us": v.get("avg_ns", 0.0) / 1e3, "counter_bytes": v.get("bytes_per_launch"), "mfma_busy_frac": v.get("mfma_busy_frac")}
+                    for k, v in tj["kernels"].items() if v.get("calls", 0) >= 100}
+            cb = sum(r["counter_bytes"] or 0.0 for r in rows.values())
+            step_prof = {"file": stored["file"] if stored else None, "per_kernel": rows, "sum_of_kernel_us": sum(r["us"] for r in rows.values()),
+                         "counter_bytes_per_step": cb, "algorithmic_bytes_per_step": ALGO_BYTES_PER_STEP,
+                         "counter_over_algorithmic": cb / ALGO_BYTES_PER_STEP if cb else None,
+                         "algorithmic_note": "SURVEY 8(d): 1036 B per patch x 5120 + optimiser state (24 B per parameter read + written, two 16-bit copies of the wide "
+                                             "layers written) = what must cross HBM at least once per step; saved activations (5120 x 512 x 2 B per layer output, "
+                                             "gradient and residual tile) round-trip through the 256 MB Infinity Cache and are counted by the L2-side counters"}
+        elif seq:
+            traffic_source = why_not
+        # the single longest kernel of the step (the input-gradient chain, rowseq_kernel<true>) beside the average over both chains
+        dg_us = prof["gemm_dgrad"][0] / 20 * 1e3
+        dg_layers = prof["gemm_dgrad"][1] / 20
+        dg_tflops = BATCH * GEMM_FLOP_PER_LAUNCH_PER_ROW * dg_layers / (dg_us * 1e-6) / 1e12 if dg_us > 0 else 0.0
+        dominant = {"kernel": "rowseq_kernel<true> (the 7 input-gradient layers, one launch)" if seq else "the 7 input-gradient rowgemm80 launches",
+                    "us_per_step": dg_us, "layers": dg_layers, "achieved": dg_tflops, "frac": dg_tflops / MFMA_PEAK_TFLOPS,
+                    "forward_chain": {"us_per_step": prof["gemm_fwd"][0] / 20 * 1e3, "layers": prof["gemm_fwd"][1] / 20,
+                                      "frac": (BATCH * GEMM_FLOP_PER_LAUNCH_PER_ROW * (prof["gemm_fwd"][1] / 20) / max(prof["gemm_fwd"][0] / 20 * 1e-3, 1e-12) / 1e12) / MFMA_PEAK_TFLOPS}}
         wg_s = prof["wgrad"][0] / max(prof["wgrad"][1], 1) * 1e-3
         wg_tflops = BATCH * 8 * GEMM_FLOP_PER_LAUNCH_PER_ROW / wg_s / 1e12 if wg_s > 0 else 0.0
         out = {
@@ -587,6 +649,7 @@ def main():
                                    "map_bytes_per_s": pipe["cloud_frames"] * world * 57600 / pipe["cloud_s"]},
             "roofline": {"bound": "mfma", "kernel": gemm_kernel_name, "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "dominant_kernel": dominant, "stored_step_profile": step_prof,
                          "traffic_source": traffic_source, "mfma_busy_frac": mfma_busy, "stored_profile": stored,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": gemm_n,
                          "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()},
@@ -595,6 +658,9 @@ def main():
                                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_tflops / MFMA_PEAK_TFLOPS, "traffic": None,
                                "avg_launch_us": wg_s * 1e6},
             "roofline_ransac": ransac_roofline(nreg * world / dt_reg),
+            "parity": parity_table(),
+            "precision_note": "dtype bf16 is what BASELINE north_star names; the reference runs fp16 autocast (ace_trainer.py:517-518): `dtype_fp16` is the "
+                              "same step at the reference's operand precision (scene coordinates within 2e-3 of the reference's fp32 arithmetic, bf16: 3e-2)",
             "final_loss": st["loss"], "device_state": dev_state,
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N = 1 only

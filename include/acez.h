@@ -252,10 +252,14 @@ int acez_train_update(acez_trainer* tr, void* stream);
  *                                   replicated); closes the step's schedule bookkeeping like acez_train_update
  *   acez_trainer_export_weights16   16-bit W[out][in] of layers [layer_lo, layer_hi) -> d_dst  ((hi - lo) x 512 x 512 elements)
  *   acez_trainer_import_weights16   d_src -> the 16-bit W of those layers, and rebuilds their transposed copies
+ *   acez_trainer_import_weights16_all  the receiving side of the all-gather in ONE launch: d_src_all = [L][512][512] 16-bit (every rank's
+ *                                   layers); all layers OUTSIDE [own_lo, own_hi) are taken over (W and W^T), the rank's own stay as its
+ *                                   optimiser wrote them
  * The fp32 masters / moments of layers a rank does not own go stale on it; the host copies the owners' values in before it reads them. */
 int acez_train_update_layers(acez_trainer* tr, int layer_lo, int layer_hi, void* stream);
 int acez_trainer_export_weights16(acez_trainer* tr, int layer_lo, int layer_hi, void* d_dst, void* stream);
 int acez_trainer_import_weights16(acez_trainer* tr, int layer_lo, int layer_hi, const void* d_src, void* stream);
+int acez_trainer_import_weights16_all(acez_trainer* tr, int own_lo, int own_hi, const void* d_src_all, void* stream);
 
 /* Single-GPU step = backward + update, with the wide-layer weight gradients handed from the split-K slabs straight to the
  * optimiser: bitwise the same parameters as the two calls above; afterwards d_grad holds the bias / fc3 gradients and the

@@ -1,4 +1,6 @@
 """Shared helpers of the parity tests (inputs identical to tests/golden/make_head_golden.py)."""
+import os
+
 import numpy as np
 import torch
 
@@ -243,3 +245,13 @@ def pose_file_cases(n=12, seed=5):
     conf = rng.integers(0, 3000, size=n)
     conf[1], conf[2] = 499, 500          # the threshold itself is kept (confidence < threshold is dropped), 499 is not
     return out, conf
+
+
+def _parity_tolerances():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_tolerances.json")) as f:
+        return json.load(f)
+
+
+# the tolerance table of the T path: one file read by the tests that assert it and by bench.py, which quotes it on its JSON line
+PARITY = _parity_tolerances()

@@ -48,3 +48,23 @@ def test_bench_json_line_contract(monkeypatch, seq):
     rr = d["roofline_ransac"]
     assert rr["frac"] is None or rr["stored_profile"]["source_digest"] == bench.src_digest(bench.RANSAC_SOURCES)
     assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["roofline_wgrad"]["frac"] > 0 and "roofline_ransac" in d
+    # round 4: the tolerance table the parity tests assert, the longest single kernel beside the averaged figure, and the recipe to recompute
+    assert d["parity"]["scene_coordinates_rel"] == {"bf16_vs_oracle_bf16": 1e-3, "bf16_vs_reference_fp32": 3e-2, "fp16_vs_reference_fp32": 2e-3}
+    dom = r["dominant_kernel"]
+    assert abs(dom["us_per_step"] - 0.94 / 20 * 1e3) < 1e-9 and dom["layers"] == 7
+    assert abs(dom["frac"] - 7 * 2 * 5120 * 512 * 512 / (0.94 / 20 * 1e-3) / 1e12 / 2500.0) < 1e-9
+    sp = r["stored_step_profile"]
+    assert sp is None or (sp["algorithmic_bytes_per_step"] == bench.ALGO_BYTES_PER_STEP and sp["counter_bytes_per_step"] > 0)
+    assert 60e6 < bench.ALGO_BYTES_PER_STEP < 70e6            # ~65 MB per step
+
+
+def test_cpu_baseline_quotes_the_stored_reference_figure():
+    """The reference's own training_step cannot run on the GPU box; its figure from the build container is stored with its core count
+    (profiles/r04_cpu_reference_training_step.json) and quoted beside the live port, never instead of it."""
+    import json as js
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rs = js.load(open(os.path.join(root, "profiles", "r04_cpu_reference_training_step.json")))
+    assert rs["patches_per_s"] > 1e3 and rs["threads"] >= 1 and "training_step" in rs["what"]
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "reference (stored)" in src and "r04_cpu_reference_training_step.json" in src
