@@ -404,6 +404,188 @@ __global__ __launch_bounds__(512) void rowseq_wreg_kernel(SeqArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4, third variant: the WHOLE weight tile of the next layer in flight before its K loop starts. rowseq requests 64 KiB of the next
+// layer's 128 KiB behind the K loop and streams the rest with the In tile through the 4-slot ring -- at the L2's delivered rate (53 MB
+// per layer over the chip, 2.6 us) while the chip's L2 -> CU paths sit idle during the epilogue / hand-off phase every layer goes
+// through in near lock step. Here the LDS holds EIGHT weight slots (the layer's whole 128 x 512 tile, 128 KiB) and three 80-row In
+// slots (30 KiB); the staging tile of the epilogue overlays the two weight slots the K loop frees first, and a layer's stage s lives in
+// slot (2 layer + s) & 7, so that at the end of a K loop six stages of the next layer can be requested at once into the six slots
+// that are not the staging tile, and the last two once the copy-out has drained it. The K loop then only streams In (80 KiB per layer).
+// Wave roles: 0..3 multiply, 4..5 load In, copy out and signal, 6..7 load In and prefetch weights (they never store, so nobody's
+// vmcnt(0) in front of the hand-off signal has to drain a weight prefetch).
+template <bool SPLIT>   // SPLIT: waves 6, 7 prefetch and never store (first form); else all four loader waves prefetch and all eight waves copy out
+__global__ __launch_bounds__(512) void rowseq_fullw_kernel(SeqArgs a) {
+  constexpr int WSLOT = 128 * 64, ISLOT = 80 * 64, NI = 3;
+  __shared__ __attribute__((aligned(16))) uint16_t smem[8 * WSLOT + NI * ISLOT];
+  uint16_t* const sIn = smem + 8 * WSLOT;
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int mtiles = (a.M + 79) / 80;
+  const int per_xcd = (mtiles + 7) >> 3;
+  const int jx = blockIdx.x >> 3;
+  const int mt = (blockIdx.x & 7) * per_xcd + (jx >> 2);
+  if (mt >= mtiles) return;
+  const int n0 = (jx & 3) * 128, m0 = mt * 80;
+  const int M = a.M;
+  constexpr int K = 512, KT = 8, N = 512;
+  const int fr = l & 15, fq = l >> 4;
+
+  for (int layer = 0; layer < a.L; ++layer) {
+    const uint16_t* In = layer ? a.out[layer - 1] : a.In;
+    const int base = (2 * layer) & 7;                       // W stage s of this layer: slot (base + s) & 7; staging = slots base, base + 1
+    uint16_t* const stB = smem + ((base)&7) * WSLOT;        // 20 KiB of the 32 KiB of two adjacent slots (base is even: never wraps)
+    if (w >= 4) {
+      const int lw = w - 4;
+      const bool prefetcher = SPLIT ? lw >= 2 : true;
+      const int NIw = lw < 2 ? 3 : 2;                       // In DMA instructions per stage of this wave (10 groups of 8 rows over 4 waves)
+      const uint16_t* gI[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int row = (lw + 4 * j) * 8 + (l >> 3);
+        gI[j] = In + (size_t)min(m0 + row, M - 1) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8;
+      }
+      auto issueI = [&](int kt) {
+        uint16_t* slot = sIn + (kt % NI) * ISLOT;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < NIw) __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)(slot + (lw + 4 * j) * 8 * 64), 16, 0, 0);
+      };
+      // weight stage s of layer ly, this prefetcher's half: 8 instructions of 8 rows each
+      auto issueW = [&](int ly, int s) {
+        const uint16_t* Wl = a.W + (size_t)ly * 512 * 512;
+        uint16_t* slot = smem + ((2 * ly + s) & 7) * WSLOT;
+        constexpr int PJ = SPLIT ? 8 : 4;
+        const int pw = SPLIT ? lw - 2 : lw;
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+          const int row = (pw * PJ + j) * 8 + (l >> 3);
+          __builtin_amdgcn_global_load_lds((gvoid_t*)(Wl + (size_t)(n0 + row) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8 + s * 64),
+                                           (lvoid_t*)(slot + (pw * PJ + j) * 8 * 64), 16, 0, 0);
+        }
+      };
+      if (layer == 0 && prefetcher) {
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) issueW(0, s2);
+      }
+      if (layer > 0 && !(a.mode & 4)) {
+        const uint32_t target = (a.base + (uint32_t)layer) * (SPLIT ? 24u : 32u);       // 4 workgroups x 6 (8) storing waves per seam
+        uint32_t seen;
+        do {
+          asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(a.flags + mt * 32) : "memory");
+          if ((int32_t)(seen - target) < 0) __builtin_amdgcn_s_sleep(1);
+        } while ((int32_t)(seen - target) < 0);
+      }
+      issueI(0); issueI(1); issueI(2);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        // in order: [all W stages of this layer] I0 I1 I2 | I3 | I4 ... : before barrier kt, stage kt must have landed
+        const int after = (kt <= 5) ? 2 : (7 - kt);         // In stages requested after stage kt at this point
+        if (NIw == 3) ACEZ_VMCNT_DYN(3 * after); else ACEZ_VMCNT_DYN(2 * after);
+        __builtin_amdgcn_s_barrier();                       // stage kt has landed; the multipliers are done with stage kt - 1
+        if (kt >= 1 && kt + 2 < KT) issueI(kt + 2);
+      }
+      __builtin_amdgcn_s_barrier();                         // K loop over: every weight slot is free
+      if (prefetcher && layer + 1 < a.L) {
+#pragma unroll
+        for (int s2 = 0; s2 < 6; ++s2) issueW(layer + 1, s2);
+      }
+      __builtin_amdgcn_s_barrier();                         // output tile complete
+    } else {
+      f32x4 acc[2][5];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+      float4 bias[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) bias[i] = *reinterpret_cast<const float4*>(a.bias + layer * 512 + n0 + w * 32 + i * 16 + 4 * fq);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint16_t* sW = smem + ((base + kt) & 7) * WSLOT;
+        const uint16_t* sI = sIn + (kt % NI) * ISLOT;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int c = kk * 4 + fq;
+          bf16x8 fa[2], fb[5];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz(w * 32 + i * 16 + fr, c)]);
+#pragma unroll
+          for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz(j * 16 + fr, c)]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // K loop over
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int ml = j * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int nl = w * 32 + i * 16 + 4 * fq;
+          float v[4] = {acc[i][j][0] + bias[i].x, acc[i][j][1] + bias[i].y, acc[i][j][2] + bias[i].z, acc[i][j][3] + bias[i].w};
+          *reinterpret_cast<uint2*>(&stB[st_off(ml, nl)]) = pack4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // output tile complete
+    }
+    // copy-out by waves 0..5 (384 lanes, 1280 16-byte chunks of the 80 x 128 tile)
+    constexpr int NSTW = SPLIT ? 6 : 8;                     // storing waves
+    if (w < NSTW) {
+      uint16_t* out = a.out[layer];
+      const int tt = w * 64 + l;
+      uint4 v[4];
+      int q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        q[u] = (SPLIT || u < 3) ? tt + NSTW * 64 * u : 1280;
+        const int qq = q[u] < 1280 ? q[u] : 0;
+        v[u] = *reinterpret_cast<const uint4*>(&stB[(qq >> 4) * 128 + (((qq & 15) ^ ((qq >> 4) & 15)) << 3)]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = m0 + (q[u] >> 4);
+        if (q[u] < 1280 && r < M) *reinterpret_cast<uint4*>(out + (size_t)r * N + n0 + (q[u] & 15) * 8) = v[u];
+      }
+    }
+    __builtin_amdgcn_s_barrier();                           // staging drained: its two weight slots may be refilled
+    if (w >= (SPLIT ? 6 : 4) && layer + 1 < a.L) {
+      // (the same lambda is not visible here: re-stated) weight stages 6, 7 of the next layer into this layer's staging slots
+      constexpr int PJ = SPLIT ? 8 : 4;
+      const int pw = SPLIT ? w - 6 : w - 4;
+      const uint16_t* Wl = a.W + (size_t)(layer + 1) * 512 * 512;
+#pragma unroll
+      for (int s2 = 6; s2 < 8; ++s2) {
+        uint16_t* slot = smem + ((2 * (layer + 1) + s2) & 7) * WSLOT;
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+          const int row = (pw * PJ + j) * 8 + (l >> 3);
+          __builtin_amdgcn_global_load_lds((gvoid_t*)(Wl + (size_t)(n0 + row) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8 + s2 * 64),
+                                           (lvoid_t*)(slot + (pw * PJ + j) * 8 * 64), 16, 0, 0);
+        }
+      }
+    }
+    if (w < NSTW && layer + 1 < a.L) {
+      if (!(a.mode & 8)) ACEZ_VMCNT(0);
+      if (l == 0) {
+        const uint32_t one = 1;
+        asm volatile("global_atomic_add %0, %1, off" ::"v"(a.flags + mt * 32), "v"(one) : "memory");
+      }
+    }
+  }
+}
+
 static uint16_t f2bf_host(float f) {
   uint32_t u; memcpy(&u, &f, 4);
   u += 0x7fffu + ((u >> 16) & 1u);
@@ -481,6 +663,39 @@ int main() {
       printf("L=%d mode=%d: %zu mismatching of %zu (non-zero %zu)\n", L, mode, bad, ra.size(), nz);
     }
   }
+  uint32_t* flags2; CK(hipMalloc(&flags2, 64 * 32 * 4)); CK(hipMemset(flags2, 0, 64 * 32 * 4));
+  uint32_t base2 = 0;
+  uint32_t* flags3; CK(hipMalloc(&flags3, 64 * 32 * 4)); CK(hipMemset(flags3, 0, 64 * 32 * 4));
+  uint32_t base3 = 0;
+  int fullw_split = 0;
+  auto run_fullw = [&](int L, int mode) {
+    SeqArgs a{};
+    a.In = In; a.W = W; a.bias = bias; a.M = M; a.L = L; a.mode = mode;
+    for (int i = 0; i < LMAX; ++i) a.out[i] = outB[i];
+    if (fullw_split) { a.flags = flags2; a.base = base2; hipLaunchKernelGGL(rowseq_fullw_kernel<true>, dim3(256), dim3(512), 0, 0, a); base2 += (uint32_t)(L - 1); }
+    else { a.flags = flags3; a.base = base3; hipLaunchKernelGGL(rowseq_fullw_kernel<false>, dim3(256), dim3(512), 0, 0, a); base3 += (uint32_t)(L - 1); }
+  };
+  for (fullw_split = 0; fullw_split < 2; ++fullw_split)
+  for (int L : {1, 2, 8}) {
+    for (int i = 0; i < LMAX; ++i) CK(hipMemset(outB[i], 0xff, (size_t)M * 512 * 2));
+    run_ref(L); run_fullw(L, 0);
+    CK(hipDeviceSynchronize());
+    size_t bad = 0;
+    for (int li = 0; li < L; ++li) {
+      CK(hipMemcpy(ra.data(), outA[li], ra.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(rb.data(), outB[li], rb.size() * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < ra.size(); ++i) bad += ra[i] != rb[i];
+    }
+    printf("full-W prefetch (%s) L=%d: %zu mismatching of %zu (all layers)\n", fullw_split ? "2 prefetch waves" : "4 prefetch waves", L, bad, ra.size() * L);
+  }
+  for (int rep = 0; rep < 2; ++rep)
+    for (fullw_split = 0; fullw_split < 2; ++fullw_split)
+    for (int L : {1, 2, 8})
+      for (int mode : {0, 12}) {
+        float ms; const int n = 200;
+        for (int i = 0; i < 10; ++i) run_fullw(L, mode);
+        CK(hipEventRecord(e0, 0)); for (int i = 0; i < n; ++i) run_fullw(L, mode); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("L=%d  full-W prefetch (%s) mode %2d%s: %7.2f us (%.2f per layer)\n", L, fullw_split ? "2 prefetch waves" : "4 prefetch waves", mode, mode ? " (timing only)" : "              ", ms * 1e3 / n, ms * 1e3 / n / L);
+      }
   for (int L : {2, 8})
     for (int fragw = 0; fragw < 2; ++fragw) {
       for (int i = 0; i < LMAX; ++i) CK(hipMemset(outB[i], 0xff, (size_t)M * 512 * 2));
