@@ -241,7 +241,9 @@ def ransac_roofline(images_per_s):
     instructions per frame come from the committed PMC pass (profiles/r02_ransac_pmc.json, SQ_INSTS_VALU / frames of the same
     2048-frame launch), the rate from the live run; peak = 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz fp64 lane-operations
     (= the 78.6 TFLOP/s fp64 vector peak / 2 flops per FMA)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_ransac_pmc.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", tag + "_ransac_pmc.json") for tag in (PROFILE_TAG, "r02")) if os.path.exists(q)),
+                os.path.join(ROOT, "profiles", "r02_ransac_pmc.json"))
+    pname = "profiles/" + os.path.basename(path)
     peak = 256 * 4 * 16 * 2.4e9 / 1e12
     out = {"bound": "valu_fp64", "kernel": "ransac_kernel<false> (one 256-thread workgroup per 60x80 frame)", "peak": peak,
            "unit": "T lane-ops/s", "achieved": None, "frac": None, "traffic": None}
@@ -259,13 +261,13 @@ def ransac_roofline(images_per_s):
     try:
         side = json.load(open(path.replace(".json", ".digest.json")))
         if side.get("source_digest") != src_digest(RANSAC_SOURCES):   # the kernel has changed since the counter pass: nothing stale is quoted
-            out["stored_profile"] = "profiles/r02_ransac_pmc.json does not match the running build's ransac sources: not used"
+            out["stored_profile"] = pname + " does not match the running build's ransac sources: not used"
             return out
         c = json.load(open(path))["ransac_kernel"]
         insts_per_frame = c["SQ_INSTS_VALU"]["mean_per_launch"] / 2048
         out.update(achieved=images_per_s * insts_per_frame * 64 / 1e12, valu_insts_per_frame=insts_per_frame,
                    lane_utilisation=c["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (c["SQ_INSTS_VALU"]["mean_per_launch"] * 64),
-                   stored_profile={"file": "profiles/r02_ransac_pmc.json", "source_digest": side["source_digest"],
+                   stored_profile={"file": pname, "source_digest": side["source_digest"],
                                    "what": "SQ_INSTS_VALU / frames of one 2048-frame launch (a STORED instruction count, checked against the "
                                            "running build's ransac sources); `achieved` = that count x the LIVE images/s of this run"})
         out["frac"] = out["achieved"] / peak

@@ -52,6 +52,12 @@ if g("SQ_WAVE_CYCLES") and g("SQ_ACTIVE_INST_VALU"):
         "valu_insts_per_wave": g("SQ_INSTS_VALU") / g("SQ_WAVES") if g("SQ_WAVES") else None,
     }
 json.dump(summary, open(keep + "/%s_ransac_pmc.json" % tag, "w"), indent=1, sort_keys=True)
+# the digest of the sources this pass was measured on: bench.py quotes the stored instruction count only while it matches the running build
+import sys
+sys.path.insert(0, root)
+import bench
+json.dump({"source_digest": bench.src_digest(bench.RANSAC_SOURCES), "sources": list(bench.RANSAC_SOURCES),
+           "note": "digest of the ransac kernel sources %s_ransac_pmc.json was measured on" % tag}, open(keep + "/%s_ransac_pmc.digest.json" % tag, "w"), indent=1)
 print(json.dumps(summary, indent=1)[:5000])
 PY
 cp $OUT/trace.log $KEEP/${TAG}_ransac_sweep.log 2>/dev/null
