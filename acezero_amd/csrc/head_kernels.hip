@@ -780,12 +780,16 @@ __device__ __forceinline__ typename E::frag tr_frag(const uint16_t* p) {
   return __builtin_bit_cast(typename E::frag, r);
 }
 
+#ifndef ACEZ_WGRAD_RING
+#define ACEZ_WGRAD_RING 4
+#endif
 constexpr int WGRAD_LOADERS = 8;                    // loader waves per workgroup (beside the 4 multiplier waves)
 constexpr int WGRAD_THREADS = 256 + 64 * WGRAD_LOADERS;
 template <class E = EltBf16>
 __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
   const int active = a.st ? a.st->active : 1;  // tested before the stores only (see rowgemm_kernel)
-  __shared__ __attribute__((aligned(16))) uint16_t smem[4][2][64 * 128];  // 4-slot ring of [dZ | In] stages, 128 KiB
+  constexpr int RING = ACEZ_WGRAD_RING;   // slots of the [dZ | In] stage ring, 32 KiB each (RING - 1 stages in flight per CU)
+  __shared__ __attribute__((aligned(16))) uint16_t smem[RING][2][64 * 128];
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   // Role split: waves 0..3 multiply (2 x 2 grid of 64 x 64 sub-tiles: 4 fragment reads feed 4 MFMAs), waves 4..7 only
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
   // physical 16-byte chunk l&15, which must receive the logical chunk whose 32-byte segment index is XOR-swizzled
   const int prow = l >> 4, pq = l & 15;
   auto issue = [&](int kt) {
-    const int slot = kt & 3;
+    const int slot = kt % RING;
 #pragma unroll
     for (int j = 0; j < GPL; ++j) {
       const int srow = (lw * GPL + j) * 4 + prow;
@@ -851,23 +855,24 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
       for (int kt = 0; kt < KT; ++kt) __builtin_amdgcn_s_barrier();
       return;
     }
-    for (int kt = 0; kt < 4 && kt < KT; ++kt) issue(kt);
+    for (int kt = 0; kt < RING && kt < KT; ++kt) issue(kt);
     for (int kt = 0; kt < KT; ++kt) {
-      // stages issued so far: 0..3 at kt = 0, 0..kt+2 afterwards; a loader wave has 2 * GPL DMA instructions per stage in flight
-      const int later = (kt == 0) ? min(3, KT - 1) : min(2, KT - 1 - kt);
-      if (later >= 3) ACEZ_VMCNT_C(6 * GPL);
+      // stages issued so far: 0..RING-1 at kt = 0, 0..kt+RING-2 afterwards; a loader wave has 2 * GPL DMA instructions per stage in flight
+      const int later = (kt == 0) ? min(RING - 1, KT - 1) : min(RING - 2, KT - 1 - kt);
+      if (later >= 4) ACEZ_VMCNT_C(8 * GPL);
+      else if (later == 3) ACEZ_VMCNT_C(6 * GPL);
       else if (later == 2) ACEZ_VMCNT_C(4 * GPL);
       else if (later == 1) ACEZ_VMCNT_C(2 * GPL);
       else ACEZ_VMCNT(0);
       __builtin_amdgcn_s_barrier();  // stage kt has landed; the multipliers are done with stage kt - 1
-      if (kt >= 1 && kt + 3 < KT) issue(kt + 3);
+      if (kt >= 1 && kt + RING - 1 < KT) issue(kt + RING - 1);
     }
     return;
   }
   for (int kt = 0; kt < KT; ++kt) {
     __builtin_amdgcn_s_barrier();
     if (ACEZ_DBG(a.dbg) & 2) continue;
-    const int slot = kt & 3;
+    const int slot = kt % RING;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       typename E::frag fa[2], fb[2];
