@@ -104,9 +104,11 @@ class HeadTrainer:
                         float(self.buffers["max_inv_scale"]), float(self.buffers["min_inv_scale"]), float(self.buffers["h_beta"]))
         self.n_params = int(self.lib.acez_head_num_params(C.byref(hd)))
         dev = self.device
-        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
-        self.adam_m = torch.zeros_like(self.params)
-        self.adam_v = torch.zeros_like(self.params)
+        # fp32 masters and AdamW moments: three views of ONE allocation (like the library's arenas, acez_trainer_create: one contiguous
+        # virtual range instead of three; each view starts on a 4 KiB boundary)
+        npad = (self.n_params + 1023) // 1024 * 1024
+        self._state = torch.zeros(3 * npad, dtype=torch.float32, device=dev)
+        self.params, self.adam_m, self.adam_v = (self._state[i * npad:i * npad + self.n_params] for i in range(3))
         if pose_refinement not in ("none", "naive", "mlp"):
             raise ValueError("pose_refinement must be 'none', 'naive' or 'mlp'")
         self.pose_mlp = pose_refinement == "mlp"
