@@ -115,6 +115,15 @@ struct acez_trainer {
   int seq_faults = 0;                  // fall-backs taken so far
   int seq_probe = -1;                  // -1 not run, 0 failed (seq disabled), 1 passed
   long seq_launches = 0, seq_fault_at = -1;   // tests: ACEZ_SEQ_FAULT_AT=<n> makes the n-th launch time out
+  // wgrad_opt_kernel (head_kernels.hip): the optimiser step of the wide layers inside the weight-gradient launch of the single-GPU fused
+  // step. Same placement contract and safety net as the one-launch chains (tr->seq, the probe, the bounded poll, seq_err): usable only
+  // while they are, and only when every workgroup of the launch is resident (wgrad_opt_usable).
+  bool wgrad_opt = true;          // ACEZ_WGRAD_OPT=0 (diagnostics build): wgrad_kernel + the optimiser's tile workgroups, as before
+  float* wg_xch = nullptr;        // [L * 16 tiles][2][64][128] fp32 exchange tiles
+  uint32_t* wg_flags = nullptr;   // [L * 16 tiles][2][32] hand-off counters
+  uint32_t wg_epoch = 0;          // wgrad_opt launches so far (a counter reaches 2 * epoch in each of them)
+  bool wide_done = false;         // this step's backward has already applied the optimiser to the wide layers' weights
+  long wgo_fault_at = -1;         // tests: ACEZ_WGO_FAULT_AT=<n> makes the n-th wgrad_opt launch time out
 };
 
 enum { KC_SCHED = 0, KC_GATHER, KC_GEMM_FWD, KC_LOSS, KC_GEMM_DGRAD, KC_WGRAD, KC_REDUCE, KC_ADAMW, KC_COUNT };
@@ -337,6 +346,11 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
     A((void**)&tr->chain_trace, 512 * sizeof(unsigned long long));
     if (rc == ACEZ_OK) (void)hipMemset(tr->chain_trace, 0, 512 * sizeof(unsigned long long));
   }
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGRAD_OPT")) tr->wgrad_opt = atoi(e) != 0;
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_AT")) tr->wgo_fault_at = atol(e);
+  A((void**)&tr->wg_xch, (size_t)tr->L * 16 * 2 * 8192 * sizeof(float));
+  A((void**)&tr->wg_flags, (size_t)tr->L * 16 * 2 * 32 * sizeof(uint32_t));
+  if (rc == ACEZ_OK) (void)hipMemset(tr->wg_flags, 0, (size_t)tr->L * 16 * 2 * 32 * sizeof(uint32_t));
   tr->dRc.resize(tr->nb + 1, nullptr);
   for (int b = 0; b <= tr->nb; ++b) A((void**)&tr->dRc[b], act_bytes);
   A((void**)&tr->zeros, 1024);
@@ -477,6 +491,13 @@ static uint16_t* launch_forward_fused(acez_trainer*, const uint16_t*, const int6
 static bool seq_usable(const acez_trainer* tr, int n) {
   const int mtiles = (n + 79) / 80;
   return tr->seq && tr->gemm_tile == 80 && mtiles <= 64 && 32 * ((mtiles + 7) / 8) <= tr->n_cus;
+}
+
+// wgrad_opt_kernel's workgroups wait for each other too: same conditions, its own grid (both slabs of a layer on one XCD: 32 workgroups
+// per layer, layers round-robin over the XCDs)
+static bool wgrad_opt_usable(const acez_trainer* tr) {
+  return tr->wgrad_opt && tr->seq && tr->gemm_tile == 80 && !tr->chain && !tr->fused_fwd && tr->wgrad_tile == 128 && tr->nslabs == 2 &&
+         256 * ((tr->L + 7) / 8) <= tr->n_cus;
 }
 
 template <bool BWD>
@@ -876,7 +897,21 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
 
   delete dchain;
   }
+  // the partial buffers of this step (reduced by grad_reduce_kernel in the split flow, by the optimiser launches in the fused step)
+  {
+    GradReduceArgs a{};
+    a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.nslabs = tr->nslabs; a.fc3_partials = tr->fc3_partials;
+    a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials; a.n_loss_blocks = nblk; a.grad = tr->pb.d_grad;
+    a.n_wide = tr->n_wide; a.n_params = tr->n_params; a.st = st;
+    a.bias_partials = tr->bias_partials; a.bias_layer_stride = tr->bias_layer_stride; a.n_layers = tr->L;
+    a.skip_wide = fused ? 1 : 0;
+    a.fault = tr->seq_err;
+    // partial rows per layer: one per 32-row workgroup from the chain kernel / the loss kernel, one per row tile from rowgemm
+    for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2 || tr->chain) ? nblk : (tr->gemm_tile == 80 ? (n + 79) / 80 : 2 * ((n + 127) / 128));
+    tr->last_reduce = a;   // the fused update reduces the partials itself
+  }
   // weight gradients of all wide layers in one launch
+  tr->wide_done = false;
   {
     WgradArgs a{};
     for (int l = 0; l < tr->L; ++l) {
@@ -890,7 +925,21 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.n_layers = tr->L; a.st = st; a.zeros = tr->zeros; a.dbg = 0;
     ProfScope ps(tr, s, KC_WGRAD);
     const int groups = tr->L * tr->nslabs;
-    if (tr->f16) hipLaunchKernelGGL(wgrad_kernel<EltF16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
+    if (fused && wgrad_opt_usable(tr)) {
+      // single-GPU fused step: the launch applies the optimiser to the wide layers' weights itself (wgrad_opt_kernel); the update that
+      // follows (train_update_impl) only has the small parameters, the statistics and the schedule left
+      WgradOptArgs o{};
+      fill_adam_args(tr, o.ad);
+      o.ad.tail = tr->last_reduce;
+      o.xch = tr->wg_xch; o.flags = tr->wg_flags; o.spin_limit = tr->seq_spin_limit;
+      o.target = 2u * ++tr->wg_epoch;
+      if ((long)tr->wg_epoch - 1 == tr->wgo_fault_at) o.target += 1u << 20;   // tests: a partner that never arrives
+      const dim3 grid(256 * ((tr->L + 7) / 8));
+      if (tr->f16) hipLaunchKernelGGL(wgrad_opt_kernel<EltF16>, grid, dim3(WGRAD_THREADS), 0, s, a, o);
+      else hipLaunchKernelGGL(wgrad_opt_kernel<EltBf16>, grid, dim3(WGRAD_THREADS), 0, s, a, o);
+      tr->wide_done = true;
+    }
+    else if (tr->f16) hipLaunchKernelGGL(wgrad_kernel<EltF16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
     else if (tr->wgrad_tile == 128) hipLaunchKernelGGL(wgrad_kernel<EltBf16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
 #ifdef ACEZ_DIAG
     else hipLaunchKernelGGL(wgrad256_kernel, dim3(64 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
@@ -898,23 +947,11 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     else abort();   // (wgrad_tile is 128 in the product build)
 #endif
   }
-  {
-    GradReduceArgs a{};
-    a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.nslabs = tr->nslabs; a.fc3_partials = tr->fc3_partials;
-    a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials; a.n_loss_blocks = nblk; a.grad = tr->pb.d_grad;
-    a.n_wide = tr->n_wide; a.n_params = tr->n_params; a.st = st;
-    a.bias_partials = tr->bias_partials; a.bias_layer_stride = tr->bias_layer_stride; a.n_layers = tr->L;
-    a.skip_wide = fused ? 1 : 0;
-    a.fault = tr->seq_err;
-    // partial rows per layer: one per 32-row workgroup from the chain kernel / the loss kernel, one per row tile from rowgemm
-    for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2 || tr->chain) ? nblk : (tr->gemm_tile == 80 ? (n + 79) / 80 : 2 * ((n + 127) / 128));
-    tr->last_reduce = a;   // the fused update reduces the partials itself
-    if (!fused) {
-      const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
-      const int64_t tail_blocks = (((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4) * 64 + 255) / 256;
-      ProfScope ps(tr, s, KC_REDUCE);
-      hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, a);
-    }
+  if (!fused) {
+    const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
+    const int64_t tail_blocks = (((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4) * 64 + 255) / 256;
+    ProfScope ps(tr, s, KC_REDUCE);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, tr->last_reduce);
   }
   if (ps != s) ACEZ_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_pose_bwd, 0));   // d_grad's pose tail: read by the all-reduce and by the pose AdamW
   if (pf && !fused) {
@@ -950,13 +987,17 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
   fill_adam_args(tr, a);
   if (fused) { a.slabs = tr->slabs; a.nslabs = tr->nslabs; a.slab_stride = tr->n_wide; a.tail = tr->last_reduce; }
   const int nsmall = adamw_small_blocks(tr->L, (int64_t)tr->no * 513, fused);   // small-parameter workgroups come first in the grid
+  // wgrad_opt_kernel of this step's backward has already updated the wide layers' weights: no tile workgroups
+  const bool wide_done = fused && tr->wide_done;
+  tr->wide_done = false;
+  const int ntile = wide_done ? 0 : tr->L * 64;
   const bool pf = tr->pose_fused && !tr->chain && !tr->fused_fwd;
   if (pf && fused) {
     // the head's AdamW with the pose network's reduce + backward chain (S1) as the first workgroups of the same launch, then the
     // pose weight gradients with AdamW in their epilogue (S2: needs S1 of every image tile)
     const int T = tr->pose_tile, np = (tr->buf.n_images + T - 1) / T;
     { ProfScope ps(tr, s, KC_ADAMW);
-#define ACEZ_AP(TT) hipLaunchKernelGGL(adamw_pose_kernel<TT>, dim3(np + tr->L * 64 + nsmall), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active), \
+#define ACEZ_AP(TT) hipLaunchKernelGGL(adamw_pose_kernel<TT>, dim3(np + ntile + nsmall), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active), \
                                        (const float*)tr->row_dT, (const int*)tr->row_image, tr->last_n, np)
       if (T == 16) ACEZ_AP(16); else if (T == 4) ACEZ_AP(4); else ACEZ_AP(8);
 #undef ACEZ_AP
@@ -969,7 +1010,11 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
   a.layer_lo = layer_lo; a.layer_hi = layer_hi;
   if (fused && d_next && n_next > 0 && tr->cfg.pose_refinement == 0 && !tr->chain && !tr->fused_fwd && tr->have_buf) {
     // the next batch is known: its gather and this step's schedule bookkeeping ride in the optimiser's launch (adamw_next_kernel)
-    const int n_adam = tr->L * 64 + nsmall;
+    int n_adam = ntile + nsmall;
+    // timing experiments (diagnostics build; results wrong by construction): 1 = no optimiser workgroups at all, 2 = no gather
+    const int tail_abl = ACEZ_DIAG_ENV("ACEZ_TAIL_ABL") ? atoi(ACEZ_DIAG_ENV("ACEZ_TAIL_ABL")) : 0;
+    if (tail_abl & 1) n_adam = 0;
+    if (tail_abl & 2) n_next = 0;
     // every workgroup of the launch resident at once (4 of these 256-thread workgroups per CU): gather workgroups that had to wait for a
     // free slot started when the optimiser's tiles were done and ran their three load levels as the launch's tail. ACEZ_NEXT_GBLOCKS
     // overrides the count (timing experiments).
@@ -988,7 +1033,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     ACEZ_HIP_CHECK(hipGetLastError());
     return ACEZ_OK;
   }
-  { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3((layer_hi - layer_lo) * 64 + nsmall), dim3(256), 0, s, a); }
+  { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3((wide_done ? 0 : (layer_hi - layer_lo) * 64) + nsmall), dim3(256), 0, s, a); }
   if (tr->cfg.pose_refinement != 0) tr->pose_wt_valid = false;   // adamw_small_kernel does not refresh the transposed copies
   if (tr->cfg.pose_refinement != 0)
     hipLaunchKernelGGL(adamw_small_kernel, dim3((unsigned)((tr->pb.n_pose_params + 255) / 256)), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,

@@ -177,4 +177,16 @@ struct AdamArgs {
                             // layers); biases, fc3 and the statistics are always handled. 0 .. n_layers = everything
 };
 
+// wgrad_opt_kernel (single-GPU fused step): the weight-gradient launch finishes the optimiser step of the wide layers itself. The two
+// row slabs of a 128 x 128 gradient tile run on two CUs of ONE XCD; each sends the half of its partial tile the other one owns through
+// that XCD's L2 (`xch`) and bumps the owner's counter (`flags`, the hand-off of rowseq_kernel: L2-local atomic, bounded sc1 poll, no
+// fence), then applies AdamW to its own half: slab 0 + slab 1 in that order, the additions grad_reduce_kernel / adamw_kernel perform.
+struct WgradOptArgs {
+  AdamArgs ad;           // the optimiser's arguments (slabs unused; tail = the partial buffers of this step: NaN / overflow guards)
+  float* xch;            // [n_layers * 16 tiles][2 owners][64][128] fp32
+  uint32_t* flags;       // [n_layers * 16 tiles][2 owners][32]: one counter per receiving workgroup on its own 128-byte line
+  uint32_t target;       // value of a counter once both sending waves of this launch have stored (2 x launches so far)
+  uint32_t spin_limit;   // poll budget, as RowSeqArgs::spin_limit
+};
+
 }  // namespace acez

@@ -785,30 +785,42 @@ __device__ __forceinline__ typename E::frag tr_frag(const uint16_t* p) {
 #endif
 constexpr int WGRAD_LOADERS = 8;                    // loader waves per workgroup (beside the 4 multiplier waves)
 constexpr int WGRAD_THREADS = 256 + 64 * WGRAD_LOADERS;
-template <class E = EltBf16>
-__global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
-  const int active = a.st ? a.st->active : 1;  // tested before the stores only (see rowgemm_kernel)
+// s_waitcnt vmcnt(n) for a wave-uniform n that is only known at run time (a multiple of 4 up to 28 here; anything else waits for everything)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  switch (n) {
+    case 4: ACEZ_VMCNT(4); break;
+    case 8: ACEZ_VMCNT(8); break;
+    case 12: ACEZ_VMCNT(12); break;
+    case 16: ACEZ_VMCNT(16); break;
+    case 20: ACEZ_VMCNT(20); break;
+    case 24: ACEZ_VMCNT(24); break;
+    case 28: ACEZ_VMCNT(28); break;
+    default: ACEZ_VMCNT(0); break;
+  }
+}
+
+// The K loop of one (layer, row slab, 128 x 128 tile) workgroup, shared by wgrad_kernel and wgrad_opt_kernel. Returns true in the
+// loader waves (their loop is over: every stage has landed and every barrier of the loop has been passed), false in the four multiplier
+// waves, whose accumulators then hold the slab's partial tile. KT = number of 64-row stages of this slab.
+// PFN > 0: `prefetch()` issues exactly PFN vector-memory loads (wgrad_opt_kernel: the optimiser state of the workgroup's half tile) from
+// inside the loader loop, about a dozen stages before its end, so that they travel beside the operand stream instead of after it; loads
+// complete in order, so the counted waits of the stages requested BEFORE the prefetch allow PFN more instructions in flight.
+template <class E, int PFN, class PF>
+__device__ __forceinline__ bool wgrad_kloop(const WgradArgs& a, uint16_t (*smem)[2][64 * 128], const int layer, const int slab, const int tile,
+                                            f32x16 (&acc)[2][2], int& KT_out, PF&& prefetch) {
   constexpr int RING = ACEZ_WGRAD_RING;   // slots of the [dZ | In] stage ring, 32 KiB each (RING - 1 stages in flight per CU)
-  __shared__ __attribute__((aligned(16))) uint16_t smem[RING][2][64 * 128];
+  static_assert(PFN % 4 == 0 && 2 * (16 / WGRAD_LOADERS) * (RING - 1) + PFN <= 28, "wait_vmcnt_dyn covers multiples of 4 up to 28");
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  // Role split: waves 0..3 multiply (2 x 2 grid of 64 x 64 sub-tiles: 4 fragment reads feed 4 MFMAs), waves 4..7 only
+  // Role split: waves 0..3 multiply (2 x 2 grid of 64 x 64 sub-tiles: 4 fragment reads feed 4 MFMAs), waves 4..11 only
   // issue the LDS-DMA. A wave's instruction stream is in-order: with every wave loading AND multiplying, the ~0.4 us a
   // stage's DMA instructions need to get through the memory pipeline was added to the MFMA time instead of hidden
   // behind it (ablation: 18 us loads-only + 23 us MFMA-only = 41 us). Waves w and w + 4 share a SIMD, so every SIMD
-  // has one multiplier and one loader.
+  // has one multiplier and two loaders.
   const bool loader = w >= 4;
   const int cw = w & 3, wn = cw >> 1, wc = cw & 1;
   const int lw = w - 4;                         // loader index
   constexpr int GPL = 16 / WGRAD_LOADERS;       // 4-row DMA groups (x 2 operands) per loader and stage
-  // XCD-aware decode: the 16 output tiles of one (layer, slab) group re-read the same dZ / In rows (4x each); they
-  // are placed on ONE XCD (workgroup b runs on XCD b % 8) so that the re-reads hit that XCD's L2 instead of the
-  // fabric. Placement only affects speed.
-  const int b = blockIdx.x;
-  const int xcd = b & 7, jx = b >> 3;
-  const int group = xcd + 8 * (jx >> 4), tile = jx & 15;
-  if (group >= a.n_layers * a.nslabs) return;
-  const int layer = group / a.nslabs, slab = group - layer * a.nslabs;
   const int n0 = (tile >> 2) * 128, c0 = (tile & 3) * 128;
   const uint16_t* __restrict__ Z = a.dZ[layer];
   const uint16_t* __restrict__ X = a.In[layer];
@@ -818,8 +830,9 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
   const int mb = slab * rows_per_slab;
   const int me = min(M, mb + rows_per_slab);
   const int KT = (me > mb) ? (me - mb + 63) >> 6 : 0;
+  KT_out = KT;
 
-  // DMA instruction j (0..3) of loader wave cw covers stage rows (cw*4+j)*4 .. +3 of both operands; this lane: row + (l>>4),
+  // DMA instruction j of loader wave lw covers stage rows (lw*GPL+j)*4 .. +3 of both operands; this lane: row + (l>>4),
   // physical 16-byte chunk l&15, which must receive the logical chunk whose 32-byte segment index is XOR-swizzled
   const int prow = l >> 4, pq = l & 15;
   auto issue = [&](int kt) {
@@ -838,7 +851,6 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
     }
   };
 
-  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -846,29 +858,38 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int offA[2] = {tr_base(wn * 64, l), tr_base(wn * 64 + 32, l)};
-  const int offB[2] = {tr_base(wc * 64, l), tr_base(wc * 64 + 32, l)};
   // Two separate loops (one per role) with the same number of barriers: sharing one loop body makes the compiler
   // carry the 64 accumulator registers through the loader's control flow (moves on every iteration).
   if (loader) {
     if (ACEZ_DBG(a.dbg) & 4) {
       for (int kt = 0; kt < KT; ++kt) __builtin_amdgcn_s_barrier();
-      return;
+      if (PFN > 0) prefetch();
+      return true;
     }
     for (int kt = 0; kt < RING && kt < KT; ++kt) issue(kt);
-    for (int kt = 0; kt < KT; ++kt) {
+    // stage kt: wait until it has landed, meet the multipliers (they are done with stage kt - 1), refill the slot of stage kt - 1
+    auto stage = [&](int kt, int extra) {
       // stages issued so far: 0..RING-1 at kt = 0, 0..kt+RING-2 afterwards; a loader wave has 2 * GPL DMA instructions per stage in flight
       const int later = (kt == 0) ? min(RING - 1, KT - 1) : min(RING - 2, KT - 1 - kt);
-      if (later >= 4) ACEZ_VMCNT_C(8 * GPL);
-      else if (later == 3) ACEZ_VMCNT_C(6 * GPL);
-      else if (later == 2) ACEZ_VMCNT_C(4 * GPL);
-      else if (later == 1) ACEZ_VMCNT_C(2 * GPL);
-      else ACEZ_VMCNT(0);
-      __builtin_amdgcn_s_barrier();  // stage kt has landed; the multipliers are done with stage kt - 1
+      wait_vmcnt_dyn(2 * GPL * later + extra);
+      __builtin_amdgcn_s_barrier();
       if (kt >= 1 && kt + RING - 1 < KT) issue(kt + RING - 1);
+    };
+    if (PFN == 0) {
+      for (int kt = 0; kt < KT; ++kt) stage(kt, 0);
+    } else {
+      // the prefetch goes out behind the issue of iteration P (P < 0: behind the first RING stages); the last stage requested before
+      // it is S: stages kt <= S are older than the prefetch, their waits allow it to be in flight
+      const int P = KT > 16 ? KT - 13 : -1;
+      for (int kt = 0; kt <= P; ++kt) stage(kt, 0);
+      prefetch();
+      const int S = P < 0 ? min(RING, KT) - 1 : min(P + RING - 1, KT - 1);
+      for (int kt = P + 1; kt < KT; ++kt) stage(kt, kt <= S ? PFN : 0);
     }
-    return;
+    return true;
   }
+  const int offA[2] = {tr_base(wn * 64, l), tr_base(wn * 64 + 32, l)};
+  const int offB[2] = {tr_base(wc * 64, l), tr_base(wc * 64 + 32, l)};
   for (int kt = 0; kt < KT; ++kt) {
     __builtin_amdgcn_s_barrier();
     if (ACEZ_DBG(a.dbg) & 2) continue;
@@ -886,6 +907,27 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
         for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma32(fa[i], fb[j], acc[i][j]);
     }
   }
+  return false;
+}
+
+template <class E = EltBf16>
+__global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
+  const int active = a.st ? a.st->active : 1;  // tested before the stores only (see rowgemm_kernel)
+  __shared__ __attribute__((aligned(16))) uint16_t smem[ACEZ_WGRAD_RING][2][64 * 128];
+  const int l = threadIdx.x & 63;
+  const int cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3, wn = cw >> 1, wc = cw & 1;
+  // XCD-aware decode: the 16 output tiles of one (layer, slab) group re-read the same dZ / In rows (4x each); they
+  // are placed on ONE XCD (workgroup b runs on XCD b % 8) so that the re-reads hit that XCD's L2 instead of the
+  // fabric. Placement only affects speed.
+  const int b = blockIdx.x;
+  const int xcd = b & 7, jx = b >> 3;
+  const int group = xcd + 8 * (jx >> 4), tile = jx & 15;
+  if (group >= a.n_layers * a.nslabs) return;
+  const int layer = group / a.nslabs, slab = group - layer * a.nslabs;
+  const int n0 = (tile >> 2) * 128, c0 = (tile & 3) * 128;
+  f32x16 acc[2][2];
+  int KT;
+  if (wgrad_kloop<E, 0>(a, smem, layer, slab, tile, acc, KT, [] {})) return;
 
   if (ACEZ_DBG(a.dbg) & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
   if (!active) return;
@@ -1598,8 +1640,78 @@ __device__ __forceinline__ float adamw_one(float p, float g, float& m, float& v,
 // round trips -- partials -> butterfly -> p, m, v -> store -- that should run under the streaming tile blocks, not after them.)
 __host__ __device__ inline int adamw_small_blocks(int n_layers, int64_t n_fc3, bool fused) {
   const int64_t n_small = (int64_t)n_layers * 512 + n_fc3;
-  return fused ? (int)(((n_small + 4 + 7) / 8 * 64 + 255) / 256)   // fused: a wavefront per EIGHT outputs (tail_output8)
+  return fused ? (int)((n_small + 4 + 63) / 64)   // fused: 64 outputs per workgroup, four lanes each (adamw_small_columns)
                : (int)((n_small + 255) / 256);
+}
+
+// The small parameters of the fused step (biases of the wide layers, fc3) and the four statistics: 64 consecutive outputs per
+// workgroup, FOUR lanes (a DPP quad) per output. An output is a column sum over partial rows (one per row tile of the GEMM chain, or per
+// workgroup of the loss kernel): a load instruction of a wavefront reads 16 adjacent columns of 4 rows -- four full 64-byte lines --
+// where tail_output / tail_output8 (a wavefront per output, lanes striding the ROWS) touch 64 different lines with every instruction:
+// 193 workgroups of those were the long pole of the optimiser launch (18 us by themselves at batch 5120, against 9.5 us for gather +
+// schedule; round 4). The summation ORDER is tail_output's, so the bits are: partial j = rows j, j + 64, ... added in that order, then
+// the xor butterfly 32, 16, ..., 1, which pairs partial j with j ^ off at every level -- a fixed binary tree (addition commutes). Lane q
+// of the quad holds the partials j = 4 i + q: the levels 32 .. 4 pair i with i ^ 8, 4, 2, 1 inside the lane's registers, the levels 2
+// and 1 are two quad permutes.
+__device__ __forceinline__ void adamw_small_columns(const AdamArgs& a, const int b, const AdamScalars& s) {
+  const int t = threadIdx.x, lane = t & 63, q = t & 3;
+  const GradReduceArgs& r = a.tail;
+  const int64_t n_bias = (int64_t)a.n_layers * 512, n_fc3 = a.n_fc3, n_out = n_bias + n_fc3 + 4;
+  const int64_t k = (int64_t)b * 64 + (t >> 2);
+  const float* base = r.stat_partials;
+  int cnt = 0;
+  int64_t stride = 0, dst = -1, ome = -1;
+  if (k < n_bias) {
+    const int layer = (int)(k >> 9), c = (int)(k & 511);
+    base = r.bias_partials + (size_t)layer * r.bias_layer_stride + c; cnt = r.bias_count[layer]; stride = 512;
+    dst = (int64_t)layer * 262656 + 262144 + c;
+    ome = a.b_off[layer] + c;
+  } else if (k < n_bias + n_fc3) {
+    base = r.fc3_partials + (k - n_bias); cnt = r.n_loss_blocks; stride = r.fc3_stride;
+    dst = r.n_wide + (k - n_bias);
+    ome = a.fc3_off + (k - n_bias);
+  } else if (k < n_out) {
+    const int64_t kk = k - n_bias - n_fc3;
+    if (kk < 3) { base = r.stat_partials + kk; cnt = r.n_loss_blocks; stride = 4; }
+    dst = r.n_params + kk;
+  }
+  float p = 0.f, m = 0.f, v = 0.f;
+  if (q == 0 && ome >= 0) { p = a.params[ome]; m = a.m[ome]; v = a.v[ome]; }   // requested before the reduction
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int last = max(cnt - 1, 0);
+  for (int u = 0; __any(64 * u < cnt); ++u) {
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 64 * u + 4 * i + q;
+      const float y = base[(size_t)min(row, last) * stride];   // unconditional load, masked afterwards
+      x[i] = row < cnt ? y : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += x[i];   // (+0.f where tail_output adds nothing: acc is never -0, so the bits are the same)
+  }
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1)
+#pragma unroll
+    for (int i = 0; i < off; ++i) acc[i] = acc[i] + acc[i + off];
+  float g = acc[0];
+  g = ACEZ_DPP_ADD(g, 0x4E, 0xF);   // quad_perm [2,3,0,1]: butterfly level 2
+  g = ACEZ_DPP_ADD(g, 0xB1, 0xF);   // quad_perm [1,0,3,2]: butterfly level 1
+  if (b == (int)((n_out - 1) >> 6) && r.fault) {   // statistics slot 3: the fault word + the fp16 overflow flag (see tail_output)
+    const uint32_t amax_bits = absmax_all(r.st, lane);
+    if (k == n_out - 1) g = (*r.fault ? 1.f : 0.f) + (amax_bits >= 0x7f800000u ? 1024.f : 0.f);
+  }
+  if (k < n_bias + n_fc3) g *= r.st->inv_grad_scale;   // (fp16: gradients arrive scaled; 1 for bf16, an exact product)
+  if (q != 0 || dst < 0) return;
+  r.grad[dst] = g;
+  if (ome >= 0) {
+    p = adamw_one(p, g, m, v, s);
+    a.params[ome] = p; a.m[ome] = m; a.v[ome] = v;
+    const int64_t kf = k - n_bias;
+    if (kf >= 0 && kf < (int64_t)a.no * 512) a.W3b[kf] = a.f16 ? EltF16::from_f(p) : f2bf(p);
+  }
 }
 
 // One workgroup's share of the optimiser step (b = workgroup index inside the optimiser's part of a launch; tileT: 64 x 66 bf16 LDS).
@@ -1706,35 +1818,8 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
   } else {
     // small parameters: biases of the wide layers, fc3 weight + bias
     const int64_t n_bias = (int64_t)a.n_layers * 512;
-    if (a.slabs) {
-      // fused step: a wavefront reduces the partials of eight consecutive outputs (exactly grad_reduce_kernel's tail, output by
-      // output), stores the gradients / statistics and applies the optimiser: lane j < 8 owns output k0 + j, and its p, m, v are
-      // requested before the reduction
-      const int lane = t & 63;
-      const int64_t k0 = (((int64_t)b * 256 + t) >> 6) * 8;
-      const int64_t n_out = n_bias + a.n_fc3 + 4;
-      if (k0 >= n_out) return;
-      const int64_t kme = k0 + (lane & 7);
-      int64_t ome = -1;
-      if (kme < n_bias) ome = a.b_off[kme >> 9] + (kme & 511);
-      else if (kme < n_bias + a.n_fc3) ome = a.fc3_off + (kme - n_bias);
-      float p = 0.f, m = 0.f, v = 0.f;
-      if (lane < 8 && ome >= 0) { p = a.params[ome]; m = a.m[ome]; v = a.v[ome]; }
-      float acc[8];
-      int64_t dst[8];
-      tail_output8(a.tail, k0, lane, acc, dst);
-      float g = 0.f;
-      int64_t o = -1;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if ((lane & 7) == j) { g = acc[j]; o = dst[j]; }
-      if (lane >= 8 || o < 0) return;
-      a.tail.grad[o] = g;
-      if (ome >= 0) {
-        p = adamw_one(p, g, m, v, s);
-        a.params[ome] = p; a.m[ome] = m; a.v[ome] = v;
-        if (kme >= n_bias && (kme - n_bias) < (int64_t)a.no * 512) a.W3b[kme - n_bias] = a.f16 ? EltF16::from_f(p) : f2bf(p);
-      }
+    if (a.slabs) {   // fused step: the partials are reduced here as well (grad_reduce_kernel's tail, output by output, the same bits)
+      adamw_small_columns(a, b, s);
       return;
     }
     const int64_t k = (int64_t)b * 256 + t;
@@ -1753,6 +1838,179 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   __shared__ uint16_t tileT[64][66];
   adamw_body(a, blockIdx.x, tileT);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad_opt: wgrad_kernel's product with the optimiser step of the wide layers as its epilogue (single-GPU fused step). wgrad + adamw
+// as two launches round-trip both split-K slabs through HBM (16.8 MB written, 16.8 MB read), start the optimiser's 25 MB of state
+// reads only when the gradients are complete, and pay a kernel boundary; here
+//  * both row slabs of a 128 x 128 tile are placed on ONE XCD (layer = XCD, 32 workgroups each for the default head). A workgroup
+//    finalises the 64 x 128 half tile of its slab index: its two multiplier waves of the OTHER half store their accumulators to the
+//    partner's exchange tile (this XCD's L2), wait for the acknowledgement and bump the partner's counter -- rowseq_kernel's hand-off:
+//    L2-local atomic, bounded sc1 poll on the other side, no fence, nothing read before it is produced;
+//  * the eight loader waves, idle once the last stage is requested, fetch p, m, v of the half tile a dozen stages before the K loop
+//    ends, then poll, add own (through LDS) + partner partial in slab order (slab 0 + slab 1: the additions of grad_reduce_kernel /
+//    adamw_body, so the parameters are bitwise those of backward + update), apply adamw_one and store p, m, v, W and -- through an
+//    LDS transpose -- W^T.
+// The guards are adamw_body's (schedule inactive, chain fault, NaN loss, fp16 overflow: nothing is stored); the exchange itself is
+// unconditional, so the two partners never disagree about it. A poll that expires raises the trainer's fault word exactly like a
+// rowseq hand-off (the host falls back to wgrad_kernel + adamw_kernel at its next state read); the stores of that wave are skipped.
+// Host: only when the grid fits the CUs (every workgroup resident) and the placement probe has passed (head_api.hip).
+// ---------------------------------------------------------------------------------------------------
+constexpr int WGO_PF = 12;   // prefetch loads per loader lane: 4 x (p, m, v) float4
+template <class E = EltBf16>
+__global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, WgradOptArgs o) {
+  constexpr int RING = ACEZ_WGRAD_RING;
+  static_assert(RING >= 3, "two free ring slots are used as staging areas after the K loop");
+  __shared__ __attribute__((aligned(16))) uint16_t smem[RING][2][64 * 128];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  // workgroup b runs on XCD b % 8: both slabs of all 16 tiles of a layer on one XCD (placement affects speed AND the hand-off, hence the probe)
+  const int b = blockIdx.x;
+  const int xcd = b & 7, jx = b >> 3;
+  const int layer = xcd + 8 * (jx >> 5), slab = (jx >> 4) & 1, tile = jx & 15;
+  if (layer >= a.n_layers) return;
+  const int n0 = (tile >> 2) * 128, c0 = (tile & 3) * 128;
+  const AdamArgs& ad = o.ad;
+  // this lane's share of the workgroup's 64 x 128 half tile in the epilogue (loader waves): rows rb + 16 i, columns col4 .. col4 + 3
+  const int e = t - 256, rb = e >> 5, col4 = (e & 31) * 4;
+  const int64_t woff = ad.w_off[layer];
+  const int nrow0 = n0 + 64 * slab;   // first row of the half tile this workgroup finalises
+  float4 p4[4], m4[4], v4[4];
+  auto prefetch = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t off = woff + (int64_t)(nrow0 + rb + 16 * i) * 512 + c0 + col4;
+      p4[i] = *reinterpret_cast<const float4*>(ad.params + off);
+      m4[i] = *reinterpret_cast<const float4*>(ad.m + off);
+      v4[i] = *reinterpret_cast<const float4*>(ad.v + off);
+    }
+  };
+  f32x16 acc[2][2];
+  int KT;
+  const bool loader = wgrad_kloop<E, WGO_PF>(a, smem, layer, slab, tile, acc, KT, prefetch);
+  // Slot KT % RING was last written for stage KT - RING and slot (KT + 1) % RING for stage KT - RING + 1: every wave is past the barrier
+  // of stage KT - 1, i.e. done with both; the slot of stage KT - 1 itself may still be read by a slower multiplier wave.
+  float* const stage = reinterpret_cast<float*>(&smem[KT % RING][0][0]);                                  // [64][128] fp32: own partial
+  uint16_t (*const tileT)[66] = reinterpret_cast<uint16_t (*)[66]>(&smem[(KT + 1) % RING][0][0]);         // [128][66]: W^T staging
+  const int pair = layer * 16 + tile;
+  if (!loader) {
+    const int cw = w & 3, wn = cw >> 1, wc = cw & 1, h = l >> 5;
+    if (wn != slab) {
+      float* __restrict__ X = o.xch + (size_t)(pair * 2 + (1 - slab)) * 8192;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            X[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + wc * 64 + j * 32 + (l & 31)] = acc[i][j][r];
+      ACEZ_VMCNT(0);   // acknowledged by the L2 both workgroups share
+      if (l == 0) {
+        const uint32_t one = 1;
+        asm volatile("global_atomic_add %0, %1, off" ::"v"(o.flags + (size_t)(pair * 2 + (1 - slab)) * 32), "v"(one) : "memory");
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + wc * 64 + j * 32 + (l & 31)] = acc[i][j][r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // (B1) the own half is in LDS
+    __builtin_amdgcn_s_barrier();   // (B2) the loaders' transpose tile
+    return;
+  }
+  // ------------------------------------------------------------------ loader waves: the optimiser step of the half tile
+  const TrainState* st = ad.st;
+  const int active = st->active;
+  const AdamScalars s = st->adam;
+  const float inv_scale = st->inv_grad_scale;
+  const int fault_now = *ad.fault;
+  int64_t dummy;
+  const float lossv = tail_output(ad.tail, (int64_t)ad.n_layers * 512 + ad.n_fc3, l, dummy);
+  bool skip = !active || fault_now || lossv != lossv;   // adamw_body's guards
+  if (E::is_f16) skip = skip || absmax_all(st, l) >= 0x7f800000u;
+  {
+    uint32_t vseen, sseen, spins, timed;
+    const uint32_t* flag = o.flags + (size_t)(pair * 2 + slab) * 32;
+    asm volatile(
+        "s_mov_b32 %[spins], 0\n\t"
+        "s_mov_b32 %[timed], 0\n"
+        "1:\n\t"
+        "global_load_dword %[vseen], %[flag], off sc1\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[sseen], %[vseen]\n\t"
+        "s_sub_i32 %[sseen], %[sseen], %[target]\n\t"
+        "s_cmp_ge_i32 %[sseen], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sleep " ACEZ_SEQ_SLEEP "\n\t"
+        "s_add_u32 %[spins], %[spins], 1\n\t"
+        "s_cmp_lt_u32 %[spins], %[limit]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_mov_b32 %[timed], 1\n"
+        "2:"
+        : [vseen] "=&v"(vseen), [sseen] "=&s"(sseen), [spins] "=&s"(spins), [timed] "=&s"(timed)
+        : [flag] "v"(flag), [target] "s"(o.target), [limit] "s"(o.spin_limit)
+        : "memory", "scc");
+    if (timed) {   // the partner never arrived (the two slabs of a tile are not on one XCD after all): fault word, step switched off
+      skip = true;
+      if (l == 0) {
+        __hip_atomic_store(ad.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(const_cast<int*>(&st->active), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  float4 oth[4];
+  {
+    const float* __restrict__ Xin = o.xch + (size_t)(pair * 2 + slab) * 8192;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) oth[i] = *reinterpret_cast<const float4*>(Xin + (rb + 16 * i) * 128 + col4);
+  }
+  __builtin_amdgcn_s_barrier();   // (B1)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rb + 16 * i;
+    const float4 own = *reinterpret_cast<const float4*>(stage + row * 128 + col4);
+    // slab 0 + slab 1 (fp32 addition commutes: the same bits whichever of the two is `own`), then the un-scaling of the fp16 chain
+    float4 g;
+    g.x = (own.x + oth[i].x) * inv_scale; g.y = (own.y + oth[i].y) * inv_scale;
+    g.z = (own.z + oth[i].z) * inv_scale; g.w = (own.w + oth[i].w) * inv_scale;
+    float4 p = p4[i], m = m4[i], v = v4[i];
+    p.x = adamw_one(p.x, g.x, m.x, v.x, s);
+    p.y = adamw_one(p.y, g.y, m.y, v.y, s);
+    p.z = adamw_one(p.z, g.z, m.z, v.z, s);
+    p.w = adamw_one(p.w, g.w, m.w, v.w, s);
+    const uint2 pk = E::pk4(p.x, p.y, p.z, p.w);
+    if (!skip) {
+      const int64_t off = woff + (int64_t)(nrow0 + row) * 512 + c0 + col4;
+      *reinterpret_cast<float4*>(ad.params + off) = p;
+      *reinterpret_cast<float4*>(ad.m + off) = m;
+      *reinterpret_cast<float4*>(ad.v + off) = v;
+      *reinterpret_cast<uint2*>(ad.Wb + (size_t)layer * 262144 + (size_t)(nrow0 + row) * 512 + c0 + col4) = pk;
+    }
+    tileT[col4 + 0][row] = (uint16_t)(pk.x & 0xffff);
+    tileT[col4 + 1][row] = (uint16_t)(pk.x >> 16);
+    tileT[col4 + 2][row] = (uint16_t)(pk.y & 0xffff);
+    tileT[col4 + 3][row] = (uint16_t)(pk.y >> 16);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // (B2)
+  {
+    // W^T: row c0 + cl holds the 64 values n = nrow0 .. nrow0 + 63 of column cl: 128 contiguous bytes, 32 per lane
+    const int cl = e >> 2, part = e & 3;
+    uint32_t q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = (uint32_t)tileT[cl][part * 16 + 2 * k] | ((uint32_t)tileT[cl][part * 16 + 2 * k + 1] << 16);
+    if (!skip) {
+      uint16_t* dst = ad.WbT + (size_t)layer * 262144 + (size_t)(c0 + cl) * 512 + nrow0 + part * 16;
+      *reinterpret_cast<uint4*>(dst) = make_uint4(q[0], q[1], q[2], q[3]);
+      *reinterpret_cast<uint4*>(dst + 8) = make_uint4(q[4], q[5], q[6], q[7]);
+    }
+  }
 }
 
 // W^T of wide layers layer_lo .. from their 16-bit W (acez_trainer_import_weights16: the sharded data-parallel update receives the
