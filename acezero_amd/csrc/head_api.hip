@@ -122,7 +122,15 @@ struct acez_trainer {
   float* wg_xch = nullptr;        // [L * 16 tiles][2][64][128] fp32 exchange tiles
   uint32_t* wg_flags = nullptr;   // [L * 16 tiles][2][32] hand-off counters
   uint32_t wg_epoch = 0;          // wgrad_opt launches so far (a counter reaches 2 * epoch in each of them)
-  bool wide_done = false;         // this step's backward has already applied the optimiser to the wide layers' weights
+  bool wide_done = false;         // this step's backward has already applied the optimiser to the wide layers' weights AND the small parameters
+  bool post_done = false;         // ... and run the schedule wave that closes the step (no pose refinement)
+  // acez_train_step_next on this path: the next batch is gathered beside the loss kernel (loss_gather_kernel) into the OTHER input
+  // buffer / metadata table (the weight-gradient launch of the running step still reads the current ones); swapped when the step ends
+  uint16_t* R0_alt = nullptr;
+  int4* batch_meta_alt = nullptr;
+  bool next_gathered = false;
+  const int64_t* next_idx = nullptr;
+  int next_n = 0;
   long wgo_fault_at = -1;         // tests: ACEZ_WGO_FAULT_AT=<n> makes the n-th wgrad_opt launch time out
 };
 
@@ -348,6 +356,8 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   }
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGRAD_OPT")) tr->wgrad_opt = atoi(e) != 0;
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_AT")) tr->wgo_fault_at = atol(e);
+  A((void**)&tr->R0_alt, act_bytes);
+  A((void**)&tr->batch_meta_alt, (size_t)tr->max_batch * sizeof(int4));
   A((void**)&tr->wg_xch, (size_t)tr->L * 16 * 2 * 8192 * sizeof(float));
   A((void**)&tr->wg_flags, (size_t)tr->L * 16 * 2 * 32 * sizeof(uint32_t));
   if (rc == ACEZ_OK) (void)hipMemset(tr->wg_flags, 0, (size_t)tr->L * 16 * 2 * 32 * sizeof(uint32_t));
@@ -741,7 +751,8 @@ static void flush_post(acez_trainer* tr, hipStream_t s) {
   st_flip(tr);
 }
 
-static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n, void* stream, bool fused) {
+static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n, void* stream, bool fused, const int64_t* d_next = nullptr,
+                               int n_next = 0) {
   ACEZ_REQUIRE(tr && d_indices, "null pointer");
   ACEZ_REQUIRE(tr->have_buf, "acez_trainer_set_buffer has not been called");
   ACEZ_REQUIRE(n > 0 && n <= tr->max_batch, "n must be in [1, max_batch]");
@@ -850,7 +861,20 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     fill_loss_train(tr, a, act, d_indices, n, pose_mlp);
     tr->last_nblk = nblk;   // (after this step's step_begin, whose schedule wave closed the step BEFORE with that step's count)
     ProfScope ps(tr, s, KC_LOSS);
-    launch_loss(tr, nblk, s, a);
+    tr->next_gathered = false;
+    if (fused && d_next && n_next > 0 && tr->cfg.pose_refinement == 0 && wgrad_opt_usable(tr) && tr->loss_rows == 4) {
+      // the next batch's gather as extra workgroups of the loss launch (this path has no optimiser launch to carry it): 32 rows per
+      // workgroup and pass, as many workgroups as the loss kernel leaves free (two of these workgroups fit a CU)
+      const int want = (n_next + 31) / 32, room = std::max(32, 2 * tr->n_cus - nblk);
+      const int gblocks = std::min(want, room);
+      GatherMeta gm = gather_meta(tr);
+      gm.dst = tr->batch_meta_alt;
+      if (tr->f16) hipLaunchKernelGGL((loss_gather_kernel<EltF16, 4>), dim3(nblk + gblocks), dim3(256), 0, s, a, nblk, (const uint16_t*)tr->buf.d_features, d_next, tr->R0_alt, n_next, gm);
+      else hipLaunchKernelGGL((loss_gather_kernel<EltBf16, 4>), dim3(nblk + gblocks), dim3(256), 0, s, a, nblk, (const uint16_t*)tr->buf.d_features, d_next, tr->R0_alt, n_next, gm);
+      tr->next_gathered = true; tr->next_idx = d_next; tr->next_n = n_next;
+    } else {
+      launch_loss(tr, nblk, s, a);
+    }
   }
 
   if (ps != s) {   // the pose gradients start from the per-row pose gradients the loss kernel has just written
@@ -923,6 +947,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     }
     a.In[f1] = tr->R[tr->nb + 1]; a.In[f2] = tr->out[f1];
     a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.n_layers = tr->L; a.st = st; a.zeros = tr->zeros; a.dbg = 0;
+    if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_DBG")) a.dbg = atoi(e);   // timing experiments (wgrad_opt_kernel's ablation bits)
     ProfScope ps(tr, s, KC_WGRAD);
     const int groups = tr->L * tr->nslabs;
     if (fused && wgrad_opt_usable(tr)) {
@@ -934,10 +959,18 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
       o.xch = tr->wg_xch; o.flags = tr->wg_flags; o.spin_limit = tr->seq_spin_limit;
       o.target = 2u * ++tr->wg_epoch;
       if ((long)tr->wg_epoch - 1 == tr->wgo_fault_at) o.target += 1u << 20;   // tests: a partner that never arrives
+      // the small parameters ride in the multiplier waves of the first workgroups; without pose refinement the schedule wave that closes
+      // the step rides too (with it, the bookkeeping stays with the next step's gather launch, which also runs the pose network)
+      o.nsmall = small_cols_blocks(tr->L, (int64_t)tr->no * 513, 8);
+      o.do_post = tr->cfg.pose_refinement == 0 ? 1 : 0;
+      if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_POST")) o.do_post = o.do_post && atoi(e) != 0;   // timing experiments: the schedule wave as its own launch
       const dim3 grid(256 * ((tr->L + 7) / 8));
-      if (tr->f16) hipLaunchKernelGGL(wgrad_opt_kernel<EltF16>, grid, dim3(WGRAD_THREADS), 0, s, a, o);
-      else hipLaunchKernelGGL(wgrad_opt_kernel<EltBf16>, grid, dim3(WGRAD_THREADS), 0, s, a, o);
+      if ((int)grid.x < o.nsmall) abort();
+      const PostArgs post = post_args(tr);
+      if (tr->f16) hipLaunchKernelGGL(wgrad_opt_kernel<EltF16>, grid, dim3(WGRAD_THREADS), 0, s, a, o, post);
+      else hipLaunchKernelGGL(wgrad_opt_kernel<EltBf16>, grid, dim3(WGRAD_THREADS), 0, s, a, o, post);
       tr->wide_done = true;
+      tr->post_done = o.do_post != 0;
     }
     else if (tr->f16) hipLaunchKernelGGL(wgrad_kernel<EltF16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
     else if (tr->wgrad_tile == 128) hipLaunchKernelGGL(wgrad_kernel<EltBf16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
@@ -987,17 +1020,31 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
   fill_adam_args(tr, a);
   if (fused) { a.slabs = tr->slabs; a.nslabs = tr->nslabs; a.slab_stride = tr->n_wide; a.tail = tr->last_reduce; }
   const int nsmall = adamw_small_blocks(tr->L, (int64_t)tr->no * 513, fused);   // small-parameter workgroups come first in the grid
-  // wgrad_opt_kernel of this step's backward has already updated the wide layers' weights: no tile workgroups
+  // wgrad_opt_kernel of this step's backward has already updated the wide layers' weights and the small parameters: no optimiser
+  // workgroups for the head are left
   const bool wide_done = fused && tr->wide_done;
   tr->wide_done = false;
   const int ntile = wide_done ? 0 : tr->L * 64;
+  if (wide_done && tr->cfg.pose_refinement == 0) {
+    // ... and it has closed the step; the next batch (acez_train_step_next) was gathered beside the loss kernel into the other buffers
+    if (tr->post_done) { st_flip(tr); tr->post_pending = false; } else { tr->post_pending = true; }
+    tr->post_done = false;
+    if (tr->next_gathered) {
+      std::swap(tr->R[0], tr->R0_alt);
+      std::swap(tr->batch_meta, tr->batch_meta_alt);
+      tr->pre_idx = tr->next_idx; tr->pre_n = tr->next_n;
+      tr->next_gathered = false;
+    }
+    return ACEZ_OK;
+  }
+  const int nsmall_l = wide_done ? 0 : nsmall;
   const bool pf = tr->pose_fused && !tr->chain && !tr->fused_fwd;
   if (pf && fused) {
     // the head's AdamW with the pose network's reduce + backward chain (S1) as the first workgroups of the same launch, then the
     // pose weight gradients with AdamW in their epilogue (S2: needs S1 of every image tile)
     const int T = tr->pose_tile, np = (tr->buf.n_images + T - 1) / T;
     { ProfScope ps(tr, s, KC_ADAMW);
-#define ACEZ_AP(TT) hipLaunchKernelGGL(adamw_pose_kernel<TT>, dim3(np + ntile + nsmall), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active), \
+#define ACEZ_AP(TT) hipLaunchKernelGGL(adamw_pose_kernel<TT>, dim3(np + ntile + nsmall_l), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active), \
                                        (const float*)tr->row_dT, (const int*)tr->row_image, tr->last_n, np)
       if (T == 16) ACEZ_AP(16); else if (T == 4) ACEZ_AP(4); else ACEZ_AP(8);
 #undef ACEZ_AP
@@ -1010,7 +1057,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
   a.layer_lo = layer_lo; a.layer_hi = layer_hi;
   if (fused && d_next && n_next > 0 && tr->cfg.pose_refinement == 0 && !tr->chain && !tr->fused_fwd && tr->have_buf) {
     // the next batch is known: its gather and this step's schedule bookkeeping ride in the optimiser's launch (adamw_next_kernel)
-    int n_adam = ntile + nsmall;
+    int n_adam = ntile + nsmall_l;
     // timing experiments (diagnostics build; results wrong by construction): 1 = no optimiser workgroups at all, 2 = no gather
     const int tail_abl = ACEZ_DIAG_ENV("ACEZ_TAIL_ABL") ? atoi(ACEZ_DIAG_ENV("ACEZ_TAIL_ABL")) : 0;
     if (tail_abl & 1) n_adam = 0;
@@ -1033,7 +1080,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     ACEZ_HIP_CHECK(hipGetLastError());
     return ACEZ_OK;
   }
-  { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3((wide_done ? 0 : (layer_hi - layer_lo) * 64) + nsmall), dim3(256), 0, s, a); }
+  if (!wide_done) { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3((layer_hi - layer_lo) * 64 + nsmall), dim3(256), 0, s, a); }
   if (tr->cfg.pose_refinement != 0) tr->pose_wt_valid = false;   // adamw_small_kernel does not refresh the transposed copies
   if (tr->cfg.pose_refinement != 0)
     hipLaunchKernelGGL(adamw_small_kernel, dim3((unsigned)((tr->pb.n_pose_params + 255) / 256)), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,
@@ -1100,7 +1147,7 @@ extern "C" int acez_train_step(acez_trainer* tr, const int64_t* d_indices, int n
 // split backward, a state read) is still correct: it simply gathers again. d_indices_next may be NULL (= acez_train_step).
 extern "C" int acez_train_step_next(acez_trainer* tr, const int64_t* d_indices, int n, const int64_t* d_indices_next, int n_next, void* stream) {
   ACEZ_REQUIRE(n_next >= 0 && n_next <= (tr ? tr->max_batch : 0), "n_next must be in [0, max_batch]");
-  int rc = train_backward_impl(tr, d_indices, n, stream, true);
+  int rc = train_backward_impl(tr, d_indices, n, stream, true, d_indices_next, n_next);
   if (rc != ACEZ_OK) return rc;
   return train_update_impl(tr, stream, true, 0, -1, d_indices_next, n_next);
 }

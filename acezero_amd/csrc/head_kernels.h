@@ -187,6 +187,8 @@ struct WgradOptArgs {
   uint32_t* flags;       // [n_layers * 16 tiles][2 owners][32]: one counter per receiving workgroup on its own 128-byte line
   uint32_t target;       // value of a counter once both sending waves of this launch have stored (2 x launches so far)
   uint32_t spin_limit;   // poll budget, as RowSeqArgs::spin_limit
+  int nsmall;            // workgroups 0 .. nsmall - 1 also run one small-parameter block of the optimiser each (adamw_small_columns); 0: none
+  int do_post;           // the last workgroup also runs the schedule wave that closes the step (sched_post_wave)
 };
 
 }  // namespace acez

@@ -31,7 +31,7 @@ namespace acez {
 // level (one row after the other, every row paid its own idx -> row round trips; two at a time -- round 3 -- the optimiser launch's 1720
 // gather waves still walked their three rows in two passes of three dependent levels each). With meta.dst the per-row metadata the
 // loss kernel needs (GatherMeta) is looked up beside the copy: a third level for the image index, overlapped with the row stores.
-constexpr int GR = 4;
+template <int GR = 4>
 __device__ __forceinline__ void gather_rows(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx, uint16_t* __restrict__ out, int n,
                                             int wave, int nwaves, int lane, const GatherMeta& meta) {
   for (int r0 = wave; r0 < n; r0 += GR * nwaves) {
@@ -785,16 +785,40 @@ __device__ __forceinline__ typename E::frag tr_frag(const uint16_t* p) {
 #endif
 constexpr int WGRAD_LOADERS = 8;                    // loader waves per workgroup (beside the 4 multiplier waves)
 constexpr int WGRAD_THREADS = 256 + 64 * WGRAD_LOADERS;
-// s_waitcnt vmcnt(n) for a wave-uniform n that is only known at run time (a multiple of 4 up to 28 here; anything else waits for everything)
+// s_waitcnt vmcnt(n) for a wave-uniform n that is only known at run time (1 .. 31; anything else waits for everything)
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
   switch (n) {
+    case 1: ACEZ_VMCNT(1); break;
+    case 2: ACEZ_VMCNT(2); break;
+    case 3: ACEZ_VMCNT(3); break;
     case 4: ACEZ_VMCNT(4); break;
+    case 5: ACEZ_VMCNT(5); break;
+    case 6: ACEZ_VMCNT(6); break;
+    case 7: ACEZ_VMCNT(7); break;
     case 8: ACEZ_VMCNT(8); break;
+    case 9: ACEZ_VMCNT(9); break;
+    case 10: ACEZ_VMCNT(10); break;
+    case 11: ACEZ_VMCNT(11); break;
     case 12: ACEZ_VMCNT(12); break;
+    case 13: ACEZ_VMCNT(13); break;
+    case 14: ACEZ_VMCNT(14); break;
+    case 15: ACEZ_VMCNT(15); break;
     case 16: ACEZ_VMCNT(16); break;
+    case 17: ACEZ_VMCNT(17); break;
+    case 18: ACEZ_VMCNT(18); break;
+    case 19: ACEZ_VMCNT(19); break;
     case 20: ACEZ_VMCNT(20); break;
+    case 21: ACEZ_VMCNT(21); break;
+    case 22: ACEZ_VMCNT(22); break;
+    case 23: ACEZ_VMCNT(23); break;
     case 24: ACEZ_VMCNT(24); break;
+    case 25: ACEZ_VMCNT(25); break;
+    case 26: ACEZ_VMCNT(26); break;
+    case 27: ACEZ_VMCNT(27); break;
     case 28: ACEZ_VMCNT(28); break;
+    case 29: ACEZ_VMCNT(29); break;
+    case 30: ACEZ_VMCNT(30); break;
+    case 31: ACEZ_VMCNT(31); break;
     default: ACEZ_VMCNT(0); break;
   }
 }
@@ -805,11 +829,14 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 // PFN > 0: `prefetch()` issues exactly PFN vector-memory loads (wgrad_opt_kernel: the optimiser state of the workgroup's half tile) from
 // inside the loader loop, about a dozen stages before its end, so that they travel beside the operand stream instead of after it; loads
 // complete in order, so the counted waits of the stages requested BEFORE the prefetch allow PFN more instructions in flight.
-template <class E, int PFN, class PF>
+// `mprefetch()` is called once by the multiplier waves, right behind their last MFMA (wgrad_opt_kernel: the loads of their small-parameter
+// share go out before the accumulators are staged / sent). Issued from INSIDE the loop, eight stages before its end, the same loads cost
+// 3 us: registers written by a load are live across the back edge, and the wave stalls on them one iteration later (measured, round 4).
+template <class E, int PFN, bool MPRE_EARLY, class PF, class MPF>
 __device__ __forceinline__ bool wgrad_kloop(const WgradArgs& a, uint16_t (*smem)[2][64 * 128], const int layer, const int slab, const int tile,
-                                            f32x16 (&acc)[2][2], int& KT_out, PF&& prefetch) {
+                                            f32x16 (&acc)[2][2], int& KT_out, PF&& prefetch, MPF&& mprefetch) {
   constexpr int RING = ACEZ_WGRAD_RING;   // slots of the [dZ | In] stage ring, 32 KiB each (RING - 1 stages in flight per CU)
-  static_assert(PFN % 4 == 0 && 2 * (16 / WGRAD_LOADERS) * (RING - 1) + PFN <= 28, "wait_vmcnt_dyn covers multiples of 4 up to 28");
+  static_assert(2 * (16 / WGRAD_LOADERS) * (RING - 1) + PFN <= 31, "wait_vmcnt_dyn covers 1 .. 31");
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   // Role split: waves 0..3 multiply (2 x 2 grid of 64 x 64 sub-tiles: 4 fragment reads feed 4 MFMAs), waves 4..11 only
@@ -890,9 +917,9 @@ __device__ __forceinline__ bool wgrad_kloop(const WgradArgs& a, uint16_t (*smem)
   }
   const int offA[2] = {tr_base(wn * 64, l), tr_base(wn * 64 + 32, l)};
   const int offB[2] = {tr_base(wc * 64, l), tr_base(wc * 64 + 32, l)};
-  for (int kt = 0; kt < KT; ++kt) {
+  auto mstage = [&](int kt) {
     __builtin_amdgcn_s_barrier();
-    if (ACEZ_DBG(a.dbg) & 2) continue;
+    if (ACEZ_DBG(a.dbg) & 2) return;
     const int slot = kt % RING;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -906,7 +933,18 @@ __device__ __forceinline__ bool wgrad_kloop(const WgradArgs& a, uint16_t (*smem)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma32(fa[i], fb[j], acc[i][j]);
     }
+  };
+  if (!MPRE_EARLY) {
+    for (int kt = 0; kt < KT; ++kt) mstage(kt);
+    mprefetch();
+    return false;
   }
+  // the last two stages are peeled off the loop: the prefetch goes out in front of them, and no back edge follows it
+  const int KT2 = KT >= 3 ? KT - 2 : 0;
+  for (int kt = 0; kt < KT2; ++kt) mstage(kt);
+  mprefetch();
+  if (KT2 < KT) mstage(KT2);
+  if (KT2 + 1 < KT) mstage(KT2 + 1);
   return false;
 }
 
@@ -927,7 +965,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
   const int n0 = (tile >> 2) * 128, c0 = (tile & 3) * 128;
   f32x16 acc[2][2];
   int KT;
-  if (wgrad_kloop<E, 0>(a, smem, layer, slab, tile, acc, KT, [] {})) return;
+  if (wgrad_kloop<E, 0, false>(a, smem, layer, slab, tile, acc, KT, [] {}, [] {})) return;
 
   if (ACEZ_DBG(a.dbg) & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
   if (!active) return;
@@ -1481,6 +1519,27 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   loss_body<false, true, E, LR>(a, blockIdx.x, wv, t, nullptr, scratch, LossPre{0, 0, 0, 0.f, 0.f}, [] { __syncthreads(); });
 }
 
+// loss_kernel's launch with the batch gather of the NEXT step as extra workgroups behind it (acez_train_step_next on the wgrad_opt path:
+// the optimiser launch that used to carry the gather no longer exists). The loss kernel is a latency chain that leaves most wave slots
+// of the chip empty (320 workgroups of 16 rows on 256 CUs, two fit per CU), the gather another (index -> row -> metadata): the
+// two overlap. The rows go to the OTHER of the trainer's two input buffers / metadata tables -- this step's weight-gradient launch
+// still reads the current ones. Eight rows per wavefront and pass: the free slots hold the whole batch in one pass.
+template <class E = EltBf16, int LR = 8>
+__global__ __launch_bounds__(256) void loss_gather_kernel(LossArgs a, int nblk, const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx_next,
+                                                          uint16_t* __restrict__ out, int n_next, GatherMeta meta) {
+  if ((int)blockIdx.x >= nblk) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (((int)blockIdx.x - nblk) * (int)blockDim.x + (int)threadIdx.x) >> 6;
+    const int nwaves = (((int)gridDim.x - nblk) * (int)blockDim.x) >> 6;
+    gather_rows<8>(feat, idx_next, out, n_next, wave, nwaves, lane, meta);
+    return;
+  }
+  if (a.st && !a.st->active) return;
+  __shared__ float scratch[LOSS_SCRATCH_FLOATS];
+  const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
+  loss_body<false, true, E, LR>(a, blockIdx.x, wv, t, nullptr, scratch, LossPre{0, 0, 0, 0.f, 0.f}, [] { __syncthreads(); });
+}
+
 // ---------------------------------------------------------------------------------------------------
 // grad_reduce: flat gradient = fixed-order sum of the wgrad slabs (wide layers) and of the per-workgroup
 // partials of the loss kernel (fc3 + statistics). Deterministic: no atomics anywhere in the step.
@@ -1653,65 +1712,125 @@ __host__ __device__ inline int adamw_small_blocks(int n_layers, int64_t n_fc3, b
 // the xor butterfly 32, 16, ..., 1, which pairs partial j with j ^ off at every level -- a fixed binary tree (addition commutes). Lane q
 // of the quad holds the partials j = 4 i + q: the levels 32 .. 4 pair i with i ^ 8, 4, 2, 1 inside the lane's registers, the levels 2
 // and 1 are two quad permutes.
-__device__ __forceinline__ void adamw_small_columns(const AdamArgs& a, const int b, const AdamScalars& s) {
-  const int t = threadIdx.x, lane = t & 63, q = t & 3;
-  const GradReduceArgs& r = a.tail;
-  const int64_t n_bias = (int64_t)a.n_layers * 512, n_fc3 = a.n_fc3, n_out = n_bias + n_fc3 + 4;
-  const int64_t k = (int64_t)b * 64 + (t >> 2);
-  const float* base = r.stat_partials;
-  int cnt = 0;
-  int64_t stride = 0, dst = -1, ome = -1;
-  if (k < n_bias) {
-    const int layer = (int)(k >> 9), c = (int)(k & 511);
-    base = r.bias_partials + (size_t)layer * r.bias_layer_stride + c; cnt = r.bias_count[layer]; stride = 512;
-    dst = (int64_t)layer * 262656 + 262144 + c;
-    ome = a.b_off[layer] + c;
-  } else if (k < n_bias + n_fc3) {
-    base = r.fc3_partials + (k - n_bias); cnt = r.n_loss_blocks; stride = r.fc3_stride;
-    dst = r.n_wide + (k - n_bias);
-    ome = a.fc3_off + (k - n_bias);
-  } else if (k < n_out) {
-    const int64_t kk = k - n_bias - n_fc3;
-    if (kk < 3) { base = r.stat_partials + kk; cnt = r.n_loss_blocks; stride = 4; }
-    dst = r.n_params + kk;
+// LPO lanes per output (4, or 8: half the registers per lane -- wgrad_opt_kernel's multiplier waves request the rows from inside their
+// K loop and keep them in registers next to the accumulators): lane q holds the partials j = LPO i + q; the butterfly levels that pair
+// i with i ^ (32 / LPO), ... , 1 run in the lane's registers, the last log2(LPO) levels across the lanes of the output.
+// issue() requests everything (p, m, v of the parameter and the first 320 partial rows: ONE memory round trip -- as a loop of
+// load-then-add rounds the five rounds of the fc3 columns were five dependent round trips, 7 us); finish() reduces, applies the
+// optimiser and stores. `late_skip()` (wgrad_opt_kernel: adamw_body's guards) is evaluated inside finish() before anything is stored.
+template <int LPO>
+struct SmallCols {
+  static_assert(LPO == 4 || LPO == 8, "lanes per output");
+  static constexpr int NI = 64 / LPO, TD = 5, PER_BLOCK = 256 / LPO;   // partials per lane; 64-row rounds requested at once; outputs per 256 threads
+  float x[TD][NI];
+  float p, m, v;
+  struct Col {
+    const float* base;
+    int cnt;
+    int64_t stride, dst, ome, k;
+  };
+  static __device__ __forceinline__ Col decode(const AdamArgs& a, const int b) {
+    const GradReduceArgs& r = a.tail;
+    const int64_t n_bias = (int64_t)a.n_layers * 512, n_fc3 = a.n_fc3, n_out = n_bias + n_fc3 + 4;
+    Col c;
+    c.k = (int64_t)b * PER_BLOCK + ((int)threadIdx.x / LPO);
+    c.base = r.stat_partials; c.cnt = 0; c.stride = 0; c.dst = -1; c.ome = -1;
+    if (c.k < n_bias) {
+      const int layer = (int)(c.k >> 9), col = (int)(c.k & 511);
+      c.base = r.bias_partials + (size_t)layer * r.bias_layer_stride + col; c.cnt = r.bias_count[layer]; c.stride = 512;
+      c.dst = (int64_t)layer * 262656 + 262144 + col;
+      c.ome = a.b_off[layer] + col;
+    } else if (c.k < n_bias + n_fc3) {
+      c.base = r.fc3_partials + (c.k - n_bias); c.cnt = r.n_loss_blocks; c.stride = r.fc3_stride;
+      c.dst = r.n_wide + (c.k - n_bias);
+      c.ome = a.fc3_off + (c.k - n_bias);
+    } else if (c.k < n_out) {
+      const int64_t kk = c.k - n_bias - n_fc3;
+      if (kk < 3) { c.base = r.stat_partials + kk; c.cnt = r.n_loss_blocks; c.stride = 4; }
+      c.dst = r.n_params + kk;
+    }
+    return c;
   }
-  float p = 0.f, m = 0.f, v = 0.f;
-  if (q == 0 && ome >= 0) { p = a.params[ome]; m = a.m[ome]; v = a.v[ome]; }   // requested before the reduction
-  float acc[16];
+  __device__ __forceinline__ void issue(const AdamArgs& a, const int b) {
+    const int q = (int)threadIdx.x & (LPO - 1);
+    const Col c = decode(a, b);
+    p = 0.f; m = 0.f; v = 0.f;
+    if (q == 0 && c.ome >= 0) { p = a.params[c.ome]; m = a.m[c.ome]; v = a.v[c.ome]; }
+    const int last = max(c.cnt - 1, 0);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const int last = max(cnt - 1, 0);
-  for (int u = 0; __any(64 * u < cnt); ++u) {
-    float x[16];
+    for (int u = 0; u < TD; ++u) {
+      if (__any(64 * u < c.cnt)) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = 64 * u + 4 * i + q;
-      const float y = base[(size_t)min(row, last) * stride];   // unconditional load, masked afterwards
-      x[i] = row < cnt ? y : 0.f;
+        for (int i = 0; i < NI; ++i) {
+          const int row = 64 * u + LPO * i + q;
+          const float y = c.base[(size_t)min(row, last) * c.stride];   // unconditional load, masked afterwards
+          x[u][i] = row < c.cnt ? y : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) x[u][i] = 0.f;
+      }
+    }
+  }
+  template <class G>
+  __device__ __forceinline__ void finish(const AdamArgs& a, const int b, const AdamScalars& s, G&& late_skip) {
+    const int lane = (int)threadIdx.x & 63, q = (int)threadIdx.x & (LPO - 1);
+    const GradReduceArgs& r = a.tail;
+    const int64_t n_bias = (int64_t)a.n_layers * 512, n_fc3 = a.n_fc3, n_out = n_bias + n_fc3 + 4;
+    const Col c = decode(a, b);
+    const bool skip = late_skip();
+    float acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int u = 0; u < TD; ++u)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[i] += x[u][i];   // (+0.f where tail_output adds nothing: acc is never -0, so the bits are the same)
+    const int last = max(c.cnt - 1, 0);
+    for (int u = TD; __any(64 * u < c.cnt); ++u) {
+      float y[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = 64 * u + LPO * i + q;
+        const float z = c.base[(size_t)min(row, last) * c.stride];
+        y[i] = row < c.cnt ? z : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[i] += y[i];
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += x[i];   // (+0.f where tail_output adds nothing: acc is never -0, so the bits are the same)
-  }
+    for (int off = NI / 2; off >= 1; off >>= 1)
 #pragma unroll
-  for (int off = 8; off >= 1; off >>= 1)
-#pragma unroll
-    for (int i = 0; i < off; ++i) acc[i] = acc[i] + acc[i + off];
-  float g = acc[0];
-  g = ACEZ_DPP_ADD(g, 0x4E, 0xF);   // quad_perm [2,3,0,1]: butterfly level 2
-  g = ACEZ_DPP_ADD(g, 0xB1, 0xF);   // quad_perm [1,0,3,2]: butterfly level 1
-  if (b == (int)((n_out - 1) >> 6) && r.fault) {   // statistics slot 3: the fault word + the fp16 overflow flag (see tail_output)
-    const uint32_t amax_bits = absmax_all(r.st, lane);
-    if (k == n_out - 1) g = (*r.fault ? 1.f : 0.f) + (amax_bits >= 0x7f800000u ? 1024.f : 0.f);
+      for (int i = 0; i < off; ++i) acc[i] = acc[i] + acc[i + off];
+    float g = acc[0];
+    if (LPO == 8) g = g + __shfl_xor(g, 4);   // butterfly level 4
+    g = ACEZ_DPP_ADD(g, 0x4E, 0xF);           // quad_perm [2,3,0,1]: butterfly level 2
+    g = ACEZ_DPP_ADD(g, 0xB1, 0xF);           // quad_perm [1,0,3,2]: butterfly level 1
+    if (b == (int)((n_out - 1) / PER_BLOCK) && r.fault) {   // statistics slot 3: the fault word + the fp16 overflow flag (see tail_output)
+      const uint32_t amax_bits = absmax_all(r.st, lane);
+      if (c.k == n_out - 1) g = (*r.fault ? 1.f : 0.f) + (amax_bits >= 0x7f800000u ? 1024.f : 0.f);
+    }
+    if (c.k < n_bias + n_fc3) g *= r.st->inv_grad_scale;   // (fp16: gradients arrive scaled; 1 for bf16, an exact product)
+    if (q != 0 || c.dst < 0 || skip) return;
+    r.grad[c.dst] = g;
+    if (c.ome >= 0) {
+      float pp = p, mm = m, vv = v;
+      pp = adamw_one(pp, g, mm, vv, s);
+      a.params[c.ome] = pp; a.m[c.ome] = mm; a.v[c.ome] = vv;
+      const int64_t kf = c.k - n_bias;
+      if (kf >= 0 && kf < (int64_t)a.no * 512) a.W3b[kf] = a.f16 ? EltF16::from_f(pp) : f2bf(pp);
+    }
   }
-  if (k < n_bias + n_fc3) g *= r.st->inv_grad_scale;   // (fp16: gradients arrive scaled; 1 for bf16, an exact product)
-  if (q != 0 || dst < 0) return;
-  r.grad[dst] = g;
-  if (ome >= 0) {
-    p = adamw_one(p, g, m, v, s);
-    a.params[ome] = p; a.m[ome] = m; a.v[ome] = v;
-    const int64_t kf = k - n_bias;
-    if (kf >= 0 && kf < (int64_t)a.no * 512) a.W3b[kf] = a.f16 ? EltF16::from_f(p) : f2bf(p);
-  }
+};
+// small-parameter workgroups of a fused optimiser launch (wgrad_opt_kernel: one per 32 outputs, in the multiplier waves of the first ones)
+__host__ __device__ inline int small_cols_blocks(int n_layers, int64_t n_fc3, int lanes_per_output) {
+  const int64_t per = 256 / lanes_per_output;
+  return (int)(((int64_t)n_layers * 512 + n_fc3 + 4 + per - 1) / per);
+}
+__device__ __forceinline__ void adamw_small_columns(const AdamArgs& a, const int b, const AdamScalars& s) {
+  SmallCols<4> sm;
+  sm.issue(a, b);
+  sm.finish(a, b, s, [] { return false; });
 }
 
 // One workgroup's share of the optimiser step (b = workgroup index inside the optimiser's part of a launch; tileT: 64 x 66 bf16 LDS).
@@ -1838,179 +1957,6 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   __shared__ uint16_t tileT[64][66];
   adamw_body(a, blockIdx.x, tileT);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// wgrad_opt: wgrad_kernel's product with the optimiser step of the wide layers as its epilogue (single-GPU fused step). wgrad + adamw
-// as two launches round-trip both split-K slabs through HBM (16.8 MB written, 16.8 MB read), start the optimiser's 25 MB of state
-// reads only when the gradients are complete, and pay a kernel boundary; here
-//  * both row slabs of a 128 x 128 tile are placed on ONE XCD (layer = XCD, 32 workgroups each for the default head). A workgroup
-//    finalises the 64 x 128 half tile of its slab index: its two multiplier waves of the OTHER half store their accumulators to the
-//    partner's exchange tile (this XCD's L2), wait for the acknowledgement and bump the partner's counter -- rowseq_kernel's hand-off:
-//    L2-local atomic, bounded sc1 poll on the other side, no fence, nothing read before it is produced;
-//  * the eight loader waves, idle once the last stage is requested, fetch p, m, v of the half tile a dozen stages before the K loop
-//    ends, then poll, add own (through LDS) + partner partial in slab order (slab 0 + slab 1: the additions of grad_reduce_kernel /
-//    adamw_body, so the parameters are bitwise those of backward + update), apply adamw_one and store p, m, v, W and -- through an
-//    LDS transpose -- W^T.
-// The guards are adamw_body's (schedule inactive, chain fault, NaN loss, fp16 overflow: nothing is stored); the exchange itself is
-// unconditional, so the two partners never disagree about it. A poll that expires raises the trainer's fault word exactly like a
-// rowseq hand-off (the host falls back to wgrad_kernel + adamw_kernel at its next state read); the stores of that wave are skipped.
-// Host: only when the grid fits the CUs (every workgroup resident) and the placement probe has passed (head_api.hip).
-// ---------------------------------------------------------------------------------------------------
-constexpr int WGO_PF = 12;   // prefetch loads per loader lane: 4 x (p, m, v) float4
-template <class E = EltBf16>
-__global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, WgradOptArgs o) {
-  constexpr int RING = ACEZ_WGRAD_RING;
-  static_assert(RING >= 3, "two free ring slots are used as staging areas after the K loop");
-  __shared__ __attribute__((aligned(16))) uint16_t smem[RING][2][64 * 128];
-  const int t = threadIdx.x, l = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  // workgroup b runs on XCD b % 8: both slabs of all 16 tiles of a layer on one XCD (placement affects speed AND the hand-off, hence the probe)
-  const int b = blockIdx.x;
-  const int xcd = b & 7, jx = b >> 3;
-  const int layer = xcd + 8 * (jx >> 5), slab = (jx >> 4) & 1, tile = jx & 15;
-  if (layer >= a.n_layers) return;
-  const int n0 = (tile >> 2) * 128, c0 = (tile & 3) * 128;
-  const AdamArgs& ad = o.ad;
-  // this lane's share of the workgroup's 64 x 128 half tile in the epilogue (loader waves): rows rb + 16 i, columns col4 .. col4 + 3
-  const int e = t - 256, rb = e >> 5, col4 = (e & 31) * 4;
-  const int64_t woff = ad.w_off[layer];
-  const int nrow0 = n0 + 64 * slab;   // first row of the half tile this workgroup finalises
-  float4 p4[4], m4[4], v4[4];
-  auto prefetch = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t off = woff + (int64_t)(nrow0 + rb + 16 * i) * 512 + c0 + col4;
-      p4[i] = *reinterpret_cast<const float4*>(ad.params + off);
-      m4[i] = *reinterpret_cast<const float4*>(ad.m + off);
-      v4[i] = *reinterpret_cast<const float4*>(ad.v + off);
-    }
-  };
-  f32x16 acc[2][2];
-  int KT;
-  const bool loader = wgrad_kloop<E, WGO_PF>(a, smem, layer, slab, tile, acc, KT, prefetch);
-  // Slot KT % RING was last written for stage KT - RING and slot (KT + 1) % RING for stage KT - RING + 1: every wave is past the barrier
-  // of stage KT - 1, i.e. done with both; the slot of stage KT - 1 itself may still be read by a slower multiplier wave.
-  float* const stage = reinterpret_cast<float*>(&smem[KT % RING][0][0]);                                  // [64][128] fp32: own partial
-  uint16_t (*const tileT)[66] = reinterpret_cast<uint16_t (*)[66]>(&smem[(KT + 1) % RING][0][0]);         // [128][66]: W^T staging
-  const int pair = layer * 16 + tile;
-  if (!loader) {
-    const int cw = w & 3, wn = cw >> 1, wc = cw & 1, h = l >> 5;
-    if (wn != slab) {
-      float* __restrict__ X = o.xch + (size_t)(pair * 2 + (1 - slab)) * 8192;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            X[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + wc * 64 + j * 32 + (l & 31)] = acc[i][j][r];
-      ACEZ_VMCNT(0);   // acknowledged by the L2 both workgroups share
-      if (l == 0) {
-        const uint32_t one = 1;
-        asm volatile("global_atomic_add %0, %1, off" ::"v"(o.flags + (size_t)(pair * 2 + (1 - slab)) * 32), "v"(one) : "memory");
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + wc * 64 + j * 32 + (l & 31)] = acc[i][j][r];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // (B1) the own half is in LDS
-    __builtin_amdgcn_s_barrier();   // (B2) the loaders' transpose tile
-    return;
-  }
-  // ------------------------------------------------------------------ loader waves: the optimiser step of the half tile
-  const TrainState* st = ad.st;
-  const int active = st->active;
-  const AdamScalars s = st->adam;
-  const float inv_scale = st->inv_grad_scale;
-  const int fault_now = *ad.fault;
-  int64_t dummy;
-  const float lossv = tail_output(ad.tail, (int64_t)ad.n_layers * 512 + ad.n_fc3, l, dummy);
-  bool skip = !active || fault_now || lossv != lossv;   // adamw_body's guards
-  if (E::is_f16) skip = skip || absmax_all(st, l) >= 0x7f800000u;
-  {
-    uint32_t vseen, sseen, spins, timed;
-    const uint32_t* flag = o.flags + (size_t)(pair * 2 + slab) * 32;
-    asm volatile(
-        "s_mov_b32 %[spins], 0\n\t"
-        "s_mov_b32 %[timed], 0\n"
-        "1:\n\t"
-        "global_load_dword %[vseen], %[flag], off sc1\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_readfirstlane_b32 %[sseen], %[vseen]\n\t"
-        "s_sub_i32 %[sseen], %[sseen], %[target]\n\t"
-        "s_cmp_ge_i32 %[sseen], 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "s_sleep " ACEZ_SEQ_SLEEP "\n\t"
-        "s_add_u32 %[spins], %[spins], 1\n\t"
-        "s_cmp_lt_u32 %[spins], %[limit]\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "s_mov_b32 %[timed], 1\n"
-        "2:"
-        : [vseen] "=&v"(vseen), [sseen] "=&s"(sseen), [spins] "=&s"(spins), [timed] "=&s"(timed)
-        : [flag] "v"(flag), [target] "s"(o.target), [limit] "s"(o.spin_limit)
-        : "memory", "scc");
-    if (timed) {   // the partner never arrived (the two slabs of a tile are not on one XCD after all): fault word, step switched off
-      skip = true;
-      if (l == 0) {
-        __hip_atomic_store(ad.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(const_cast<int*>(&st->active), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-  float4 oth[4];
-  {
-    const float* __restrict__ Xin = o.xch + (size_t)(pair * 2 + slab) * 8192;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) oth[i] = *reinterpret_cast<const float4*>(Xin + (rb + 16 * i) * 128 + col4);
-  }
-  __builtin_amdgcn_s_barrier();   // (B1)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = rb + 16 * i;
-    const float4 own = *reinterpret_cast<const float4*>(stage + row * 128 + col4);
-    // slab 0 + slab 1 (fp32 addition commutes: the same bits whichever of the two is `own`), then the un-scaling of the fp16 chain
-    float4 g;
-    g.x = (own.x + oth[i].x) * inv_scale; g.y = (own.y + oth[i].y) * inv_scale;
-    g.z = (own.z + oth[i].z) * inv_scale; g.w = (own.w + oth[i].w) * inv_scale;
-    float4 p = p4[i], m = m4[i], v = v4[i];
-    p.x = adamw_one(p.x, g.x, m.x, v.x, s);
-    p.y = adamw_one(p.y, g.y, m.y, v.y, s);
-    p.z = adamw_one(p.z, g.z, m.z, v.z, s);
-    p.w = adamw_one(p.w, g.w, m.w, v.w, s);
-    const uint2 pk = E::pk4(p.x, p.y, p.z, p.w);
-    if (!skip) {
-      const int64_t off = woff + (int64_t)(nrow0 + row) * 512 + c0 + col4;
-      *reinterpret_cast<float4*>(ad.params + off) = p;
-      *reinterpret_cast<float4*>(ad.m + off) = m;
-      *reinterpret_cast<float4*>(ad.v + off) = v;
-      *reinterpret_cast<uint2*>(ad.Wb + (size_t)layer * 262144 + (size_t)(nrow0 + row) * 512 + c0 + col4) = pk;
-    }
-    tileT[col4 + 0][row] = (uint16_t)(pk.x & 0xffff);
-    tileT[col4 + 1][row] = (uint16_t)(pk.x >> 16);
-    tileT[col4 + 2][row] = (uint16_t)(pk.y & 0xffff);
-    tileT[col4 + 3][row] = (uint16_t)(pk.y >> 16);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();   // (B2)
-  {
-    // W^T: row c0 + cl holds the 64 values n = nrow0 .. nrow0 + 63 of column cl: 128 contiguous bytes, 32 per lane
-    const int cl = e >> 2, part = e & 3;
-    uint32_t q[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) q[k] = (uint32_t)tileT[cl][part * 16 + 2 * k] | ((uint32_t)tileT[cl][part * 16 + 2 * k + 1] << 16);
-    if (!skip) {
-      uint16_t* dst = ad.WbT + (size_t)layer * 262144 + (size_t)(c0 + cl) * 512 + nrow0 + part * 16;
-      *reinterpret_cast<uint4*>(dst) = make_uint4(q[0], q[1], q[2], q[3]);
-      *reinterpret_cast<uint4*>(dst + 8) = make_uint4(q[4], q[5], q[6], q[7]);
-    }
-  }
 }
 
 // W^T of wide layers layer_lo .. from their 16-bit W (acez_trainer_import_weights16: the sharded data-parallel update receives the
@@ -2270,6 +2216,15 @@ __device__ void sched_post_wave(const TrainState* src, TrainState* st, const Sch
   // every load of the wave first: the scalar state (used by lane 0), the statistics, this lane's two ring entries
   SchedHot h = load_hot(src);
   const float ring0 = src->crit_buf[lane], ring1 = (lane + 64 < 100) ? src->crit_buf[lane + 64] : 0.f;
+  // tail mode: the loss kernel's partials are requested with the state above, before anything is looked at (they sat behind the branch
+  // below: a second dependent round trip of the wave that closes every step)
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (tail) {   // inside the optimiser's own launch (adamw_next_kernel / wgrad_opt_kernel): the reduced statistics are being written by sibling
+                // workgroups of this launch, so the wave reduces the loss kernel's partials itself -- tail_output's arithmetic: the same bits
+    int64_t d;
+    const int64_t k0 = (int64_t)tail->n_layers * 512 + (tail->n_params - tail->n_wide);
+    g0 = tail_output(*tail, k0, lane, d); g1 = tail_output(*tail, k0 + 1, lane, d); g2 = tail_output(*tail, k0 + 2, lane, d);
+  }
   if ((fault && *fault) || !h.active) {
     // the step was abandoned (rowseq fault: no iteration is counted, nothing is logged) or the schedule has ended (state frozen,
     // ace_trainer.py:509-510): the other slot becomes a copy
@@ -2281,15 +2236,7 @@ __device__ void sched_post_wave(const TrainState* src, TrainState* st, const Sch
     }
     return;
   }
-  float g0, g1, g2;
-  if (tail) {   // inside the optimiser's own launch (adamw_next_kernel): the reduced statistics are being written by sibling workgroups of
-                // this launch, so the wave reduces the loss kernel's partials itself -- tail_output's arithmetic: the same bits
-    int64_t d;
-    const int64_t k0 = (int64_t)tail->n_layers * 512 + (tail->n_params - tail->n_wide);
-    g0 = tail_output(*tail, k0, lane, d); g1 = tail_output(*tail, k0 + 1, lane, d); g2 = tail_output(*tail, k0 + 2, lane, d);
-  } else {
-    g0 = grad_stats[0]; g1 = grad_stats[1]; g2 = grad_stats[2];
-  }
+  if (!tail) { g0 = grad_stats[0]; g1 = grad_stats[1]; g2 = grad_stats[2]; }
   const float loss = g0 * inv_global_batch;
   const float inl = g1 * inv_global_batch;
   // minimum of the ring as it will be after this step's push: the entries that stay, and the new value
@@ -2455,6 +2402,240 @@ __device__ double det_cos_pi(double x) {
     sum += term;
   }
   return -sum;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad_opt: wgrad_kernel's product with the optimiser step of the wide layers as its epilogue (single-GPU fused step). wgrad + adamw
+// as two launches round-trip both split-K slabs through HBM (16.8 MB written, 16.8 MB read), start the optimiser's 25 MB of state
+// reads only when the gradients are complete, and pay a kernel boundary; here
+//  * both row slabs of a 128 x 128 tile are placed on ONE XCD (layer = XCD, 32 workgroups each for the default head). A workgroup
+//    finalises the 64 x 128 half tile of its slab index: its two multiplier waves of the OTHER half store their accumulators to the
+//    partner's exchange tile (this XCD's L2), wait for the acknowledgement and bump the partner's counter -- rowseq_kernel's hand-off:
+//    L2-local atomic, bounded sc1 poll on the other side, no fence, nothing read before it is produced;
+//  * the eight loader waves, idle once the last stage is requested, fetch p, m, v of the half tile a dozen stages before the K loop
+//    ends, then poll, add own (through LDS) + partner partial in slab order (slab 0 + slab 1: the additions of grad_reduce_kernel /
+//    adamw_body, so the parameters are bitwise those of backward + update), apply adamw_one and store p, m, v, W and -- through an
+//    LDS transpose -- W^T.
+// The guards are adamw_body's (schedule inactive, chain fault, NaN loss, fp16 overflow: nothing is stored); the exchange itself is
+// unconditional, so the two partners never disagree about it. A poll that expires raises the trainer's fault word exactly like a
+// rowseq hand-off (the host falls back to wgrad_kernel + adamw_kernel at its next state read); the stores of that wave are skipped.
+// Host: only when the grid fits the CUs (every workgroup resident) and the placement probe has passed (head_api.hip).
+// The four multiplier waves of a workgroup have nothing to do while its loader waves run the optimiser arithmetic (~3.5 us of VALU work
+// per CU): in the first `nsmall` workgroups they are the small-parameter workgroups of the optimiser launch (adamw_small_columns: biases,
+// fc3, statistics), and wave 0 of the last workgroup is the schedule wave that closes the step (do_post) -- with the next batch
+// gathered beside the loss kernel (loss_gather_kernel), a step without pose refinement has no optimiser launch left at all.
+// ---------------------------------------------------------------------------------------------------
+#ifndef ACEZ_WGO_MPRE_EARLY
+#define ACEZ_WGO_MPRE_EARLY false   // true: the multiplier waves' small-parameter loads go out two stages before the end of the K loop (peeled
+                                    // stages, no back edge behind them). Measured equal to issuing them right behind the loop (47.6 / 47.5 us, one box).
+#endif
+constexpr int WGO_PF = 17;   // prefetch loads per loader lane: 4 x (p, m, v) float4 + the first five rows of the loss partials
+// spin until an LDS counter of this workgroup reaches `target` (the waves of a workgroup meet through these after the K loop instead of
+// s_barrier: a barrier would make the loader waves' arithmetic wait for the multiplier waves' small-parameter work and vice versa)
+__device__ __forceinline__ void lds_wait_ge(uint32_t* f, uint32_t target) {
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void lds_bump(uint32_t* f) {   // after this wave's earlier LDS operations (the LDS executes a wave's operations in order)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <class E = EltBf16>
+__global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, WgradOptArgs o, PostArgs post) {
+  constexpr int RING = ACEZ_WGRAD_RING;
+  static_assert(RING >= 3, "two free ring slots are used as staging areas after the K loop");
+  __shared__ __attribute__((aligned(16))) uint16_t smem[RING][2][64 * 128];
+  __shared__ uint32_t wsync[2];   // [0]: multiplier waves that have staged their accumulators, [1]: loader waves that have written their W^T rows
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  // workgroup b runs on XCD b % 8: both slabs of all 16 tiles of a layer on one XCD (placement affects speed AND the hand-off, hence the probe)
+  const int b = blockIdx.x;
+  const int xcd = b & 7, jx = b >> 3;
+  const int layer = xcd + 8 * (jx >> 5), slab = (jx >> 4) & 1, tile = jx & 15;
+  if (layer >= a.n_layers) return;
+  if (t < 2) wsync[t] = 0;   // (ordered before its first use by the barriers of the K loop; a slab without rows has none)
+  const int n0 = (tile >> 2) * 128, c0 = (tile & 3) * 128;
+  const AdamArgs& ad = o.ad;
+  // this lane's share of the workgroup's 64 x 128 half tile in the epilogue (loader waves): rows rb + 16 i, columns col4 .. col4 + 3
+  const int e = t - 256, rb = e >> 5, col4 = (e & 31) * 4;
+  const int64_t woff = ad.w_off[layer];
+  const int nrow0 = n0 + 64 * slab;   // first row of the half tile this workgroup finalises
+  float4 p4[4], m4[4], v4[4];
+  float lp[5];   // the loss partials tail_output reads first (NaN guard)
+  const int nlb = ad.tail.n_loss_blocks;
+  auto prefetch = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t off = woff + (int64_t)(nrow0 + rb + 16 * i) * 512 + c0 + col4;
+      p4[i] = *reinterpret_cast<const float4*>(ad.params + off);
+      m4[i] = *reinterpret_cast<const float4*>(ad.m + off);
+      v4[i] = *reinterpret_cast<const float4*>(ad.v + off);
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) lp[u] = ad.tail.stat_partials[(size_t)min(l + 64 * u, max(nlb - 1, 0)) * 4];
+  };
+  // the multiplier waves' small-parameter share (workgroups b < nsmall): requested right behind the K loop
+  SmallCols<8> sm;
+  float lpm[5];
+  const bool do_small = b < o.nsmall && !(ACEZ_DBG(a.dbg) & 64);
+  auto mprefetch = [&]() {
+    if (do_small) {
+      sm.issue(ad, b);
+#pragma unroll
+      for (int u = 0; u < 5; ++u) lpm[u] = ad.tail.stat_partials[(size_t)min(l + 64 * u, max(nlb - 1, 0)) * 4];
+    }
+  };
+  // tail_output's sum of the loss partials (the same additions in the same order) from five prefetched rows per lane
+  auto loss_sum = [&](const float (&v5)[5]) {
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+      if (l + 64 * u < nlb) sum += v5[u];
+    for (int r = l + 320; r < nlb; r += 64) sum += ad.tail.stat_partials[(size_t)r * 4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    return sum;
+  };
+  f32x16 acc[2][2];
+  int KT;
+  const bool loader = wgrad_kloop<E, WGO_PF, ACEZ_WGO_MPRE_EARLY>(a, smem, layer, slab, tile, acc, KT, prefetch, mprefetch);
+  if (KT == 0) __builtin_amdgcn_s_barrier();   // (wsync)
+  // Slot KT % RING was last written for stage KT - RING and slot (KT + 1) % RING for stage KT - RING + 1: every wave is past the barrier
+  // of stage KT - 1, i.e. done with both; the slot of stage KT - 1 itself may still be read by a slower multiplier wave.
+  float* const stage = reinterpret_cast<float*>(&smem[KT % RING][0][0]);                                  // [64][128] fp32: own partial
+  uint16_t (*const tileT)[66] = reinterpret_cast<uint16_t (*)[66]>(&smem[(KT + 1) % RING][0][0]);         // [128][66]: W^T staging
+  const int pair = layer * 16 + tile;
+  const TrainState* st = ad.st;
+  if (!loader) {
+    const int cw = w & 3, wn = cw >> 1, wc = cw & 1, h = l >> 5;
+    if (wn != slab) {
+      if (!(ACEZ_DBG(a.dbg) & 32)) {
+        float* __restrict__ X = o.xch + (size_t)(pair * 2 + (1 - slab)) * 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              X[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + wc * 64 + j * 32 + (l & 31)] = acc[i][j][r];
+        ACEZ_VMCNT(0);   // acknowledged by the L2 both workgroups share
+        if (l == 0) {
+          const uint32_t one = 1;
+          asm volatile("global_atomic_add %0, %1, off" ::"v"(o.flags + (size_t)(pair * 2 + (1 - slab)) * 32), "v"(one) : "memory");
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + wc * 64 + j * 32 + (l & 31)] = acc[i][j][r];
+      lds_bump(&wsync[0]);   // the own half is in LDS (two waves)
+    }
+    // from here on the multiplier waves are free: the small parameters and the schedule wave run beside the loader waves' arithmetic
+    if (do_small) {   // this workgroup's share of the small parameters, under adamw_body's guards
+      const int active = st->active;
+      const AdamScalars sc = st->adam;
+      const int fault_now = *ad.fault;
+      sm.finish(ad, b, sc, [&] {
+        const float lossv = loss_sum(lpm);
+        bool skip = !active || fault_now || lossv != lossv;
+        if (E::is_f16) skip = skip || absmax_all(st, l) >= 0x7f800000u;
+        return skip;
+      });
+    }
+    if (o.do_post && b == (int)gridDim.x - 1 && w == 0 && !(ACEZ_DBG(a.dbg) & 128))
+      sched_post_wave(post.src, post.st, post.c, post.grad_stats, post.inv_global_batch, post.log_loss, post.log_inl, post.log_cap, post.fault,
+                      post.stat_partials, post.n_loss_blocks, &ad.tail);
+    return;
+  }
+  // ------------------------------------------------------------------ loader waves: the optimiser step of the half tile
+  const int active = st->active;
+  const AdamScalars s = st->adam;
+  const float inv_scale = st->inv_grad_scale;
+  const int fault_now = *ad.fault;
+  const float lossv = loss_sum(lp);
+  bool skip = !active || fault_now || lossv != lossv || (ACEZ_DBG(a.dbg) & 8);   // adamw_body's guards
+  if (E::is_f16) skip = skip || absmax_all(st, l) >= 0x7f800000u;
+  if (!(ACEZ_DBG(a.dbg) & 48)) {   // (ablation bits of the diagnostics build, timing only: 8 = no final stores, 16 = no poll, 32 = no send, 64 = no small parameters, 128 = no schedule wave)
+    uint32_t vseen, sseen, spins, timed;
+    const uint32_t* flag = o.flags + (size_t)(pair * 2 + slab) * 32;
+    asm volatile(
+        "s_mov_b32 %[spins], 0\n\t"
+        "s_mov_b32 %[timed], 0\n"
+        "1:\n\t"
+        "global_load_dword %[vseen], %[flag], off sc1\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[sseen], %[vseen]\n\t"
+        "s_sub_i32 %[sseen], %[sseen], %[target]\n\t"
+        "s_cmp_ge_i32 %[sseen], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sleep " ACEZ_SEQ_SLEEP "\n\t"
+        "s_add_u32 %[spins], %[spins], 1\n\t"
+        "s_cmp_lt_u32 %[spins], %[limit]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_mov_b32 %[timed], 1\n"
+        "2:"
+        : [vseen] "=&v"(vseen), [sseen] "=&s"(sseen), [spins] "=&s"(spins), [timed] "=&s"(timed)
+        : [flag] "v"(flag), [target] "s"(o.target), [limit] "s"(o.spin_limit)
+        : "memory", "scc");
+    if (timed) {   // the partner never arrived (the two slabs of a tile are not on one XCD after all): fault word, step switched off
+      skip = true;
+      if (l == 0) {
+        __hip_atomic_store(ad.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(const_cast<int*>(&st->active), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  float4 oth[4];
+  {
+    const float* __restrict__ Xin = o.xch + (size_t)(pair * 2 + slab) * 8192;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) oth[i] = *reinterpret_cast<const float4*>(Xin + (rb + 16 * i) * 128 + col4);
+  }
+  lds_wait_ge(&wsync[0], 2);   // the own half is in LDS
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rb + 16 * i;
+    const float4 own = *reinterpret_cast<const float4*>(stage + row * 128 + col4);
+    // slab 0 + slab 1 (fp32 addition commutes: the same bits whichever of the two is `own`), then the un-scaling of the fp16 chain
+    float4 g;
+    g.x = (own.x + oth[i].x) * inv_scale; g.y = (own.y + oth[i].y) * inv_scale;
+    g.z = (own.z + oth[i].z) * inv_scale; g.w = (own.w + oth[i].w) * inv_scale;
+    float4 p = p4[i], m = m4[i], v = v4[i];
+    p.x = adamw_one(p.x, g.x, m.x, v.x, s);
+    p.y = adamw_one(p.y, g.y, m.y, v.y, s);
+    p.z = adamw_one(p.z, g.z, m.z, v.z, s);
+    p.w = adamw_one(p.w, g.w, m.w, v.w, s);
+    const uint2 pk = E::pk4(p.x, p.y, p.z, p.w);
+    if (!skip) {
+      const int64_t off = woff + (int64_t)(nrow0 + row) * 512 + c0 + col4;
+      *reinterpret_cast<float4*>(ad.params + off) = p;
+      *reinterpret_cast<float4*>(ad.m + off) = m;
+      *reinterpret_cast<float4*>(ad.v + off) = v;
+      *reinterpret_cast<uint2*>(ad.Wb + (size_t)layer * 262144 + (size_t)(nrow0 + row) * 512 + c0 + col4) = pk;
+    }
+    tileT[col4 + 0][row] = (uint16_t)(pk.x & 0xffff);
+    tileT[col4 + 1][row] = (uint16_t)(pk.x >> 16);
+    tileT[col4 + 2][row] = (uint16_t)(pk.y & 0xffff);
+    tileT[col4 + 3][row] = (uint16_t)(pk.y >> 16);
+  }
+  lds_bump(&wsync[1]);
+  lds_wait_ge(&wsync[1], WGRAD_LOADERS);   // every loader wave's rows of the transpose tile
+  {
+    // W^T: row c0 + cl holds the 64 values n = nrow0 .. nrow0 + 63 of column cl: 128 contiguous bytes, 32 per lane
+    const int cl = e >> 2, part = e & 3;
+    uint32_t q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = (uint32_t)tileT[cl][part * 16 + 2 * k] | ((uint32_t)tileT[cl][part * 16 + 2 * k + 1] << 16);
+    if (!skip) {
+      uint16_t* dst = ad.WbT + (size_t)layer * 262144 + (size_t)(c0 + cl) * 512 + nrow0 + part * 16;
+      *reinterpret_cast<uint4*>(dst) = make_uint4(q[0], q[1], q[2], q[3]);
+      *reinterpret_cast<uint4*>(dst + 8) = make_uint4(q[4], q[5], q[6], q[7]);
+    }
+  }
 }
 
 }  // namespace acez
