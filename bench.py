@@ -656,9 +656,14 @@ def main():
                          "avg_launch_us": avg_s * 1e6, "launches_timed": gemm_n,
                          "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()},
                          "note": gemm_note},
-            "roofline_wgrad": {"bound": "mfma", "kernel": "wgrad_kernel (8 layers x 512x512x5120 bf16 in one launch)", "achieved": wg_tflops,
+            "roofline_wgrad": {"bound": "mfma", "kernel": "wgrad_opt_kernel (8 layers x 512x512x5120 bf16 weight gradients in one launch; since round 4 the same "
+                                                          "launch also exchanges the split-K halves, applies AdamW to the wide layers and the small parameters and "
+                                                          "closes the step's schedule: there is no optimiser launch any more)" if "adamw" not in prof or prof["adamw"][0] == 0
+                               else "wgrad_kernel (8 layers x 512x512x5120 bf16 in one launch)", "achieved": wg_tflops,
                                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": wg_tflops / MFMA_PEAK_TFLOPS, "traffic": None,
-                               "avg_launch_us": wg_s * 1e6},
+                               "avg_launch_us": wg_s * 1e6,
+                               "note": "achieved = the weight-gradient FLOPs over the WHOLE launch, optimiser epilogue included (round 3: wgrad_kernel alone 27-29 us + "
+                                       "a 23-26 us optimiser launch)"},
             "roofline_ransac": ransac_roofline(nreg * world / dt_reg),
             "parity": parity_table(),
             "precision_note": "dtype bf16 is what BASELINE north_star names; the reference runs fp16 autocast (ace_trainer.py:517-518): `dtype_fp16` is the "

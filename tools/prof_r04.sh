@@ -90,7 +90,7 @@ for name, c in summary.items():
     g = lambda n: c.get(n, {}).get("mean_per_launch")
     e = {}
     if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
-        gemm = ("rowseq_kernel" in name) or ("wgrad_kernel" in name) or ("rowgemm" in name)
+        gemm = ("rowseq_kernel" in name) or ("wgrad_kernel" in name) or ("wgrad_opt_kernel" in name) or ("rowgemm" in name)
         ff, wf = (F_ROWS, W_ROWS) if gemm else (F_STREAM, W_STREAM)
         e.update(bytes_per_launch=(ff * g("FETCH_SIZE") + wf * g("WRITE_SIZE")) * 1024, fetch_kib_raw=g("FETCH_SIZE"), write_kib_raw=g("WRITE_SIZE"),
                  fetch_factor=ff, write_factor=wf)
