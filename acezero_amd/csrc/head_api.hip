@@ -132,6 +132,7 @@ struct acez_trainer {
   const int64_t* next_idx = nullptr;
   int next_n = 0;
   long wgo_fault_at = -1;         // tests: ACEZ_WGO_FAULT_AT=<n> makes the n-th wgrad_opt launch time out
+  unsigned long long* wgo_trace = nullptr;   // ACEZ_WGO_TRACE=1 (diagnostics build): s_memtime stamps of wgrad_opt_kernel's last launch (debug_read kind 7)
 };
 
 enum { KC_SCHED = 0, KC_GATHER, KC_GEMM_FWD, KC_LOSS, KC_GEMM_DGRAD, KC_WGRAD, KC_REDUCE, KC_ADAMW, KC_COUNT };
@@ -356,6 +357,10 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   }
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGRAD_OPT")) tr->wgrad_opt = atoi(e) != 0;
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_AT")) tr->wgo_fault_at = atol(e);
+  if (ACEZ_DIAG_ENV("ACEZ_WGO_TRACE")) {
+    A((void**)&tr->wgo_trace, 256 * 12 * 8 * sizeof(unsigned long long));
+    if (rc == ACEZ_OK) (void)hipMemset(tr->wgo_trace, 0, 256 * 12 * 8 * sizeof(unsigned long long));
+  }
   A((void**)&tr->R0_alt, act_bytes);
   A((void**)&tr->batch_meta_alt, (size_t)tr->max_batch * sizeof(int4));
   A((void**)&tr->wg_xch, (size_t)tr->L * 16 * 2 * 8192 * sizeof(float));
@@ -957,6 +962,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
       fill_adam_args(tr, o.ad);
       o.ad.tail = tr->last_reduce;
       o.xch = tr->wg_xch; o.flags = tr->wg_flags; o.spin_limit = tr->seq_spin_limit;
+      o.trace = tr->wgo_trace;
       o.target = 2u * ++tr->wg_epoch;
       if ((long)tr->wg_epoch - 1 == tr->wgo_fault_at) o.target += 1u << 20;   // tests: a partner that never arrives
       // the small parameters ride in the multiplier waves of the first workgroups; without pose refinement the schedule wave that closes
@@ -1303,6 +1309,7 @@ extern "C" int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, vo
   else if (kind == 4 && index >= 0 && index < tr->L) { src = tr->bias_partials + (size_t)index * tr->bias_layer_stride; cap = tr->bias_layer_stride * 4; }
   else if (kind == 5 && tr->chain_trace) { src = tr->chain_trace; cap = 512 * 8; }
   else if (kind == 6 && tr->seq_xcc) { src = tr->seq_xcc; cap = (8 + 256) * 4; }
+  else if (kind == 7 && tr->wgo_trace) { src = tr->wgo_trace; cap = 256 * 12 * 8 * 8; }
   ACEZ_REQUIRE(src && bytes <= cap, "unknown buffer or size out of range");
   ACEZ_HIP_CHECK(hipMemcpyAsync(h_out, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));

@@ -189,6 +189,7 @@ struct WgradOptArgs {
   uint32_t spin_limit;   // poll budget, as RowSeqArgs::spin_limit
   int nsmall;            // workgroups 0 .. nsmall - 1 also run one small-parameter block of the optimiser each (adamw_small_columns); 0: none
   int do_post;           // the last workgroup also runs the schedule wave that closes the step (sched_post_wave)
+  unsigned long long* trace;   // diagnostics build (ACEZ_WGO_TRACE=1, tools/wgo_trace.py): [256 workgroups][12 waves][8] s_memtime stamps; else null
 };
 
 }  // namespace acez

@@ -829,12 +829,9 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 // PFN > 0: `prefetch()` issues exactly PFN vector-memory loads (wgrad_opt_kernel: the optimiser state of the workgroup's half tile) from
 // inside the loader loop, about a dozen stages before its end, so that they travel beside the operand stream instead of after it; loads
 // complete in order, so the counted waits of the stages requested BEFORE the prefetch allow PFN more instructions in flight.
-// `mprefetch()` is called once by the multiplier waves, right behind their last MFMA (wgrad_opt_kernel: the loads of their small-parameter
-// share go out before the accumulators are staged / sent). Issued from INSIDE the loop, eight stages before its end, the same loads cost
-// 3 us: registers written by a load are live across the back edge, and the wave stalls on them one iteration later (measured, round 4).
-template <class E, int PFN, bool MPRE_EARLY, class PF, class MPF>
+template <class E, int PFN, class PF>
 __device__ __forceinline__ bool wgrad_kloop(const WgradArgs& a, uint16_t (*smem)[2][64 * 128], const int layer, const int slab, const int tile,
-                                            f32x16 (&acc)[2][2], int& KT_out, PF&& prefetch, MPF&& mprefetch) {
+                                            f32x16 (&acc)[2][2], int& KT_out, PF&& prefetch) {
   constexpr int RING = ACEZ_WGRAD_RING;   // slots of the [dZ | In] stage ring, 32 KiB each (RING - 1 stages in flight per CU)
   static_assert(2 * (16 / WGRAD_LOADERS) * (RING - 1) + PFN <= 31, "wait_vmcnt_dyn covers 1 .. 31");
   const int t = threadIdx.x, l = t & 63;
@@ -917,9 +914,9 @@ __device__ __forceinline__ bool wgrad_kloop(const WgradArgs& a, uint16_t (*smem)
   }
   const int offA[2] = {tr_base(wn * 64, l), tr_base(wn * 64 + 32, l)};
   const int offB[2] = {tr_base(wc * 64, l), tr_base(wc * 64 + 32, l)};
-  auto mstage = [&](int kt) {
+  for (int kt = 0; kt < KT; ++kt) {
     __builtin_amdgcn_s_barrier();
-    if (ACEZ_DBG(a.dbg) & 2) return;
+    if (ACEZ_DBG(a.dbg) & 2) continue;
     const int slot = kt % RING;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -933,18 +930,7 @@ __device__ __forceinline__ bool wgrad_kloop(const WgradArgs& a, uint16_t (*smem)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma32(fa[i], fb[j], acc[i][j]);
     }
-  };
-  if (!MPRE_EARLY) {
-    for (int kt = 0; kt < KT; ++kt) mstage(kt);
-    mprefetch();
-    return false;
   }
-  // the last two stages are peeled off the loop: the prefetch goes out in front of them, and no back edge follows it
-  const int KT2 = KT >= 3 ? KT - 2 : 0;
-  for (int kt = 0; kt < KT2; ++kt) mstage(kt);
-  mprefetch();
-  if (KT2 < KT) mstage(KT2);
-  if (KT2 + 1 < KT) mstage(KT2 + 1);
   return false;
 }
 
@@ -965,7 +951,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
   const int n0 = (tile >> 2) * 128, c0 = (tile & 3) * 128;
   f32x16 acc[2][2];
   int KT;
-  if (wgrad_kloop<E, 0, false>(a, smem, layer, slab, tile, acc, KT, [] {}, [] {})) return;
+  if (wgrad_kloop<E, 0>(a, smem, layer, slab, tile, acc, KT, [] {})) return;
 
   if (ACEZ_DBG(a.dbg) & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
   if (!active) return;
@@ -1736,7 +1722,9 @@ struct SmallCols {
     c.k = (int64_t)b * PER_BLOCK + ((int)threadIdx.x / LPO);
     c.base = r.stat_partials; c.cnt = 0; c.stride = 0; c.dst = -1; c.ome = -1;
     if (c.k < n_bias) {
-      const int layer = (int)(c.k >> 9), col = (int)(c.k & 511);
+      // (the outputs of a wavefront never straddle a layer -- 512 is a multiple of the outputs per wavefront --, so the layer is a scalar:
+      // bias_count[layer] / b_off[layer] become scalar loads of the kernel arguments instead of a per-lane load the addresses below wait for)
+      const int layer = __builtin_amdgcn_readfirstlane((int)(c.k >> 9)), col = (int)(c.k & 511);
       c.base = r.bias_partials + (size_t)layer * r.bias_layer_stride + col; c.cnt = r.bias_count[layer]; c.stride = 512;
       c.dst = (int64_t)layer * 262656 + 262144 + col;
       c.ome = a.b_off[layer] + col;
@@ -2425,10 +2413,6 @@ __device__ double det_cos_pi(double x) {
 // fc3, statistics), and wave 0 of the last workgroup is the schedule wave that closes the step (do_post) -- with the next batch
 // gathered beside the loss kernel (loss_gather_kernel), a step without pose refinement has no optimiser launch left at all.
 // ---------------------------------------------------------------------------------------------------
-#ifndef ACEZ_WGO_MPRE_EARLY
-#define ACEZ_WGO_MPRE_EARLY false   // true: the multiplier waves' small-parameter loads go out two stages before the end of the K loop (peeled
-                                    // stages, no back edge behind them). Measured equal to issuing them right behind the loop (47.6 / 47.5 us, one box).
-#endif
 constexpr int WGO_PF = 17;   // prefetch loads per loader lane: 4 x (p, m, v) float4 + the first five rows of the loss partials
 // spin until an LDS counter of this workgroup reaches `target` (the waves of a workgroup meet through these after the K loop instead of
 // s_barrier: a barrier would make the loader waves' arithmetic wait for the multiplier waves' small-parameter work and vice versa)
@@ -2440,6 +2424,11 @@ __device__ __forceinline__ void lds_bump(uint32_t* f) {   // after this wave's e
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+#ifdef ACEZ_DIAG   // timeline of the epilogue (tools/wgo_trace.py): stamp i of this wave
+#define WGO_STAMP(i) do { if (o.trace && (threadIdx.x & 63) == 0) o.trace[((size_t)blockIdx.x * 12 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WGO_STAMP(i) do { } while (0)
+#endif
 template <class E = EltBf16>
 __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, WgradOptArgs o, PostArgs post) {
   constexpr int RING = ACEZ_WGRAD_RING;
@@ -2454,6 +2443,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
   const int layer = xcd + 8 * (jx >> 5), slab = (jx >> 4) & 1, tile = jx & 15;
   if (layer >= a.n_layers) return;
   if (t < 2) wsync[t] = 0;   // (ordered before its first use by the barriers of the K loop; a slab without rows has none)
+  WGO_STAMP(0);   // kernel entry
   const int n0 = (tile >> 2) * 128, c0 = (tile & 3) * 128;
   const AdamArgs& ad = o.ad;
   // this lane's share of the workgroup's 64 x 128 half tile in the epilogue (loader waves): rows rb + 16 i, columns col4 .. col4 + 3
@@ -2474,7 +2464,9 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
 #pragma unroll
     for (int u = 0; u < 5; ++u) lp[u] = ad.tail.stat_partials[(size_t)min(l + 64 * u, max(nlb - 1, 0)) * 4];
   };
-  // the multiplier waves' small-parameter share (workgroups b < nsmall): requested right behind the K loop
+  // the multiplier waves' small-parameter share (workgroups b < nsmall): requested once the accumulators are on their way. (In front of
+  // the send it delayed every exchange by the 2.5 us the requests take to issue -- tools/wgo_trace.py; from inside the K loop, two or
+  // eight stages before its end, it bought nothing or stalled the loop on the loaded registers one iteration later: measured, round 4.)
   SmallCols<8> sm;
   float lpm[5];
   const bool do_small = b < o.nsmall && !(ACEZ_DBG(a.dbg) & 64);
@@ -2498,8 +2490,9 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
   };
   f32x16 acc[2][2];
   int KT;
-  const bool loader = wgrad_kloop<E, WGO_PF, ACEZ_WGO_MPRE_EARLY>(a, smem, layer, slab, tile, acc, KT, prefetch, mprefetch);
+  const bool loader = wgrad_kloop<E, WGO_PF>(a, smem, layer, slab, tile, acc, KT, prefetch);
   if (KT == 0) __builtin_amdgcn_s_barrier();   // (wsync)
+  WGO_STAMP(1);   // K loop done
   // Slot KT % RING was last written for stage KT - RING and slot (KT + 1) % RING for stage KT - RING + 1: every wave is past the barrier
   // of stage KT - 1, i.e. done with both; the slot of stage KT - 1 itself may still be read by a slower multiplier wave.
   float* const stage = reinterpret_cast<float*>(&smem[KT % RING][0][0]);                                  // [64][128] fp32: own partial
@@ -2534,6 +2527,8 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
             stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + wc * 64 + j * 32 + (l & 31)] = acc[i][j][r];
       lds_bump(&wsync[0]);   // the own half is in LDS (two waves)
     }
+    WGO_STAMP(2);   // multipliers: accumulators sent (acknowledged) / staged
+    mprefetch();
     // from here on the multiplier waves are free: the small parameters and the schedule wave run beside the loader waves' arithmetic
     if (do_small) {   // this workgroup's share of the small parameters, under adamw_body's guards
       const int active = st->active;
@@ -2546,9 +2541,11 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
         return skip;
       });
     }
+    WGO_STAMP(3);   // multipliers: small parameters done
     if (o.do_post && b == (int)gridDim.x - 1 && w == 0 && !(ACEZ_DBG(a.dbg) & 128))
       sched_post_wave(post.src, post.st, post.c, post.grad_stats, post.inv_global_batch, post.log_loss, post.log_inl, post.log_cap, post.fault,
                       post.stat_partials, post.n_loss_blocks, &ad.tail);
+    WGO_STAMP(4);   // multipliers: (schedule wave) done
     return;
   }
   // ------------------------------------------------------------------ loader waves: the optimiser step of the half tile
@@ -2589,6 +2586,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
       }
     }
   }
+  WGO_STAMP(2);   // loaders: guards evaluated, partner's counter seen
   float4 oth[4];
   {
     const float* __restrict__ Xin = o.xch + (size_t)(pair * 2 + slab) * 8192;
@@ -2596,6 +2594,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
     for (int i = 0; i < 4; ++i) oth[i] = *reinterpret_cast<const float4*>(Xin + (rb + 16 * i) * 128 + col4);
   }
   lds_wait_ge(&wsync[0], 2);   // the own half is in LDS
+  WGO_STAMP(3);   // loaders: own half staged (the partner's half is still in flight)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = rb + 16 * i;
@@ -2622,8 +2621,10 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
     tileT[col4 + 2][row] = (uint16_t)(pk.y & 0xffff);
     tileT[col4 + 3][row] = (uint16_t)(pk.y >> 16);
   }
+  WGO_STAMP(4);   // loaders: optimiser arithmetic done, p / m / v / W stores issued
   lds_bump(&wsync[1]);
   lds_wait_ge(&wsync[1], WGRAD_LOADERS);   // every loader wave's rows of the transpose tile
+  WGO_STAMP(5);   // loaders: all eight waves' transpose rows written
   {
     // W^T: row c0 + cl holds the 64 values n = nrow0 .. nrow0 + 63 of column cl: 128 contiguous bytes, 32 per lane
     const int cl = e >> 2, part = e & 3;
@@ -2636,6 +2637,9 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
       *reinterpret_cast<uint4*>(dst + 8) = make_uint4(q[4], q[5], q[6], q[7]);
     }
   }
+#ifdef ACEZ_DIAG
+  if (o.trace) { ACEZ_VMCNT(0); WGO_STAMP(6); }   // loaders: every store of this wave acknowledged
+#endif
 }
 
 }  // namespace acez
