@@ -988,7 +988,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   }
   if (!fused) {
     const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
-    const int64_t tail_blocks = (((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4) * 64 + 255) / 256;
+    const int64_t tail_blocks = ((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4 + 63) / 64;   // 64 outputs per workgroup (SmallCols<4>)
     ProfScope ps(tr, s, KC_REDUCE);
     hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, tr->last_reduce);
   }

@@ -1578,91 +1578,7 @@ __device__ __forceinline__ float tail_output(const GradReduceArgs& a, int64_t k,
   return k < n_bias + n_fc3 ? acc * a.st->inv_grad_scale : acc;   // (fp16: gradients arrive scaled; 1 for bf16, an exact product)
 }
 
-// Eight consecutive tail outputs k0 .. k0 + 7 by ONE wavefront: the partial-row loads of all eight are issued before anything is
-// summed (one memory round trip for the eight, not eight), then each output is reduced exactly as tail_output does it (same
-// lane-strided sums, same butterfly: identical bits). acc[j] / dst[j] are valid in every lane; dst[j] = -1 past the end.
-__device__ __forceinline__ void tail_output8(const GradReduceArgs& a, int64_t k0, int lane, float acc[8], int64_t dst[8]) {
-  const int64_t n_bias = (int64_t)a.n_layers * 512;
-  const int64_t n_fc3 = a.n_params - a.n_wide;
-  const int64_t n_out = n_bias + n_fc3 + 4;
-  constexpr int TD = 5;   // up to 320 partial rows per output in one round trip (rowseq: 64 row tiles, loss: 320 workgroups at batch 5120); more are looped below
-  float v[8][TD];
-  const float* base[8];
-  int cnt[8];
-  int64_t stride[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int64_t k = k0 + j;
-    base[j] = a.stat_partials; cnt[j] = 0; stride[j] = 0; dst[j] = -1;
-    if (k < n_bias) {
-      const int layer = (int)(k >> 9), c = (int)(k & 511);
-      base[j] = a.bias_partials + (size_t)layer * a.bias_layer_stride + c; cnt[j] = a.bias_count[layer]; stride[j] = 512;
-      dst[j] = (int64_t)layer * 262656 + 262144 + c;
-    } else if (k < n_bias + n_fc3) {
-      base[j] = a.fc3_partials + (k - n_bias); cnt[j] = a.n_loss_blocks; stride[j] = a.fc3_stride;
-      dst[j] = a.n_wide + (k - n_bias);
-    } else if (k < n_out) {
-      const int64_t kk = k - n_bias - n_fc3;
-      if (kk < 3) { base[j] = a.stat_partials + kk; cnt[j] = a.n_loss_blocks; stride[j] = 4; }
-      dst[j] = a.n_params + kk;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int u = 0; u < TD; ++u) {
-      const int b = lane + 64 * u;
-      const float x = base[j][(size_t)min(b, max(cnt[j] - 1, 0)) * stride[j]];   // unconditional load, masked afterwards
-      v[j][u] = b < cnt[j] ? x : 0.f;
-    }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int u = 0; u < TD; ++u)
-      if (lane + 64 * u < cnt[j]) s += v[j][u];          // the additions tail_output performs, in its order (b = lane, lane + 64, ...)
-    for (int b = lane + 64 * TD; b < cnt[j]; b += 64) s += base[j][(size_t)b * stride[j]];
-    const int64_t k = k0 + j;
-    if (k == n_out - 1 && a.fault) {   // statistics slot 3: the fault word + the fp16 overflow flag (see tail_output)
-      const uint32_t amax_bits = absmax_all(a.st, lane);
-      if (lane == 0) s = (*a.fault ? 1.f : 0.f) + (amax_bits >= 0x7f800000u ? 1024.f : 0.f);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    acc[j] = k < n_bias + n_fc3 ? s * a.st->inv_grad_scale : s;
-  }
-}
-
-__global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
-  if (a.st && !a.st->active) {
-    // switched off by a rowseq fault in THIS step (not by the end of the schedule): the bucket keeps whatever it held, but statistics
-    // slot 3 must still tell the other ranks, which then all skip the optimiser step
-    if (a.fault && *a.fault && blockIdx.x == 0 && threadIdx.x == 0) a.grad[a.n_params + 3] = 1.f;
-    return;
-  }
-  const int wide_blocks = (int)((a.n_wide / 4 + 255) / 256);
-  const int bx = (int)blockIdx.x + (a.skip_wide ? wide_blocks : 0);
-  if (bx < wide_blocks) {  // weights: 16-byte loads, slabs summed in slab order
-    const int64_t i4 = ((int64_t)bx * 256 + threadIdx.x) * 4;
-    if (i4 >= a.n_wide) return;
-    if ((i4 % 262656) >= 262144) return;  // bias slots are produced by the tail path below
-    float4 acc = *reinterpret_cast<const float4*>(a.slabs + i4);
-    for (int s = 1; s < a.nslabs; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)s * a.slab_stride + i4);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    const float inv = a.st->inv_grad_scale;
-    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
-    *reinterpret_cast<float4*>(a.grad + i4) = acc;
-    return;
-  }
-  const int lane = threadIdx.x & 63;
-  const int64_t k = ((int64_t)(bx - wide_blocks) * 256 + threadIdx.x) >> 6;
-  if (k >= (int64_t)a.n_layers * 512 + (a.n_params - a.n_wide) + 4) return;
-  int64_t dst;
-  const float acc = tail_output(a, k, lane, dst);
-  if (lane == 0) a.grad[dst] = acc;
-}
+// (grad_reduce_kernel itself follows SmallCols below: its tail is reduced with it)
 
 // ---------------------------------------------------------------------------------------------------
 // adamw: torch.optim.AdamW single-tensor semantics on the flat fp32 masters, fused with the bf16 recast of
@@ -1692,7 +1608,7 @@ __host__ __device__ inline int adamw_small_blocks(int n_layers, int64_t n_fc3, b
 // The small parameters of the fused step (biases of the wide layers, fc3) and the four statistics: 64 consecutive outputs per
 // workgroup, FOUR lanes (a DPP quad) per output. An output is a column sum over partial rows (one per row tile of the GEMM chain, or per
 // workgroup of the loss kernel): a load instruction of a wavefront reads 16 adjacent columns of 4 rows -- four full 64-byte lines --
-// where tail_output / tail_output8 (a wavefront per output, lanes striding the ROWS) touch 64 different lines with every instruction:
+// where tail_output (a wavefront per output, lanes striding the ROWS; round 3's tail_output8: eight outputs) touches 64 different lines with every instruction:
 // 193 workgroups of those were the long pole of the optimiser launch (18 us by themselves at batch 5120, against 9.5 us for gather +
 // schedule; round 4). The summation ORDER is tail_output's, so the bits are: partial j = rows j, j + 64, ... added in that order, then
 // the xor butterfly 32, 16, ..., 1, which pairs partial j with j ^ off at every level -- a fixed binary tree (addition commutes). Lane q
@@ -1704,6 +1620,15 @@ __host__ __device__ inline int adamw_small_blocks(int n_layers, int64_t n_fc3, b
 // issue() requests everything (p, m, v of the parameter and the first 320 partial rows: ONE memory round trip -- as a loop of
 // load-then-add rounds the five rounds of the fc3 columns were five dependent round trips, 7 us); finish() reduces, applies the
 // optimiser and stores. `late_skip()` (wgrad_opt_kernel: adamw_body's guards) is evaluated inside finish() before anything is stored.
+// where the optimiser of the small parameters lives (null params: reduce only -- grad_reduce_kernel's tail)
+struct SmallOpt {
+  float *params, *m, *v;
+  uint16_t* W3b;
+  const int64_t* b_off;
+  int64_t fc3_off;
+  int no, f16;
+};
+__device__ __forceinline__ SmallOpt small_opt(const AdamArgs& a) { return SmallOpt{a.params, a.m, a.v, a.W3b, a.b_off, a.fc3_off, a.no, a.f16}; }
 template <int LPO>
 struct SmallCols {
   static_assert(LPO == 4 || LPO == 8, "lanes per output");
@@ -1715,9 +1640,8 @@ struct SmallCols {
     int cnt;
     int64_t stride, dst, ome, k;
   };
-  static __device__ __forceinline__ Col decode(const AdamArgs& a, const int b) {
-    const GradReduceArgs& r = a.tail;
-    const int64_t n_bias = (int64_t)a.n_layers * 512, n_fc3 = a.n_fc3, n_out = n_bias + n_fc3 + 4;
+  static __device__ __forceinline__ Col decode(const GradReduceArgs& r, const SmallOpt& o, const int b) {
+    const int64_t n_bias = (int64_t)r.n_layers * 512, n_fc3 = r.n_params - r.n_wide, n_out = n_bias + n_fc3 + 4;
     Col c;
     c.k = (int64_t)b * PER_BLOCK + ((int)threadIdx.x / LPO);
     c.base = r.stat_partials; c.cnt = 0; c.stride = 0; c.dst = -1; c.ome = -1;
@@ -1727,11 +1651,11 @@ struct SmallCols {
       const int layer = __builtin_amdgcn_readfirstlane((int)(c.k >> 9)), col = (int)(c.k & 511);
       c.base = r.bias_partials + (size_t)layer * r.bias_layer_stride + col; c.cnt = r.bias_count[layer]; c.stride = 512;
       c.dst = (int64_t)layer * 262656 + 262144 + col;
-      c.ome = a.b_off[layer] + col;
+      if (o.params) c.ome = o.b_off[layer] + col;
     } else if (c.k < n_bias + n_fc3) {
       c.base = r.fc3_partials + (c.k - n_bias); c.cnt = r.n_loss_blocks; c.stride = r.fc3_stride;
       c.dst = r.n_wide + (c.k - n_bias);
-      c.ome = a.fc3_off + (c.k - n_bias);
+      if (o.params) c.ome = o.fc3_off + (c.k - n_bias);
     } else if (c.k < n_out) {
       const int64_t kk = c.k - n_bias - n_fc3;
       if (kk < 3) { c.base = r.stat_partials + kk; c.cnt = r.n_loss_blocks; c.stride = 4; }
@@ -1739,11 +1663,11 @@ struct SmallCols {
     }
     return c;
   }
-  __device__ __forceinline__ void issue(const AdamArgs& a, const int b) {
+  __device__ __forceinline__ void issue(const GradReduceArgs& r, const SmallOpt& o, const int b) {
     const int q = (int)threadIdx.x & (LPO - 1);
-    const Col c = decode(a, b);
+    const Col c = decode(r, o, b);
     p = 0.f; m = 0.f; v = 0.f;
-    if (q == 0 && c.ome >= 0) { p = a.params[c.ome]; m = a.m[c.ome]; v = a.v[c.ome]; }
+    if (q == 0 && c.ome >= 0) { p = o.params[c.ome]; m = o.m[c.ome]; v = o.v[c.ome]; }
     const int last = max(c.cnt - 1, 0);
 #pragma unroll
     for (int u = 0; u < TD; ++u) {
@@ -1761,11 +1685,10 @@ struct SmallCols {
     }
   }
   template <class G>
-  __device__ __forceinline__ void finish(const AdamArgs& a, const int b, const AdamScalars& s, G&& late_skip) {
+  __device__ __forceinline__ void finish(const GradReduceArgs& r, const SmallOpt& o, const int b, const AdamScalars& s, G&& late_skip) {
     const int lane = (int)threadIdx.x & 63, q = (int)threadIdx.x & (LPO - 1);
-    const GradReduceArgs& r = a.tail;
-    const int64_t n_bias = (int64_t)a.n_layers * 512, n_fc3 = a.n_fc3, n_out = n_bias + n_fc3 + 4;
-    const Col c = decode(a, b);
+    const int64_t n_bias = (int64_t)r.n_layers * 512, n_fc3 = r.n_params - r.n_wide, n_out = n_bias + n_fc3 + 4;
+    const Col c = decode(r, o, b);
     const bool skip = late_skip();
     float acc[NI];
 #pragma unroll
@@ -1804,9 +1727,9 @@ struct SmallCols {
     if (c.ome >= 0) {
       float pp = p, mm = m, vv = v;
       pp = adamw_one(pp, g, mm, vv, s);
-      a.params[c.ome] = pp; a.m[c.ome] = mm; a.v[c.ome] = vv;
+      o.params[c.ome] = pp; o.m[c.ome] = mm; o.v[c.ome] = vv;
       const int64_t kf = c.k - n_bias;
-      if (kf >= 0 && kf < (int64_t)a.no * 512) a.W3b[kf] = a.f16 ? EltF16::from_f(pp) : f2bf(pp);
+      if (kf >= 0 && kf < (int64_t)o.no * 512) o.W3b[kf] = o.f16 ? EltF16::from_f(pp) : f2bf(pp);
     }
   }
 };
@@ -1817,8 +1740,40 @@ __host__ __device__ inline int small_cols_blocks(int n_layers, int64_t n_fc3, in
 }
 __device__ __forceinline__ void adamw_small_columns(const AdamArgs& a, const int b, const AdamScalars& s) {
   SmallCols<4> sm;
-  sm.issue(a, b);
-  sm.finish(a, b, s, [] { return false; });
+  const SmallOpt o = small_opt(a);
+  sm.issue(a.tail, o, b);
+  sm.finish(a.tail, o, b, s, [] { return false; });
+}
+
+__global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
+  if (a.st && !a.st->active) {
+    // switched off by a rowseq fault in THIS step (not by the end of the schedule): the bucket keeps whatever it held, but statistics
+    // slot 3 must still tell the other ranks, which then all skip the optimiser step
+    if (a.fault && *a.fault && blockIdx.x == 0 && threadIdx.x == 0) a.grad[a.n_params + 3] = 1.f;
+    return;
+  }
+  const int wide_blocks = (int)((a.n_wide / 4 + 255) / 256);
+  const int bx = (int)blockIdx.x + (a.skip_wide ? wide_blocks : 0);
+  if (bx < wide_blocks) {  // weights: 16-byte loads, slabs summed in slab order
+    const int64_t i4 = ((int64_t)bx * 256 + threadIdx.x) * 4;
+    if (i4 >= a.n_wide) return;
+    if ((i4 % 262656) >= 262144) return;  // bias slots are produced by the tail path below
+    float4 acc = *reinterpret_cast<const float4*>(a.slabs + i4);
+    for (int s = 1; s < a.nslabs; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)s * a.slab_stride + i4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float inv = a.st->inv_grad_scale;
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    *reinterpret_cast<float4*>(a.grad + i4) = acc;
+    return;
+  }
+  // the tail: 64 outputs per workgroup, four lanes each, coalesced partial-row reads (SmallCols: tail_output's summation order, the same bits;
+  // a wavefront per output -- 1538 workgroups whose lanes stride the partial ROWS -- touched 64 cache lines with every load)
+  SmallCols<4> sm;
+  const SmallOpt none{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  sm.issue(a, none, bx - wide_blocks);
+  sm.finish(a, none, bx - wide_blocks, AdamScalars{}, [] { return false; });
 }
 
 // One workgroup's share of the optimiser step (b = workgroup index inside the optimiser's part of a launch; tileT: 64 x 66 bf16 LDS).
@@ -2472,7 +2427,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
   const bool do_small = b < o.nsmall && !(ACEZ_DBG(a.dbg) & 64);
   auto mprefetch = [&]() {
     if (do_small) {
-      sm.issue(ad, b);
+      sm.issue(ad.tail, small_opt(ad), b);
 #pragma unroll
       for (int u = 0; u < 5; ++u) lpm[u] = ad.tail.stat_partials[(size_t)min(l + 64 * u, max(nlb - 1, 0)) * 4];
     }
@@ -2534,7 +2489,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
       const int active = st->active;
       const AdamScalars sc = st->adam;
       const int fault_now = *ad.fault;
-      sm.finish(ad, b, sc, [&] {
+      sm.finish(ad.tail, small_opt(ad), b, sc, [&] {
         const float lossv = loss_sum(lpm);
         bool skip = !active || fault_now || lossv != lossv;
         if (E::is_f16) skip = skip || absmax_all(st, l) >= 0x7f800000u;
