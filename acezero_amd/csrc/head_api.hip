@@ -510,9 +510,12 @@ static bool seq_usable(const acez_trainer* tr, int n) {
 
 // wgrad_opt_kernel's workgroups wait for each other too: same conditions, its own grid (both slabs of a layer on one XCD: 32 workgroups
 // per layer, layers round-robin over the XCDs)
+// Without pose refinement only: with it the optimiser launch also carries the pose network's per-image reduction and backward chain
+// (adamw_pose_kernel), 18 us that the weight tiles used to run beside for free -- measured with wgrad_opt on that path: 191.6 us per
+// step against 176.7 (profiles/r04_*_trace_mlp.csv history in DESIGN.md section 3).
 static bool wgrad_opt_usable(const acez_trainer* tr) {
   return tr->wgrad_opt && tr->seq && tr->gemm_tile == 80 && !tr->chain && !tr->fused_fwd && tr->wgrad_tile == 128 && tr->nslabs == 2 &&
-         256 * ((tr->L + 7) / 8) <= tr->n_cus;
+         tr->cfg.pose_refinement == 0 && 256 * ((tr->L + 7) / 8) <= tr->n_cus;
 }
 
 template <bool BWD>
@@ -867,7 +870,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     tr->last_nblk = nblk;   // (after this step's step_begin, whose schedule wave closed the step BEFORE with that step's count)
     ProfScope ps(tr, s, KC_LOSS);
     tr->next_gathered = false;
-    if (fused && d_next && n_next > 0 && tr->cfg.pose_refinement == 0 && wgrad_opt_usable(tr) && tr->loss_rows == 4) {
+    if (fused && d_next && n_next > 0 && wgrad_opt_usable(tr) && tr->loss_rows == 4) {
       // the next batch's gather as extra workgroups of the loss launch (this path has no optimiser launch to carry it): 32 rows per
       // workgroup and pass, as many workgroups as the loss kernel leaves free (two of these workgroups fit a CU)
       const int want = (n_next + 31) / 32, room = std::max(32, 2 * tr->n_cus - nblk);
@@ -965,10 +968,9 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
       o.trace = tr->wgo_trace;
       o.target = 2u * ++tr->wg_epoch;
       if ((long)tr->wg_epoch - 1 == tr->wgo_fault_at) o.target += 1u << 20;   // tests: a partner that never arrives
-      // the small parameters ride in the multiplier waves of the first workgroups; without pose refinement the schedule wave that closes
-      // the step rides too (with it, the bookkeeping stays with the next step's gather launch, which also runs the pose network)
+      // the small parameters ride in the multiplier waves of the first workgroups, the schedule wave that closes the step in the last one
       o.nsmall = small_cols_blocks(tr->L, (int64_t)tr->no * 513, 8);
-      o.do_post = tr->cfg.pose_refinement == 0 ? 1 : 0;
+      o.do_post = 1;
       if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_POST")) o.do_post = o.do_post && atoi(e) != 0;   // timing experiments: the schedule wave as its own launch
       const dim3 grid(256 * ((tr->L + 7) / 8));
       if ((int)grid.x < o.nsmall) abort();
@@ -1030,8 +1032,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
   // workgroups for the head are left
   const bool wide_done = fused && tr->wide_done;
   tr->wide_done = false;
-  const int ntile = wide_done ? 0 : tr->L * 64;
-  if (wide_done && tr->cfg.pose_refinement == 0) {
+  if (wide_done) {
     // ... and it has closed the step; the next batch (acez_train_step_next) was gathered beside the loss kernel into the other buffers
     if (tr->post_done) { st_flip(tr); tr->post_pending = false; } else { tr->post_pending = true; }
     tr->post_done = false;
@@ -1043,14 +1044,13 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     }
     return ACEZ_OK;
   }
-  const int nsmall_l = wide_done ? 0 : nsmall;
   const bool pf = tr->pose_fused && !tr->chain && !tr->fused_fwd;
   if (pf && fused) {
     // the head's AdamW with the pose network's reduce + backward chain (S1) as the first workgroups of the same launch, then the
     // pose weight gradients with AdamW in their epilogue (S2: needs S1 of every image tile)
     const int T = tr->pose_tile, np = (tr->buf.n_images + T - 1) / T;
     { ProfScope ps(tr, s, KC_ADAMW);
-#define ACEZ_AP(TT) hipLaunchKernelGGL(adamw_pose_kernel<TT>, dim3(np + ntile + nsmall_l), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active), \
+#define ACEZ_AP(TT) hipLaunchKernelGGL(adamw_pose_kernel<TT>, dim3(np + tr->L * 64 + nsmall), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active), \
                                        (const float*)tr->row_dT, (const int*)tr->row_image, tr->last_n, np)
       if (T == 16) ACEZ_AP(16); else if (T == 4) ACEZ_AP(4); else ACEZ_AP(8);
 #undef ACEZ_AP
@@ -1063,7 +1063,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
   a.layer_lo = layer_lo; a.layer_hi = layer_hi;
   if (fused && d_next && n_next > 0 && tr->cfg.pose_refinement == 0 && !tr->chain && !tr->fused_fwd && tr->have_buf) {
     // the next batch is known: its gather and this step's schedule bookkeeping ride in the optimiser's launch (adamw_next_kernel)
-    int n_adam = ntile + nsmall_l;
+    int n_adam = tr->L * 64 + nsmall;
     // timing experiments (diagnostics build; results wrong by construction): 1 = no optimiser workgroups at all, 2 = no gather
     const int tail_abl = ACEZ_DIAG_ENV("ACEZ_TAIL_ABL") ? atoi(ACEZ_DIAG_ENV("ACEZ_TAIL_ABL")) : 0;
     if (tail_abl & 1) n_adam = 0;
@@ -1086,7 +1086,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     ACEZ_HIP_CHECK(hipGetLastError());
     return ACEZ_OK;
   }
-  if (!wide_done) { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3((layer_hi - layer_lo) * 64 + nsmall), dim3(256), 0, s, a); }
+  { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3((layer_hi - layer_lo) * 64 + nsmall), dim3(256), 0, s, a); }
   if (tr->cfg.pose_refinement != 0) tr->pose_wt_valid = false;   // adamw_small_kernel does not refresh the transposed copies
   if (tr->cfg.pose_refinement != 0)
     hipLaunchKernelGGL(adamw_small_kernel, dim3((unsigned)((tr->pb.n_pose_params + 255) / 256)), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,
