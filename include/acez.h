@@ -261,13 +261,16 @@ int acez_trainer_export_weights16(acez_trainer* tr, int layer_lo, int layer_hi, 
 int acez_trainer_import_weights16(acez_trainer* tr, int layer_lo, int layer_hi, const void* d_src, void* stream);
 int acez_trainer_import_weights16_all(acez_trainer* tr, int own_lo, int own_hi, const void* d_src_all, void* stream);
 
-/* Single-GPU step = backward + update, with the wide-layer weight gradients handed from the split-K slabs straight to the
- * optimiser: bitwise the same parameters as the two calls above; afterwards d_grad holds the bias / fc3 gradients and the
- * statistics only (its wide-layer weight part is not written). Use backward / all-reduce / update when ranks exchange d_grad. */
+/* Single-GPU step = backward + update, with the wide-layer weight gradients handed straight to the optimiser: bitwise the same
+ * parameters as the two calls above; afterwards d_grad holds the bias / fc3 gradients and the statistics only (its wide-layer weight
+ * part is not written). Without pose refinement, and while the one-launch chains are enabled (acez_trainer_seq_status), the weight-gradient
+ * launch applies the whole optimiser step itself (wgrad_opt_kernel: the split-K halves of a tile are exchanged inside one XCD's L2 and
+ * never reach memory) and closes the step's schedule; otherwise the slabs go through memory to a separate optimiser launch. Use
+ * backward / all-reduce / update when ranks exchange d_grad. */
 int acez_train_step(acez_trainer* tr, const int64_t* d_indices, int n, void* stream);
 /* acez_train_step with the NEXT step's indices announced (run_epoch walks consecutive slices of one permutation, ace_trainer.py:466-494,
- * so the caller knows them): the next batch is gathered, and this step's schedule bookkeeping done, inside this step's optimiser
- * launch. The next call must pass the same device pointer and count to profit; a different pointer or count is still correct (the batch
+ * so the caller knows them): the next batch is gathered inside this step's launches (beside the loss kernel, into the second of the
+ * trainer's two input buffers; with pose refinement: inside the optimiser launch, with the schedule bookkeeping). The next call must pass the same device pointer and count to profit; a different pointer or count is still correct (the batch
  * is then gathered again). The rows gathered ahead are recognised by (pointer, count) only: the n_next indices at d_indices_next must
  * not be rewritten, nor their memory freed and reused, between this call and the next step call -- acez_trainer_set_buffer and
  * acez_trainer_sync_weights drop the rows gathered ahead. NULL = acez_train_step. */
