@@ -1181,6 +1181,19 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
 #pragma unroll
     for (int i = 0; i < 9; ++i) Km[i] = a.view_K[(size_t)pre_view * 9 + i];
   }
+  // phase C's loads too (training, loss_kernel): the rows come back from the L1 / L2 this workgroup has just pulled them through, but
+  // requested behind the workgroup's meeting point they were one more round trip on the kernel's critical path
+  constexpr bool EARLY_C = !LDSACT;
+  const int chC = wv * 128 + 2 * t;
+  uint32_t w3c[4] = {0u, 0u, 0u, 0u}, xv[LDSACT ? 1 : 4 * LOSS_ROWS];
+  if (EARLY_C && a.idx) {
+    const int mb = block * 4 * LOSS_ROWS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w3c[j] = *reinterpret_cast<const uint32_t*>(a.W3 + (size_t)(j < no ? j : 0) * 512 + chC);
+#pragma unroll
+    for (int r = 0; r < 4 * LOSS_ROWS; ++r)   // rows past the end carry ds == 0 and are not stored
+      xv[LDSACT ? 0 : r] = *reinterpret_cast<const uint32_t*>(a.act + (size_t)min(mb + r, n - 1) * 512 + chC);
+  }
   {
     float w3[4][8];
 #pragma unroll
@@ -1425,14 +1438,11 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
     const int mb = block * 4 * LOSS_ROWS;
     float w3[4][2], gw[4][2], bsum[2] = {0.f, 0.f};
     float amax = 0.f;   // fp16: largest |dZ| this lane produces (scaled units) -> the gradient-scale control of the schedule wave
-    // every load of the phase first (row by row, a load was followed by a full wait: 32 serial round trips)
-    uint32_t w3c[4], xv[LDSACT ? 1 : 4 * LOSS_ROWS];
+    // every load of the phase first (row by row, a load was followed by a full wait: 32 serial round trips); loss_kernel: they were
+    // requested in front of phase B already (EARLY_C)
+    if (!EARLY_C) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w3c[j] = *reinterpret_cast<const uint32_t*>(a.W3 + (size_t)(j < no ? j : 0) * 512 + ch);
-    if (!LDSACT) {
-#pragma unroll
-      for (int r = 0; r < 4 * LOSS_ROWS; ++r)   // rows past the end carry ds == 0 and are not stored
-        xv[LDSACT ? 0 : r] = *reinterpret_cast<const uint32_t*>(a.act + (size_t)min(mb + r, n - 1) * 512 + ch);
+      for (int j = 0; j < 4; ++j) w3c[j] = *reinterpret_cast<const uint32_t*>(a.W3 + (size_t)(j < no ? j : 0) * 512 + ch);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1513,17 +1523,18 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
 template <class E = EltBf16, int LR = 8>
 __global__ __launch_bounds__(256) void loss_gather_kernel(LossArgs a, int nblk, const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx_next,
                                                           uint16_t* __restrict__ out, int n_next, GatherMeta meta) {
-  if ((int)blockIdx.x >= nblk) {
+  const int ng = (int)gridDim.x - nblk;   // the gather workgroups come FIRST: three dependent load levels, the longest chain of the launch
+  if ((int)blockIdx.x < ng) {
     const int lane = threadIdx.x & 63;
-    const int wave = (((int)blockIdx.x - nblk) * (int)blockDim.x + (int)threadIdx.x) >> 6;
-    const int nwaves = (((int)gridDim.x - nblk) * (int)blockDim.x) >> 6;
+    const int wave = ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x) >> 6;
+    const int nwaves = (ng * (int)blockDim.x) >> 6;
     gather_rows<8>(feat, idx_next, out, n_next, wave, nwaves, lane, meta);
     return;
   }
   if (a.st && !a.st->active) return;
   __shared__ float scratch[LOSS_SCRATCH_FLOATS];
   const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
-  loss_body<false, true, E, LR>(a, blockIdx.x, wv, t, nullptr, scratch, LossPre{0, 0, 0, 0.f, 0.f}, [] { __syncthreads(); });
+  loss_body<false, true, E, LR>(a, (int)blockIdx.x - ng, wv, t, nullptr, scratch, LossPre{0, 0, 0, 0.f, 0.f}, [] { __syncthreads(); });
 }
 
 // ---------------------------------------------------------------------------------------------------
