@@ -251,6 +251,7 @@ def ransac_roofline(images_per_s):
     # divide, 2 FMA, norm, clamp, sigmoid) = 4.9 MFLOP per 60x80 frame at 32 hypotheses (the kernel evaluates it in fp64: determinism);
     # the refinement rounds are data dependent and not counted. Bytes: 57.6 KB of coordinates in, 64 B pose + 4.8 KB mask out per frame.
     score_flop = 32 * 4800 * 32
+    out["algorithmic_frac"] = images_per_s * score_flop / 1e12 / (2 * peak)   # the R headline figure: SURVEY 8(d)'s scoring flops over the fp64 VALU peak
     out["algorithmic"] = {"scoring_flop_per_frame": score_flop, "scoring_tflops": images_per_s * score_flop / 1e12,
                           "scoring_frac_of_fp64_valu_peak": images_per_s * score_flop / 1e12 / (2 * peak),
                           "hbm_bytes_per_frame": 57600 + 64 + 4800, "hbm_GBps": images_per_s * (57600 + 64 + 4800) / 1e9,
@@ -271,6 +272,7 @@ def ransac_roofline(images_per_s):
                                    "what": "SQ_INSTS_VALU / frames of one 2048-frame launch (a STORED instruction count, checked against the "
                                            "running build's ransac sources); `achieved` = that count x the LIVE images/s of this run"})
         out["frac"] = out["achieved"] / peak
+        out["frac_is"] = "issue-slot occupancy (vector instructions issued / fp64 issue peak), NOT an algorithmic roofline: see algorithmic_frac"
     except (OSError, KeyError, ValueError):
         pass
     return out
@@ -603,6 +605,18 @@ def main():
                                       "frac": (BATCH * GEMM_FLOP_PER_LAUNCH_PER_ROW * (prof["gemm_fwd"][1] / 20) / max(prof["gemm_fwd"][0] / 20 * 1e-3, 1e-12) / 1e12) / MFMA_PEAK_TFLOPS}}
         wg_s = prof["wgrad"][0] / max(prof["wgrad"][1], 1) * 1e-3
         wg_tflops = BATCH * 8 * GEMM_FLOP_PER_LAUNCH_PER_ROW / wg_s / 1e12 if wg_s > 0 else 0.0
+        rr = ransac_roofline(nreg * world / dt_reg)
+        enc_frac = ENC_FLOP_PER_FRAME * pipe["frames"] / (pipe["encoder_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS
+        # Flat scalars: the driver's record keeps the scalars of `config` / `roofline` and drops nested objects and unknown top-level keys, so
+        # the figures a reader needs first are repeated there; `summary` is the same for a reader of the raw line.
+        summary = {"dominant_kernel_frac": dominant["frac"], "dominant_kernel_us": dg_us, "forward_chain_frac": dominant["forward_chain"]["frac"],
+                   "wgrad_opt_frac": wg_tflops / MFMA_PEAK_TFLOPS, "whole_step_frac": patches_per_s / world * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS * 1e12),
+                   "refinement_ms_per_step": float(np.median(st_ref["window_ms_per_step"])), "fp16_ms_per_step": float(np.median(st_f16["window_ms_per_step"])),
+                   "garden_ms_per_step": float(np.median(st_gar["window_ms_per_step"])),
+                   "registration_images_per_s": nreg * world / dt_reg, "registration_e2e_images_per_s": pipe["frames"] * world / pipe["e2e_s"],
+                   "encoder_frac_of_mfma_peak": enc_frac, "encoder_ms_per_frame": pipe["encoder_ms"] / pipe["frames"],
+                   "buffer_rows_per_s": pipe["buffer_rows"] * world / pipe["buffer_s"],
+                   "ransac_algorithmic_frac": rr["algorithmic_frac"], "ransac_issue_occupancy": rr["frac"]}
         out = {
             "metric": "ACE patches/sec", "value": patches_per_s, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": float(np.median(st["window_ms_per_step"])), "ms_per_step_mean": dt / args.steps * 1e3,
@@ -612,6 +626,7 @@ def main():
                                    "default head (1 block, 2 103 300 params), tanh loss, 1cyclepoly AdamW, pose_refinement " + args.pose_refinement,
                        "buffer_patches": args.buffer_patches, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "parallelism": f"dp{world}" + ("" if world == 1 else " (" + ("one all-reduce of the gradient bucket, replicated AdamW" if os.environ.get("ACEZ_DP_MODE", "sharded").lower() == "allreduce" else "reduce-scatter of the weight gradients by layer, AdamW on the owned layers, all-gather of the 16-bit weights") + ")")},
+            "summary": summary,
             "whole_step_flop_frac_of_mfma_peak": patches_per_s / world * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS * 1e12),
             "strong_scaling": None if dt_strong is None else {
                 "metric": "ACE patches/sec, the reference's step: global batch 5120 split over the ranks by buffer shard, one gradient exchange per step (see `collective`)",
@@ -651,6 +666,7 @@ def main():
                                    "map_bytes_per_s": pipe["cloud_frames"] * world * 57600 / pipe["cloud_s"]},
             "roofline": {"bound": "mfma", "kernel": gemm_kernel_name, "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         **{"summary_" + k: v for k, v in summary.items()},
                          "dominant_kernel": dominant, "stored_step_profile": step_prof,
                          "traffic_source": traffic_source, "mfma_busy_frac": mfma_busy, "stored_profile": stored,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": gemm_n,
@@ -664,7 +680,7 @@ def main():
                                "avg_launch_us": wg_s * 1e6,
                                "note": "achieved = the weight-gradient FLOPs over the WHOLE launch, optimiser epilogue included (round 3: wgrad_kernel alone 27-29 us + "
                                        "a 23-26 us optimiser launch)"},
-            "roofline_ransac": ransac_roofline(nreg * world / dt_reg),
+            "roofline_ransac": rr,
             "parity": parity_table(),
             "precision_note": "dtype bf16 is what BASELINE north_star names; the reference runs fp16 autocast (ace_trainer.py:517-518): `dtype_fp16` is the "
                               "same step at the reference's operand precision (scene coordinates within 2e-3 of the reference's fp32 arithmetic, bf16: 3e-2)",

@@ -56,6 +56,14 @@ def test_bench_json_line_contract(monkeypatch, seq):
     sp = r["stored_step_profile"]
     assert sp is None or (sp["algorithmic_bytes_per_step"] == bench.ALGO_BYTES_PER_STEP and sp["counter_bytes_per_step"] > 0)
     assert 60e6 < bench.ALGO_BYTES_PER_STEP < 70e6            # ~65 MB per step
+    # round 5: the figures a reader needs first, as flat scalars inside `roofline` (the driver's record keeps those) and as `summary`
+    sm = d["summary"]
+    for k in ("dominant_kernel_frac", "refinement_ms_per_step", "fp16_ms_per_step", "registration_images_per_s", "registration_e2e_images_per_s",
+              "encoder_frac_of_mfma_peak", "ransac_algorithmic_frac", "ransac_issue_occupancy"):
+        assert k in sm and r["summary_" + k] == sm[k]
+    assert abs(sm["dominant_kernel_frac"] - dom["frac"]) < 1e-12 and sm["registration_images_per_s"] == d["registration"]["value"]
+    assert list(d).index("summary") < list(d).index("roofline")
+    assert abs(rr["algorithmic_frac"] - rr["algorithmic"]["scoring_frac_of_fp64_valu_peak"]) < 1e-15 and (rr["frac"] is None or "occupancy" in rr["frac_is"])
 
 
 def test_cpu_baseline_quotes_the_stored_reference_figure():
