@@ -144,8 +144,9 @@ _diag = None
 @contextlib.contextmanager
 def diag_library():
     """tests/ and tools/ only: inside the block lib() is the diagnostics build (libacez_diag.so = the same sources with -DACEZ_DIAG), the
-    only build in which the ACEZ_* ablation switches, the measured-and-rejected kernels and the fault-injection hooks exist. Objects
-    created inside keep that library (HeadTrainer.lib) and must be used and closed inside the block."""
+    only build in which the ACEZ_* ablation switches, the measured-and-rejected kernels and the fault-injection hooks exist. Every
+    handle-owning object pins the library that created its handle (HeadTrainer.lib, Encoder.lib, the RANSAC contexts of dsacstar.py are
+    cached per (device, library)), so an object created under one build is never driven through the other, inside or outside the block."""
     global _lib, _diag
     if _diag is None:
         _diag = _load(_build.build(diag=True))

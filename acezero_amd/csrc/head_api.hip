@@ -132,6 +132,12 @@ struct acez_trainer {
   const int64_t* next_idx = nullptr;
   int next_n = 0;
   long wgo_fault_at = -1;         // tests: ACEZ_WGO_FAULT_AT=<n> makes the n-th wgrad_opt launch time out
+  int wgo_fault_mod = 0;          // tests: ACEZ_WGO_FAULT_MOD=<m>: ... only in the workgroups with b % m == 1 (a partially applied step)
+  uint32_t* wg_status = nullptr;  // [workgroups][8 loader waves] WgradOptArgs::status
+  WgoFaultRec* wg_rec = nullptr;  // WgradOptArgs::rec
+  int wgo_recovered = 0;          // faulted wgrad_opt steps the fall-back has finished (wgo_recover)
+  bool sizing = false;            // acez_trainer_create's first pass: dmalloc only adds up
+  size_t sized_total = 0;
   unsigned long long* wgo_trace = nullptr;   // ACEZ_WGO_TRACE=1 (diagnostics build): s_memtime stamps of wgrad_opt_kernel's last launch (debug_read kind 7)
 };
 
@@ -163,13 +169,18 @@ struct ProfScope {
 // 41.2-42.5; buffers PACKED into one arena 40.1-40.7 us in every process (and the input-gradient chain 44.2-44.3 instead of 44.8-45.4) --
 // one contiguous virtual range maps with large page-table fragments, so the 256 CUs' concurrent row streams over a dozen 5 MiB buffers
 // stop missing in the address-translation caches.
+// acez_trainer_create sizes its arena exactly: a first pass over its allocation list (tr->sizing) adds the requests up, ONE hipMalloc of
+// that sum follows, the second pass hands the pieces out (round 4 rounded every arena up to 256 MiB / eight times the largest request:
+// 2.4 GB for an inference context with 300 MB activations, 256 MiB for the short-lived per-call heads of session.scene_coordinates).
+// Allocations after creation (acez_trainer_set_buffer: the pose tables) open a chunk of their own, 32 MiB at least.
 static int dmalloc(acez_trainer* tr, void** p, size_t bytes) {
   constexpr size_t A = 4096;
+  if (tr->sizing) { tr->sized_total += (bytes + A - 1) / A * A; *p = nullptr; return ACEZ_OK; }
   size_t cur = (tr->arena_cursor + A - 1) / A * A;
   if (!tr->arena_base || cur + bytes > tr->arena_size) {
-    // a chunk holds at least eight buffers of the size that did not fit (inference contexts allocate 300 MB activations), 256 MiB at least
-    size_t chunk = bytes > ((size_t)512 << 20) ? bytes + A : 8 * bytes;
-    if (chunk < ((size_t)256 << 20)) chunk = (size_t)256 << 20;
+    size_t chunk = std::max(tr->sized_total, bytes) + A;
+    tr->sized_total = 0;   // (only the first chunk is pre-sized)
+    if (tr->arena_base) chunk = std::max((size_t)8 * bytes, (size_t)32 << 20);
     ACEZ_HIP_CHECK(hipMalloc((void**)&tr->arena_base, chunk));
     tr->allocs.push_back(tr->arena_base);
     tr->arena_size = chunk;
@@ -226,12 +237,42 @@ static int seq_placement_probe(acez_trainer* tr) {
   return ACEZ_OK;
 }
 
+static void fill_adam_args(acez_trainer* tr, AdamArgs& a);
+static void fill_wgrad_args(acez_trainer* tr, WgradArgs& a, int n, const TrainState* st);
+
+// A hand-off poll of wgrad_opt_kernel expired (WgoFaultRec::epoch != 0): unlike a rowseq fault -- whose step is a device-side no-op -- that
+// step WAS applied in part: the small parameters, the schedule wave (both read the fault word long before it is raised) and every half
+// tile whose exchange completed. The fall-back finishes it instead of leaving the trainer between two steps: since the fault word went up
+// every launch that writes a step's buffers has returned at entry (rowseq_kernel, loss_kernel, the gather beside it), so the faulted
+// step's activations and gradients are still in place; wgrad_kernel recomputes the slabs from them and wgo_recover_kernel applies AdamW
+// to exactly the rows whose wave gave up, with that step's scalars. Result: bitwise the two-launch flow's step (tests/test_wgrad_opt_gpu.py).
+static void wgo_recover(acez_trainer* tr, hipStream_t s) {
+  if (!tr->wg_rec) return;
+  WgoFaultRec rec{};
+  if (hipMemcpyAsync(&rec, tr->wg_rec, sizeof(rec), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess || !rec.epoch) return;
+  WgradArgs a{};
+  fill_wgrad_args(tr, a, rec.M, nullptr);   // (st = null: the fault handler has cleared `active`)
+  a.In[0] = rec.in0;
+  const int groups = tr->L * tr->nslabs;
+  if (tr->f16) hipLaunchKernelGGL(wgrad_kernel<EltF16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
+  else hipLaunchKernelGGL(wgrad_kernel<EltBf16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
+  AdamArgs ad;
+  fill_adam_args(tr, ad);
+  const dim3 grid(256 * ((tr->L + 7) / 8));
+  if (tr->f16) hipLaunchKernelGGL(wgo_recover_kernel<EltF16>, grid, dim3(512), 0, s, ad, (const float*)tr->slabs, tr->n_wide, (const uint32_t*)tr->wg_status, (const WgoFaultRec*)tr->wg_rec, tr->L);
+  else hipLaunchKernelGGL(wgo_recover_kernel<EltBf16>, grid, dim3(512), 0, s, ad, (const float*)tr->slabs, tr->n_wide, (const uint32_t*)tr->wg_status, (const WgoFaultRec*)tr->wg_rec, tr->L);
+  (void)hipMemsetAsync(tr->wg_rec, 0, sizeof(WgoFaultRec), s);
+  ++tr->wgo_recovered;
+}
+
 // Read the fault word (the caller has synchronised the stream or is about to): on a fault, reset the hand-off state and switch the
 // trainer to per-layer launches. Returns 1 if a fall-back was taken.
 static int seq_fault_check(acez_trainer* tr, hipStream_t s) {
   int err = 0;
   if (hipMemcpyAsync(&err, tr->seq_err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 0;
   if (!err) return 0;
+  wgo_recover(tr, s);   // (before the fault word comes down: nothing else may run on this trainer's buffers in between)
+  tr->pre_idx = nullptr; tr->pre_n = 0; tr->next_gathered = false;   // batches "gathered ahead" since the fault were held back
   (void)hipMemsetAsync(tr->seq_flags, 0, (64 * 32 + 1) * sizeof(uint32_t), s);   // counters + fault word (the poll budget behind them stays)
   hipLaunchKernelGGL(sched_reactivate_kernel, dim3(1), dim3(64), 0, s, tr->st);
   const int one = 1;
@@ -320,6 +361,12 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   int rc = ACEZ_OK;
   const size_t act_bytes = (size_t)tr->max_batch * 512 * sizeof(uint16_t);
   auto A = [&](void** p, size_t bytes) { if (rc == ACEZ_OK) rc = dmalloc(tr, p, bytes); };
+  // buffers only a trainer that trains needs (iterations = 1 is how the hosts create inference-only heads, session.scene_coordinates): the
+  // second input buffer / metadata table of the pre-gathered next batch and wgrad_opt_kernel's exchange tiles, counters and fault record
+  const bool trains = cfg->iterations > 1;
+  const int wgo_grid = 256 * ((tr->L + 7) / 8);
+  for (int pass = 0; pass < 2; ++pass) {   // pass 0 adds the requests up (dmalloc, tr->sizing), pass 1 hands out pieces of ONE exact arena
+  tr->sizing = pass == 0;
   A((void**)&tr->Wb, (size_t)tr->L * 262144 * 2);
   A((void**)&tr->WbT, (size_t)tr->L * 262144 * 2);
   A((void**)&tr->W3b, (size_t)tr->no * 512 * 2);
@@ -342,30 +389,17 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->maskbits, (size_t)tr->L * max_blocks * 512 * sizeof(uint32_t));
   A((void**)&tr->chain_err, sizeof(int));
   A((void**)&tr->seq_flags, (64 * 32 + 32) * sizeof(uint32_t));
-  if (rc == ACEZ_OK) (void)hipMemset(tr->seq_flags, 0, (64 * 32 + 32) * sizeof(uint32_t));
-  tr->seq_err = reinterpret_cast<int*>(tr->seq_flags + 64 * 32);
-  if (const char* e = getenv("ACEZ_SEQ_SPIN_US")) tr->seq_spin_limit = (uint32_t)std::max(1L, atol(e)) * 2u;
-  if (rc == ACEZ_OK) (void)hipMemcpy(tr->seq_flags + 64 * 32 + 1, &tr->seq_spin_limit, sizeof(uint32_t), hipMemcpyHostToDevice);
-  if (const char* e = ACEZ_DIAG_ENV("ACEZ_SEQ_FAULT_AT")) tr->seq_fault_at = atol(e);
-  if (ACEZ_DIAG_ENV("ACEZ_SEQ_XCC")) {
-    A((void**)&tr->seq_xcc, (8 + 256) * sizeof(uint32_t));
-    if (rc == ACEZ_OK) (void)hipMemset(tr->seq_xcc, 0, (8 + 256) * sizeof(uint32_t));
+  if (ACEZ_DIAG_ENV("ACEZ_SEQ_XCC")) A((void**)&tr->seq_xcc, (8 + 256) * sizeof(uint32_t));
+  if (ACEZ_DIAG_ENV("ACEZ_CHAIN_TRACE")) A((void**)&tr->chain_trace, 512 * sizeof(unsigned long long));
+  if (ACEZ_DIAG_ENV("ACEZ_WGO_TRACE")) A((void**)&tr->wgo_trace, 256 * 12 * 8 * sizeof(unsigned long long));
+  if (trains) {
+    A((void**)&tr->R0_alt, act_bytes);
+    A((void**)&tr->batch_meta_alt, (size_t)tr->max_batch * sizeof(int4));
+    A((void**)&tr->wg_xch, (size_t)tr->L * 16 * 2 * 8192 * sizeof(float));
+    A((void**)&tr->wg_flags, (size_t)tr->L * 16 * 2 * 32 * sizeof(uint32_t));
+    A((void**)&tr->wg_status, (size_t)wgo_grid * WGRAD_LOADERS * sizeof(uint32_t));
+    A((void**)&tr->wg_rec, sizeof(WgoFaultRec));
   }
-  if (ACEZ_DIAG_ENV("ACEZ_CHAIN_TRACE")) {
-    A((void**)&tr->chain_trace, 512 * sizeof(unsigned long long));
-    if (rc == ACEZ_OK) (void)hipMemset(tr->chain_trace, 0, 512 * sizeof(unsigned long long));
-  }
-  if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGRAD_OPT")) tr->wgrad_opt = atoi(e) != 0;
-  if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_AT")) tr->wgo_fault_at = atol(e);
-  if (ACEZ_DIAG_ENV("ACEZ_WGO_TRACE")) {
-    A((void**)&tr->wgo_trace, 256 * 12 * 8 * sizeof(unsigned long long));
-    if (rc == ACEZ_OK) (void)hipMemset(tr->wgo_trace, 0, 256 * 12 * 8 * sizeof(unsigned long long));
-  }
-  A((void**)&tr->R0_alt, act_bytes);
-  A((void**)&tr->batch_meta_alt, (size_t)tr->max_batch * sizeof(int4));
-  A((void**)&tr->wg_xch, (size_t)tr->L * 16 * 2 * 8192 * sizeof(float));
-  A((void**)&tr->wg_flags, (size_t)tr->L * 16 * 2 * 32 * sizeof(uint32_t));
-  if (rc == ACEZ_OK) (void)hipMemset(tr->wg_flags, 0, (size_t)tr->L * 16 * 2 * 32 * sizeof(uint32_t));
   tr->dRc.resize(tr->nb + 1, nullptr);
   for (int b = 0; b <= tr->nb; ++b) A((void**)&tr->dRc[b], act_bytes);
   A((void**)&tr->zeros, 1024);
@@ -376,7 +410,26 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->st_slot[1], sizeof(TrainState));
   tr->st = tr->st_slot[0];
   A((void**)&tr->st_infer, sizeof(TrainState));
+  }   // (allocation passes)
   if (rc != ACEZ_OK) { acez_trainer_destroy(tr); return rc; }
+  ACEZ_HIP_CHECK(hipMemset(tr->seq_flags, 0, (64 * 32 + 32) * sizeof(uint32_t)));
+  tr->seq_err = reinterpret_cast<int*>(tr->seq_flags + 64 * 32);
+  if (const char* e = getenv("ACEZ_SEQ_SPIN_US")) tr->seq_spin_limit = (uint32_t)std::max(1L, atol(e)) * 2u;
+  ACEZ_HIP_CHECK(hipMemcpy(tr->seq_flags + 64 * 32 + 1, &tr->seq_spin_limit, sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_SEQ_FAULT_AT")) tr->seq_fault_at = atol(e);
+  if (tr->seq_xcc) ACEZ_HIP_CHECK(hipMemset(tr->seq_xcc, 0, (8 + 256) * sizeof(uint32_t)));
+  if (tr->chain_trace) ACEZ_HIP_CHECK(hipMemset(tr->chain_trace, 0, 512 * sizeof(unsigned long long)));
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGRAD_OPT")) tr->wgrad_opt = atoi(e) != 0;
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_AT")) tr->wgo_fault_at = atol(e);
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_MOD")) tr->wgo_fault_mod = atoi(e);
+  if (tr->wgo_trace) ACEZ_HIP_CHECK(hipMemset(tr->wgo_trace, 0, 256 * 12 * 8 * sizeof(unsigned long long)));
+  if (trains) {
+    ACEZ_HIP_CHECK(hipMemset(tr->wg_flags, 0, (size_t)tr->L * 16 * 2 * 32 * sizeof(uint32_t)));
+    ACEZ_HIP_CHECK(hipMemset(tr->wg_status, 0, (size_t)wgo_grid * WGRAD_LOADERS * sizeof(uint32_t)));
+    ACEZ_HIP_CHECK(hipMemset(tr->wg_rec, 0, sizeof(WgoFaultRec)));
+  } else {
+    tr->wgrad_opt = false;   // (no exchange tiles: an inference-only head never runs the fused step)
+  }
 
   SchedConfig& sc = tr->sc;
   sc.schedule = cfg->schedule; sc.iterations = cfg->iterations; sc.warmup_iterations = cfg->warmup_iterations;
@@ -616,6 +669,7 @@ static void fill_loss_train(acez_trainer* tr, LossArgs& a, const uint16_t* act, 
   a.fc3_partials = tr->fc3_partials; a.fc3_stride = tr->fc3_stride; a.stat_partials = tr->stat_partials;
   a.bias_partials = tr->bias_partials + (size_t)f2 * tr->bias_layer_stride; a.dbg = 0;
   a.absmax = tr->f16 ? tr->st->dz_absmax_slots : nullptr;
+  a.fault = tr->seq_err;
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_LOSS_DBG")) a.dbg = atoi(e);   // ablation: 1 = stop after phase A, 2 = after phase B (timing only)
 }
 
@@ -759,6 +813,20 @@ static void flush_post(acez_trainer* tr, hipStream_t s) {
   st_flip(tr);
 }
 
+// operands of the weight-gradient launch of a step on n rows (wgrad_kernel / wgrad_opt_kernel; wgo_recover runs it again on a faulted step)
+static void fill_wgrad_args(acez_trainer* tr, WgradArgs& a, int n, const TrainState* st) {
+  const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
+  for (int l = 0; l < tr->L; ++l) {
+    a.dZ[l] = tr->dZ[l];
+    a.w_off[l] = (int64_t)l * 262656; a.b_off[l] = a.w_off[l] + 262144;
+  }
+  for (int b = 0; b <= tr->nb; ++b) {
+    a.In[3 * b] = tr->R[b]; a.In[3 * b + 1] = tr->out[3 * b]; a.In[3 * b + 2] = tr->out[3 * b + 1];
+  }
+  a.In[f1] = tr->R[tr->nb + 1]; a.In[f2] = tr->out[f1];
+  a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.n_layers = tr->L; a.st = st; a.zeros = tr->zeros; a.dbg = 0;
+}
+
 static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n, void* stream, bool fused, const int64_t* d_next = nullptr,
                                int n_next = 0) {
   ACEZ_REQUIRE(tr && d_indices, "null pointer");
@@ -877,6 +945,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
       const int gblocks = std::min(want, room);
       GatherMeta gm = gather_meta(tr);
       gm.dst = tr->batch_meta_alt;
+      gm.hold = tr->seq_err;   // after a fault nothing of the faulted step may be overwritten before the host has finished it (wgo_recover)
       if (tr->f16) hipLaunchKernelGGL((loss_gather_kernel<EltF16, 4>), dim3(nblk + gblocks), dim3(256), 0, s, a, nblk, (const uint16_t*)tr->buf.d_features, d_next, tr->R0_alt, n_next, gm);
       else hipLaunchKernelGGL((loss_gather_kernel<EltBf16, 4>), dim3(nblk + gblocks), dim3(256), 0, s, a, nblk, (const uint16_t*)tr->buf.d_features, d_next, tr->R0_alt, n_next, gm);
       tr->next_gathered = true; tr->next_idx = d_next; tr->next_n = n_next;
@@ -946,15 +1015,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   tr->wide_done = false;
   {
     WgradArgs a{};
-    for (int l = 0; l < tr->L; ++l) {
-      a.dZ[l] = tr->dZ[l];
-      a.w_off[l] = (int64_t)l * 262656; a.b_off[l] = a.w_off[l] + 262144;
-    }
-    for (int b = 0; b <= tr->nb; ++b) {
-      a.In[3 * b] = tr->R[b]; a.In[3 * b + 1] = tr->out[3 * b]; a.In[3 * b + 2] = tr->out[3 * b + 1];
-    }
-    a.In[f1] = tr->R[tr->nb + 1]; a.In[f2] = tr->out[f1];
-    a.slabs = tr->slabs; a.slab_stride = tr->n_wide; a.M = n; a.nslabs = tr->nslabs; a.n_layers = tr->L; a.st = st; a.zeros = tr->zeros; a.dbg = 0;
+    fill_wgrad_args(tr, a, n, st);
     if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_DBG")) a.dbg = atoi(e);   // timing experiments (wgrad_opt_kernel's ablation bits)
     ProfScope ps(tr, s, KC_WGRAD);
     const int groups = tr->L * tr->nslabs;
@@ -967,7 +1028,11 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
       o.xch = tr->wg_xch; o.flags = tr->wg_flags; o.spin_limit = tr->seq_spin_limit;
       o.trace = tr->wgo_trace;
       o.target = 2u * ++tr->wg_epoch;
-      if ((long)tr->wg_epoch - 1 == tr->wgo_fault_at) o.target += 1u << 20;   // tests: a partner that never arrives
+      o.epoch = tr->wg_epoch; o.status = tr->wg_status; o.rec = tr->wg_rec;
+      if ((long)tr->wg_epoch - 1 == tr->wgo_fault_at) {   // tests: a partner that never arrives (in every workgroup, or in every fault_mod-th)
+        if (tr->wgo_fault_mod > 0) o.fault_mod = tr->wgo_fault_mod;
+        else o.target += 1u << 20;
+      }
       // the small parameters ride in the multiplier waves of the first workgroups, the schedule wave that closes the step in the last one
       o.nsmall = small_cols_blocks(tr->L, (int64_t)tr->no * 513, 8);
       o.do_post = 1;

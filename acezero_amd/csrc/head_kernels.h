@@ -59,6 +59,8 @@ struct GatherMeta {
   const int32_t* view_idx;
   const int32_t* view_image;
   const float* target_px;
+  const int* hold;   // null, or the trainer's sticky fault word: while it is set the gather stores nothing (the rows of the faulted step must
+                     // survive until the host has finished that step, head_api.hip wgo_recover)
 };
 
 struct SchedConfig {
@@ -132,6 +134,8 @@ struct LossArgs {
   float* bias_partials;  // [blocks][512] column sums of dZ
   int dbg;               // ablation (tools/ablate_rowgemm.hip): 1 = stop after phase A, 2 = stop after phase B
   uint32_t* absmax;      // fp16 training: TrainState::dz_absmax_slots (else null)
+  const int* fault;      // training: the trainer's sticky fault word (null: none). While it is set the launch is a no-op: the buffers of the
+                         // faulted step stay as they are until the host's fall-back has finished that step
 };
 
 struct GradReduceArgs {
@@ -181,6 +185,18 @@ struct AdamArgs {
 // row slabs of a 128 x 128 gradient tile run on two CUs of ONE XCD; each sends the half of its partial tile the other one owns through
 // that XCD's L2 (`xch`) and bumps the owner's counter (`flags`, the hand-off of rowseq_kernel: L2-local atomic, bounded sc1 poll, no
 // fence), then applies AdamW to its own half: slab 0 + slab 1 in that order, the additions grad_reduce_kernel / adamw_kernel perform.
+// What a loader wave of wgrad_opt_kernel whose exchange poll expired leaves behind, so that the host's fall-back can FINISH the step
+// (head_api.hip wgo_recover: wgrad_kernel on the step's untouched buffers, then wgo_recover_kernel on exactly the regions whose wave
+// timed out, with the step's own optimiser scalars): after it the parameters are bitwise those of the two-launch flow's step.
+struct WgoFaultRec {
+  AdamScalars s;          // st->adam of the faulted step (the schedule wave of that launch has already moved the state on)
+  float inv_scale;        // st->inv_grad_scale of the faulted step
+  int M;                  // its batch rows
+  uint32_t epoch;         // WgradOptArgs::epoch of the faulted launch (0: no wgrad_opt fault is pending)
+  uint32_t pad;
+  const uint16_t* in0;    // WgradArgs::In[0] of the faulted launch (the trainer swaps its two input buffers every step)
+};
+
 struct WgradOptArgs {
   AdamArgs ad;           // the optimiser's arguments (slabs unused; tail = the partial buffers of this step: NaN / overflow guards)
   float* xch;            // [n_layers * 16 tiles][2 owners][64][128] fp32
@@ -190,6 +206,11 @@ struct WgradOptArgs {
   int nsmall;            // workgroups 0 .. nsmall - 1 also run one small-parameter block of the optimiser each (adamw_small_columns); 0: none
   int do_post;           // the last workgroup also runs the schedule wave that closes the step (sched_post_wave)
   unsigned long long* trace;   // diagnostics build (ACEZ_WGO_TRACE=1, tools/wgo_trace.py): [256 workgroups][12 waves][8] s_memtime stamps; else null
+  uint32_t epoch;        // launches so far, this one included (> 0)
+  uint32_t* status;      // [workgroups][8 loader waves]: epoch * 4 + 3 = "this wave's poll expired in launch `epoch`, its rows of the half tile
+                         // were NOT updated" (written by timed-out waves only: nothing is stored on the normal path)
+  WgoFaultRec* rec;      // written by the timed-out waves of the FIRST faulting launch (later launches see the fault word and skip by guard)
+  int fault_mod;         // diagnostics build: workgroups with b % fault_mod == 1 wait for a count that never comes (a partial fault); 0: none
 };
 
 }  // namespace acez

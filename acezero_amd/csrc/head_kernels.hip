@@ -34,6 +34,9 @@ namespace acez {
 template <int GR = 4>
 __device__ __forceinline__ void gather_rows(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx, uint16_t* __restrict__ out, int n,
                                             int wave, int nwaves, int lane, const GatherMeta& meta) {
+  // (meta.hold: the trainer's sticky fault word, a wave-uniform load that travels with the first level and is only looked at in front of
+  // the stores; while it is set nothing is stored)
+  const bool held = meta.hold && *meta.hold;
   for (int r0 = wave; r0 < n; r0 += GR * nwaves) {
     int r[GR];
     bool ok[GR];
@@ -51,7 +54,7 @@ __device__ __forceinline__ void gather_rows(const uint16_t* __restrict__ feat, c
     }
 #pragma unroll
     for (int j = 0; j < GR; ++j)
-      if (ok[j]) *reinterpret_cast<uint4*>(out + (size_t)r[j] * 512 + lane * 8) = v[j];
+      if (ok[j] && !held) *reinterpret_cast<uint4*>(out + (size_t)r[j] * 512 + lane * 8) = v[j];
     if (meta.dst) {
       int img[GR];
 #pragma unroll
@@ -59,7 +62,7 @@ __device__ __forceinline__ void gather_rows(const uint16_t* __restrict__ feat, c
       if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < GR; ++j)
-          if (ok[j]) meta.dst[r[j]] = make_int4(view[j], img[j], __float_as_int(tp[j].x), __float_as_int(tp[j].y));
+          if (ok[j] && !held) meta.dst[r[j]] = make_int4(view[j], img[j], __float_as_int(tp[j].x), __float_as_int(tp[j].y));
       }
     }
   }
@@ -675,7 +678,9 @@ __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
     a.xcc_dbg[8 + mt * 4 + (jx & 3)] = xcc;
   }
   // (after an expired poll the fault handler has cleared `active`: nothing of this trainer runs until the host has fallen back)
-  if (a.st && !a.st->active) {   // training has ended on the device: no work, but the counters keep step with the host's bases
+  // (... or a hand-off poll of this trainer has expired in an EARLIER launch -- the sticky fault word behind the counters: the buffers of
+  // the faulted step are left alone until the host has fallen back; both words are wave-uniform loads issued together)
+  if ((a.st && !a.st->active) || a.flags[64 * 32]) {   // training has ended on the device: no work, but the counters keep step with the host's bases
     if (threadIdx.x == 0) {      // (the same L2-local atomic as the hand-off itself)
       const uint32_t inc = 8u * (uint32_t)(a.n_layers - 1);
       asm volatile("global_atomic_add %0, %1, off" ::"v"(a.flags + mt * 32), "v"(inc) : "memory");
@@ -1509,7 +1514,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& a, const int block, co
 
 template <class E = EltBf16, int LR = 8>
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
-  if (a.st && !a.st->active) return;
+  if ((a.st && !a.st->active) || (a.fault && *a.fault)) return;
   __shared__ float scratch[LOSS_SCRATCH_FLOATS];
   const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
   loss_body<false, true, E, LR>(a, blockIdx.x, wv, t, nullptr, scratch, LossPre{0, 0, 0, 0.f, 0.f}, [] { __syncthreads(); });
@@ -1531,7 +1536,7 @@ __global__ __launch_bounds__(256) void loss_gather_kernel(LossArgs a, int nblk, 
     gather_rows<8>(feat, idx_next, out, n_next, wave, nwaves, lane, meta);
     return;
   }
-  if (a.st && !a.st->active) return;
+  if ((a.st && !a.st->active) || (a.fault && *a.fault)) return;
   __shared__ float scratch[LOSS_SCRATCH_FLOATS];
   const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
   loss_body<false, true, E, LR>(a, (int)blockIdx.x - ng, wv, t, nullptr, scratch, LossPre{0, 0, 0, 0.f, 0.f}, [] { __syncthreads(); });
@@ -2522,9 +2527,14 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
   const float lossv = loss_sum(lp);
   bool skip = !active || fault_now || lossv != lossv || (ACEZ_DBG(a.dbg) & 8);   // adamw_body's guards
   if (E::is_f16) skip = skip || absmax_all(st, l) >= 0x7f800000u;
+  const bool skip_by_guard = skip;   // (uniform over the launch: every wave evaluates the same words)
   if (!(ACEZ_DBG(a.dbg) & 48)) {   // (ablation bits of the diagnostics build, timing only: 8 = no final stores, 16 = no poll, 32 = no send, 64 = no small parameters, 128 = no schedule wave)
     uint32_t vseen, sseen, spins, timed;
     const uint32_t* flag = o.flags + (size_t)(pair * 2 + slab) * 32;
+    uint32_t wgo_target = o.target;
+#ifdef ACEZ_DIAG   // fault injection in SOME workgroups (ACEZ_WGO_FAULT_MOD): a partially applied step
+    if (o.fault_mod > 0 && b % o.fault_mod == 1) wgo_target += 1u << 20;
+#endif
     asm volatile(
         "s_mov_b32 %[spins], 0\n\t"
         "s_mov_b32 %[timed], 0\n"
@@ -2542,11 +2552,20 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
         "s_mov_b32 %[timed], 1\n"
         "2:"
         : [vseen] "=&v"(vseen), [sseen] "=&s"(sseen), [spins] "=&s"(spins), [timed] "=&s"(timed)
-        : [flag] "v"(flag), [target] "s"(o.target), [limit] "s"(o.spin_limit)
+        : [flag] "v"(flag), [target] "s"(wgo_target), [limit] "s"(o.spin_limit)
         : "memory", "scc");
     if (timed) {   // the partner never arrived (the two slabs of a tile are not on one XCD after all): fault word, step switched off
       skip = true;
       if (l == 0) {
+        // What the host needs to finish this step (wgo_recover, head_api.hip): which rows were not updated, and with what they would have
+        // been. The small parameters and the schedule wave of this launch read the fault word long before it is raised and DO apply the
+        // step; tiles whose exchange completed are updated too -- so the fall-back completes the step instead of undoing it. Every kernel
+        // of the trainer that writes a step's buffers returns at entry while the word is set: the operands are still there.
+        if (!skip_by_guard && o.status) {
+          o.status[(size_t)b * WGRAD_LOADERS + (w - 4)] = o.epoch * 4u + 3u;
+          o.rec->s = s; o.rec->inv_scale = inv_scale; o.rec->M = a.M; o.rec->in0 = a.In[0];
+          __hip_atomic_store(&o.rec->epoch, o.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __hip_atomic_store(ad.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(const_cast<int*>(&st->active), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -2606,6 +2625,49 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
 #ifdef ACEZ_DIAG
   if (o.trace) { ACEZ_VMCNT(0); WGO_STAMP(6); }   // loaders: every store of this wave acknowledged
 #endif
+}
+
+// The rows of wgrad_opt_kernel's half tiles whose loader wave timed out in launch rec->epoch (WgradOptArgs::status), finished from the
+// slabs wgrad_kernel has just recomputed on the faulted step's untouched buffers: slab 0 + slab 1, the step's own AdamW scalars and
+// gradient scale, adamw_one -- the arithmetic of the wave that gave up, so the parameters end up bitwise those of the two-launch flow.
+// Same grid decode and the same lane -> (row, column) map as wgrad_opt_kernel's loader waves; one 512-thread workgroup per half tile.
+template <class E = EltBf16>
+__global__ __launch_bounds__(512) void wgo_recover_kernel(AdamArgs ad, const float* __restrict__ slabs, int64_t slab_stride, const uint32_t* __restrict__ status,
+                                                          const WgoFaultRec* __restrict__ rec, int n_layers) {
+  const int t = threadIdx.x, l = t & 63, lw = t >> 6;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, jx = b >> 3;
+  const int layer = xcd + 8 * (jx >> 5), slab = (jx >> 4) & 1, tile = jx & 15;
+  if (layer >= n_layers) return;
+  if (status[(size_t)b * WGRAD_LOADERS + lw] != rec->epoch * 4u + 3u) return;
+  const AdamScalars s = rec->s;
+  const float inv_scale = rec->inv_scale;
+  const int n0 = (tile >> 2) * 128, c0 = (tile & 3) * 128;
+  const int e = t, rb = e >> 5, col4 = (e & 31) * 4;
+  const int64_t woff = ad.w_off[layer];
+  const int nrow0 = n0 + 64 * slab;
+  (void)l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rb + 16 * i;
+    const int64_t off = woff + (int64_t)(nrow0 + row) * 512 + c0 + col4;
+    const float4 s0 = *reinterpret_cast<const float4*>(slabs + off);
+    const float4 s1 = *reinterpret_cast<const float4*>(slabs + slab_stride + off);
+    float4 g;
+    g.x = (s0.x + s1.x) * inv_scale; g.y = (s0.y + s1.y) * inv_scale; g.z = (s0.z + s1.z) * inv_scale; g.w = (s0.w + s1.w) * inv_scale;
+    float4 p = *reinterpret_cast<const float4*>(ad.params + off), m = *reinterpret_cast<const float4*>(ad.m + off), v = *reinterpret_cast<const float4*>(ad.v + off);
+    p.x = adamw_one(p.x, g.x, m.x, v.x, s);
+    p.y = adamw_one(p.y, g.y, m.y, v.y, s);
+    p.z = adamw_one(p.z, g.z, m.z, v.z, s);
+    p.w = adamw_one(p.w, g.w, m.w, v.w, s);
+    const uint2 pk = E::pk4(p.x, p.y, p.z, p.w);
+    *reinterpret_cast<float4*>(ad.params + off) = p;
+    *reinterpret_cast<float4*>(ad.m + off) = m;
+    *reinterpret_cast<float4*>(ad.v + off) = v;
+    *reinterpret_cast<uint2*>(ad.Wb + (size_t)layer * 262144 + (size_t)(nrow0 + row) * 512 + c0 + col4) = pk;
+    uint16_t* wt = ad.WbT + (size_t)layer * 262144 + (size_t)(c0 + col4) * 512 + nrow0 + row;
+    wt[0] = (uint16_t)(pk.x & 0xffff); wt[512] = (uint16_t)(pk.x >> 16); wt[1024] = (uint16_t)(pk.y & 0xffff); wt[1536] = (uint16_t)(pk.y >> 16);
+  }
 }
 
 }  // namespace acez

@@ -32,18 +32,21 @@ MAX_REF_STEPS = 100  # dsacstar.cpp:47
 
 
 def _context(max_frames, h, w, device):
-    key = (device,)
+    """-> (handle, library that owns it). One cached context per device AND library build: inside N.diag_library() the module-wide
+    library is the diagnostics build, and a handle must only ever be driven through the library that created it."""
+    L = N.lib()
+    key = (device, L._name)
     c = _ctx.get(key)
     if c is None or c["frames"] < max_frames or c["h"] < h or c["w"] < w:
         mf, mh, mw = max(max_frames, c["frames"] if c else 1), max(h, c["h"] if c else 0), max(w, c["w"] if c else 0)
         hnd = C.c_void_p()
-        N.check(N.lib().acez_ransac_create(C.byref(hnd), mf, mh, mw, device))   # raises before the old context is touched
+        N.check(L.acez_ransac_create(C.byref(hnd), mf, mh, mw, device))   # raises before the old context is touched
         if c is not None:
             del _ctx[key]
-            N.lib().acez_ransac_destroy(c["h_"])                                  # waits for the launches still using it
-        c = {"h_": hnd, "frames": mf, "h": mh, "w": mw}
+            L.acez_ransac_destroy(c["h_"])                                  # waits for the launches still using it
+        c = {"h_": hnd, "frames": mf, "h": mh, "w": mw, "lib": L}
         _ctx[key] = c
-    return c["h_"]
+    return c["h_"], c["lib"]
 
 
 def _params(hyps, thr, alpha, max_reproj, sub, max_tries):
@@ -69,7 +72,7 @@ def forward_rgb(sceneCoordinates, outPose, ransacHypotheses, inlierThreshold, fo
     frame_id = _calls
     _calls += 1
     dev = sc.device.index if sc.is_cuda else torch.cuda.current_device()
-    ctx = _context(1, H, W, dev)
+    ctx, L = _context(1, H, W, dev)
     prm = _params(ransacHypotheses, inlierThreshold, inlierAlpha, maxReproj, subSampling, max_hypotheses_tries)
     intr = N.Intrinsics(float(focalLength), float(ppointX), float(ppointY))
     import time
@@ -87,7 +90,7 @@ def forward_rgb(sceneCoordinates, outPose, ransacHypotheses, inlierThreshold, fo
     pose = np.zeros(16, np.float32)
     inliers = C.c_int32(0)
     st = sc.stride()
-    N.check(N.lib().acez_register_rgb_host(ctx, C.c_void_p(sc.data_ptr()), st[1], st[2], st[3], H, W, C.byref(prm), C.byref(intr),
+    N.check(L.acez_register_rgb_host(ctx, C.c_void_p(sc.data_ptr()), st[1], st[2], st[3], H, W, C.byref(prm), C.byref(intr),
                                            C.c_uint64(int(randomSeed)), C.c_uint64(frame_id), pose.ctypes.data_as(C.c_void_p),
                                            C.byref(inliers), None))
     outPose.copy_(torch.from_numpy(pose.reshape(4, 4)))
@@ -104,7 +107,7 @@ def register_batch(scene_coords, intrinsics, params, seed, frame_ids=None, want_
     sc = scene_coords.contiguous()
     n, _, H, W = sc.shape
     dev = sc.device
-    ctx = _context(n, H, W, dev.index)
+    ctx, L = _context(n, H, W, dev.index)
     if not isinstance(params, N.RansacParams):
         params = _params(**params)
     arr = (N.Intrinsics * n)()
@@ -118,7 +121,7 @@ def register_batch(scene_coords, intrinsics, params, seed, frame_ids=None, want_
     masks = torch.empty(n, H, W, dtype=torch.uint8, device=dev) if want_masks else None
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        N.check(N.lib().acez_register_rgb_device(ctx, C.c_void_p(sc.data_ptr()), n, H, W, C.byref(params), arr, C.c_uint64(int(seed)),
+        N.check(L.acez_register_rgb_device(ctx, C.c_void_p(sc.data_ptr()), n, H, W, C.byref(params), arr, C.c_uint64(int(seed)),
                                                  ids, C.c_void_p(poses.data_ptr()), C.c_void_p(inl.data_ptr()),
                                                  C.c_void_p(masks.data_ptr()) if masks is not None else None, stream))
     return poses, inl, masks
@@ -126,8 +129,9 @@ def register_batch(scene_coords, intrinsics, params, seed, frame_ids=None, want_
 
 def debug_fetch(n, hyps, device=None):
     dev = torch.cuda.current_device() if device is None else device
-    ctx = _ctx[(dev,)]["h_"]
+    L = N.lib()
+    ctx = _ctx[(dev, L._name)]["h_"]
     hp = np.zeros((n, hyps, 6)); sc = np.zeros((n, hyps)); best = np.zeros(n, np.int32); ref = np.zeros((n, 6))
-    N.check(N.lib().acez_ransac_debug_fetch(ctx, n, hyps, hp.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+    N.check(L.acez_ransac_debug_fetch(ctx, n, hyps, hp.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
                                             best.ctypes.data_as(C.c_void_p), ref.ctypes.data_as(C.c_void_p)))
     return {"hyp_poses": hp, "scores": sc, "best": best, "refined": ref}

@@ -40,8 +40,9 @@ class Encoder:
         wp = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
         bp = (C.c_void_p * len(bs))(*[b.data_ptr() for b in bs])
         h = C.c_void_p()
-        N.check(N.lib().acez_encoder_create(C.byref(h), wp, bp, self.out_channels, int(max_frames), int(max_h), int(max_w),
-                                            self.device.index))
+        self.lib = N.lib()   # the library that owns the handle: pinned, like HeadTrainer.lib (N.diag_library() swaps the module-wide one)
+        N.check(self.lib.acez_encoder_create(C.byref(h), wp, bp, self.out_channels, int(max_frames), int(max_h), int(max_w),
+                                             self.device.index))
         self._h = h
         self.max_h, self.max_w, self.max_frames = int(max_h), int(max_w), int(max_frames)
 
@@ -54,7 +55,7 @@ class Encoder:
 
     def close(self):
         if getattr(self, "_h", None):
-            N.lib().acez_encoder_destroy(self._h)
+            self.lib.acez_encoder_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -73,7 +74,7 @@ class Encoder:
             out = torch.empty((b * oh * ow, self.out_channels), dtype=torch.bfloat16, device=self.device)
         assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.shape == (b * oh * ow, self.out_channels)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        N.check(N.lib().acez_encoder_forward(self._h, img.data_ptr(), b, h, w, out.data_ptr(), C.c_void_p(stream)))
+        N.check(self.lib.acez_encoder_forward(self._h, img.data_ptr(), b, h, w, out.data_ptr(), C.c_void_p(stream)))
         return out
 
     def forward(self, image_b1hw):

@@ -94,7 +94,7 @@ class Regressor:
 
     def _maps(self, rows, b, h, w):
         out = torch.empty((b, 3, h, w), dtype=torch.float32, device=self.device)
-        N.check(N.lib().acez_head_forward_maps(self.heads._h, _ptr(rows), int(b), int(h), int(w), _ptr(out), _stream()))
+        N.check(self.heads.lib.acez_head_forward_maps(self.heads._h, _ptr(rows), int(b), int(h), int(w), _ptr(out), _stream()))
         return out
 
     def forward(self, inputs):

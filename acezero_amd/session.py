@@ -462,7 +462,7 @@ class ReconstructionSession:
         for c0 in range(0, count, 64):
             c1 = min(count, c0 + 64)
             rows = (self.features[int(slots[c0]):int(slots[c0]) + (c1 - c0)] if contiguous else self.features[slots[c0:c1]]).reshape(-1, self.enc.out_channels)
-            N.check(N.lib().acez_head_forward_maps(head._h, _ptr(rows), c1 - c0, self.oh, self.ow, _ptr(out[c0:c1]), _stream()))
+            N.check(head.lib.acez_head_forward_maps(head._h, _ptr(rows), c1 - c0, self.oh, self.ow, _ptr(out[c0:c1]), _stream()))
         torch.cuda.synchronize(self.dev)
         head.close()
         return out

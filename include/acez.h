@@ -292,7 +292,12 @@ int acez_trainer_get_profile(acez_trainer* tr, float* h_ms8, int32_t* h_counts8)
  * of the placement probe run by acez_trainer_create (1 passed, 0 failed -> per-layer launches from the start, -1 not run), *faults =
  * number of times a bounded hand-off poll expired and the trainer fell back to per-layer launches (acez_trainer_get_state performs the
  * fall-back; the abandoned iterations are device-side no-ops and are not counted in acez_train_state.iteration). No reference
- * counterpart. Any pointer may be NULL. */
+ * counterpart. Any pointer may be NULL.
+ * A step is atomic under either kind of fault (ace_trainer.py:620-640): a poll that expires inside one of the GEMM chains abandons the
+ * step before anything of it is applied (state = the step before); a poll that expires in the fused weight-gradient / optimiser launch
+ * (wgrad_opt_kernel) is FINISHED by the same fall-back -- the launches issued after it were no-ops, the step's operands are intact, the
+ * rows that were not updated are updated with that step's optimiser scalars -- so that the state is exactly the step after, bit for bit
+ * what acez_train_backward + acez_train_update would have produced. */
 int acez_trainer_seq_status(acez_trainer* tr, int* enabled, int* probe, int* faults);
 
 /* Diagnostics for the tests: copy one intermediate device buffer of the last backward call to the host (synchronous).
@@ -309,7 +314,11 @@ int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, void* h_out, 
 int acez_trainer_get_poses(acez_trainer* tr, float* h_poses34, void* stream);
 
 /* Head inference (Regressor.get_scene_coordinates, ace_network.py:262-263) on n feature rows:
- *   d_features bf16 [n][512]  ->  d_out_xyz f32 [n][3].   Asynchronous. */
+ *   d_features bf16 [n][512]  ->  d_out_xyz f32 [n][3].
+ * Asynchronous for passes of more than 5120 rows per max_batch chunk. A pass small enough for the one-launch chains (<= 5120 rows) ends
+ * with a read of the trainer's fault word, i.e. it SYNCHRONISES `stream` before it returns: an expired hand-off poll would have left
+ * garbage in d_out_xyz, and the call repeats the pass on per-layer launches in that case (it also performs a pending training
+ * fall-back, see acez_trainer_seq_status). */
 int acez_head_forward(acez_trainer* tr, const void* d_features, int n, float* d_out_xyz, void* stream);
 
 /* Head.forward for whole frames, written as Regressor.forward's [B,3,H,W] maps (ace_network.py:265-270): the input of
