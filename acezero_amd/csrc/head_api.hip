@@ -6,6 +6,7 @@
 #ifdef ACEZ_DIAG   // measured-and-rejected row-persistent kernels: diagnostics build only
 #include "head_fused.hip"
 #include "head_chain.hip"
+#include "head_infer.hip"
 #endif
 #include "conv_launch.h"
 #include <stdlib.h>
@@ -34,6 +35,11 @@ struct acez_trainer {
   int last_n = 0;
   // device allocations
   uint16_t *Wb = nullptr, *WbT = nullptr, *W3b = nullptr;
+  uint16_t* Wp = nullptr;       // the wide layers' weights in headinfer_kernel's stream order (head_infer.hip), re-packed from Wb when stale
+  bool wp_valid = false;
+  int hi_group = 8;             // wide layers per headinfer_kernel launch (ACEZ_HI_GROUP)
+  bool head_infer = false;      // ACEZ_HEAD_INFER=1 (diagnostics build only): inference passes too large for the one-launch chains run on
+                                // headinfer_kernel (head_infer.hip, round 5: bit-identical to the large-tile launches, measured 15-20 % slower)
   std::vector<uint16_t*> out;   // post-relu output of each wide layer
   std::vector<uint16_t*> R;     // residual stream, R[0] = gathered features
   std::vector<uint16_t*> dZ;    // gradient wrt each wide layer's pre-activation
@@ -262,6 +268,7 @@ static void wgo_recover(acez_trainer* tr, hipStream_t s) {
   if (tr->f16) hipLaunchKernelGGL(wgo_recover_kernel<EltF16>, grid, dim3(512), 0, s, ad, (const float*)tr->slabs, tr->n_wide, (const uint32_t*)tr->wg_status, (const WgoFaultRec*)tr->wg_rec, tr->L);
   else hipLaunchKernelGGL(wgo_recover_kernel<EltBf16>, grid, dim3(512), 0, s, ad, (const float*)tr->slabs, tr->n_wide, (const uint32_t*)tr->wg_status, (const WgoFaultRec*)tr->wg_rec, tr->L);
   (void)hipMemsetAsync(tr->wg_rec, 0, sizeof(WgoFaultRec), s);
+  tr->wp_valid = false;
   ++tr->wgo_recovered;
 }
 
@@ -370,6 +377,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->Wb, (size_t)tr->L * 262144 * 2);
   A((void**)&tr->WbT, (size_t)tr->L * 262144 * 2);
   A((void**)&tr->W3b, (size_t)tr->no * 512 * 2);
+  A((void**)&tr->Wp, (size_t)tr->L * 262144 * 2);
   tr->out.resize(tr->L, nullptr);
   tr->dZ.resize(tr->L, nullptr);
   tr->R.resize(tr->nb + 2, nullptr);
@@ -419,6 +427,8 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_SEQ_FAULT_AT")) tr->seq_fault_at = atol(e);
   if (tr->seq_xcc) ACEZ_HIP_CHECK(hipMemset(tr->seq_xcc, 0, (8 + 256) * sizeof(uint32_t)));
   if (tr->chain_trace) ACEZ_HIP_CHECK(hipMemset(tr->chain_trace, 0, 512 * sizeof(unsigned long long)));
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_HEAD_INFER")) tr->head_infer = atoi(e) != 0;
+  if (const char* e = ACEZ_DIAG_ENV("ACEZ_HI_GROUP")) tr->hi_group = std::max(1, atoi(e));
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGRAD_OPT")) tr->wgrad_opt = atoi(e) != 0;
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_AT")) tr->wgo_fault_at = atol(e);
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_MOD")) tr->wgo_fault_mod = atoi(e);
@@ -526,6 +536,7 @@ extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
   hipLaunchKernelGGL(recast_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
   ACEZ_HIP_CHECK(hipGetLastError());
   tr->pose_wt_valid = false;   // the caller may have rewritten the pose parameters as well
+  tr->wp_valid = false;
   tr->pre_idx = nullptr; tr->pre_n = 0;   // a restart point: the next step gathers its own batch
   return ACEZ_OK;
 }
@@ -1043,6 +1054,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
       if (tr->f16) hipLaunchKernelGGL(wgrad_opt_kernel<EltF16>, grid, dim3(WGRAD_THREADS), 0, s, a, o, post);
       else hipLaunchKernelGGL(wgrad_opt_kernel<EltBf16>, grid, dim3(WGRAD_THREADS), 0, s, a, o, post);
       tr->wide_done = true;
+      tr->wp_valid = false;
       tr->post_done = o.do_post != 0;
     }
     else if (tr->f16) hipLaunchKernelGGL(wgrad_kernel<EltF16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
@@ -1089,6 +1101,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
   // two updates without a backward in between (a data-parallel rank whose shard holds no row of a batch zeroes its gradient and
   // only takes part in the all-reduce): the schedule bookkeeping of the previous step must not be lost
   flush_post(tr, s);
+  tr->wp_valid = false;   // (the 16-bit weights change below)
   AdamArgs a;
   fill_adam_args(tr, a);
   if (fused) { a.slabs = tr->slabs; a.nslabs = tr->nslabs; a.slab_stride = tr->n_wide; a.tail = tr->last_reduce; }
@@ -1187,6 +1200,7 @@ extern "C" int acez_trainer_import_weights16(acez_trainer* tr, int layer_lo, int
   ACEZ_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= tr->L, "layer range out of bounds");
   if (layer_hi == layer_lo) return ACEZ_OK;
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  tr->wp_valid = false;
   ACEZ_HIP_CHECK(hipMemcpyAsync(tr->Wb + (size_t)layer_lo * 262144, d_src, (size_t)(layer_hi - layer_lo) * 262144 * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   hipLaunchKernelGGL(transpose16_kernel, dim3((layer_hi - layer_lo) * 64), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)tr->Wb, tr->WbT, layer_lo);
   ACEZ_HIP_CHECK(hipGetLastError());
@@ -1198,6 +1212,7 @@ extern "C" int acez_trainer_import_weights16_all(acez_trainer* tr, int own_lo, i
   ACEZ_REQUIRE(own_lo >= 0 && own_lo <= own_hi && own_hi <= tr->L, "layer range out of bounds");
   if (own_hi - own_lo == tr->L) return ACEZ_OK;
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
+  tr->wp_valid = false;
   hipLaunchKernelGGL(import16_kernel, dim3(tr->L * 64), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)d_src_all, tr->Wb, tr->WbT, own_lo, own_hi);
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
@@ -1290,6 +1305,49 @@ static uint16_t* launch_forward_conv(acez_trainer* tr, const uint16_t* in0, int 
   return tr->out[f2];
 }
 
+#ifdef ACEZ_DIAG
+// Inference on more rows than the one-launch chains take: headinfer_kernel (head_infer.hip), all wide layers in one launch with the
+// activations of a 64-row tile resident in LDS; only the input rows and the last layer's output cross HBM.
+static uint16_t* launch_forward_infer(acez_trainer* tr, const uint16_t* in0, int n, hipStream_t s) {
+  if (!tr->wp_valid) {
+    hipLaunchKernelGGL(headinfer_pack_kernel, dim3((unsigned)((int64_t)tr->L * 512 * 64 / 256)), dim3(256), 0, s, (const uint16_t*)tr->Wb, tr->Wp, tr->L);
+    tr->wp_valid = true;
+  }
+  // the layers' residual wiring: x = res + relu(conv(relu(conv(relu(conv(res))))))   ace_network.py:122-133
+  HeadInferLayer all[MAX_LAYERS] = {};
+  {
+    const uint16_t* r = in0;
+    for (int b = 0; b <= tr->nb; ++b) {
+      all[3 * b + 2].res_in = r;
+      all[3 * b + 2].res_out = b < tr->nb ? tr->R[b + 1] : nullptr;   // the next block adds it; after the last block nothing does
+      r = tr->R[b + 1];
+    }
+  }
+  // The layers go out in groups of tr->hi_group (head_infer.hip: the weights of ALL layers are exactly one XCD's L2 for the default head,
+  // and a cyclic stream over a working set of the cache's size never hits; a group's weights must stay well inside it). Between two
+  // groups the activations make one round trip through HBM.
+  const int f2 = 3 * (tr->nb + 1) + 1;
+  const uint16_t* in = in0;
+  for (int l0 = 0; l0 < tr->L; l0 += tr->hi_group) {
+    const int cnt = std::min(tr->hi_group, tr->L - l0), last = l0 + cnt - 1;
+    HeadInferArgs a{};
+    a.feat = in; a.Wp = tr->Wp + (size_t)l0 * 262144; a.params = tr->pb.d_params + (int64_t)l0 * 262656; a.n = n; a.n_layers = cnt;
+    for (int i = 0; i < cnt; ++i) a.layer[i] = all[l0 + i];
+    // the group's last layer writes ONE tile: its output; if a later layer also adds that output as its residual, that buffer is it
+    a.out = all[last].res_out ? all[last].res_out : tr->out[last];
+    const dim3 grid((unsigned)((n + HI_ROWS - 1) / HI_ROWS));
+    if (tr->f16) hipLaunchKernelGGL(headinfer_kernel<EltF16>, grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(headinfer_kernel<EltBf16>, grid, dim3(512), 0, s, a);
+    in = a.out;
+  }
+  (void)f2;
+  return const_cast<uint16_t*>(in);
+}
+
+#else
+static uint16_t* launch_forward_infer(acez_trainer*, const uint16_t*, int, hipStream_t) { abort(); }   // (tr->head_infer is never set in the product build)
+#endif
+
 static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, float* d_out, int planar_hw, void* stream) {
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1298,9 +1356,12 @@ static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, fl
   auto pass = [&]() {
     for (int done = 0; done < n; done += tr->max_batch) {
       const int cnt = (n - done < tr->max_batch) ? n - done : tr->max_batch;
-      const bool conv = cnt >= 256 * 128 && !tr->f16;   // (the large-tile conv kernels are bf16)
-      used_seq = used_seq || (!tr->fused_fwd && !conv && seq_usable(tr, cnt));
+      const bool seqp = !tr->fused_fwd && seq_usable(tr, cnt);
+      const bool infer = !tr->fused_fwd && !seqp && tr->head_infer;
+      const bool conv = !infer && cnt >= 256 * 128 && !tr->f16;   // (round 4's path for large passes; the large-tile conv kernels are bf16)
+      used_seq = used_seq || (seqp && !conv);
       uint16_t* act = tr->fused_fwd ? launch_forward_fused(tr, f + (size_t)done * 512, nullptr, cnt, false, nullptr, s)
+                      : infer       ? launch_forward_infer(tr, f + (size_t)done * 512, cnt, s)
                       : conv        ? launch_forward_conv(tr, f + (size_t)done * 512, cnt, s)
                                     : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
       LossArgs a{};

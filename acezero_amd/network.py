@@ -41,8 +41,9 @@ class Regressor:
         # layers run on the encoder's large-tile kernels)
         # dtype is pinned: the encoder emits bf16 rows and they reach the head by raw pointer (acez_head_forward_maps), so the head's
         # operand format must not follow $ACEZ_DTYPE here
+        # iterations = 1: an inference-only head (no second input buffer, no exchange tiles: acez_trainer_create)
         self.heads = HeadTrainer(mean, num_head_blocks=num_head_blocks, use_homogeneous=use_homogeneous, max_batch=max(4, max_frames) * oh * ow,
-                                 device=device, dtype="bf16", **kw)
+                                 device=device, dtype="bf16", iterations=1, **kw)
         self.heads.load_state_dict(hs)
         self.device = self.heads.device
 

@@ -96,10 +96,10 @@ def test_product_library_has_no_ablation_surface():
     names = set(m.decode() for m in re.findall(rb"ACEZ_[A-Z][A-Z0-9_]{2,}", prod))
     env_like = {n for n in names if not n.startswith(("ACEZ_ERR", "ACEZ_OK", "ACEZ_DTYPE", "ACEZ_POSE_MLP", "ACEZ_HIP_CHECK", "ACEZ_REQUIRE", "ACEZ_LOSS_"))}
     assert env_like == {"ACEZ_SEQ", "ACEZ_SEQ_SPIN_US"}, sorted(env_like)
-    for kern in (b"chain_kernel", b"headfwd_kernel", b"wgrad256_kernel", b"14rowgemm_kernelI"):
+    for kern in (b"chain_kernel", b"headfwd_kernel", b"wgrad256_kernel", b"14rowgemm_kernelI", b"headinfer_kernel"):
         assert kern not in prod, kern
     diag = open(b.build(diag=True), "rb").read()
-    for kern in (b"chain_kernel", b"headfwd_kernel", b"wgrad256_kernel", b"14rowgemm_kernelI", b"ACEZ_SEQ_FAULT_AT", b"ACEZ_CHAIN"):
+    for kern in (b"chain_kernel", b"headfwd_kernel", b"wgrad256_kernel", b"14rowgemm_kernelI", b"headinfer_kernel", b"ACEZ_SEQ_FAULT_AT", b"ACEZ_CHAIN"):
         assert kern in diag, kern
     # the same C ABI in both builds
     def exported(path):
