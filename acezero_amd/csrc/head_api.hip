@@ -902,7 +902,10 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     st = tr->st;
     act = launch_forward_fused(tr, (const uint16_t*)tr->buf.d_features, d_indices, n, true, st, s);
   } else {
-  const bool pregathered = !pf && tr->pre_idx == d_indices && tr->pre_n == n && !tr->post_pending;
+  // (pose refinement folded into the step's launches: the batch may have been gathered ahead too -- beside the loss kernel of the step
+  // before, round 5 -- but the launch below still runs: the pose network's forward and the schedule wave ride in it, with no gather blocks)
+  const bool pre_ok = tr->pre_idx == d_indices && tr->pre_n == n;
+  const bool pregathered = !pf && pre_ok && !tr->post_pending;
   tr->pre_idx = nullptr; tr->pre_n = 0;
   if (pregathered) {
     // acez_train_step_next of the step before has gathered exactly this batch into R[0] and closed that step's bookkeeping
@@ -912,7 +915,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     tr->pose_wt_valid = true;
   }
   ProfScope* psg = new ProfScope(tr, s, KC_GATHER);
-  const int gblocks = (n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024;
+  const int gblocks = (pf && pre_ok) ? 0 : ((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
   if (pf) {   // + the pose network's forward for all images, as the first workgroups of the same launch
     const int T = tr->pose_tile_fwd, np = (tr->buf.n_images + T - 1) / T;
     const int do_post = tr->post_pending ? 1 : 0;
@@ -949,7 +952,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     tr->last_nblk = nblk;   // (after this step's step_begin, whose schedule wave closed the step BEFORE with that step's count)
     ProfScope ps(tr, s, KC_LOSS);
     tr->next_gathered = false;
-    if (fused && d_next && n_next > 0 && wgrad_opt_usable(tr) && tr->loss_rows == 4) {
+    if (fused && d_next && n_next > 0 && (wgrad_opt_usable(tr) || pf) && tr->loss_rows == 4 && tr->R0_alt) {
       // the next batch's gather as extra workgroups of the loss launch (this path has no optimiser launch to carry it): 32 rows per
       // workgroup and pass, as many workgroups as the loss kernel leaves free (two of these workgroups fit a CU)
       const int want = (n_next + 31) / 32, room = std::max(32, 2 * tr->n_cus - nblk);
@@ -1135,6 +1138,12 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     }
     launch_pose_wgrad(tr, &tr->st->active, true, s);
     tr->post_pending = true;
+    if (tr->next_gathered) {   // the next batch was gathered beside this step's loss kernel into the other input buffer (this step's wgrad read the current one)
+      std::swap(tr->R[0], tr->R0_alt);
+      std::swap(tr->batch_meta, tr->batch_meta_alt);
+      tr->pre_idx = tr->next_idx; tr->pre_n = tr->next_n;
+      tr->next_gathered = false;
+    }
     ACEZ_HIP_CHECK(hipGetLastError());
     return ACEZ_OK;
   }

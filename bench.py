@@ -289,9 +289,10 @@ def bench_pipeline(args, rank, world, device):
     from acezero_amd import synth
     from acezero_amd.buffer import BufferBuilder
     from acezero_amd.network import Regressor
-    # frames per encoder pass: 64 (0.062 ms per frame against 0.069 at 32: the large-tile convolution kernels fill the chip better;
-    # ACEZ_E2E_CHUNK for the comparison)
-    chunk, total = int(os.environ.get("ACEZ_E2E_CHUNK", "64")), args.e2e_frames // world
+    # frames per encoder pass: 128 (round 5; 64 before: a 3x3 layer of 64 frames is 2400 tiles of 118 us = 9.4 waves over 256 CUs, and the
+    # last, 37 % full wave costs a whole tile time -- 6.5 % of the launch; at 128 frames it is 1.3 %. tools/e2e_chunk_sweep.py: 64 / 128 /
+    # 256 frames -> 0.0646 / 0.0621 / 0.0618 ms per frame; ACEZ_E2E_CHUNK for the comparison)
+    chunk, total = int(os.environ.get("ACEZ_E2E_CHUNK", "128")), args.e2e_frames // world
     esd = {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights(seed=4099).items()}
     hsd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(synth.init_head_params(3)).items()}
     net = Regressor.create_from_split_state_dict(esd, hsd, max_frames=chunk, max_h=480, max_w=640)

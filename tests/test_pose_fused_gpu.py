@@ -136,3 +136,40 @@ def test_loaded_pose_parameters_reach_the_fused_forward():
     torch.cuda.synchronize()
     assert _same(a, b)
     np.testing.assert_array_equal(a.current_poses(), b.current_poses())
+
+
+def test_refinement_step_with_the_next_batch_announced_equals_plain_steps_bitwise():
+    """Round 5: with pose refinement folded into the step's launches the NEXT batch is gathered beside the loss kernel too (into the
+    trainer's second input buffer; the step's own launch then carries the pose network's forward and the schedule wave only). Head and
+    pose-network parameters, all moments, the schedule state and the log must equal plain acez_train_step calls bit for bit -- also
+    when the announcement is wrong, when a state read or a split step comes in between, and with ragged batch sizes."""
+    from tests.test_chain_gpu import _big_problem
+    from tests.test_head_gpu import _trainer
+    from oracle import head_oracle
+    prob = _big_problem(n_images=8, patches_per_view=512)
+    flat0 = head_oracle.init_params(helpers.SEED + 1)
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_posemlp"], prob)
+    cfg.update(global_batch=2048, iterations=60, refine_calibration=True)
+    plain, piped = (_trainer(prob, flat0, cfg, max_batch=2048) for _ in range(2))
+    rng = np.random.default_rng(19)
+    N = prob["features"].shape[0]
+    batches = [torch.from_numpy(rng.permutation(N)[:(2048 if i % 5 else 1111)].astype(np.int64)).cuda() for i in range(24)]
+    other = torch.from_numpy(rng.permutation(N)[:2048].astype(np.int64)).cuda()
+    for i, b in enumerate(batches):
+        plain.step(b)
+        nxt = batches[i + 1] if i + 1 < len(batches) else None
+        if i % 7 == 3:
+            nxt = other                       # a wrong announcement: the next call must notice and gather its own batch
+        if i % 11 == 5:
+            piped.backward(b); piped.update()   # a split step in between
+        else:
+            piped.step(b, nxt)
+        if i % 9 == 4:
+            assert plain.state() == piped.state()
+    torch.cuda.synchronize()
+    assert torch.equal(plain.params, piped.params) and torch.equal(plain.adam_m, piped.adam_m) and torch.equal(plain.adam_v, piped.adam_v)
+    assert torch.equal(plain.pose_params, piped.pose_params) and torch.equal(plain.pose_m, piped.pose_m) and torch.equal(plain.pose_v, piped.pose_v)
+    sp, sq = plain.state(), piped.state()
+    assert sp == sq and sp["iteration"] == 24
+    lp, lq = plain.log(0, 24), piped.log(0, 24)
+    assert np.array_equal(lp[0], lq[0]) and np.array_equal(lp[1], lq[1])
