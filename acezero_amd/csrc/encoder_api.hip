@@ -90,6 +90,7 @@ struct Conv12Args {
   const float* b2;         // [64]
   uint16_t* out;           // NHWC bf16 [F][H2][W2][64]
   int F, H, W, H2, W2, Kp2, tiles_y, tiles_x, n_tiles;
+  const float* zero;       // >= 4 bytes of zeros (conv12p: source of the image-patch DMA outside the image)
 };
 
 constexpr int C12_IMG_PITCH = 68, C12_IMG_ROWS = 19, C12_IMG_N = C12_IMG_ROWS * C12_IMG_PITCH;   // 1292
@@ -243,6 +244,251 @@ __global__ __launch_bounds__(512) void conv12_kernel(Conv12Args a) {
           *reinterpret_cast<uint4*>(a.out + (((size_t)f * a.H2 + oy) * a.W2 + ox) * 64 + chk * 8) =
               *reinterpret_cast<const uint4*>(so + pxl * 64 + ((chk ^ (pxl & 7)) << 3));
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv12p (round 5): the same two layers, software-pipelined across tiles. conv12_kernel runs its phases one after the other on all
+// eight waves -- image patch -> LDS | conv1 (a handful of MFMAs under ~150 vector instructions per 32-pixel fragment: bias, ReLU,
+// padding select, pack) | conv2 (36 MFMAs per wave, nothing else) | store -- so the matrix pipe idles through conv1 and the vector
+// pipe through conv2: 7.1 us per 8 x 32 tile for 1.1 us of MFMA time (profiles/r05_encoder_pmc.json: MFMA busy 0.155, 57 % of the
+// wave cycles waiting; profiles/r05_encoder_layers.json: 545 us per 64 frames = 14 % of the encoder at 0.14 of the MFMA peak).
+// Here the two layers of DIFFERENT tiles run beside each other: waves 4 .. 7 compute conv1 of tile i + 1 into one of two LDS patches
+// while waves 0 .. TR-1 run conv2 of tile i from the other (and stage the image patch of tile i + 2); waves w and w + 4 share a SIMD, so
+// every SIMD has one MFMA-bound and one VALU-bound wave. One s_barrier per tile. Tiles are TR = 4 output rows x 32 columns (two patches
+// of 9 x 65 conv1 pixels = 76 KiB; an 8-row tile's 17-row patch does not fit twice). Same MFMAs on the same operands in the same order:
+// the output is bit-identical to conv12_kernel's.
+// ---------------------------------------------------------------------------------------------------
+// 16-byte chunk swizzle of conv12p's conv1 patch (a pixel = 32 channels = four chunks; q = column index inside a parity plane). conv2's
+// B-fragment reads take 16 consecutive q with one chunk index: conflict free iff the swizzle differs between q, q + 4, q + 8, q + 12;
+// conv1's epilogue writes 8 consecutive pixels = 4 consecutive q x 2 planes per lane group: conflict poor iff it also differs between
+// q .. q + 3. (q >> 2) & 3 (round 1) does the first only -- the writes were 4-way conflicts, 180 of the kernel's 573 us (ablation, round
+// 5); ((q >> 2) + q) & 3 does both.
+__device__ __forceinline__ int c12p_swz(int q) { return ((q >> 2) + q) & 3; }
+
+__device__ __forceinline__ void wait_vmcnt_dyn_c12(int n) {   // s_waitcnt vmcnt(n), n = 0 .. 4 wave-uniform
+  switch (n) {
+    case 1: ACEZ_VMCNT(1); break;
+    case 2: ACEZ_VMCNT(2); break;
+    case 3: ACEZ_VMCNT(3); break;
+    case 4: ACEZ_VMCNT(4); break;
+    default: ACEZ_VMCNT(0); break;
+  }
+}
+#ifndef C12_ABL
+#define C12_ABL 0   // timing-only ablation of conv12p (tools/c12_variants.sh): 1 = no conv1, 2 = no conv2, 4 = no output stores, 8 = no patch writes
+#endif
+template <int TR>
+__global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
+  constexpr int PR = 2 * TR + 1;                 // conv1 patch rows
+  constexpr int IMG_N = (PR + 2) * C12_IMG_PITCH;   // image patch: PR + 2 rows of 67 (+ 1 pad) grey values
+  constexpr int PLANE = PR * 33 * 32;            // elements per column-parity plane of a conv1 patch
+  constexpr int NF = (PR * 65 + 31) / 32;        // 32-pixel conv1 fragments per tile
+  static_assert(IMG_N <= 3 * 256, "three image entries per staging thread");
+  __shared__ __attribute__((aligned(16))) float s_img[2][3 * 256];   // fp32 as in memory (LDS-DMA); rounded to bf16 where conv1 gathers its taps
+  __shared__ __attribute__((aligned(16))) uint16_t s_patch[2][2 * PLANE];
+  __shared__ __attribute__((aligned(16))) uint16_t s_out[TR * 32 * 64];
+  __shared__ __attribute__((aligned(16))) float s_bias[32 + 64];   // b1 | b2
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int fr = l & 31, fh = l >> 5;
+  if (t < 96) s_bias[t] = t < 32 ? a.b1[t] : a.b2[t - 32];   // visible after the first barrier
+  const int tiles_y = (a.H2 + TR - 1) / TR, tiles_x = (a.W2 + 31) / 32, tpf = tiles_y * tiles_x;
+  const int n_tiles = a.F * tpf;
+  const int K = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;   // tiles of this workgroup
+  auto tile_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
+
+  if (w < 4) {
+    // ------------------------------------------------------------------ conv2 waves (w < TR multiply; all four stage the image patches)
+    bf16x8 a2[9][2][2];
+    if (w < TR) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            a2[tap][kk][i] = *reinterpret_cast<const bf16x8*>(a.w2 + (size_t)(i * 32 + fr) * a.Kp2 + tap * 32 + kk * 16 + 8 * fh);
+    }
+    // image patch staging by LDS-DMA, one dword per lane: entries t, t + 256, t + 512 of the [PR + 2][68] patch (coordinates are tile
+    // independent); outside the image (and past the patch) the source is a zero word. No registers, no conversion here, and the
+    // transfers are OLDER than this iteration's output stores, so a counted wait certifies them without draining the stores.
+    int epy[3], epx[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = t + 256 * i;
+      epy[i] = min(e, IMG_N - 1) / C12_IMG_PITCH;
+      epx[i] = (e < IMG_N) ? e - epy[i] * C12_IMG_PITCH : 67;   // 67 = the pad column: never valid
+    }
+    auto stage_img = [&](int k) {   // tile k of this workgroup -> s_img[k & 1]
+      const int tl = tile_of(k);
+      const int f = tl / tpf, r = tl - f * tpf;
+      const int ty = r / tiles_x, tx = r - ty * tiles_x;
+      const float* base = a.img + (size_t)f * a.H * a.W;
+      float* dst = s_img[k & 1] + w * 64;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int iy = 2 * TR * ty - 2 + epy[i], ix = 64 * tx - 2 + epx[i];
+        const bool ok = epx[i] < 67 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const float* g = ok ? base + (size_t)iy * a.W + ix : a.zero;
+        __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(dst + 256 * i), 4, 0, 0);
+      }
+    };
+    if (0 < K) stage_img(0);
+    for (int j = -2; j < K; ++j) {
+      // ---- image patch of tile j + 2 -> s_img[j & 1] (read by conv1 of tile j, one iteration ago); tile 0's went out above
+      int n_stores = 0;
+      if (j + 2 < K && j + 2 > 0) stage_img(j + 2);
+      // ---- conv2 of tile j: output row w, pixels x = fr, channels 2 x 32
+      if (j >= 0 && w < TR && !(C12_ABL & 2)) {
+        const int tile = tile_of(j);
+        const int f = tile / tpf, r = tile - f * tpf;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const uint16_t* sp = s_patch[j & 1];
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int q = fr + (kx >> 1);
+            const uint16_t* src = sp + (kx & 1) * PLANE + ((2 * w + ky) * 33 + q) * 32;
+            const int sw = c12p_swz(q);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+              const bf16x8 b = *reinterpret_cast<const bf16x8*>(src + (((kk * 2 + fh) ^ sw) << 3));
+#pragma unroll
+              for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ky * 3 + kx][kk][i], b, acc[i], 0, 0, 0);
+            }
+          }
+        // bias + ReLU -> wave-private staging row [32 px][64 ch] -> 4 KiB contiguous store
+        uint16_t* so = s_out + w * (32 * 64);
+        float4 b2v[2][4];   // (all eight LDS reads in flight before the first is used: as eight read-wait pairs they were eight serial round trips per tile)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) b2v[i][g] = *reinterpret_cast<const float4*>(s_bias + 32 + i * 32 + 8 * g + 4 * fh);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int ch = i * 32 + 8 * g + 4 * fh;
+            const float4 b = b2v[i][g];
+            const uint2 y = pack4(fmaxf(acc[i][4 * g + 0] + b.x, 0.f), fmaxf(acc[i][4 * g + 1] + b.y, 0.f), fmaxf(acc[i][4 * g + 2] + b.z, 0.f),
+                                  fmaxf(acc[i][4 * g + 3] + b.w, 0.f));
+            *reinterpret_cast<uint2*>(so + fr * 64 + ((((ch >> 3) ^ (fr & 7)) << 3) | (ch & 7))) = y;
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int oy = TR * ty + w, ox0 = 32 * tx;
+        if (oy < a.H2 && !(C12_ABL & 4)) {
+          n_stores = min(4, max(0, (a.W2 - ox0 + 7) >> 3));   // store instructions with at least one active lane (the others are branched over)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int pxl = it * 8 + (l >> 3), chk = l & 7;
+            const int ox = ox0 + pxl;
+            if (ox < a.W2)
+              *reinterpret_cast<uint4*>(a.out + (((size_t)f * a.H2 + oy) * a.W2 + ox) * 64 + chk * 8) =
+                  *reinterpret_cast<const uint4*>(so + pxl * 64 + ((chk ^ (pxl & 7)) << 3));
+          }
+        }
+      }
+      // the image patch requested at the top of this iteration must have landed before conv1 reads it in the next one; it is older than
+      // this tile's output stores, which may stay in flight (in-order completion). Raw barrier: __syncthreads() would drain them.
+      wait_vmcnt_dyn_c12(n_stores);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    // ------------------------------------------------------------------ conv1 waves: tile j + 1 while the others run conv2 of tile j
+    const int lw = w - 4;
+    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a.w1 + fr * 16 + 8 * fh);
+    // this lane's sixteen conv1 bias values, in registers for the whole kernel (read from LDS inside the fragment loop each of the four
+    // reads was followed by a full lgkmcnt(0) wait: four serial LDS round trips per 32-pixel fragment -- found in the ISA, round 5)
+    float4 b1v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b1v[g] = *reinterpret_cast<const float4*>(a.b1 + 8 * g + 4 * fh);
+    // per-lane constants of this wave's fragments fg = lw, lw + 4, ... (tile independent): patch pixel p = fg * 32 + fr -> (py, px), the
+    // offset of its taps in the image patch and of its 64-byte record in the conv1 patch (the division by 65 and the address arithmetic
+    // ran once per fragment and tile)
+    constexpr int NFW = (NF + 3) / 4;
+    int f_py[NFW], f_px[NFW], f_ip[NFW], f_dst[NFW], f_sw[NFW];
+#pragma unroll
+    for (int u = 0; u < NFW; ++u) {
+      const int p = (lw + 4 * u) * 32 + fr;
+      const int py = min(p / 65, PR - 1), px = p - (p / 65) * 65, q = px >> 1;
+      f_py[u] = (lw + 4 * u < NF && p < PR * 65) ? py : -1;   // -1: no such pixel (nothing is written)
+      f_px[u] = px;
+      f_ip[u] = py * C12_IMG_PITCH + px;
+      f_dst[u] = (px & 1) * PLANE + (py * 33 + q) * 32 + 4 * fh;
+      f_sw[u] = c12p_swz(q);
+    }
+    for (int j = -2; j < K; ++j) {
+      const int c = j + 1;
+      if (c >= 0 && c < K && !(C12_ABL & 1)) {
+        const int tile = tile_of(c);
+        const int f = tile / tpf, r = tile - f * tpf;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        (void)f;
+        const float* si = s_img[c & 1];
+        uint16_t* sp = s_patch[c & 1];
+        const int cy0 = 2 * TR * ty - 1, cx0 = 64 * tx - 1;          // conv1 pixel of patch position (0, 0)
+        // a tile whose whole patch lies inside the image (all but the border tiles) needs no zeroing of outside pixels
+        const bool interior = cy0 >= 0 && cy0 + PR <= a.H && cx0 >= 0 && cx0 + 65 <= a.W;
+        auto fragment = [&](int u, auto chk) {
+          constexpr bool CHECK = decltype(chk)::value;
+          const float* ip = si + f_ip[u];   // taps: ip[ky * 68 + kx], rounded to bf16 here (round to nearest even, as conv12_kernel's staging)
+          float tp[9];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) tp[ky * 3 + kx] = ip[ky * C12_IMG_PITCH + kx];
+          uint32_t bw[4];
+          if (fh == 0) {
+            bw[0] = pack2(tp[0], tp[1]); bw[1] = pack2(tp[2], tp[3]); bw[2] = pack2(tp[4], tp[5]); bw[3] = pack2(tp[6], tp[7]);
+          } else {
+            bw[0] = pack2(tp[8], 0.f); bw[1] = 0u; bw[2] = 0u; bw[3] = 0u;
+          }
+          const uint4 bq = make_uint4(bw[0], bw[1], bw[2], bw[3]);
+          f32x16 c1;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) c1[q] = 0.f;
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, bq), c1, 0, 0, 0);
+          // conv1 pixel (cy, cx) of this lane; outside the image the map is ZERO (conv2's padding)
+          bool inside = true;
+          if (CHECK) {
+            const int cy = cy0 + f_py[u], cx = cx0 + f_px[u];
+            inside = cy >= 0 && cy < a.H && cx >= 0 && cx < a.W;
+          }
+          if (f_py[u] >= 0 && !(C12_ABL & 8)) {
+            uint16_t* dst = sp + f_dst[u];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {   // channels 8g + 4 fh .. +3 = half of logical chunk g
+              const float4 b = b1v[g];
+              float v0 = fmaxf(c1[4 * g + 0] + b.x, 0.f), v1 = fmaxf(c1[4 * g + 1] + b.y, 0.f);
+              float v2 = fmaxf(c1[4 * g + 2] + b.z, 0.f), v3 = fmaxf(c1[4 * g + 3] + b.w, 0.f);
+              if (CHECK && !inside) v0 = v1 = v2 = v3 = 0.f;
+              *reinterpret_cast<uint2*>(dst + ((g ^ f_sw[u]) << 3)) = pack4(v0, v1, v2, v3);
+            }
+          }
+        };
+        if (interior) {
+#pragma unroll
+          for (int u = 0; u < NFW; ++u)
+            if (lw + 4 * u < NF) fragment(u, std::integral_constant<bool, false>{});
+        } else {
+#pragma unroll
+          for (int u = 0; u < NFW; ++u)
+            if (lw + 4 * u < NF) fragment(u, std::integral_constant<bool, true>{});
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
   }
 }
@@ -1532,9 +1778,17 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
     if (e->fuse12) {
       Conv12Args c{};
       c.img = img; c.w1 = e->w1b; c.b1 = e->bias[0]; c.w2 = e->W[1]; c.b2 = e->bias[1]; c.out = e->a2;
-      c.F = F; c.H = h; c.W = w; c.H2 = h2; c.W2 = w2; c.Kp2 = e->Kp[1];
+      c.F = F; c.H = h; c.W = w; c.H2 = h2; c.W2 = w2; c.Kp2 = e->Kp[1]; c.zero = reinterpret_cast<const float*>(e->zeros);
       c.tiles_y = (h2 + 7) / 8; c.tiles_x = (w2 + 31) / 32; c.n_tiles = F * c.tiles_y * c.tiles_x;
-      hipLaunchKernelGGL(conv12_kernel, dim3(c.n_tiles < 256 ? c.n_tiles : 256), dim3(512), 0, s, c);
+      // round 5: the software-pipelined kernel on 4 x 32 tiles (conv1 of tile i + 1 beside conv2 of tile i); ACEZ_CONV12P=0
+      // (diagnostics build): round 1's phase-by-phase kernel on 8 x 32 tiles. Bit-identical outputs.
+      static const int pipelined = [] { const char* v = ACEZ_DIAG_ENV("ACEZ_CONV12P"); return v ? atoi(v) : 1; }();
+      if (pipelined) {
+        const int nt4 = F * ((h2 + 3) / 4) * c.tiles_x;
+        hipLaunchKernelGGL(conv12p_kernel<4>, dim3(nt4 < 256 ? nt4 : 256), dim3(512), 0, s, c);
+      } else {
+        hipLaunchKernelGGL(conv12_kernel, dim3(c.n_tiles < 256 ? c.n_tiles : 256), dim3(512), 0, s, c);
+      }
     } else {
       const int64_t npix = (int64_t)F * h * w;
       hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, img, (const float*)e->w1, (const float*)e->bias[0], e->a1, h, w,
