@@ -484,23 +484,76 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
       if (ACEZ_DBG(a.dbg) & 2) continue;
       const uint16_t* sW = smem + (kt & 3) * STAGE;
       const uint16_t* sI = sW + 128 * 64;
+      if constexpr (!HAS_MASK) {
+        // forward instantiations: the scheduler's own order (reads of the second K step behind the first MFMAs) is the better one
+        // (A/B, round 5: the explicit order below costs the forward chain 0.5-1.5 us)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int c = kk * 4 + fq;
+          typename E::frag fa[2], fb[5];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const typename E::frag*>(&sW[swz(w * 32 + i * 16 + fr, c)]);
+#pragma unroll
+          for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const typename E::frag*>(&sI[swz(j * 16 + fr, c)]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc[i][j] = E::mfma16(fa[i], fb[j], acc[i][j]);
+        }
+      } else {
+      // Input-gradient instantiations: all fourteen fragment reads of the stage are requested before its first MFMA and every MFMA
+      // waits for exactly the reads it needs. A multiplier wave is ALONE on its SIMD (its neighbour only issues DMA), so every LDS
+      // round trip left between two MFMAs is matrix-pipe idle time: left to the scheduler, these instantiations read a fragment, waited
+      // for it -- lgkmcnt(0) -- and multiplied, two to three times per stage (60 such read-wait pairs in rowseq_kernel<true>'s K loops
+      // against 3 in the forward chain's; ISA scan, round 5: -2.0 ... -2.6 us on the input-gradient chain). Same MFMAs, same order.
+      typename E::frag fa[2][2], fb[2][5];
+      // request order = use order: fa[kk][0], fb[kk][0..4], fa[kk][1] for kk = 0, 1 (LDS returns in order)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int c = kk * 4 + fq;
-        typename E::frag fa[2], fb[5];
+        fa[kk][0] = *reinterpret_cast<const typename E::frag*>(&sW[swz(w * 32 + fr, c)]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const typename E::frag*>(&sW[swz(w * 32 + i * 16 + fr, c)]);
-#pragma unroll
-        for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const typename E::frag*>(&sI[swz(j * 16 + fr, c)]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 5; ++j) acc[i][j] = E::mfma16(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < 5; ++j) fb[kk][j] = *reinterpret_cast<const typename E::frag*>(&sI[swz(j * 16 + fr, c)]);
+        fa[kk][1] = *reinterpret_cast<const typename E::frag*>(&sW[swz(w * 32 + 16 + fr, c)]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // each MFMA waits for exactly the reads it needs: 14 in flight, the first needs two of them, ... (counts = reads that may remain)
+#define ACEZ_KSTEP(KK, BASE)                                                                                   \
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((BASE) + 5) : "memory"); acc[0][0] = E::mfma16(fa[KK][0], fb[KK][0], acc[0][0]); \
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((BASE) + 4) : "memory"); acc[0][1] = E::mfma16(fa[KK][0], fb[KK][1], acc[0][1]); \
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((BASE) + 3) : "memory"); acc[0][2] = E::mfma16(fa[KK][0], fb[KK][2], acc[0][2]); \
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((BASE) + 2) : "memory"); acc[0][3] = E::mfma16(fa[KK][0], fb[KK][3], acc[0][3]); \
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((BASE) + 1) : "memory"); acc[0][4] = E::mfma16(fa[KK][0], fb[KK][4], acc[0][4]); \
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(BASE) : "memory");                                           \
+      acc[1][0] = E::mfma16(fa[KK][1], fb[KK][0], acc[1][0]); acc[1][1] = E::mfma16(fa[KK][1], fb[KK][1], acc[1][1]); \
+      acc[1][2] = E::mfma16(fa[KK][1], fb[KK][2], acc[1][2]); acc[1][3] = E::mfma16(fa[KK][1], fb[KK][3], acc[1][3]); \
+      acc[1][4] = E::mfma16(fa[KK][1], fb[KK][4], acc[1][4]);
+      ACEZ_KSTEP(0, 7)
+      __builtin_amdgcn_sched_barrier(0);
+      ACEZ_KSTEP(1, 0)
+#undef ACEZ_KSTEP
       }
     }
     stage_barrier();                    // epilogue inputs have landed
     if (!SEQ && ((ACEZ_DBG(a.dbg) & 1) || !active)) return;
     float amax = 0.f;                   // fp16 gradient layers: largest |value| before the conversion (absmax_publish)
+    // The epilogue inputs this lane needs from the staging tiles (`add` values in stA, mask / residual values in stB: up to 2 x 10 eight-byte
+    // reads), ALL requested before the first is used: written as read-compute-write per fragment the compiler could not move a read above
+    // the previous fragment's write to the same tile (it cannot see that the addresses differ) and followed every read by a full
+    // lgkmcnt(0) -- ten to twenty serial LDS round trips per layer in the input-gradient chain (85 read-wait pairs in rowseq_kernel<true>'s
+    // ISA against 2 in the forward chain's; found with a scan for load-wait pairs, round 5). Same values, same arithmetic.
+    uint2 ra[2][5], rb[2][5];
+    if (HAS_ADD || HAS_IN2) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int o = st_off(j * 16 + fr, w * 32 + i * 16 + 4 * fq);
+          if (HAS_ADD) ra[i][j] = *reinterpret_cast<const uint2*>(&stA[o]);
+          if (HAS_IN2) rb[i][j] = *reinterpret_cast<const uint2*>(&stB[o]);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int ml = j * 16 + fr;
@@ -515,7 +568,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         }
         if (HAS_ADD) {
           float ad[4];
-          E::un4(*reinterpret_cast<const uint2*>(pa), ad);
+          E::un4(ra[i][j], ad);
           v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
         }
         if (BIAS_RELU) {
@@ -526,13 +579,13 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         if (AUX == AUX_RESIDUAL) {
           float yf[4], rf[4];
           E::un4(y, yf);
-          E::un4(*reinterpret_cast<const uint2*>(pb), rf);
+          E::un4(rb[i][j], rf);
           *reinterpret_cast<uint2*>(pa) = E::pk4(yf[0] + rf[0], yf[1] + rf[1], yf[2] + rf[2], yf[3] + rf[3]);
         } else if (AUX == AUX_UNMASKED) {
           *reinterpret_cast<uint2*>(pa) = y;
         }
         if (HAS_MASK) {
-          const uint2 mk = *reinterpret_cast<const uint2*>(pb);
+          const uint2 mk = rb[i][j];
           const uint32_t m0b = mk.x & 0xffffu, m1b = mk.x >> 16, m2b = mk.y & 0xffffu, m3b = mk.y >> 16;
           uint32_t lo = y.x, hi = y.y;
           if (!(m0b != 0 && m0b < 0x8000u)) lo &= 0xffff0000u;
@@ -598,11 +651,17 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
     // combined in a fixed order (the ring is free by now)
     const int col = t & 127, g = t >> 7;
     const int rows = min(80, M - m0);
+    // (all twenty reads first, then the adds in row order: as a read-add loop every read was followed by a full lgkmcnt(0) -- twenty serial
+    // LDS round trips per layer, found with the same scan as the epilogue reads above)
+    uint16_t colv[20];
+#pragma unroll
+    for (int r = 0; r < 20; ++r) colv[r] = stB[st_off(g * 20 + r, col)];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float sacc = 0.f;
 #pragma unroll
     for (int r = 0; r < 20; ++r) {
       const int row = g * 20 + r;
-      const float v = E::to_f(stB[st_off(row, col)]);
+      const float v = E::to_f(colv[r]);
       sacc += (row < rows) ? v : 0.f;
     }
     float* red = reinterpret_cast<float*>(SEQ ? smem + RG80_SMEM : smem);
