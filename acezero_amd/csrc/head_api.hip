@@ -144,6 +144,7 @@ struct acez_trainer {
   int wgo_recovered = 0;          // faulted wgrad_opt steps the fall-back has finished (wgo_recover)
   bool sizing = false;            // acez_trainer_create's first pass: dmalloc only adds up
   size_t sized_total = 0;
+  unsigned long long* pose_trace = nullptr;  // ACEZ_POSE_TRACE=1 (diagnostics build): [2][1024][16] stamps of the pose forward (S3) / S1 workgroups (debug_read kind 8)
   unsigned long long* wgo_trace = nullptr;   // ACEZ_WGO_TRACE=1 (diagnostics build): s_memtime stamps of wgrad_opt_kernel's last launch (debug_read kind 7)
 };
 
@@ -399,6 +400,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->seq_flags, (64 * 32 + 32) * sizeof(uint32_t));
   if (ACEZ_DIAG_ENV("ACEZ_SEQ_XCC")) A((void**)&tr->seq_xcc, (8 + 256) * sizeof(uint32_t));
   if (ACEZ_DIAG_ENV("ACEZ_CHAIN_TRACE")) A((void**)&tr->chain_trace, 512 * sizeof(unsigned long long));
+  if (ACEZ_DIAG_ENV("ACEZ_POSE_TRACE")) A((void**)&tr->pose_trace, 2 * 1024 * 16 * sizeof(unsigned long long));
   if (ACEZ_DIAG_ENV("ACEZ_WGO_TRACE")) A((void**)&tr->wgo_trace, 256 * 12 * 8 * sizeof(unsigned long long));
   if (trains) {
     A((void**)&tr->R0_alt, act_bytes);
@@ -432,6 +434,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGRAD_OPT")) tr->wgrad_opt = atoi(e) != 0;
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_AT")) tr->wgo_fault_at = atol(e);
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_MOD")) tr->wgo_fault_mod = atoi(e);
+  if (tr->pose_trace) ACEZ_HIP_CHECK(hipMemset(tr->pose_trace, 0, 2 * 1024 * 16 * sizeof(unsigned long long)));
   if (tr->wgo_trace) ACEZ_HIP_CHECK(hipMemset(tr->wgo_trace, 0, 256 * 12 * 8 * sizeof(unsigned long long)));
   if (trains) {
     ACEZ_HIP_CHECK(hipMemset(tr->wg_flags, 0, (size_t)tr->L * 16 * 2 * 32 * sizeof(uint32_t)));
@@ -737,8 +740,9 @@ static void launch_chain(acez_trainer*, const int64_t*, int, int, bool, hipStrea
 #endif
 
 // ---- pose refinement (the flat parameter offsets in PoseNetwork.named_parameters() order are PN_* in pose_kernels.hip)
-static PoseNetArgs pose_net_args(acez_trainer* tr, const int* active) {
+static PoseNetArgs pose_net_args(acez_trainer* tr, const int* active, int trace_slot = 0) {
   PoseNetArgs a{};
+  if (tr->pose_trace && (tr->buf.n_images + 3) / 4 <= 1024) a.trace = tr->pose_trace + (size_t)trace_slot * 1024 * 16;
   a.P = tr->pb.d_pose_params; a.T0 = tr->buf.d_image_pose_inv; a.I = tr->buf.n_images; a.w = tr->cfg.pose_refinement_weight;
   a.a1 = tr->pa1; a.a2 = tr->pa2; a.a3 = tr->pa3; a.r = tr->pr; a.f1 = tr->pf1; a.f2 = tr->pf2; a.delta = tr->pdlt; a.pose_cur = tr->pose_cur;
   a.dT = tr->pdT; a.ddelta = tr->pddelta; a.dz2 = tr->pdz2; a.dz1 = tr->pdz1; a.dr = tr->pdr; a.dzc3 = tr->pdzc3; a.dzc2 = tr->pdzc2;
@@ -1131,7 +1135,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     // pose weight gradients with AdamW in their epilogue (S2: needs S1 of every image tile)
     const int T = tr->pose_tile, np = (tr->buf.n_images + T - 1) / T;
     { ProfScope ps(tr, s, KC_ADAMW);
-#define ACEZ_AP(TT) hipLaunchKernelGGL(adamw_pose_kernel<TT>, dim3(np + tr->L * 64 + nsmall), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active), \
+#define ACEZ_AP(TT) hipLaunchKernelGGL(adamw_pose_kernel<TT>, dim3(np + tr->L * 64 + nsmall), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active, 1), \
                                        (const float*)tr->row_dT, (const int*)tr->row_image, tr->last_n, np)
       if (T == 16) ACEZ_AP(16); else if (T == 4) ACEZ_AP(4); else ACEZ_AP(8);
 #undef ACEZ_AP
@@ -1445,6 +1449,7 @@ extern "C" int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, vo
   else if (kind == 5 && tr->chain_trace) { src = tr->chain_trace; cap = 512 * 8; }
   else if (kind == 6 && tr->seq_xcc) { src = tr->seq_xcc; cap = (8 + 256) * 4; }
   else if (kind == 7 && tr->wgo_trace) { src = tr->wgo_trace; cap = 256 * 12 * 8 * 8; }
+  else if (kind == 8 && tr->pose_trace) { src = tr->pose_trace; cap = 2 * 1024 * 16 * 8; }
   ACEZ_REQUIRE(src && bytes <= cap, "unknown buffer or size out of range");
   ACEZ_HIP_CHECK(hipMemcpyAsync(h_out, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));

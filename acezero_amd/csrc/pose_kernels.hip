@@ -238,7 +238,13 @@ struct PoseNetArgs {
   float *ddelta, *dz2, *dz1, *dr, *dzc3, *dzc2, *dzc1;   // backward: gradients wrt each layer's pre-activation output
   const int* active;
   int ortho;               // 0 gram-schmidt, 1 procrustes (--refinement_ortho)
+  unsigned long long* trace;   // diagnostics build (ACEZ_POSE_TRACE=1, tools/pose_trace.py): [tiles][16] s_memtime stamps of thread 0; else null
 };
+#ifdef ACEZ_DIAG
+#define PN_STAMP(a, tile, i) do { __builtin_amdgcn_sched_barrier(0); if ((a).trace && threadIdx.x == 0) (a).trace[(size_t)(tile) * 16 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PN_STAMP(a, tile, i) do { } while (0)
+#endif
 constexpr int64_t PN_SKIP_W = 0, PN_SKIP_B = 1536, PN_C1_W = 1664, PN_C1_B = 3200, PN_C2_W = 3328, PN_C2_B = 19712, PN_C3_W = 19840,
                   PN_C3_B = 36224, PN_F1_W = 36352, PN_F1_B = 52736, PN_F2_W = 52864, PN_F2_B = 69248, PN_F3_W = 69376, PN_F3_B = 70912;
 constexpr int PN_IMG = 16;     // images per workgroup
@@ -590,9 +596,16 @@ __global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? PW_WAVES / 2 : 2) v
 // The three phases as a body over caller-provided LDS (MAX_HITS: list capacity per workgroup and pass, a multiple of 256):
 //   sRow int[MAX_HITS], sRel u8[MAX_HITS], sVal float[MAX_HITS][12], sCnt int[4];  out192: [16][12] sums (LDS or global), written by
 // threads 0..191. Every thread of the 256-thread workgroup must call it.
+constexpr int PGR_SCAN = 20;
 template <int MAX_HITS, int TILE = 16>
 __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ row_dT, const int* __restrict__ row_image, const int n, const int i0,
-                                                      int* sRow, unsigned char* sRel, float (*sVal)[12], int* sCnt, float* out192) {
+                                                      int* sRow, unsigned char* sRel, float (*sVal)[12], int* sCnt, float* out192,
+                                                      unsigned long long* stamps = nullptr) {
+#ifdef ACEZ_DIAG
+#define PGR_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PGR_STAMP(i) do { } while (0)
+#endif
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   constexpr int cap = MAX_HITS / 4;            // list capacity per wave
   // One pass over all rows when the lists fit (many images: ~5 rows per image). Otherwise (few images) the rows are taken in several
@@ -611,18 +624,19 @@ __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ 
       const int q = ((ce - cb + 3) / 4 + 63) / 64 * 64;      // rows per wave in this pass
       const int rb = cb + w * q, re = min(ce, rb + q);
       int cnt = 0;
-      for (int c0 = rb; c0 < re; c0 += 64 * 16) {            // 16 table entries per lane in flight
-        int rel[16];
+      for (int c0 = rb; c0 < re; c0 += 64 * PGR_SCAN) {      // 20 table entries per lane in flight (a wave's 1280 rows of a 5120-row batch: ONE round trip)
+        int rel[PGR_SCAN];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < PGR_SCAN; ++j) {
           const int r = c0 + 64 * j + lane;
           const int v = row_image[min(r, n - 1)];   // unconditional load (a load under a branch is waited for on the spot)
           rel[j] = (r < re) ? v - i0 : -1;
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < PGR_SCAN; ++j) {
           const bool hit = rel[j] >= 0 && rel[j] < TILE;
           const unsigned long long m = __ballot(hit);
+          if (m == 0ull) continue;                 // (most groups of 64 rows hold no row of the tile's images)
           if (hit) {
             const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
             if (pos < cap) { sRow[w * cap + pos] = c0 + 64 * j + lane; sRel[w * cap + pos] = (unsigned char)rel[j]; }
@@ -630,6 +644,7 @@ __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ 
           cnt += __popcll(m);
         }
       }
+      PGR_STAMP(0);                                // (this thread's table scan done)
       __syncthreads();                             // previous pass' readers of the lists are done
       if (lane == 0) sCnt[w] = cnt;
       __syncthreads();
@@ -661,11 +676,29 @@ __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ 
         }
       }
       __syncthreads();
+      PGR_STAMP(1);                                // hit rows in LDS
       if (t < TILE * 12) {
+        // the hits in list order (wave 0's list, then wave 1's, ...), eight at a time: the image tags of a group are ONE 8-byte read and
+        // its values eight unconditional reads, all requested together, then added in order -- one LDS round trip per group (hit by
+        // hit, with the value read under the tag's branch, it was two dependent round trips each: 2.2 us for the ~20 hits of a
+        // 4-image tile, tools/pose_trace.py). Entries past a list's count are read (inside the list's capacity) and not added.
         const int im = t / 12, c = t % 12;
-        for (int wv = 0; wv < 4; ++wv)
-          for (int h = 0; h < sCnt[wv]; ++h)
-            if (sRel[wv * cap + h] == im) acc += sVal[wv * cap + h][c];
+        static_assert(cap % 8 == 0, "8-byte tag reads");
+        const int cn[4] = {sCnt[0], sCnt[1], sCnt[2], sCnt[3]};
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+          for (int h0 = 0; h0 < cn[wv]; h0 += 8) {
+            const uint2 tg = *reinterpret_cast<const uint2*>(sRel + wv * cap + h0);
+            float val[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) val[u] = sVal[wv * cap + h0 + u][c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int tag = (int)(((u < 4 ? tg.x : tg.y) >> (8 * (u & 3))) & 0xffu);
+              if (h0 + u < cn[wv] && tag == im) acc += val[u];
+            }
+          }
+        }
       }
     }
     if (!overflow) { result = acc; break; }
@@ -679,7 +712,7 @@ __global__ __launch_bounds__(256) void pose_grad_reduce2_kernel(const float* row
                                                                 float* dT /*[I][12]*/, int n_images, const int* active) {
   if (active && !*active) return;
   __shared__ int sRow[PGR_MAX_HITS];
-  __shared__ unsigned char sRel[PGR_MAX_HITS];
+  __shared__ __attribute__((aligned(8))) unsigned char sRel[PGR_MAX_HITS];
   __shared__ float sVal[PGR_MAX_HITS][12];
   __shared__ int sCnt[4];
   __shared__ float sOut[16 * 12];
