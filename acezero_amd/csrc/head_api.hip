@@ -924,7 +924,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     const int T = tr->pose_tile_fwd, np = (tr->buf.n_images + T - 1) / T;
     const int do_post = tr->post_pending ? 1 : 0;
     tr->post_pending = false;
-#define ACEZ_SBP(TT) hipLaunchKernelGGL(step_begin_pose_kernel<TT>, dim3(np + gblocks + 1), dim3(256), 0, s, (const uint16_t*)tr->buf.d_features, \
+#define ACEZ_SBP(TT) hipLaunchKernelGGL(step_begin_pose_kernel<TT>, dim3(np + gblocks + 1), dim3(pose_fwd_threads<TT>()), 0, s, (const uint16_t*)tr->buf.d_features, \
                                         d_indices, tr->R[0], n, post_args(tr), do_post, pose_net_args(tr, nullptr), np, gather_meta(tr))
     if (T == 16) ACEZ_SBP(16); else if (T == 4) ACEZ_SBP(4); else ACEZ_SBP(8);
 #undef ACEZ_SBP
@@ -1084,7 +1084,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     // (S1) and the weight gradients as two launches on this stream; the single-GPU step runs S1 beside the head's AdamW instead
     const PoseNetArgs a = pose_net_args(tr, &tr->st->active);
     const int T = tr->pose_tile, np = (tr->buf.n_images + T - 1) / T;
-#define ACEZ_S1(TT) hipLaunchKernelGGL(pose_s1t_kernel<TT>, dim3(np), dim3(256), 0, s, a, (const float*)tr->row_dT, (const int*)tr->row_image, n)
+#define ACEZ_S1(TT) hipLaunchKernelGGL(pose_s1t_kernel<TT>, dim3(np), dim3(pose_threads<TT>()), 0, s, a, (const float*)tr->row_dT, (const int*)tr->row_image, n)
     if (T == 16) ACEZ_S1(16); else if (T == 4) ACEZ_S1(4); else ACEZ_S1(8);
 #undef ACEZ_S1
     launch_pose_wgrad(tr, &tr->st->active, false, s);
@@ -1135,7 +1135,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     // pose weight gradients with AdamW in their epilogue (S2: needs S1 of every image tile)
     const int T = tr->pose_tile, np = (tr->buf.n_images + T - 1) / T;
     { ProfScope ps(tr, s, KC_ADAMW);
-#define ACEZ_AP(TT) hipLaunchKernelGGL(adamw_pose_kernel<TT>, dim3(np + tr->L * 64 + nsmall), dim3(256), 0, s, a, pose_net_args(tr, &tr->st->active, 1), \
+#define ACEZ_AP(TT) hipLaunchKernelGGL(adamw_pose_kernel<TT>, dim3(np + tr->L * 64 + nsmall), dim3(pose_threads<TT>()), 0, s, a, pose_net_args(tr, &tr->st->active, 1), \
                                        (const float*)tr->row_dT, (const int*)tr->row_image, tr->last_n, np)
       if (T == 16) ACEZ_AP(16); else if (T == 4) ACEZ_AP(4); else ACEZ_AP(8);
 #undef ACEZ_AP
@@ -1467,8 +1467,8 @@ extern "C" int acez_trainer_get_poses(acez_trainer* tr, float* h_poses34, void* 
     const PoseNetArgs a = pose_net_args(tr, nullptr);
     const int T = tr->pose_tile_fwd, np = (I + T - 1) / T;
     hipLaunchKernelGGL(pose_transpose_kernel, dim3(4, 4, 4), dim3(256), 0, s, a.P, tr->pose_wt, (const int*)nullptr);
-    if (T == 4) hipLaunchKernelGGL(pose_fwd_t_kernel<4>, dim3(np), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(pose_fwd_t_kernel<8>, dim3(np), dim3(256), 0, s, a);
+    if (T == 4) hipLaunchKernelGGL(pose_fwd_t_kernel<4>, dim3(np), dim3(pose_fwd_threads<4>()), 0, s, a);
+    else hipLaunchKernelGGL(pose_fwd_t_kernel<8>, dim3(np), dim3(pose_fwd_threads<8>()), 0, s, a);
     ACEZ_HIP_CHECK(hipGetLastError());
     src = tr->pose_cur;
   } else if (tr->cfg.pose_refinement == 2) {

@@ -18,8 +18,14 @@
 
 namespace acez {
 
-// T = images per pose workgroup: 16 = the v_mfma_f32_16x16x4_f32 bodies of pose_kernels.hip, 8 / 4 = the small tiles of
-// pose_small.hip (T / 16 of the matrix time per layer, 16 / T times as many CUs; the default is 8).
+// T = images per pose workgroup: 16 = the v_mfma_f32_16x16x4_f32 bodies of pose_kernels.hip (256 threads), 8 / 4 = the small tiles of
+// pose_small.hip (T / 16 of the matrix time per layer, 16 / T times as many CUs, 512 threads; the default is 4). A launch's workgroups
+// all have pose_threads<T>() threads: in the launches shared with the optimiser its workgroups use the first 256 (the other waves
+// return at once), the gather's rows are spread over the waves there are.
+template <int T>
+constexpr int pose_threads() { return 256; }              // the launches that hold S1 (PN4_W_BWD = 4 waves)
+template <int T>
+constexpr int pose_fwd_threads() { return T == 16 ? 256 : 64 * PN4_W_FWD; }
 template <int T>
 constexpr int pose_fwd_smem_floats() { return T == 16 ? 4 : pose4_fwd_smem_floats<(T == 16 ? 8 : T)>(); }
 template <int T>
@@ -29,7 +35,7 @@ constexpr int pose_s1_smem_bytes() { return T == 16 ? PS1_SMEM_BYTES : pose4_s1_
 // closes the previous iteration (do_post) -- exactly step_begin_kernel. The pose forward does not look at st->active (the schedule
 // block of this very launch is rewriting it): refined poses computed for a step that turns out to be inactive are never used.
 template <int T>
-__global__ __launch_bounds__(256, 2) void step_begin_pose_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
+__global__ __launch_bounds__(pose_fwd_threads<T>(), T == 16 ? 2 : 1) void step_begin_pose_kernel(const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx,
                                                                  uint16_t* __restrict__ out, int n, PostArgs p, int do_post, PoseNetArgs a, int np,
                                                                  GatherMeta meta) {
   __shared__ __attribute__((aligned(16))) float smem[pose_fwd_smem_floats<T>()];
@@ -56,14 +62,14 @@ __device__ __forceinline__ void pose_s1_tile(const PoseNetArgs& pn, const float*
   else pose4_s1_body<T>(pn, row_dT, row_image, n, tile, smem);
 }
 template <int T>
-__global__ __launch_bounds__(256) void pose_s1t_kernel(PoseNetArgs a, const float* row_dT, const int* row_image, int n) {
+__global__ __launch_bounds__(pose_threads<T>()) void pose_s1t_kernel(PoseNetArgs a, const float* row_dT, const int* row_image, int n) {
   if (a.active && !*a.active) return;
   __shared__ __attribute__((aligned(16))) char smem[pose_s1_smem_bytes<T>()];
   pose_s1_tile<T>(a, row_dT, row_image, n, blockIdx.x, smem);
 }
 // stand-alone forward on small tiles (acez_trainer_get_poses, the split flow)
 template <int T>
-__global__ __launch_bounds__(256) void pose_fwd_t_kernel(PoseNetArgs a) {
+__global__ __launch_bounds__(pose_fwd_threads<T>()) void pose_fwd_t_kernel(PoseNetArgs a) {
   if (a.active && !*a.active) return;
   __shared__ __attribute__((aligned(16))) float smem[pose_fwd_smem_floats<T>()];
   if constexpr (T == 16) pose_mlp_fwd_body(a, blockIdx.x);

@@ -594,20 +594,21 @@ __global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? PW_WAVES / 2 : 2) v
 // order, to an LDS list (ballot + popcount); (2) all hit rows are fetched together into LDS; (3) thread (image, component) walks the
 // lists in order and adds from LDS.
 // The three phases as a body over caller-provided LDS (MAX_HITS: list capacity per workgroup and pass, a multiple of 256):
-//   sRow int[MAX_HITS], sRel u8[MAX_HITS], sVal float[MAX_HITS][12], sCnt int[4];  out192: [16][12] sums (LDS or global), written by
-// threads 0..191. Every thread of the 256-thread workgroup must call it.
-constexpr int PGR_SCAN = 20;
-template <int MAX_HITS, int TILE = 16>
+//   sRow int[MAX_HITS], sRel u8[MAX_HITS], sTag u8[MAX_HITS] (8-byte aligned), sVal float[MAX_HITS][12], sCnt int[W];  out192: [TILE][12] sums (LDS or
+// global), written by threads 0..12 TILE - 1. Every thread of the workgroup (W waves) must call it.
+template <int MAX_HITS, int TILE = 16, int W = 4>
 __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ row_dT, const int* __restrict__ row_image, const int n, const int i0,
-                                                      int* sRow, unsigned char* sRel, float (*sVal)[12], int* sCnt, float* out192,
+                                                      int* sRow, unsigned char* sRel, unsigned char* sTag, float (*sVal)[12], int* sCnt, float* out192,
                                                       unsigned long long* stamps = nullptr) {
 #ifdef ACEZ_DIAG
-#define PGR_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PGR_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (stamps && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define PGR_STAMP(i) do { } while (0)
 #endif
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  constexpr int cap = MAX_HITS / 4;            // list capacity per wave
+  constexpr int NT = 64 * W;                   // threads of the workgroup (W waves: sCnt int[W])
+  constexpr int cap = MAX_HITS / W;            // list capacity per wave
+  constexpr int SCAN = 80 / W;                 // table entries per lane in flight: a wave's share of a 5120-row batch in ONE round trip
   // One pass over all rows when the lists fit (many images: ~5 rows per image). Otherwise (few images) the rows are taken in several
   // passes: first of a size chosen from the number of hits the failed pass counted (half-full lists on average), and if a list still
   // overflows, of MAX_HITS rows, which cannot. Row order is preserved in every case.
@@ -621,19 +622,19 @@ __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ 
       // appends overwrote entries other waves were still summing -- wrong pose gradients whenever a tile needed more than one pass)
       if (cb > 0) __syncthreads();
       const int ce = min(n, cb + chunk);
-      const int q = ((ce - cb + 3) / 4 + 63) / 64 * 64;      // rows per wave in this pass
+      const int q = ((ce - cb + W - 1) / W + 63) / 64 * 64;      // rows per wave in this pass
       const int rb = cb + w * q, re = min(ce, rb + q);
       int cnt = 0;
-      for (int c0 = rb; c0 < re; c0 += 64 * PGR_SCAN) {      // 20 table entries per lane in flight (a wave's 1280 rows of a 5120-row batch: ONE round trip)
-        int rel[PGR_SCAN];
+      for (int c0 = rb; c0 < re; c0 += 64 * SCAN) {
+        int rel[SCAN];
 #pragma unroll
-        for (int j = 0; j < PGR_SCAN; ++j) {
+        for (int j = 0; j < SCAN; ++j) {
           const int r = c0 + 64 * j + lane;
           const int v = row_image[min(r, n - 1)];   // unconditional load (a load under a branch is waited for on the spot)
           rel[j] = (r < re) ? v - i0 : -1;
         }
 #pragma unroll
-        for (int j = 0; j < PGR_SCAN; ++j) {
+        for (int j = 0; j < SCAN; ++j) {
           const bool hit = rel[j] >= 0 && rel[j] < TILE;
           const unsigned long long m = __ballot(hit);
           if (m == 0ull) continue;                 // (most groups of 64 rows hold no row of the tile's images)
@@ -648,55 +649,52 @@ __device__ __forceinline__ void pose_grad_reduce_body(const float* __restrict__ 
       __syncthreads();                             // previous pass' readers of the lists are done
       if (lane == 0) sCnt[w] = cnt;
       __syncthreads();
-      if (sCnt[0] > cap || sCnt[1] > cap || sCnt[2] > cap || sCnt[3] > cap) {
+      int cn[W], pre[W + 1];                       // the lists' counts and their prefix sums (list order = wave order = row order)
+      pre[0] = 0;
+      bool over = false;
+#pragma unroll
+      for (int v = 0; v < W; ++v) { cn[v] = sCnt[v]; pre[v + 1] = pre[v] + cn[v]; over = over || cn[v] > cap; }
+      const int H = pre[W];
+      if (over) {
         overflow = true;
-        // hits per row seen in this pass -> rows per pass that would leave the lists half full (a multiple of 256, at least MAX_HITS)
-        const int hits = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
-        const long rows = (long)(ce - cb) * (MAX_HITS / 2) / hits;
-        chunk = attempt == 0 ? (int)max((long)MAX_HITS, rows / 256 * 256) : MAX_HITS;   // MAX_HITS / 4 rows per wave: the lists cannot overflow
+        // hits per row seen in this pass -> rows per pass that would leave the lists half full (a multiple of the workgroup's threads, at least MAX_HITS)
+        const long rows = (long)(ce - cb) * (MAX_HITS / 2) / H;
+        chunk = attempt == 0 ? (int)max((long)MAX_HITS, rows / NT * NT) : MAX_HITS;   // MAX_HITS / W rows per wave: the lists cannot overflow
         break;
       }
-      {   // fetch all hit rows: 8 independent loads per thread and round trip
-        const int b1 = sCnt[0], b2 = b1 + sCnt[1], b3 = b2 + sCnt[2], H = b3 + sCnt[3];
-        for (int f0 = 0; f0 < H * 12; f0 += 256 * 8) {
-          float tmp[8];
-          int slot[8];
+      {   // fetch all hit rows, COMPACTED: hit hh of the lists' concatenation (wave order = row order) goes to sVal[hh], its image tag
+          // to sTag[hh]. One load per thread covers 64 W / 12 hits (a 4-image tile of a 5120-row batch has ~20); more hits, more rounds.
+        for (int f0 = 0; f0 < H * 12; f0 += NT) {
+          const int f = f0 + t;
+          const int hh = min(f / 12, H - 1), c = f % 12;
+          int wv = 0, base = 0;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int f = f0 + t + 256 * u;
-            const int hh = min(f / 12, H - 1), c = f % 12;
-            const int wv = (hh >= b3) ? 3 : (hh >= b2) ? 2 : (hh >= b1) ? 1 : 0;
-            const int base = (wv == 3) ? b3 : (wv == 2) ? b2 : (wv == 1) ? b1 : 0;
-            slot[u] = (f < H * 12) ? wv * cap + (hh - base) : -1;
-            tmp[u] = row_dT[(size_t)sRow[wv * cap + (hh - base)] * 12 + c];
+          for (int v = 1; v < W; ++v) { wv += hh >= pre[v] ? 1 : 0; base = hh >= pre[v] ? pre[v] : base; }
+          const int slot = wv * cap + (hh - base);
+          const float x = row_dT[(size_t)sRow[slot] * 12 + c];
+          if (f < H * 12) {
+            sVal[hh][c] = x;
+            if (c == 0) sTag[hh] = sRel[slot];
           }
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (slot[u] >= 0) sVal[slot[u]][(f0 + t + 256 * u) % 12] = tmp[u];
         }
       }
       __syncthreads();
       PGR_STAMP(1);                                // hit rows in LDS
       if (t < TILE * 12) {
-        // the hits in list order (wave 0's list, then wave 1's, ...), eight at a time: the image tags of a group are ONE 8-byte read and
-        // its values eight unconditional reads, all requested together, then added in order -- one LDS round trip per group (hit by
-        // hit, with the value read under the tag's branch, it was two dependent round trips each: 2.2 us for the ~20 hits of a
-        // 4-image tile, tools/pose_trace.py). Entries past a list's count are read (inside the list's capacity) and not added.
+        // the hits in row order, eight at a time: the image tags of a group are ONE 8-byte read and its values eight unconditional
+        // reads, all requested together, then added in order -- one LDS round trip per group (hit by hit, with the value read under
+        // the tag's branch, it was two dependent round trips each: 2.2 us for the ~20 hits of a 4-image tile, tools/pose_trace.py).
+        // Entries past H are read (inside the arrays) and not added.
         const int im = t / 12, c = t % 12;
-        static_assert(cap % 8 == 0, "8-byte tag reads");
-        const int cn[4] = {sCnt[0], sCnt[1], sCnt[2], sCnt[3]};
+        for (int h0 = 0; h0 < H; h0 += 8) {
+          const uint2 tg = *reinterpret_cast<const uint2*>(sTag + h0);
+          float val[8];
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
-          for (int h0 = 0; h0 < cn[wv]; h0 += 8) {
-            const uint2 tg = *reinterpret_cast<const uint2*>(sRel + wv * cap + h0);
-            float val[8];
+          for (int u = 0; u < 8; ++u) val[u] = sVal[min(h0 + u, MAX_HITS - 1)][c];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) val[u] = sVal[wv * cap + h0 + u][c];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int tag = (int)(((u < 4 ? tg.x : tg.y) >> (8 * (u & 3))) & 0xffu);
-              if (h0 + u < cn[wv] && tag == im) acc += val[u];
-            }
+          for (int u = 0; u < 8; ++u) {
+            const int tag = (int)(((u < 4 ? tg.x : tg.y) >> (8 * (u & 3))) & 0xffu);
+            if (h0 + u < H && tag == im) acc += val[u];
           }
         }
       }
@@ -712,12 +710,13 @@ __global__ __launch_bounds__(256) void pose_grad_reduce2_kernel(const float* row
                                                                 float* dT /*[I][12]*/, int n_images, const int* active) {
   if (active && !*active) return;
   __shared__ int sRow[PGR_MAX_HITS];
-  __shared__ __attribute__((aligned(8))) unsigned char sRel[PGR_MAX_HITS];
+  __shared__ unsigned char sRel[PGR_MAX_HITS];
+  __shared__ __attribute__((aligned(8))) unsigned char sTag[PGR_MAX_HITS];
   __shared__ float sVal[PGR_MAX_HITS][12];
   __shared__ int sCnt[4];
   __shared__ float sOut[16 * 12];
   const int t = threadIdx.x, i0 = blockIdx.x * 16;
-  pose_grad_reduce_body<PGR_MAX_HITS>(row_dT, row_image, n, i0, sRow, sRel, sVal, sCnt, sOut);
+  pose_grad_reduce_body<PGR_MAX_HITS>(row_dT, row_image, n, i0, sRow, sRel, sTag, sVal, sCnt, sOut);
   if (t < 16 * 12 && i0 + t / 12 < n_images) dT[(size_t)(i0 + t / 12) * 12 + t % 12] = sOut[t];   // (each thread reads its own word back)
 }
 
@@ -728,15 +727,16 @@ __global__ __launch_bounds__(256) void pose_grad_reduce2_kernel(const float* row
 // activation tiles share storage.
 // ---------------------------------------------------------------------------------------------------
 constexpr int PS1_HITS = 512;
-constexpr int PS1_SMEM_BYTES = PS1_HITS * 4 + PS1_HITS + 16 + 16 * 12 * 4 + PS1_HITS * 12 * 4;   // sRow, sRel, sCnt, sDT, sVal | (sD, sX, sY)
+constexpr int PS1_SMEM_BYTES = PS1_HITS * 4 + 2 * PS1_HITS + 16 + 16 * 12 * 4 + PS1_HITS * 12 * 4;   // sRow, sRel, sTag, sCnt, sDT, sVal | (sD, sX, sY)
 static_assert(PS1_HITS * 12 * 4 >= (12 + 128 + 128) * PN_IMG * 4, "the chain's tiles must fit in the hit-value area");
 __device__ __forceinline__ void pose_s1_body(const PoseNetArgs& a, const float* row_dT, const int* row_image, const int n, const int tile, char* smem) {
   int* sRow = reinterpret_cast<int*>(smem);
   unsigned char* sRel = reinterpret_cast<unsigned char*>(smem + PS1_HITS * 4);
-  int* sCnt = reinterpret_cast<int*>(smem + PS1_HITS * 5);
-  float* sDT = reinterpret_cast<float*>(smem + PS1_HITS * 5 + 16);
+  unsigned char* sTag = reinterpret_cast<unsigned char*>(smem + PS1_HITS * 5);
+  int* sCnt = reinterpret_cast<int*>(smem + PS1_HITS * 6);
+  float* sDT = reinterpret_cast<float*>(smem + PS1_HITS * 6 + 16);
   float* area = sDT + 16 * 12;
-  pose_grad_reduce_body<PS1_HITS>(row_dT, row_image, n, tile * PN_IMG, sRow, sRel, reinterpret_cast<float (*)[12]>(area), sCnt, sDT);
+  pose_grad_reduce_body<PS1_HITS>(row_dT, row_image, n, tile * PN_IMG, sRow, sRel, sTag, reinterpret_cast<float (*)[12]>(area), sCnt, sDT);
   __syncthreads();   // sDT complete; the hit values are dead, their area becomes the chain's tiles
   pose_mlp_bwd_body(a, tile, sDT, area, area + 12 * PN_IMG, area + (12 + 128) * PN_IMG);
 }

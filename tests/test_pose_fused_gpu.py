@@ -76,9 +76,10 @@ def test_fused_pose_launches_equal_separate_launches_bitwise(name, n_images, n):
 @pytest.mark.parametrize("name,n_images,n", [("head_tanh_posemlp", 37, 1024), ("head_tanh_posemlp", 1000, 5120),
                                              ("head_tanh_posemlp_procrustes", 21, 333), ("head_tanh_posemlp", 3, 2048)])
 def test_small_image_tiles_match_the_16_image_tiles(tile, name, n_images, n):
-    """The default tile of the fused path is 8 images (pose_small.hip: v_mfma_f32_4x4x1_16b_f32, the reduction split in two halves
-    combined in a fixed order), a different -- equally valid -- summation order than the 16-image tiles: refined poses and pose
-    gradients agree to fp32 rounding, not bit for bit. What must still hold bit for bit is that the fused single-GPU step and the
+    """The default tile of the fused path is 4 images (pose_small.hip: v_mfma_f32_4x4x1_16b_f32, the reduction split in four slices in
+    the forward and two in the backward chain, combined in a fixed order), a different -- equally valid -- summation order than the
+    16-image tiles: refined poses and pose gradients agree to fp32 rounding, not bit for bit (3e-5 of the gradient's norm: seven
+    128-deep fp32 reductions each way, and an activation within rounding of zero flips its relu mask). What must still hold bit for bit is that the fused single-GPU step and the
     split backward / update flow of the SAME tile size agree (same kernels' bodies), and two runs (determinism)."""
     prob = _problem(n_images, patches_per_view=max(128, 2 * n // (2 * n_images) + 1))
     cfg = helpers.full_cfg(helpers.HEAD_CONFIGS[name], prob)
@@ -100,7 +101,7 @@ def test_small_image_tiles_match_the_16_image_tiles(tile, name, n_images, n):
         split.backward(idx)
         torch.cuda.synchronize()
         g_ref, g_new = ref.grad[npar + 4:].cpu().numpy(), split.grad[npar + 4:].cpu().numpy()
-        assert np.linalg.norm(g_new - g_ref) <= 2e-5 * np.linalg.norm(g_ref), (it, np.linalg.norm(g_new - g_ref) / np.linalg.norm(g_ref))
+        assert np.linalg.norm(g_new - g_ref) <= 3e-5 * np.linalg.norm(g_ref), (it, np.linalg.norm(g_new - g_ref) / np.linalg.norm(g_ref))
         h_ref, h_new = ref.grad[:npar].cpu().numpy(), split.grad[:npar].cpu().numpy()   # (the head sees refined poses that differ in the last bits)
         assert np.linalg.norm(h_new - h_ref) <= 2e-3 * np.linalg.norm(h_ref)
         ref.update()
