@@ -144,7 +144,7 @@ struct acez_trainer {
   int wgo_recovered = 0;          // faulted wgrad_opt steps the fall-back has finished (wgo_recover)
   bool sizing = false;            // acez_trainer_create's first pass: dmalloc only adds up
   size_t sized_total = 0;
-  unsigned long long* pose_trace = nullptr;  // ACEZ_POSE_TRACE=1 (diagnostics build): [2][1024][16] stamps of the pose forward (S3) / S1 workgroups (debug_read kind 8)
+  unsigned long long* pose_trace = nullptr;  // ACEZ_POSE_TRACE=1 (diagnostics build): [3][1024][16] stamps of the pose forward (S3) / S1 / S2 workgroups (debug_read kind 8)
   unsigned long long* wgo_trace = nullptr;   // ACEZ_WGO_TRACE=1 (diagnostics build): s_memtime stamps of wgrad_opt_kernel's last launch (debug_read kind 7)
 };
 
@@ -400,7 +400,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   A((void**)&tr->seq_flags, (64 * 32 + 32) * sizeof(uint32_t));
   if (ACEZ_DIAG_ENV("ACEZ_SEQ_XCC")) A((void**)&tr->seq_xcc, (8 + 256) * sizeof(uint32_t));
   if (ACEZ_DIAG_ENV("ACEZ_CHAIN_TRACE")) A((void**)&tr->chain_trace, 512 * sizeof(unsigned long long));
-  if (ACEZ_DIAG_ENV("ACEZ_POSE_TRACE")) A((void**)&tr->pose_trace, 2 * 1024 * 16 * sizeof(unsigned long long));
+  if (ACEZ_DIAG_ENV("ACEZ_POSE_TRACE")) A((void**)&tr->pose_trace, 3 * 1024 * 16 * sizeof(unsigned long long));
   if (ACEZ_DIAG_ENV("ACEZ_WGO_TRACE")) A((void**)&tr->wgo_trace, 256 * 12 * 8 * sizeof(unsigned long long));
   if (trains) {
     A((void**)&tr->R0_alt, act_bytes);
@@ -434,7 +434,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGRAD_OPT")) tr->wgrad_opt = atoi(e) != 0;
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_AT")) tr->wgo_fault_at = atol(e);
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_MOD")) tr->wgo_fault_mod = atoi(e);
-  if (tr->pose_trace) ACEZ_HIP_CHECK(hipMemset(tr->pose_trace, 0, 2 * 1024 * 16 * sizeof(unsigned long long)));
+  if (tr->pose_trace) ACEZ_HIP_CHECK(hipMemset(tr->pose_trace, 0, 3 * 1024 * 16 * sizeof(unsigned long long)));
   if (tr->wgo_trace) ACEZ_HIP_CHECK(hipMemset(tr->wgo_trace, 0, 256 * 12 * 8 * sizeof(unsigned long long)));
   if (trains) {
     ACEZ_HIP_CHECK(hipMemset(tr->wg_flags, 0, (size_t)tr->L * 16 * 2 * 32 * sizeof(uint32_t)));
@@ -779,6 +779,7 @@ static void launch_pose_wgrad(acez_trainer* tr, const int* active, bool fuse, hi
   w.I = I; w.grad = tr->pb.d_grad + tr->n_params + 4; w.active = active;
   w.fuse = fuse ? 1 : 0; w.p = tr->pb.d_pose_params; w.m = tr->pb.d_pose_m; w.v = tr->pb.d_pose_v; w.Wt = tr->pose_wt;
   w.sc = &tr->st->pose_adam; w.enable = &tr->st->pose_enable; w.fault = tr->seq_err;
+  if (tr->pose_trace && jobs <= 1024) w.trace = tr->pose_trace + (size_t)2 * 1024 * 16;
   static const int wb = ACEZ_DIAG_ENV("ACEZ_POSE_WB") ? atoi(ACEZ_DIAG_ENV("ACEZ_POSE_WB")) : 16;   // operand steps requested per round trip
   static const int ww = ACEZ_DIAG_ENV("ACEZ_POSE_WW") ? atoi(ACEZ_DIAG_ENV("ACEZ_POSE_WW")) : 8;    // waves per workgroup
   if (wb == 16 && ww == 4) hipLaunchKernelGGL((pose_mlp_wgrad_kernel<16, 4>), dim3(jobs), dim3(256), 0, s, w);
@@ -1449,7 +1450,7 @@ extern "C" int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, vo
   else if (kind == 5 && tr->chain_trace) { src = tr->chain_trace; cap = 512 * 8; }
   else if (kind == 6 && tr->seq_xcc) { src = tr->seq_xcc; cap = (8 + 256) * 4; }
   else if (kind == 7 && tr->wgo_trace) { src = tr->wgo_trace; cap = 256 * 12 * 8 * 8; }
-  else if (kind == 8 && tr->pose_trace) { src = tr->pose_trace; cap = 2 * 1024 * 16 * 8; }
+  else if (kind == 8 && tr->pose_trace) { src = tr->pose_trace; cap = 3 * 1024 * 16 * 8; }
   ACEZ_REQUIRE(src && bytes <= cap, "unknown buffer or size out of range");
   ACEZ_HIP_CHECK(hipMemcpyAsync(h_out, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));

@@ -470,16 +470,25 @@ struct PoseWgradArgs {
   const AdamScalars* sc;
   const int* enable;      // st->pose_enable (ace_trainer.py:634-636)
   const int* fault;       // rowseq fault word: an abandoned step updates nothing
+  unsigned long long* trace;   // diagnostics build (ACEZ_POSE_TRACE=1): [jobs][16] s_memtime stamps of thread 0; else null
 };
-// PW_WAVES waves per workgroup: each takes 1 / PW_WAVES of the images (8 waves at 1000 images: 32 MFMA steps = ONE batch of loads)
+// PW_WAVES waves per workgroup: each takes 1 / PW_WAVES of the images (8 waves at 1000 images: 32 MFMA steps = two batches of 16 loads;
+// ten waves with ONE batch of 26 -- measured in round 5 -- shortened the slowest workgroup from 10.7 to 8.5 us and still lengthened the
+// launch by 18 %: 640-thread workgroups take longer to place than the round trip they save)
 template <int PW_BATCH, int PW_WAVES>
 __global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? PW_WAVES / 2 : 2) void pose_mlp_wgrad_kernel(PoseWgradArgs a) {   // (<= 128 registers: two workgroups per CU, the 354 jobs in one round)
-  if (a.active && !*a.active) return;
+  // the launch's three flag words in ONE scalar round trip (tested one after the other -- `active` in front of everything, the other
+  // two in front of the optimiser's operands -- they were two dependent ones: tools/pose_trace.py, 1.6 us from entry to the first request)
+  const int f_active = a.active ? *a.active : 1, f_enable = a.fuse ? *a.enable : 0, f_fault = a.fuse ? *a.fault : 0;
+  if (!f_active) return;
+  const bool upd = a.fuse && f_enable && !f_fault;
+  PN_STAMP(a, blockIdx.x, 0);
   __shared__ float sAcc[PW_WAVES][2][16][17];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = l & 15, lk = l >> 4;
-  int layer = 0;
-  while (layer < 6 && (int)blockIdx.x >= a.job_start[layer + 1]) ++layer;
+  int layer = 0;   // (all seven bounds in one scalar load, compared in registers: the search loop was up to six dependent kernel-argument loads)
+#pragma unroll
+  for (int q = 1; q <= 6; ++q) layer += (int)blockIdx.x >= a.job_start[q] ? 1 : 0;
   const int O = a.O[layer], K = a.K[layer], xp = a.xpitch[layer];
   const int kb = (K + 15) / 16;
   const int job = (int)blockIdx.x - a.job_start[layer];
@@ -490,7 +499,8 @@ __global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? PW_WAVES / 2 : 2) v
   const int ib = w * per, ie = min(a.I, ib + per);
   const bool vo = o0 + li < O, vk = k0 + li < K;
   const int oc = min(o0 + li, O - 1), kc = min(k0 + li, K - 1);
-  pn_f4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f}, accb2 = {0.f, 0.f, 0.f, 0.f};
+  pn_f4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;   // sum over this lane's images (4 g + lk) of dY[img][o0 + li]
   const bool want_bias = k0 == 0;
   // full groups of 4 images: plain pointer walks (the address arithmetic, not the MFMA, was the cost of this loop)
   const int nfull = (ie > ib) ? (ie - ib) / 4 : 0;
@@ -498,7 +508,6 @@ __global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? PW_WAVES / 2 : 2) v
   const float* pb = X + (size_t)(ib + lk) * xp + kc;
   const size_t sa = (size_t)4 * O, sb = (size_t)4 * xp;
   // the optimiser's operands (fused epilogue) do not depend on anything computed here: requested first
-  const bool upd = a.fuse && *a.enable && !*a.fault;
   float pw[4], mw[4], vw[4], pb4[4], mb4[4], vb4[4];
   if (upd && w == 0) {
 #pragma unroll
@@ -509,6 +518,7 @@ __global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? PW_WAVES / 2 : 2) v
       pb4[r] = a.p[ib]; mb4[r] = a.m[ib]; vb4[r] = a.v[ib];
     }
   }
+  PN_STAMP(a, blockIdx.x, 1);
   // PW_BATCH steps of operands are requested together (the compiler keeps a runtime-trip-count loop at one step per L2 round trip;
   // with 16 per batch a wave's 63 steps at 1000 images were four dependent round trips, with 64 they are one)
   for (int g0 = 0; g0 < nfull; g0 += PW_BATCH) {
@@ -528,16 +538,16 @@ __global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? PW_WAVES / 2 : 2) v
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
       acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j + 1], bv[j + 1], acc2, 0, 0, 0);
     }
+    // the bias gradient (tiles with k-block 0): this lane's images summed in order on the vector ALU. (As a second MFMA chain against
+    // B = 1 it doubled the matrix time of exactly the tiles that end the launch: 8.5 us against 6.5 us for the others, tools/pose_trace.py.)
     if (want_bias) {
 #pragma unroll
-      for (int j = 0; j < PW_BATCH; j += 2) {
-        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], (g0 + j < nfull) ? 1.f : 0.f, accb, 0, 0, 0);
-        accb2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j + 1], (g0 + j + 1 < nfull) ? 1.f : 0.f, accb2, 0, 0, 0);
-      }
+      for (int j = 0; j < PW_BATCH; ++j) bsum += av[j];
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { acc[r] += acc2[r]; accb[r] += accb2[r]; }
+  for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+  PN_STAMP(a, blockIdx.x, 2);
   if (ie > ib && ib + 4 * nfull < ie) {   // ragged last group
     const int img = ib + 4 * nfull + lk;
     const bool vi = img < ie;
@@ -546,15 +556,19 @@ __global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? PW_WAVES / 2 : 2) v
     if (!(vi && vo)) av = 0.f;
     if (!(vi && vk)) bv = 0.f;
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-    if (want_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av, vi ? 1.f : 0.f, accb, 0, 0, 0);
+    if (want_bias) bsum += av;
   }
   // lane: column li (k), rows 4 * lk + r (o)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    sAcc[w][0][4 * lk + r][li] = acc[r];
-    sAcc[w][1][4 * lk + r][li] = accb[r];
+  for (int r = 0; r < 4; ++r) sAcc[w][0][4 * lk + r][li] = acc[r];
+  if (want_bias) {   // the four image residues of the wave, (0 + 1) + (2 + 3) in every lane, then one value per output row
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lk == 0) sAcc[w][1][0][li] = bsum;
   }
+  PN_STAMP(a, blockIdx.x, 3);
   __syncthreads();
+  PN_STAMP(a, blockIdx.x, 4);
   if (w == 0) {
     AdamScalars s{};
     if (upd) s = *a.sc;
@@ -574,9 +588,9 @@ __global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? PW_WAVES / 2 : 2) v
         }
       }
       if (want_bias && li == 0 && o < O) {
-        float gb = sAcc[0][1][oo][0];
+        float gb = sAcc[0][1][0][oo];
 #pragma unroll
-        for (int wv = 1; wv < PW_WAVES; ++wv) gb += sAcc[wv][1][oo][0];
+        for (int wv = 1; wv < PW_WAVES; ++wv) gb += sAcc[wv][1][0][oo];
         const size_t ib = a.offB[layer] + o;
         a.grad[ib] = gb;
         if (upd) {
@@ -586,6 +600,7 @@ __global__ __launch_bounds__(64 * PW_WAVES, PW_BATCH <= 32 ? PW_WAVES / 2 : 2) v
       }
     }
   }
+  PN_STAMP(a, blockIdx.x, 5);
 }
 
 // dT[i][:] = sum over the batch rows whose image is i of row_dT[row][:], rows in increasing order (fixed order, no atomics).

@@ -31,20 +31,21 @@ with N.diag_library():
     for i in range(40):
         tr.step(batches[i], batches[i + 1])
     torch.cuda.synchronize()
-    raw = np.zeros(2 * 1024 * 16, np.uint64)
+    raw = np.zeros(3 * 1024 * 16, np.uint64)
     N.check(tr.lib.acez_trainer_debug_read(tr._h, 8, 0, raw.ctypes.data_as(C.c_void_p), raw.nbytes, None))
-t = raw.reshape(2, 1024, 16).astype(np.int64)
+t = raw.reshape(3, 1024, 16).astype(np.int64)
 # s_memtime: the 100 MHz constant clock or the shader clock (~2.4 GHz), depending on the part's firmware: decided from the size of an
 # S1 workgroup's entry -> exit difference (the launch lasts ~20 us)
 _d = np.median((t[1][:, 8] - t[1][:, 0])[t[1][:, 0] > 0])
 tick_us = float(os.environ.get("TICK_US", "0.01" if _d < 20000 else str(1 / 2400.0)))
 print("ticks of an S1 workgroup:", _d, "-> tick =", tick_us, "us")
-names = [["entry", "conv1", "conv2", "conv3", "skip + res", "fc1", "fc2", "fc3", "poses stored", "(conv2) weights requested", "(conv2) barrier passed",
-          "(conv2) products done", "(conv2) halves exchanged"],
+names = [["entry", "conv1", "conv2", "conv3", "skip + res", "fc1", "fc2", "fc3", "poses stored"],
          ["entry", "reduce done", "compose backward", "through fc3", "through fc2", "through fc1", "conv3 mask", "through conv3", "through conv2",
-          "(reduce) table scan", "(reduce) hit rows in LDS", "(compose) raw pose ready", "(compose) arithmetic done"]]
-order = [[0, 1, 9, 10, 11, 12, 2, 3, 4, 5, 6, 7, 8], [0, 9, 10, 1, 11, 12, 2, 3, 4, 5, 6, 7, 8]]
-for slot, title in enumerate(["S3: pose forward workgroups (step_begin_pose_kernel)", "S1: reduce + backward chain workgroups (adamw_pose_kernel)"]):
+          "(reduce) table scan", "(reduce) hit rows in LDS", "(compose) raw pose ready", "(compose) arithmetic done"],
+         ["entry", "optimiser operands requested", "products done", "partial sums written", "barrier passed", "stored"]]
+order = [[0, 1, 2, 3, 4, 5, 6, 7, 8], [0, 9, 10, 1, 11, 12, 2, 3, 4, 5, 6, 7, 8], [0, 1, 2, 3, 4, 5]]
+for slot, title in enumerate(["S3: pose forward workgroups (step_begin_pose_kernel)", "S1: reduce + backward chain workgroups (adamw_pose_kernel)",
+                              "S2: weight-gradient tiles + AdamW (pose_mlp_wgrad_kernel)"]):
     x = t[slot]
     ok = x[:, 0] > 0
     rel = (x[ok] - x[ok][:, :1]) * tick_us
@@ -56,3 +57,16 @@ for slot, title in enumerate(["S3: pose forward workgroups (step_begin_pose_kern
         prev = v
     span = (x[ok][:, order[slot][-1]].max() - x[ok][:, 0].min()) * tick_us
     print(f"  first entry -> last exit over all workgroups: {span:.2f} us (one clock domain only if the counters agree across XCDs)")
+# S2 by job class: layer (job_start of launch_pose_wgrad: 8, 64, 64, 8, 64, 64, 8 tiles) and whether the tile also produces the bias gradient
+starts = [0, 8, 72, 136, 144, 208, 272, 280]
+lname = ["fc3", "fc2", "fc1", "skip", "conv3", "conv2", "conv1"]
+kb = [8, 8, 8, 1, 8, 8, 1]
+x = t[2][:280]
+tot = (x[:, 5] - x[:, 0]) * tick_us
+for l in range(7):
+    j = np.arange(starts[l], starts[l + 1])
+    bias = ((j - starts[l]) % kb[l]) == 0
+    for nm, sel in (("bias tiles", bias), ("other tiles", ~bias)):
+        if sel.any():
+            v = tot[j[sel]]
+            print(f"  S2 {lname[l]:6s} {nm:11s} n {sel.sum():3d}  median {np.median(v):6.2f}  max {v.max():6.2f}")
