@@ -1659,6 +1659,7 @@ struct acez_encoder {
   float* w1 = nullptr;                 // conv1 weights [32][9] (bf16-rounded values in fp32)
   uint16_t* w1b = nullptr;             // conv1 weights bf16 [32][16] (k = tap, zero padded): A operand of conv12_kernel
   bool fuse12 = true;                  // ACEZ_CONV12=0: separate conv1 / conv2 kernels
+  bool conv12p = true;   // conv12p_kernel (round 5); ACEZ_CONV12P=0 (diagnostics build, read at creation): conv12_kernel
   float* bias[ACEZ_ENCODER_LAYERS] = {};
   uint16_t* W[ACEZ_ENCODER_LAYERS] = {};   // bf16 [co][Kp] (layers 1..10)
   int K[ACEZ_ENCODER_LAYERS] = {}, Kp[ACEZ_ENCODER_LAYERS] = {}, co[ACEZ_ENCODER_LAYERS] = {};
@@ -1693,6 +1694,7 @@ extern "C" int acez_encoder_create(acez_encoder** out, const float* const* h_wei
   e->device = device; e->out_channels = out_channels; e->max_frames = max_frames; e->max_h = max_h; e->max_w = max_w;
   if (const char* tm = ACEZ_DIAG_ENV("ACEZ_CONV_TILE")) e->tile_mode = atoi(tm);
   if (const char* f12 = ACEZ_DIAG_ENV("ACEZ_CONV12")) e->fuse12 = atoi(f12) != 0;
+  if (const char* p12 = ACEZ_DIAG_ENV("ACEZ_CONV12P")) e->conv12p = atoi(p12) != 0;
   auto A = [&](void** p, size_t bytes) -> hipError_t {
     hipError_t rc = hipMalloc(p, bytes);
     if (rc == hipSuccess) e->allocs.push_back(*p);
@@ -1782,8 +1784,7 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
       c.tiles_y = (h2 + 7) / 8; c.tiles_x = (w2 + 31) / 32; c.n_tiles = F * c.tiles_y * c.tiles_x;
       // round 5: the software-pipelined kernel on 4 x 32 tiles (conv1 of tile i + 1 beside conv2 of tile i); ACEZ_CONV12P=0
       // (diagnostics build): round 1's phase-by-phase kernel on 8 x 32 tiles. Bit-identical outputs.
-      static const int pipelined = [] { const char* v = ACEZ_DIAG_ENV("ACEZ_CONV12P"); return v ? atoi(v) : 1; }();
-      if (pipelined) {
+      if (e->conv12p) {
         const int nt4 = F * ((h2 + 3) / 4) * c.tiles_x;
         hipLaunchKernelGGL(conv12p_kernel<4>, dim3(nt4 < 256 ? nt4 : 256), dim3(512), 0, s, c);
       } else {

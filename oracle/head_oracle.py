@@ -535,7 +535,7 @@ class TrainerOracle:
             pose_grad = self.pose.flat.grad.detach().clone()
             with torch.no_grad():
                 X = self.head.dehomogenise(sl)[0]
-            out = {"loss_sum": float(loss_sum), "inliers": inl, "ds": sl.grad.detach(), "focal_grad": 0.0, "X": X.detach()}
+            out = {"loss_sum": float(loss_sum.detach()), "inliers": inl, "ds": sl.grad.detach(), "focal_grad": 0.0, "X": X.detach()}
         grad = self.head.backward(tape, out["ds"])
         self.head.next_grad_scale()   # (fp16 mode: the device adapts its gradient scale after every step; no-op otherwise)
         loss = out["loss_sum"] / cfg["global_batch"]

@@ -46,6 +46,21 @@ def test_separate_conv1_conv2_path_still_matches(monkeypatch, diag_lib):
     assert _rel(out, ref) < 4e-3
 
 
+@pytest.mark.parametrize("shape", [(2, 72, 100), (3, 41, 77), (2, 480, 640)])
+def test_pipelined_conv12_equals_the_kernel_it_replaced_bitwise(shape, monkeypatch, diag_lib):
+    """conv12p_kernel (round 5: conv1 of tile j + 1 on four waves under conv2 of tile j on the other four, image patches staged two tiles
+    ahead) against conv12_kernel (ACEZ_CONV12P=0, diagnostics build): same products, same accumulation order, same roundings -- the
+    encoder's output must agree bit for bit, at ragged sizes (partial tiles, a workgroup with a single tile) and at 7-Scenes frames."""
+    from acezero_amd.encoder import Encoder
+    n, h, w = shape
+    sd = encoder_oracle.init_weights(seed=4099)
+    img = torch.from_numpy(synth.make_gray_images(seed=11 + w, n=n, h=h, w=w))
+    new = Encoder(sd, max_frames=n, max_h=h, max_w=w)(img).cpu()
+    monkeypatch.setenv("ACEZ_CONV12P", "0")
+    old = Encoder(sd, max_frames=n, max_h=h, max_w=w)(img).cpu()
+    assert torch.equal(new, old)
+
+
 def test_encoder_golden_reference_features():
     """Against the reference's own Encoder output (tests/golden/encoder_small.npz), at bf16 accuracy."""
     import os
