@@ -36,7 +36,7 @@ MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
 
 
 CSRC = os.path.join(ROOT, "acezero_amd", "csrc")
-STEP_SOURCES = ("head_api.hip", "head_kernels.hip", "head_kernels.h", "gemm_common.h", "pose_kernels.hip", "pose_fused.hip")
+STEP_SOURCES = ("head_api.hip", "head_kernels.hip", "head_kernels.h", "gemm_common.h", "pose_kernels.hip", "pose_small.hip", "pose_fused.hip")
 RANSAC_SOURCES = ("ransac_api.hip", "ransac_math.h", "det_math.h")
 WINDOWS = 5                       # timed windows of --steps steps each: `value` = mean over all of them, ms_per_step = their median
 

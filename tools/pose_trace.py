@@ -40,7 +40,7 @@ _d = np.median((t[1][:, 8] - t[1][:, 0])[t[1][:, 0] > 0])
 tick_us = float(os.environ.get("TICK_US", "0.01" if _d < 20000 else str(1 / 2400.0)))
 print("ticks of an S1 workgroup:", _d, "-> tick =", tick_us, "us")
 names = [["entry", "conv1", "conv2", "conv3", "skip + res", "fc1", "fc2", "fc3", "poses stored"],
-         ["entry", "reduce done", "compose backward", "through fc3", "through fc2", "through fc1", "conv3 mask", "through conv3", "through conv2",
+         ["entry", "reduce done", "compose backward", "through fc3", "through fc2", "through fc1", "a1 mask requested", "through conv3", "through conv2",
           "(reduce) table scan", "(reduce) hit rows in LDS", "(compose) raw pose ready", "(compose) arithmetic done"],
          ["entry", "optimiser operands requested", "products done", "partial sums written", "barrier passed", "stored"]]
 order = [[0, 1, 2, 3, 4, 5, 6, 7, 8], [0, 9, 10, 1, 11, 12, 2, 3, 4, 5, 6, 7, 8], [0, 1, 2, 3, 4, 5]]
@@ -55,8 +55,6 @@ for slot, title in enumerate(["S3: pose forward workgroups (step_begin_pose_kern
         v = rel[:, i]
         print(f"  {names[slot][i]:26s} median {np.median(v):7.2f}  p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f}   (+{np.median(v - prev):5.2f})")
         prev = v
-    span = (x[ok][:, order[slot][-1]].max() - x[ok][:, 0].min()) * tick_us
-    print(f"  first entry -> last exit over all workgroups: {span:.2f} us (one clock domain only if the counters agree across XCDs)")
 # S2 by job class: layer (job_start of launch_pose_wgrad: 8, 64, 64, 8, 64, 64, 8 tiles) and whether the tile also produces the bias gradient
 starts = [0, 8, 72, 136, 144, 208, 272, 280]
 lname = ["fc3", "fc2", "fc1", "skip", "conv3", "conv2", "conv1"]
