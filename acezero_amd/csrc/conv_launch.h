@@ -15,6 +15,7 @@ struct ConvGemmArgs {
   const uint16_t* zeros;  // >= 128 bytes of zeros: DMA source of every padded chunk
   int Hi, Wi, Ci, ci_shift, Ho, Wo, Co, ksize, stride, pad, K, Kp, M;
   int round_before_add;   // 1: the activation is rounded to bf16 BEFORE the residual is added (the head stores it: ace_network.py:126,133)
+  unsigned long long* trace;   // diagnostics build (tools/conv_trace.py): [tiles][8] s_memtime stamps of convgemm512's waves 0 and 8; else null
   int dbg;   // ablation (ACEZ_CONV_DBG; 0 in production). convgemm256/512: 2 = no MFMA, 4 = no loads. conv3x3p (loader side only):
              // 32 = weight DMA from 16 hot rows (same bytes into LDS), 64 = every other weight stage not fetched
 };

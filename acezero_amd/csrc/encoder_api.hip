@@ -14,6 +14,7 @@
 //                           im2col never exists in memory: a loader lane computes, per stage, the source address of its
 //                           16-byte chunk (8 input channels of one tap of one pixel) or points at a zero page for the
 //                           padding border / K padding / rows past the end.
+#include <algorithm>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -844,11 +845,22 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
   const int ntiles = Co >> 8;
   const int mtiles = (M + 255) >> 8;
   const int per_xcd = (mtiles + 7) >> 3;
+  const int KT = Kp >> 5;
+  // One workgroup per tile. A PERSISTENT walk over the tiles (one workgroup per CU, the next tile's first stages requested as soon as the
+  // output tile is out of LDS) was measured in round 5 (tools/conv_trace.py: a tile is 3.8 us to its first stage, 13.2 us of K loop, 1.6 us
+  // of epilogue, 2.4 us until its stores are acknowledged = 21.1 us of a 26.7 us period): bit-identical and 9 % SLOWER (2.55 against 2.34 ms
+  // for the head's eight layers) -- behind a tile's own 128 KiB of stores the next first stage lands after 6 us, and the hardware's
+  // overlap of one workgroup's drain with the next one's start is better than the in-workgroup sequence.
   const int jx = blockIdx.x >> 3;
   const int mt = (blockIdx.x & 7) * per_xcd + jx / ntiles;
   if (mt >= mtiles) return;
   const int n0 = (jx % ntiles) << 8, m0 = mt << 8;
-  const int KT = Kp >> 5;
+#ifdef ACEZ_DIAG   // tools/conv_trace.py: stamp i of this tile (slot 4 + i for the first loader wave)
+#define CG_STAMP(i) do { if (a.trace && (t == 0 || t == 512)) a.trace[((size_t)(mt * ntiles + jx % ntiles)) * 8 + (t ? 4 : 0) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CG_STAMP(i) do { } while (0)
+#endif
+  CG_STAMP(0);
 
   if (w >= 8) {
     // ------------------------------------------------------------------ loader waves
@@ -904,9 +916,11 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
       else if (later == 1) ACEZ_VMCNT(8);
       else ACEZ_VMCNT(0);
       __builtin_amdgcn_s_barrier();   // stage kt has landed; the multipliers are done with stage kt - 1
+      if (kt == 0) CG_STAMP(1);
       if (do_loads && kt >= 1 && kt + 3 < KT) issue(kt + 3);
     }
     __builtin_amdgcn_s_barrier();     // the multipliers have left the K loop: the ring is free
+    CG_STAMP(2);
     if (HAS_ADD) {
       // residual tile [256][256] -> ring space, 128 DMA instructions of 2 rows x 512 bytes (32 per loader)
       for (int j = 0; j < 32; ++j) {
@@ -949,6 +963,7 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
       }
     }
     __builtin_amdgcn_s_barrier();     // ring free
+    CG_STAMP(1);
     if (HAS_ADD) __builtin_amdgcn_s_barrier();
     // the eight bias vectors of this lane, fetched once before the tile is touched (inside the loops every one of the
     // 16-32 loads was followed by a full wait: as many serial L2 round trips per tile)
@@ -984,11 +999,15 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
     __builtin_amdgcn_s_barrier();
   }
   // ------------------------------------------------------------------ all twelve waves: copy the tile out, full 512-byte rows
+  CG_STAMP(2 + (t ? 1 : 0));   // (multiplier slot 2 / loader slot 3: the epilogue tile is complete)
   for (int q = t; q < 256 * 32; q += 768) {
     const int row = q >> 5, ch = q & 31, m = m0 + row;
     if (m < M)
       *reinterpret_cast<uint4*>(a.out + (size_t)m * Co + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&smem[row * 256 + ((ch ^ (row & 31)) << 3)]);
   }
+#ifdef ACEZ_DIAG
+  if (a.trace && t == 0) { ACEZ_VMCNT(0); CG_STAMP(3); }   // this wave's stores acknowledged
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1472,8 +1491,16 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
   }
 }
 
+#ifdef ACEZ_DIAG
+static unsigned long long* g_conv_trace = nullptr;
+extern "C" void diagz_conv_trace(void* buf) { g_conv_trace = static_cast<unsigned long long*>(buf); }   // tools/conv_trace.py (not an acez_ symbol: the two builds export the same C ABI)
+#endif
 // tile_mode: 0 = choose by size, 80 / 256 = force that row tile where the layer shape allows it (ACEZ_CONV_TILE, tests)
-void launch_convgemm(const ConvGemmArgs& g, bool relu, hipStream_t s, int tile_mode) {
+void launch_convgemm(const ConvGemmArgs& g_in, bool relu, hipStream_t s, int tile_mode) {
+  ConvGemmArgs g = g_in;
+#ifdef ACEZ_DIAG
+  g.trace = g_conv_trace;
+#endif
   const bool patch_ok = g.ksize == 3 && g.stride == 1 && g.pad == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.Wi <= (P3_ROWS - 258) / 2 &&
                         g.Ci % 32 == 0 && g.Co % 256 == 0 && g.K == g.Kp;
   // the patch kernel pays from one tile per CU on (16 frames of 480x640 at Co = 256: 0.0925 -> 0.0775 ms per frame against the
