@@ -1304,6 +1304,7 @@ static uint16_t* launch_forward_conv(acez_trainer* tr, const uint16_t* in0, int 
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144; g.add = add; g.out = out;
     g.zeros = tr->zeros; g.Hi = 1; g.Wi = 1; g.Ci = 512; g.ci_shift = 9; g.Ho = 1; g.Wo = 1; g.Co = 512; g.ksize = 1; g.stride = 1;
     g.pad = 0; g.K = 512; g.Kp = 512; g.M = n; g.round_before_add = 1; g.dbg = 0;
+    if (const char* e = ACEZ_DIAG_ENV("ACEZ_CONV_DBG")) g.dbg = atoi(e);   // (diagnostics build: convgemm512's ablation / stagger bits)
     static const int conv_tile = ACEZ_DIAG_ENV("ACEZ_HEAD_CONV_TILE") ? atoi(ACEZ_DIAG_ENV("ACEZ_HEAD_CONV_TILE")) : 0;   // (diagnostics build: 256 / 512 force a tile; round 5: the 256 x 128 tiles, which keep a third more input bytes in flight, are 8 % SLOWER here: 2.54 against 2.35 ms per 64 frames)
     launch_convgemm(g, true, s, conv_tile);
   };
