@@ -43,7 +43,7 @@ class TrainConfig(C.Structure):
                 ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("refine_calibration", C.c_int32),
                 ("focal_init", C.c_float), ("calib_lr", C.c_double), ("pose_refinement", C.c_int32), ("pose_refinement_wait", C.c_int32),
                 ("pose_refinement_lr", C.c_double), ("pose_refinement_weight", C.c_float), ("pose_refinement_ortho", C.c_int32),
-                ("compute_dtype", C.c_int32)]
+                ("compute_dtype", C.c_int32), ("inference_only", C.c_int32)]
 
 
 class ParamBuffers(C.Structure):
@@ -104,7 +104,7 @@ SYMBOLS = {
     "acez_buffer_sample_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "acez_encoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int,
-                                      C.c_int, C.c_int]),
+                                      C.c_int, C.c_int, C.c_int]),
     "acez_encoder_destroy": (None, [C.c_void_p]),
     "acez_encoder_output_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "acez_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -6,7 +6,7 @@
     buf = bld.finish()        # dict for HeadTrainer.set_buffer(**buf)
 
 What differs from the reference, by design: per-view data (augmentation pose, intrinsics, image index) is
-stored once per view and per-image poses once per image instead of once per patch; features are bf16. The image pipeline that
+stored once per view and per-image poses once per image instead of once per patch; features are 16-bit in the encoder's operand format (bf16, or fp16 as the reference stores them, ace_trainer.py:330). The image pipeline that
 produces the views (decode / resize / rotate / jitter, dataset.py) is not part of this package.
 There is no CPU fallback.
 """
@@ -27,7 +27,7 @@ class BufferBuilder:
         self.samples = int(samples_per_image)       # --samples_per_image (train_ace.py:128)
         self.seed = int(seed)
         self.n = 0
-        self.features = torch.empty((self.capacity, encoder.out_channels), dtype=torch.bfloat16, device=self.dev)
+        self.features = torch.empty((self.capacity, encoder.out_channels), dtype=encoder.feature_dtype, device=self.dev)
         self.target_px = torch.empty((self.capacity, 2), dtype=torch.float32, device=self.dev)
         self.view_idx = torch.empty((self.capacity,), dtype=torch.int32, device=self.dev)
         self._aug, self._K, self._Kinv, self._img = [], [], [], []
@@ -78,7 +78,7 @@ class BufferBuilder:
         n_new = v * self.samples
         take = min(n_new, self.capacity - self.n)
         if take < n_new:   # partial last view: sample into scratch, copy what fits
-            of = torch.empty((n_new, self.enc.out_channels), dtype=torch.bfloat16, device=self.dev)
+            of = torch.empty((n_new, self.enc.out_channels), dtype=self.enc.feature_dtype, device=self.dev)
             op = torch.empty((n_new, 2), dtype=torch.float32, device=self.dev)
             ov = torch.empty((n_new,), dtype=torch.int32, device=self.dev)
         else:

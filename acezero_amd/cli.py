@@ -20,6 +20,8 @@ from pathlib import Path
 
 import numpy as np
 
+from . import DEFAULT_DTYPE
+
 _logger = logging.getLogger("acezero_amd")
 
 
@@ -175,6 +177,13 @@ def _add(parser, table):
         parser.add_argument(*flags, **kw)
 
 
+def _add_dtype(p):
+    p.add_argument("--compute_dtype", default=None, choices=["bf16", "fp16"],
+                   help="[additive] 16-bit operand format of encoder and head (fp32 accumulation in both): fp16 is the reference's autocast "
+                        "arithmetic (ace_trainer.py:366-367,517-518, register_mapping.py:209-210), bf16 what BASELINE.json's north_star "
+                        "names; default: $ACEZ_DTYPE, else " + DEFAULT_DTYPE)
+
+
 def train_parser():
     p = argparse.ArgumentParser(description="Fast training of a scene coordinate regression network (MI355X head trainer).",
                                 formatter_class=argparse.ArgumentDefaultsHelpFormatter)
@@ -182,9 +191,7 @@ def train_parser():
     p.add_argument("output_map_file", type=Path, help="target file for the trained head")
     _add(p, TRAIN_FLAGS)
     p.add_argument("--feature_buffer", type=Path, default=None, help="[additive] .npz training buffer (acez_train_buffer layout)")
-    p.add_argument("--compute_dtype", default=None, choices=["bf16", "fp16"],
-                   help="[additive] 16-bit operand format of the head: bf16 (default) or fp16, the reference's autocast format "
-                        "(ace_trainer.py:517-518); default: $ACEZ_DTYPE or bf16")
+    _add_dtype(p)
     p.add_argument("--num_gpus", type=int, default=1, help="[additive] informational; multi-GPU reconstructions are launched as "
                    "`torchrun --nproc-per-node G ace_zero.py ...` (the mapping rounds inside are data parallel)")
     return p
@@ -197,6 +204,7 @@ def register_parser():
     p.add_argument("network", type=Path, help="head weights of the scene")
     _add(p, REGISTER_FLAGS)
     p.add_argument("--feature_file", type=Path, default=None, help="[additive] .npz with per-frame encoder features or scene coordinates")
+    _add_dtype(p)
     return p
 
 
@@ -208,6 +216,7 @@ def ace_zero_parser():
     _add(p, ACE_ZERO_FLAGS)
     p.add_argument("--encoder_path", type=Path, default=Path(__file__).resolve().parent.parent / "ace_encoder_pretrained.pt",
                    help="[additive] pre-trained encoder weights (train_ace.py / register_mapping.py take the same flag)")
+    _add_dtype(p)
     return p
 
 
@@ -224,6 +233,7 @@ def export_point_cloud_parser():
     p.add_argument("--confidence_threshold", type=int, default=500)
     p.add_argument("--convention", type=str, default="opengl", choices=["opengl", "opencv"], help="coordinate convention of the point cloud")
     p.add_argument("--dense_point_cloud", type=_strtobool, default=False, help="do not filter points based on reprojection error")
+    _add_dtype(p)
     return p
 
 
@@ -269,10 +279,7 @@ def train_with_options(opt):
                          "than silently run in 16 bits. Use --use_half True [--compute_dtype fp16 for the reference's autocast precision].")
     dtype = getattr(opt, "compute_dtype", None)
     if opt.feature_buffer is None:
-        if (dtype or os.environ.get("ACEZ_DTYPE", "bf16")).lower() == "fp16":
-            raise SystemExit("--compute_dtype fp16 needs fp16 features: the encoder of this package emits bf16 rows; train from a "
-                             "--feature_buffer of fp16-representable features, or use bf16")
-        return _train_from_images(opt)
+        return _train_from_images(opt)   # (the session's encoder and head take opt.compute_dtype: _session_options)
     buf = np.load(opt.feature_buffer, allow_pickle=False)
     n = min(int(buf["features"].shape[0]), opt.max_training_buffer_size)
     focal = float(opt.use_external_focal_length) if opt.use_external_focal_length is not None else float(buf["focal"])
@@ -524,8 +531,8 @@ def register_main(argv=None):
         sd = torch.load(opt.network, map_location="cpu")
         nb = sum(1 for k in sd if k.endswith("c0.weight"))
         head = HeadTrainer(sd["mean"].float().view(3), num_head_blocks=nb, use_homogeneous=sd["fc3.weight"].shape[0] == 4, max_batch=8192,
-                           iterations=1)
-        head.load_state_dict(sd)                                    # fp16 checkpoint -> fp32 masters -> bf16 compute copies
+                           iterations=1, inference_only=True, dtype=opt.compute_dtype)
+        head.load_state_dict(sd)                                    # fp16 checkpoint -> fp32 masters -> 16-bit compute copies
         h, w = int(data["h"]), int(data["w"])
         feats = torch.from_numpy(data["features"][ids].astype(np.float32)).cuda().reshape(-1, 512)
         sc = head.get_scene_coordinates(feats).reshape(n, h, w, 3).permute(0, 3, 1, 2).contiguous()
@@ -696,7 +703,8 @@ def export_point_cloud_main(argv=None):
             raise SystemExit("no pose above the confidence threshold")
         assert np.allclose(focals, focals[0]), "a single focal length is supported"
         files, frames, fscale, rgb = load_frames(None, opt.image_resolution, files=files, return_rgb=True)
-        so = default_options(use_external_focal_length=focals[0] * fscale, use_aug=False, registration_confidence=opt.confidence_threshold)
+        so = default_options(use_external_focal_length=focals[0] * fscale, use_aug=False, registration_confidence=opt.confidence_threshold,
+                             compute_dtype=opt.compute_dtype)
         ses = ReconstructionSession(torch.load(_default_encoder_path(opt.encoder_path), map_location="cpu"), frames, opt=so)
         conf = np.full(len(files), np.inf)
         xyz, src, sel = ses.point_cloud(torch.load(opt.network, map_location="cpu"), c2w, conf, ses.focal0, dense=opt.dense_point_cloud,

@@ -27,8 +27,9 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 // Diagnostics build (-DACEZ_DIAG; acezero_amd/build.py builds it as libacez_diag.so for tests/ and tools/): the ablation switches, the
-// measured-and-rejected kernels (chain_kernel, headfwd_kernel, the 128-row rowgemm tiling, wgrad256_kernel, the side-stream pose
-// launches) and the fault-injection hooks exist only there. In the product library ACEZ_DIAG_ENV() is a null constant -- every
+// side-stream pose launches of round 2 and the fault-injection hooks exist only there (the measured-and-rejected kernels of rounds 1-5 --
+// chain_kernel, headfwd_kernel, headinfer_kernel, the 128-row rowgemm tiling, wgrad256_kernel, conv12_kernel, conv3x3p_kernel -- live in
+// the git history and in DESIGN_HISTORY.md, not in the tree). In the product library ACEZ_DIAG_ENV() is a null constant -- every
 // `if (const char* e = ACEZ_DIAG_ENV("..."))` folds away -- and no environment variable can change a result. The product reads exactly two
 // variables (head_api.hip): ACEZ_SEQ=0 (per-layer launches instead of the one-launch chains; bit-identical results) and ACEZ_SEQ_SPIN_US
 // (the hand-off poll budget).

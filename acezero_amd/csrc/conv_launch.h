@@ -7,14 +7,15 @@
 namespace acez {
 
 struct ConvGemmArgs {
-  const uint16_t* In;     // NHWC bf16 [F][Hi][Wi][Ci]
-  const uint16_t* W;      // bf16 [Co][Kp]
+  const uint16_t* In;     // NHWC 16-bit [F][Hi][Wi][Ci]
+  const uint16_t* W;      // 16-bit [Co][Kp]
   const float* bias;      // [Co]
-  const uint16_t* add;    // [M][Co] bf16 or null: added (fp32) after the activation, before the single bf16 store
+  const uint16_t* add;    // [M][Co] or null: added (fp32) after the activation, before the single 16-bit store
   uint16_t* out;          // [M][Co]
   const uint16_t* zeros;  // >= 128 bytes of zeros: DMA source of every padded chunk
   int Hi, Wi, Ci, ci_shift, Ho, Wo, Co, ksize, stride, pad, K, Kp, M;
-  int round_before_add;   // 1: the activation is rounded to bf16 BEFORE the residual is added (the head stores it: ace_network.py:126,133)
+  int f16;                // 16-bit operand format of In / W / add / out: 0 = bf16, 1 = fp16 (fp32 accumulation in both)
+  int round_before_add;   // 1: the activation is rounded to 16 bits BEFORE the residual is added (the head stores it: ace_network.py:126,133)
   unsigned long long* trace;   // diagnostics build (tools/conv_trace.py): [tiles][8] s_memtime stamps of convgemm512's waves 0 and 8; else null
   int dbg;   // ablation (ACEZ_CONV_DBG; 0 in production). convgemm256/512: 2 = no MFMA, 4 = no loads. conv3x3p (loader side only):
              // 32 = weight DMA from 16 hot rows (same bytes into LDS), 64 = every other weight stage not fetched

@@ -3,17 +3,21 @@
 // the encoder is the step right before both hot paths (it fills the training buffer and it
 // produces the features the head turns into scene coordinates at registration time).
 //
-// Data layout: activations NHWC bf16 ([frame][y][x][channel]; a pixel's channels are contiguous, so a pixel is a "row" of
+// Data layout: activations NHWC 16-bit ([frame][y][x][channel]; a pixel's channels are contiguous, so a pixel is a "row" of
 // an implicit GEMM and the final [F*h*w][512] tensor is exactly the row layout of the training buffer / acez_head_forward).
-// Weights: bf16 [Co][Kp], k = (ky*3 + kx) * Ci + ci, Kp = K rounded up to 64 (zero padded).
+// Weights: 16-bit [Co][Kp], k = (ky*3 + kx) * Ci + ci, Kp = K rounded up to 64 (zero padded).
+// Every kernel is instantiated on the element trait of gemm_common.h: EltBf16 (v_mfma_f32_*_bf16) and EltF16 (v_mfma_f32_*_f16: the
+// operand format the reference's autocast runs this network in, ace_trainer.py:366-367, register_mapping.py:209-210); fp32 accumulation,
+// one rounding per layer output in both. The context's compute_dtype selects the instantiation (acez_encoder_create).
 //
-//   conv1 (1 -> 32, 3x3)    direct kernel, one thread per pixel (0.3 % of the FLOPs, HBM-bound: 64 B out per pixel)
-//   every other layer       convgemm_kernel: implicit GEMM Out[p][co] = act(sum_k In[pix(p, tap(k))][ci(k)] * W[co][k] + b)
-//                           on v_mfma_f32_16x16x32_bf16, same structure as rowgemm80 (head_kernels.hip): 80-row x NT-column
-//                           tiles, 4 multiplier waves + 4 loader waves, 4-slot LDS-DMA ring of 64-wide K stages. The
-//                           im2col never exists in memory: a loader lane computes, per stage, the source address of its
-//                           16-byte chunk (8 input channels of one tap of one pixel) or points at a zero page for the
-//                           padding border / K padding / rows past the end.
+//   conv1 + conv2           conv12p_kernel: both layers in one launch, the conv1 map never leaves LDS
+//   3 x 3, stride 1         conv3x3r_kernel: 256 x 256 tiles, the input kept as an LDS patch (85 % of the encoder's FLOPs)
+//   every other layer       implicit GEMM Out[p][co] = act(sum_k In[pix(p, tap(k))][ci(k)] * W[co][k] + b): convgemm512_kernel
+//                           (256 x 256 tiles), convgemm256_kernel (256 x 128), convgemm_kernel (80-row x NT-column tiles, 4 multiplier
+//                           waves + 4 loader waves, same structure as rowgemm80 in head_kernels.hip), chosen by size. 4-slot LDS-DMA
+//                           ring of 64-wide K stages. The im2col never exists in memory: a loader lane computes, per stage, the
+//                           source address of its 16-byte chunk (8 input channels of one tap of one pixel) or points at a zero page
+//                           for the padding border / K padding / rows past the end.
 #include <algorithm>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,236 +35,37 @@
 namespace acez {
 
 
-// 1 -> 32 channels, 3x3, stride 1, pad 1, ReLU. image fp32 [F][H][W] (rounded to bf16 on the fly), out NHWC bf16.
-__global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ img, const float* __restrict__ w /*[32][9] bf16-rounded*/,
-                                                    const float* __restrict__ bias, uint16_t* __restrict__ out, int H, int W, int64_t npix) {
-  __shared__ float sw[32 * 9 + 32];
-  for (int i = threadIdx.x; i < 32 * 9 + 32; i += 256) sw[i] = i < 288 ? w[i] : bias[i - 288];
-  __syncthreads();
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= npix) return;
-  const int64_t hw = (int64_t)H * W;
-  const int64_t f = p / hw;
-  const int r = (int)(p - f * hw);
-  const int y = r / W, x = r - y * W;
-  float v[9];
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int iy = y + ky - 1, ix = x + kx - 1;
-      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-      const float t = ok ? img[f * hw + (int64_t)iy * W + ix] : 0.f;
-      v[ky * 3 + kx] = bf2f(f2bf(t));
-    }
-  uint32_t pk[16];
-#pragma unroll
-  for (int c = 0; c < 32; c += 2) {
-    float a0 = sw[288 + c], a1 = sw[288 + c + 1];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      a0 = fmaf(sw[c * 9 + k], v[k], a0);
-      a1 = fmaf(sw[(c + 1) * 9 + k], v[k], a1);
-    }
-    pk[c >> 1] = pack2(fmaxf(a0, 0.f), fmaxf(a1, 0.f));
-  }
-  uint4* o = reinterpret_cast<uint4*>(out + p * 32);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = make_uint4(pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]);
-}
-
 // ---------------------------------------------------------------------------------------------------
-// conv12: conv1 (1 -> 32, stride 1) and conv2 (32 -> 64, stride 2) fused, persistent over 8 x 32 output tiles of conv2.
-// As separate kernels these two layers cost 27 % of the encoder's time for 5 % of its FLOPs: conv1's 32-channel map
-// (19.7 MB per 480 x 640 frame) is written and read back, and conv2's 3 x 3 taps re-read it nine times from L2 into a
-// GEMM that is only 64 columns wide. Here a workgroup keeps the conv1 patch of its tile in LDS:
-//   1. image patch 19 x 67 (grey, rounded to bf16) -> LDS; the next tile's patch is already in flight in registers;
-//   2. conv1 on the matrix cores: 35 fragments of 32 patch pixels, B = the 9 taps gathered from the image patch (K = 16),
-//      A = conv1's weights (one register quad), bias + ReLU + bf16 -> conv1 patch [2 column-parity planes][17][33][32 ch]
-//      in LDS (zero outside the image: that is conv2's padding);
-//   3. conv2: wave w owns output row w of the tile (32 pixels x 64 channels); its B fragments are read straight from the
-//      patch (tap (ky, kx) of output x = plane kx & 1, column x + (kx >> 1): unit stride, 16-byte chunk XOR (col >> 2) & 3
-//      -> conflict free), its A fragments (all of conv2's 64 x 288 weights) live in 144 registers for the whole kernel;
-//   4. bias + ReLU + bf16 through a wave-private staging row, 4 KiB contiguous store per output row.
+// conv12p: conv1 (1 -> 32, stride 1) and conv2 (32 -> 64, stride 2) fused, persistent over 4 x 32 output tiles of conv2 and
+// software-pipelined across tiles. As separate kernels these two layers cost 27 % of the encoder's time for 5 % of its FLOPs:
+// conv1's 32-channel map (19.7 MB per 480 x 640 frame) is written and read back, and conv2's 3 x 3 taps re-read it nine times from
+// L2 into a GEMM that is only 64 columns wide. Here a workgroup keeps the conv1 patch of its tile in LDS:
+//   1. image patch 11 x 67 (grey, fp32 as in memory, by LDS-DMA; rounded to 16 bits where conv1 gathers its taps);
+//   2. conv1 on the matrix cores: 32-pixel fragments of the 9 x 65 patch, B = the 9 taps gathered from the image patch (K = 16),
+//      A = conv1's weights (one register quad), bias + ReLU + 16-bit -> conv1 patch [2 column-parity planes][9][33][32 ch] in LDS
+//      (zero outside the image: that is conv2's padding);
+//   3. conv2: wave w owns output row w of the tile (32 pixels x 64 channels); its B fragments are read straight from the patch
+//      (tap (ky, kx) of output x = plane kx & 1, column x + (kx >> 1): unit stride, swizzled 16-byte chunks), its A fragments (all
+//      of conv2's 64 x 288 weights) live in 144 registers for the whole kernel;
+//   4. bias + ReLU + 16-bit through a wave-private staging row, 4 KiB contiguous store per output row.
+// The two layers of DIFFERENT tiles run beside each other: waves 4 .. 7 compute conv1 of tile i + 1 into one of two LDS patches while
+// waves 0 .. TR-1 run conv2 of tile i from the other (and stage the image patch of tile i + 2); waves w and w + 4 share a SIMD, so every
+// SIMD has one MFMA-bound and one VALU-bound wave. One s_barrier per tile. (Round 1's phase-by-phase kernel on 8 x 32 tiles -- 7.1 us per
+// tile for 1.1 us of MFMA time, 545 us per 64 frames against 352 -- is in the git history; this kernel's output is bit-identical to it.)
 // ---------------------------------------------------------------------------------------------------
 struct Conv12Args {
   const float* img;        // [F][H][W] fp32
-  const uint16_t* w1;      // bf16 [32][16]: k = tap (9 used)
+  const uint16_t* w1;      // 16-bit [32][16]: k = tap (9 used)
   const float* b1;         // [32]
-  const uint16_t* w2;      // bf16 [64][Kp2], k = tap * 32 + ci
+  const uint16_t* w2;      // 16-bit [64][Kp2], k = tap * 32 + ci
   const float* b2;         // [64]
-  uint16_t* out;           // NHWC bf16 [F][H2][W2][64]
+  uint16_t* out;           // NHWC 16-bit [F][H2][W2][64]
   int F, H, W, H2, W2, Kp2, tiles_y, tiles_x, n_tiles;
-  const float* zero;       // >= 4 bytes of zeros (conv12p: source of the image-patch DMA outside the image)
+  const float* zero;       // >= 4 bytes of zeros: source of the image-patch DMA outside the image
 };
 
-constexpr int C12_IMG_PITCH = 68, C12_IMG_ROWS = 19, C12_IMG_N = C12_IMG_ROWS * C12_IMG_PITCH;   // 1292
-constexpr int C12_PLANE = 17 * 33 * 32;                                                          // elements per parity plane
+constexpr int C12_IMG_PITCH = 68;
 
-__global__ __launch_bounds__(512) void conv12_kernel(Conv12Args a) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_img[C12_IMG_N + 4];
-  __shared__ __attribute__((aligned(16))) uint16_t s_patch[2 * C12_PLANE];
-  __shared__ __attribute__((aligned(16))) uint16_t s_out[8 * 32 * 64];
-  __shared__ __attribute__((aligned(16))) float s_bias[32 + 64];   // b1 | b2
-  const int t = threadIdx.x, l = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int fr = l & 31, fh = l >> 5;
-  if (t < 96) s_bias[t] = t < 32 ? a.b1[t] : a.b2[t - 32];   // visible after the first barrier of the tile loop
-
-  // ---- weights -> registers (once per workgroup)
-  bf16x8 a2[9][2][2];
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        a2[tap][kk][i] = *reinterpret_cast<const bf16x8*>(a.w2 + (size_t)(i * 32 + fr) * a.Kp2 + tap * 32 + kk * 16 + 8 * fh);
-  const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a.w1 + fr * 16 + 8 * fh);
-
-  // image patch prefetch: entries t, t + 512, t + 1024 of the [19][68] patch
-  // (unconditional loads from clamped addresses + select: a load inside a branch is waited for on the spot; the patch
-  // coordinates of this thread's three entries are tile independent and computed once: integer division is ~40 VALU ops)
-  int epy[3], epx[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int e = min(t + 512 * i, C12_IMG_N - 1);
-    epy[i] = e / C12_IMG_PITCH;
-    epx[i] = e - epy[i] * C12_IMG_PITCH;
-  }
-  auto load_img = [&](int tile, float v[3]) {
-    const int tl = min(tile, a.n_tiles - 1);
-    const int f = tl / (a.tiles_y * a.tiles_x), r = tl - f * (a.tiles_y * a.tiles_x);
-    const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
-    const float* base = a.img + (size_t)f * a.H * a.W;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int iy = 16 * ty - 2 + epy[i], ix = 64 * tx - 2 + epx[i];
-      const bool ok = tile < a.n_tiles && epx[i] < 67 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float x = base[(size_t)min(max(iy, 0), a.H - 1) * a.W + min(max(ix, 0), a.W - 1)];
-      v[i] = ok ? x : 0.f;
-    }
-  };
-  float nxt[3];
-  load_img(blockIdx.x, nxt);
-
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    const int f = tile / (a.tiles_y * a.tiles_x), r = tile - f * (a.tiles_y * a.tiles_x);
-    const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
-    const int oy0 = 8 * ty, ox0 = 32 * tx;
-    // ---- 1. image patch -> LDS (bf16), next tile's patch -> registers
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int e = t + 512 * i;
-      if (e < C12_IMG_N) s_img[e] = (uint16_t)(pack2(nxt[i], 0.f) & 0xffffu);
-    }
-    load_img(tile + gridDim.x, nxt);
-    // raw barriers: __syncthreads() would also drain vmcnt, i.e. wait for the prefetch just issued and for the previous
-    // tile's output stores (measured: 7.5 us per tile instead of ~2.5)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // ---- 2. conv1 on 32-pixel fragments of the 17 x 65 patch (p = py * 65 + px)
-    for (int fg = w; fg < 35; fg += 8) {
-      const int p = fg * 32 + fr;
-      const int py = min(p / 65, 16), px = p - (p / 65) * 65;
-      const uint16_t* ip = s_img + py * C12_IMG_PITCH + px;   // taps: ip[ky * 68 + kx]
-      uint16_t tp[9];
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) tp[ky * 3 + kx] = ip[ky * C12_IMG_PITCH + kx];
-      s16x8 bv;
-      if (fh == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (short)tp[e];
-      } else {
-        bv[0] = (short)tp[8];
-#pragma unroll
-        for (int e = 1; e < 8; ++e) bv[e] = 0;
-      }
-      f32x16 c1;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) c1[q] = 0.f;
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, bv), c1, 0, 0, 0);
-      // conv1 pixel (cy, cx) of this lane; outside the image the map is ZERO (conv2's padding)
-      const int cy = 16 * ty - 1 + py, cx = 64 * tx - 1 + px;
-      const bool inside = p < 17 * 65 && cy >= 0 && cy < a.H && cx >= 0 && cx < a.W;
-      if (p < 17 * 65) {
-        const int q = px >> 1;
-        uint16_t* dst = s_patch + (px & 1) * C12_PLANE + (py * 33 + q) * 32;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {   // channels 8g + 4 fh .. +3 = half of logical chunk g
-          const float4 b = *reinterpret_cast<const float4*>(s_bias + 8 * g + 4 * fh);
-          float v0 = fmaxf(c1[4 * g + 0] + b.x, 0.f), v1 = fmaxf(c1[4 * g + 1] + b.y, 0.f);
-          float v2 = fmaxf(c1[4 * g + 2] + b.z, 0.f), v3 = fmaxf(c1[4 * g + 3] + b.w, 0.f);
-          if (!inside) v0 = v1 = v2 = v3 = 0.f;
-          *reinterpret_cast<uint2*>(dst + ((g ^ ((q >> 2) & 3)) << 3) + 4 * fh) = pack4(v0, v1, v2, v3);
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // ---- 3. conv2: output row w of the tile, pixels x = fr, channels 2 x 32
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int q = fr + (kx >> 1);
-        const uint16_t* src = s_patch + (kx & 1) * C12_PLANE + ((2 * w + ky) * 33 + q) * 32;
-        const int sw = (q >> 2) & 3;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const bf16x8 b = *reinterpret_cast<const bf16x8*>(src + (((kk * 2 + fh) ^ sw) << 3));
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ky * 3 + kx][kk][i], b, acc[i], 0, 0, 0);
-        }
-      }
-    // ---- 4. bias + ReLU -> wave-private staging row [32 px][64 ch] -> 4 KiB contiguous store
-    uint16_t* so = s_out + w * (32 * 64);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int ch = i * 32 + 8 * g + 4 * fh;
-        const float4 b = *reinterpret_cast<const float4*>(s_bias + 32 + ch);
-        const uint2 y = pack4(fmaxf(acc[i][4 * g + 0] + b.x, 0.f), fmaxf(acc[i][4 * g + 1] + b.y, 0.f), fmaxf(acc[i][4 * g + 2] + b.z, 0.f),
-                              fmaxf(acc[i][4 * g + 3] + b.w, 0.f));
-        // [px][64]: 8 chunks of 8 channels, chunk index XOR px & 7
-        *reinterpret_cast<uint2*>(so + fr * 64 + ((((ch >> 3) ^ (fr & 7)) << 3) | (ch & 7))) = y;
-      }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int oy = oy0 + w;
-    if (oy < a.H2) {
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int pxl = it * 8 + (l >> 3), chk = l & 7;
-        const int ox = ox0 + pxl;
-        if (ox < a.W2)
-          *reinterpret_cast<uint4*>(a.out + (((size_t)f * a.H2 + oy) * a.W2 + ox) * 64 + chk * 8) =
-              *reinterpret_cast<const uint4*>(so + pxl * 64 + ((chk ^ (pxl & 7)) << 3));
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// conv12p (round 5): the same two layers, software-pipelined across tiles. conv12_kernel runs its phases one after the other on all
-// eight waves -- image patch -> LDS | conv1 (a handful of MFMAs under ~150 vector instructions per 32-pixel fragment: bias, ReLU,
-// padding select, pack) | conv2 (36 MFMAs per wave, nothing else) | store -- so the matrix pipe idles through conv1 and the vector
-// pipe through conv2: 7.1 us per 8 x 32 tile for 1.1 us of MFMA time (profiles/r05_encoder_pmc.json: MFMA busy 0.155, 57 % of the
-// wave cycles waiting; profiles/r05_encoder_layers.json: 545 us per 64 frames = 14 % of the encoder at 0.14 of the MFMA peak).
-// Here the two layers of DIFFERENT tiles run beside each other: waves 4 .. 7 compute conv1 of tile i + 1 into one of two LDS patches
-// while waves 0 .. TR-1 run conv2 of tile i from the other (and stage the image patch of tile i + 2); waves w and w + 4 share a SIMD, so
-// every SIMD has one MFMA-bound and one VALU-bound wave. One s_barrier per tile. Tiles are TR = 4 output rows x 32 columns (two patches
-// of 9 x 65 conv1 pixels = 76 KiB; an 8-row tile's 17-row patch does not fit twice). Same MFMAs on the same operands in the same order:
-// the output is bit-identical to conv12_kernel's.
-// ---------------------------------------------------------------------------------------------------
 // 16-byte chunk swizzle of conv12p's conv1 patch (a pixel = 32 channels = four chunks; q = column index inside a parity plane). conv2's
 // B-fragment reads take 16 consecutive q with one chunk index: conflict free iff the swizzle differs between q, q + 4, q + 8, q + 12;
 // conv1's epilogue writes 8 consecutive pixels = 4 consecutive q x 2 planes per lane group: conflict poor iff it also differs between
@@ -280,8 +85,9 @@ __device__ __forceinline__ void wait_vmcnt_dyn_c12(int n) {   // s_waitcnt vmcnt
 #ifndef C12_ABL
 #define C12_ABL 0   // timing-only ablation of conv12p (tools/c12_variants.sh): 1 = no conv1, 2 = no conv2, 4 = no output stores, 8 = no patch writes
 #endif
-template <int TR>
+template <class E, int TR>
 __global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
+  typedef typename E::frag frag;
   constexpr int PR = 2 * TR + 1;                 // conv1 patch rows
   constexpr int IMG_N = (PR + 2) * C12_IMG_PITCH;   // image patch: PR + 2 rows of 67 (+ 1 pad) grey values
   constexpr int PLANE = PR * 33 * 32;            // elements per column-parity plane of a conv1 patch
@@ -302,7 +108,7 @@ __global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
 
   if (w < 4) {
     // ------------------------------------------------------------------ conv2 waves (w < TR multiply; all four stage the image patches)
-    bf16x8 a2[9][2][2];
+    frag a2[9][2][2];
     if (w < TR) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap)
@@ -310,7 +116,7 @@ __global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            a2[tap][kk][i] = *reinterpret_cast<const bf16x8*>(a.w2 + (size_t)(i * 32 + fr) * a.Kp2 + tap * 32 + kk * 16 + 8 * fh);
+            a2[tap][kk][i] = *reinterpret_cast<const frag*>(a.w2 + (size_t)(i * 32 + fr) * a.Kp2 + tap * 32 + kk * 16 + 8 * fh);
     }
     // image patch staging by LDS-DMA, one dword per lane: entries t, t + 256, t + 512 of the [PR + 2][68] patch (coordinates are tile
     // independent); outside the image (and past the patch) the source is a zero word. No registers, no conversion here, and the
@@ -361,9 +167,9 @@ __global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
             const int sw = c12p_swz(q);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-              const bf16x8 b = *reinterpret_cast<const bf16x8*>(src + (((kk * 2 + fh) ^ sw) << 3));
+              const frag b = *reinterpret_cast<const frag*>(src + (((kk * 2 + fh) ^ sw) << 3));
 #pragma unroll
-              for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ky * 3 + kx][kk][i], b, acc[i], 0, 0, 0);
+              for (int i = 0; i < 2; ++i) acc[i] = E::mfma32(a2[ky * 3 + kx][kk][i], b, acc[i]);
             }
           }
         // bias + ReLU -> wave-private staging row [32 px][64 ch] -> 4 KiB contiguous store
@@ -380,7 +186,7 @@ __global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
           for (int g = 0; g < 4; ++g) {
             const int ch = i * 32 + 8 * g + 4 * fh;
             const float4 b = b2v[i][g];
-            const uint2 y = pack4(fmaxf(acc[i][4 * g + 0] + b.x, 0.f), fmaxf(acc[i][4 * g + 1] + b.y, 0.f), fmaxf(acc[i][4 * g + 2] + b.z, 0.f),
+            const uint2 y = E::pk4(fmaxf(acc[i][4 * g + 0] + b.x, 0.f), fmaxf(acc[i][4 * g + 1] + b.y, 0.f), fmaxf(acc[i][4 * g + 2] + b.z, 0.f),
                                   fmaxf(acc[i][4 * g + 3] + b.w, 0.f));
             *reinterpret_cast<uint2*>(so + fr * 64 + ((((ch >> 3) ^ (fr & 7)) << 3) | (ch & 7))) = y;
           }
@@ -408,7 +214,7 @@ __global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
   } else {
     // ------------------------------------------------------------------ conv1 waves: tile j + 1 while the others run conv2 of tile j
     const int lw = w - 4;
-    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a.w1 + fr * 16 + 8 * fh);
+    const frag a1 = *reinterpret_cast<const frag*>(a.w1 + fr * 16 + 8 * fh);
     // this lane's sixteen conv1 bias values, in registers for the whole kernel (read from LDS inside the fragment loop each of the four
     // reads was followed by a full lgkmcnt(0) wait: four serial LDS round trips per 32-pixel fragment -- found in the ISA, round 5)
     float4 b1v[4];
@@ -443,7 +249,7 @@ __global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
         const bool interior = cy0 >= 0 && cy0 + PR <= a.H && cx0 >= 0 && cx0 + 65 <= a.W;
         auto fragment = [&](int u, auto chk) {
           constexpr bool CHECK = decltype(chk)::value;
-          const float* ip = si + f_ip[u];   // taps: ip[ky * 68 + kx], rounded to bf16 here (round to nearest even, as conv12_kernel's staging)
+          const float* ip = si + f_ip[u];   // taps: ip[ky * 68 + kx], rounded to 16 bits here (round to nearest even)
           float tp[9];
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
@@ -451,15 +257,15 @@ __global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
             for (int kx = 0; kx < 3; ++kx) tp[ky * 3 + kx] = ip[ky * C12_IMG_PITCH + kx];
           uint32_t bw[4];
           if (fh == 0) {
-            bw[0] = pack2(tp[0], tp[1]); bw[1] = pack2(tp[2], tp[3]); bw[2] = pack2(tp[4], tp[5]); bw[3] = pack2(tp[6], tp[7]);
+            bw[0] = E::pk2(tp[0], tp[1]); bw[1] = E::pk2(tp[2], tp[3]); bw[2] = E::pk2(tp[4], tp[5]); bw[3] = E::pk2(tp[6], tp[7]);
           } else {
-            bw[0] = pack2(tp[8], 0.f); bw[1] = 0u; bw[2] = 0u; bw[3] = 0u;
+            bw[0] = E::pk2(tp[8], 0.f); bw[1] = 0u; bw[2] = 0u; bw[3] = 0u;
           }
           const uint4 bq = make_uint4(bw[0], bw[1], bw[2], bw[3]);
           f32x16 c1;
 #pragma unroll
           for (int q = 0; q < 16; ++q) c1[q] = 0.f;
-          c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, bq), c1, 0, 0, 0);
+          c1 = E::mfma32(a1, __builtin_bit_cast(frag, bq), c1);
           // conv1 pixel (cy, cx) of this lane; outside the image the map is ZERO (conv2's padding)
           bool inside = true;
           if (CHECK) {
@@ -474,7 +280,7 @@ __global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
               float v0 = fmaxf(c1[4 * g + 0] + b.x, 0.f), v1 = fmaxf(c1[4 * g + 1] + b.y, 0.f);
               float v2 = fmaxf(c1[4 * g + 2] + b.z, 0.f), v3 = fmaxf(c1[4 * g + 3] + b.w, 0.f);
               if (CHECK && !inside) v0 = v1 = v2 = v3 = 0.f;
-              *reinterpret_cast<uint2*>(dst + ((g ^ f_sw[u]) << 3)) = pack4(v0, v1, v2, v3);
+              *reinterpret_cast<uint2*>(dst + ((g ^ f_sw[u]) << 3)) = E::pk4(v0, v1, v2, v3);
             }
           }
         };
@@ -497,8 +303,9 @@ __global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
 // [80][64] staging tile of the 64-column variant: chunk index XOR row & 7
 __device__ __forceinline__ int st_off64(int row, int col) { return row * 64 + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7)); }
 
-template <int NT, bool RELU, bool HAS_ADD>
+template <class E, int NT, bool RELU, bool HAS_ADD>
 __global__ __launch_bounds__(512) void convgemm_kernel(ConvGemmArgs a) {
+  typedef typename E::frag frag;
   static_assert(NT == 64 || NT == 128, "column tile");
   static_assert(!(HAS_ADD && NT == 64), "the residual epilogue exists for 128-column tiles only");
   constexpr int CF = NT / 64;                 // 16-column fragments per multiplier wave
@@ -606,15 +413,15 @@ __global__ __launch_bounds__(512) void convgemm_kernel(ConvGemmArgs a) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int c = kk * 4 + fq;
-        bf16x8 fa[CF], fb[5];
+        frag fa[CF], fb[5];
 #pragma unroll
-        for (int i = 0; i < CF; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz(w * (NT / 4) + i * 16 + fr, c)]);
+        for (int i = 0; i < CF; ++i) fa[i] = *reinterpret_cast<const frag*>(&sW[swz(w * (NT / 4) + i * 16 + fr, c)]);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz(j * 16 + fr, c)]);
+        for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const frag*>(&sI[swz(j * 16 + fr, c)]);
 #pragma unroll
         for (int i = 0; i < CF; ++i)
 #pragma unroll
-          for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 5; ++j) acc[i][j] = E::mfma16(fa[i], fb[j], acc[i][j]);
       }
     }
     __builtin_amdgcn_s_barrier();
@@ -631,11 +438,11 @@ __global__ __launch_bounds__(512) void convgemm_kernel(ConvGemmArgs a) {
         uint16_t* po = &stO[NT == 128 ? st_off(ml, nl) : st_off64(ml, nl)];
         if (HAS_ADD) {
           float ad[4];
-          unpack4(*reinterpret_cast<const uint2*>(po), ad);
-          if (a.round_before_add) unpack4(pack4(v[0], v[1], v[2], v[3]), v);
+          E::un4(*reinterpret_cast<const uint2*>(po), ad);
+          if (a.round_before_add) E::un4(E::pk4(v[0], v[1], v[2], v[3]), v);
           v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
         }
-        *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint2*>(po) = E::pk4(v[0], v[1], v[2], v[3]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -662,8 +469,9 @@ __global__ __launch_bounds__(512) void convgemm_kernel(ConvGemmArgs a) {
 // LAST stage sits in slot 2, which leaves slots 0-1 free for the [256][128] epilogue tile one stage early: the loaders
 // fetch the residual / skip tile into it while the multipliers work on the last stage.
 // ---------------------------------------------------------------------------------------------------
-template <bool RELU, bool HAS_ADD>
+template <class E, bool RELU, bool HAS_ADD>
 __global__ __launch_bounds__(1024) void convgemm256_kernel(ConvGemmArgs a) {
+  typedef typename E::frag frag;
   constexpr int STAGE = (128 + 256) * 64;     // elements per ring slot
   __shared__ __attribute__((aligned(16))) uint16_t smem[3 * STAGE];
   uint16_t* const stO = smem;                 // epilogue tile [256][128] (slots 0-1)
@@ -766,15 +574,15 @@ __global__ __launch_bounds__(1024) void convgemm256_kernel(ConvGemmArgs a) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int c = kk * 2 + fh;
-        bf16x8 fa[2], fb[2];
+        frag fa[2], fb[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz(wn * 64 + i * 32 + fr, c)]);
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const frag*>(&sW[swz(wn * 64 + i * 32 + fr, c)]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz(wm * 64 + j * 32 + fr, c)]);
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const frag*>(&sI[swz(wm * 64 + j * 32 + fr, c)]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma32(fa[i], fb[j], acc[i][j]);
       }
     }
     __builtin_amdgcn_s_barrier();
@@ -801,11 +609,11 @@ __global__ __launch_bounds__(1024) void convgemm256_kernel(ConvGemmArgs a) {
           uint16_t* po = &stO[st_off(ml, nl)];
           if (HAS_ADD) {
             float ad[4];
-            unpack4(*reinterpret_cast<const uint2*>(po), ad);
-            if (a.round_before_add) unpack4(pack4(v[0], v[1], v[2], v[3]), v);
+            E::un4(*reinterpret_cast<const uint2*>(po), ad);
+            if (a.round_before_add) E::un4(E::pk4(v[0], v[1], v[2], v[3]), v);
             v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
           }
-          *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<uint2*>(po) = E::pk4(v[0], v[1], v[2], v[3]);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -835,8 +643,9 @@ __device__ __forceinline__ int swz32(int row, int chunk) { return row * 32 + ((c
 // [256][256] bf16 epilogue tile: chunk index (0..31) XOR row & 31
 __device__ __forceinline__ int st_off256(int row, int col) { return row * 256 + ((((col >> 3) ^ (row & 31)) << 3) | (col & 7)); }
 
-template <bool RELU, bool HAS_ADD>
+template <class E, bool RELU, bool HAS_ADD>
 __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
+  typedef typename E::frag frag;
   constexpr int STAGE = 512 * 32;             // elements per ring slot: [W 256 x 32 | In 256 x 32]
   __shared__ __attribute__((aligned(16))) uint16_t smem[4 * STAGE];
   const int t = threadIdx.x, l = t & 63;
@@ -951,15 +760,15 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int c = kk * 2 + fh;
-        bf16x8 fa[2], fb[4];
+        frag fa[2], fb[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz32(wn * 64 + i * 32 + fr, c)]);
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const frag*>(&sW[swz32(wn * 64 + i * 32 + fr, c)]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sI[swz32(wm * 128 + j * 32 + fr, c)]);
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const frag*>(&sI[swz32(wm * 128 + j * 32 + fr, c)]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[i][j] = E::mfma32(fa[i], fb[j], acc[i][j]);
       }
     }
     __builtin_amdgcn_s_barrier();     // ring free
@@ -988,11 +797,11 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
           uint16_t* po = &smem[st_off256(ml, nl)];
           if (HAS_ADD) {
             float ad[4];
-            unpack4(*reinterpret_cast<const uint2*>(po), ad);
-            if (a.round_before_add) unpack4(pack4(v[0], v[1], v[2], v[3]), v);
+            E::un4(*reinterpret_cast<const uint2*>(po), ad);
+            if (a.round_before_add) E::un4(E::pk4(v[0], v[1], v[2], v[3]), v);
             v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
           }
-          *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<uint2*>(po) = E::pk4(v[0], v[1], v[2], v[3]);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1011,7 +820,7 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// conv3x3p: the 3 x 3, stride-1 layers (res1_conv1/3, res2_conv1/3 = 85 % of the encoder's FLOPs) with the INPUT kept as an
+// The 3 x 3, stride-1 layers: conv3x3r below (round 1's conv3x3p, the first kernel of this shape, is in the git history). The 3 x 3, stride-1 layers (res1_conv1/3, res2_conv1/3 = 85 % of the encoder's FLOPs) with the INPUT kept as an
 // LDS patch. In the implicit-GEMM kernels above every tap's K stages DMA the same input pixels again (nine times per
 // 32-channel chunk); here the loaders bring, per 32-channel chunk, ONE patch of 448 consecutive input pixels (the tile's 256
 // output pixels in (frame, y, x) order plus one image row and one pixel on either side: NHWC frames are back to back, so
@@ -1023,219 +832,6 @@ __global__ __launch_bounds__(768) void convgemm512_kernel(ConvGemmArgs a) {
 // takes the whole 128 KiB. Requires W <= 95 (448-row patch), Ci % 32 == 0, Co % 256 == 0.
 // ---------------------------------------------------------------------------------------------------
 constexpr int P3_ROWS = 448;
-template <bool RELU, bool HAS_ADD, int P3_WRING>
-__global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
-  constexpr int WSTAGE = 256 * 32;            // elements per weight slot
-  constexpr int PATCH = P3_ROWS * 32;         // elements per patch buffer
-  constexpr int WRING = P3_WRING;             // weight slots: WRING - 1 stages are in flight while one is multiplied
-  constexpr int SMEM = (WRING * WSTAGE + 2 * PATCH > 65536) ? WRING * WSTAGE + 2 * PATCH : 65536;   // the epilogue tile needs 65536
-  __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM + 32];
-  uint16_t* const sPatch = smem + WRING * WSTAGE;
-  uint16_t* const sZero = smem + SMEM;        // 64 bytes of zeros: the target of every padded tap
-  const int t = threadIdx.x, l = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int M = a.M, Co = a.Co, Kp = a.Kp, Wi = a.Wi;
-  const int ntiles = Co >> 8;
-  const int mtiles = (M + 255) >> 8;
-  const int per_xcd = (mtiles + 7) >> 3;
-  const int jx = blockIdx.x >> 3;
-  const int mt = (blockIdx.x & 7) * per_xcd + jx / ntiles;
-  if (mt >= mtiles) return;
-  const int n0 = (jx % ntiles) << 8, m0 = mt << 8;
-  const int NC = a.Ci >> 5;                   // 32-channel chunks
-  const int S = NC * 9;                       // stages: chunk-major, tap-minor
-  if (t < 32) {                               // visible after the first barrier of the stage loop
-    sZero[t] = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-
-  if (w >= 8) {
-    // ------------------------------------------------------------------ loader waves
-    const int lw = w - 8;
-    const int lrow = l >> 2, lch = l & 3;     // a DMA instruction covers 16 rows x 64 bytes
-    const uint16_t* gW[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = (lw * 4 + j) * 16 + lrow;
-      gW[j] = a.W + (size_t)(n0 + row) * Kp + (lch ^ ((row >> 2) & 3)) * 8;
-      if (ACEZ_DBG(a.dbg) & 32) gW[j] = a.W + (size_t)(row & 15) * Kp + lch * 8;   // ablation: same bytes into LDS, but from 16 hot rows
-    }
-    // patch rows (lw * 7 + j) * 16 + lrow, j < 7: global pixel m0 - Wi - 1 + row, clamped (clamped rows are never validly read)
-    const uint16_t* gP[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int row = (lw * 7 + j) * 16 + lrow;
-      const int g = min(max(m0 - Wi - 1 + row, 0), M - 1);
-      gP[j] = a.In + ((size_t)g << a.ci_shift) + (lch ^ ((row >> 2) & 3)) * 8;
-    }
-    int islot = 0;                            // ring slot of the next weight stage to issue
-    auto issue_w = [&](int s) {
-      const int cc = s / 9, tap = s - cc * 9;
-      const int koff = (ACEZ_DBG(a.dbg) & 32) ? 0 : tap * a.Ci + cc * 32;
-      uint16_t* slot = smem + islot * WSTAGE;
-      islot = (islot == WRING - 1) ? 0 : islot + 1;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + koff), (lvoid_t*)(slot + (lw * 4 + j) * 16 * 32), 16, 0, 0);
-    };
-    auto issue_patch = [&](int cc) {
-      uint16_t* buf = sPatch + (cc & 1) * PATCH;
-#pragma unroll
-      for (int j = 0; j < 7; ++j)
-        __builtin_amdgcn_global_load_lds((gvoid_t*)(gP[j] + cc * 32), (lvoid_t*)(buf + (lw * 7 + j) * 16 * 32), 16, 0, 0);
-    };
-    issue_patch(0);
-    for (int s = 0; s < WRING && s < S; ++s) issue_w(s);
-    int burst_at = -100;                      // stage after whose barrier the last patch burst was issued
-    for (int s = 0; s < S; ++s) {
-      // weight stages younger than W(s) and already issued: s+1 .. min(s+WRING-1 at s = 0, s+WRING-2 otherwise); the patch burst
-      // issued at stage b (after W(b+WRING-1)) is younger than W(s) for s = b+1 .. b+WRING-1. In-order completion: vmcnt(N) with
-      // N = their instructions (4 per weight stage, 7 per burst).
-      const int later = (s == 0) ? min(WRING - 1, S - 1) : min(WRING - 2, S - 1 - s);
-      const bool burst_young = s >= burst_at + 1 && s <= burst_at + WRING - 1;
-      switch (4 * later + (burst_young ? 7 : 0)) {
-        case 0: ACEZ_VMCNT(0); break;
-        case 4: ACEZ_VMCNT(4); break;
-        case 8: ACEZ_VMCNT(8); break;
-        case 12: ACEZ_VMCNT(12); break;
-        case 16: ACEZ_VMCNT(16); break;
-        case 20: ACEZ_VMCNT(20); break;
-        case 7: ACEZ_VMCNT(7); break;
-        case 11: ACEZ_VMCNT(11); break;
-        case 15: ACEZ_VMCNT(15); break;
-        case 19: ACEZ_VMCNT(19); break;
-        case 23: ACEZ_VMCNT(23); break;
-        default: ACEZ_VMCNT(27); break;
-      }
-      __builtin_amdgcn_s_barrier();   // W(s) (and, at a chunk start, its patch) has landed; the multipliers are done with stage s - 1
-      if (s >= 1 && s + WRING - 1 < S && !((ACEZ_DBG(a.dbg) & 64) && (s & 1))) issue_w(s + WRING - 1);   // ablation 64: every other weight stage is not fetched
-      const int cc = s / 9;
-      if (s == cc * 9 && cc + 1 < NC) {   // first stage of chunk cc: the other patch buffer (chunk cc - 1) is free now
-        issue_patch(cc + 1);
-        burst_at = s;
-      }
-    }
-    __builtin_amdgcn_s_barrier();     // the multipliers have left the K loop: all of LDS is free
-    if (HAS_ADD) {
-      for (int j = 0; j < 32; ++j) {
-        const int row = (lw * 32 + j) * 2 + (l >> 5);
-        const uint16_t* g = a.add + (size_t)min(m0 + row, M - 1) * Co + n0 + (((l & 31) ^ (row & 31)) << 3);
-        __builtin_amdgcn_global_load_lds((gvoid_t*)g, (lvoid_t*)(smem + (lw * 32 + j) * 2 * 256), 16, 0, 0);
-      }
-      ACEZ_VMCNT(0);
-      __builtin_amdgcn_s_barrier();   // residual tile landed
-    }
-    __builtin_amdgcn_s_barrier();     // output tile written
-  } else {
-    // ------------------------------------------------------------------ multiplier waves
-    const int wm = w >> 2, wn = w & 3;
-    const int fr = l & 31, fh = l >> 5;
-    // this lane's four output rows (one per row fragment): patch row of tap (0, 0) and the validity of the nine taps
-    int q0[4];
-    unsigned vmask[4];
-    const int hw = a.Hi * Wi;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = wm * 128 + j * 32 + fr;
-      q0[j] = r;                                  // patch origin is pixel m0 - Wi - 1: tap (ky, kx) -> row r + ky * Wi + kx
-      const int p = m0 + r;
-      const int rem = p % hw;
-      const int y = rem / Wi, x = rem - y * Wi;
-      unsigned mk = 0;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int iy = y + ky - 1, ix = x + kx - 1;
-          if (p < M && iy >= 0 && iy < a.Hi && ix >= 0 && ix < Wi) mk |= 1u << (ky * 3 + kx);
-        }
-      vmask[j] = mk;
-    }
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    int cc = 0, tap = 0, wslot = 0;
-    for (int s = 0; s < S; ++s) {
-      __builtin_amdgcn_s_barrier();
-      const uint16_t* sW = smem + wslot * WSTAGE;
-      wslot = (wslot == WRING - 1) ? 0 : wslot + 1;
-      const uint16_t* sP = sPatch + (cc & 1) * PATCH;
-      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-      const int toff = ky * Wi + kx;
-      const uint16_t* bp[4];
-      int bsw[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int q = q0[0] + j * 32 + toff;      // q0[j] = q0[0] + 32 j: one live register instead of four
-        const bool ok = (vmask[j] >> tap) & 1u;
-        bp[j] = ok ? sP + q * 32 : sZero;
-        bsw[j] = ok ? (q >> 2) & 3 : 0;
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int c = kk * 2 + fh;
-        bf16x8 fa[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sW[swz32(wn * 64 + i * 32 + fr, c)]);
-        // the four row fragments in two halves: two B fragments live at a time (the 128 accumulator registers leave ~40 for everything else)
-#pragma unroll
-        for (int jh = 0; jh < 2; ++jh) {
-          bf16x8 fb[2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bp[jh * 2 + j] + ((c ^ bsw[jh * 2 + j]) << 3));
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][jh * 2 + j], 0, 0, 0);
-        }
-      }
-      if (++tap == 9) { tap = 0; ++cc; }
-    }
-    __builtin_amdgcn_s_barrier();     // LDS free
-    if (HAS_ADD) __builtin_amdgcn_s_barrier();
-    // the eight bias vectors of this lane, fetched once before the tile is touched (inside the loops every one of the
-    // 16-32 loads was followed by a full wait: as many serial L2 round trips per tile)
-    float4 bv[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * fh);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ml = wm * 128 + j * 32 + fr;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int nl = wn * 64 + i * 32 + 8 * q + 4 * fh;
-          const float4 b = bv[i][q];
-          float v[4] = {acc[i][j][4 * q + 0] + b.x, acc[i][j][4 * q + 1] + b.y, acc[i][j][4 * q + 2] + b.z, acc[i][j][4 * q + 3] + b.w};
-          if (RELU) {
-            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-          }
-          uint16_t* po = &smem[st_off256(ml, nl)];
-          if (HAS_ADD) {
-            float ad[4];
-            unpack4(*reinterpret_cast<const uint2*>(po), ad);
-            if (a.round_before_add) unpack4(pack4(v[0], v[1], v[2], v[3]), v);
-            v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
-          }
-          *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  for (int q = t; q < 256 * 32; q += 768) {
-    const int row = q >> 5, ch = q & 31, m = m0 + row;
-    if (m < M)
-      *reinterpret_cast<uint4*>(a.out + (size_t)m * Co + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&smem[row * 256 + ((ch ^ (row & 31)) << 3)]);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // conv3x3r: the lean stage loop (round 2). Ablation of conv3x3p on MI355X (tools/enc_kstats.sh): with the LDS-DMA AND
@@ -1257,10 +853,11 @@ __global__ __launch_bounds__(768) void conv3x3p_kernel(ConvGemmArgs a) {
 // LDS (bytes): [0, 64 K) four weight slots; [64 K, 96 K) and [96 K, 128 K) patch slots of 512 rows x 64 B (rows 0..447 data, row 511
 // zero); the epilogue tile reuses all 128 KiB.
 // ---------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
-template <bool RELU, bool HAS_ADD>
+template <class E, bool RELU, bool HAS_ADD>
 __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
+  typedef typename E::frag frag;
+  typedef __attribute__((address_space(3))) const frag lds_frag;
   constexpr unsigned WSLOT = 16384, PATCH0 = 65536, PSLOT = 32768, ZROW = 511 * 64;
   __shared__ __attribute__((aligned(16))) uint16_t smem[65536];
   lds_byte* const lds = (lds_byte*)smem;
@@ -1351,12 +948,12 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  bf16x8 faA[2], fbA[4], faB[2], fbB[4];
-  auto multiply = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[4]) {
+  frag faA[2], fbA[4], faB[2], fbB[4];
+  auto multiply = [&](const frag (&fa)[2], const frag (&fb)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i][j] = E::mfma32(fa[i], fb[j], acc[i][j]);
   };
 
   bool pdst_pending = false;                  // set per chunk: is there a patch to issue at the next chunk boundary
@@ -1365,9 +962,9 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
     constexpr int TAP = decltype(tapc)::value;
     constexpr bool LAST = decltype(lastc)::value;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) faB[i] = *(lds_bf16x8*)(lds + wsrc + (wfrag[i] ^ 32u));
+    for (int i = 0; i < 2; ++i) faB[i] = *(lds_frag*)(lds + wsrc + (wfrag[i] ^ 32u));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fbB[j] = *(lds_bf16x8*)(lds + (tapaddr[TAP][j] ^ 32u));
+    for (int j = 0; j < 4; ++j) fbB[j] = *(lds_frag*)(lds + (tapaddr[TAP][j] ^ 32u));
     multiply(faA, fbA);
     if (LAST && TAP == 8) {                   // the very last stage: nothing to advance to
       multiply(faB, fbB);
@@ -1397,9 +994,9 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
     }
     constexpr int NT = (TAP == 8) ? 0 : TAP + 1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) faA[i] = *(lds_bf16x8*)(lds + wsrc + wfrag[i]);
+    for (int i = 0; i < 2; ++i) faA[i] = *(lds_frag*)(lds + wsrc + wfrag[i]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fbA[j] = *(lds_bf16x8*)(lds + tapaddr[NT][j]);
+    for (int j = 0; j < 4; ++j) fbA[j] = *(lds_frag*)(lds + tapaddr[NT][j]);
     multiply(faB, fbB);
   };
 
@@ -1414,9 +1011,9 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
   }
   __builtin_amdgcn_s_barrier();               // W(0), patch 0 and the zero rows are in place
 #pragma unroll
-  for (int i = 0; i < 2; ++i) faA[i] = *(lds_bf16x8*)(lds + wsrc + wfrag[i]);
+  for (int i = 0; i < 2; ++i) faA[i] = *(lds_frag*)(lds + wsrc + wfrag[i]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) fbA[j] = *(lds_bf16x8*)(lds + tapaddr[0][j]);
+  for (int j = 0; j < 4; ++j) fbA[j] = *(lds_frag*)(lds + tapaddr[0][j]);
   using std::integral_constant;
   for (int cc = 0; cc + 1 < NC; ++cc) {
     pdst_pending = cc + 2 < NC;               // at the boundary to chunk cc + 1: patch cc + 2 goes into this chunk's slot
@@ -1475,11 +1072,11 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
         uint16_t* po = &smem[st_off256(ml, nl)];
         if (HAS_ADD) {
           float ad[4];
-          unpack4(*reinterpret_cast<const uint2*>(po), ad);
-          if (a.round_before_add) unpack4(pack4(v[0], v[1], v[2], v[3]), v);
+          E::un4(*reinterpret_cast<const uint2*>(po), ad);
+          if (a.round_before_add) E::un4(E::pk4(v[0], v[1], v[2], v[3]), v);
           v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
         }
-        *reinterpret_cast<uint2*>(po) = pack4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint2*>(po) = E::pk4(v[0], v[1], v[2], v[3]);
       }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1496,6 +1093,12 @@ static unsigned long long* g_conv_trace = nullptr;
 extern "C" void diagz_conv_trace(void* buf) { g_conv_trace = static_cast<unsigned long long*>(buf); }   // tools/conv_trace.py (not an acez_ symbol: the two builds export the same C ABI)
 #endif
 // tile_mode: 0 = choose by size, 80 / 256 = force that row tile where the layer shape allows it (ACEZ_CONV_TILE, tests)
+// the kernel instantiation of the context's 16-bit operand format (ConvGemmArgs::f16)
+#define ACEZ_CONV_LAUNCH(kern, grid, blk, ...)                                                    \
+  do {                                                                                            \
+    if (g.f16) hipLaunchKernelGGL((kern<EltF16, __VA_ARGS__>), grid, blk, 0, s, g);               \
+    else hipLaunchKernelGGL((kern<EltBf16, __VA_ARGS__>), grid, blk, 0, s, g);                    \
+  } while (0)
 void launch_convgemm(const ConvGemmArgs& g_in, bool relu, hipStream_t s, int tile_mode) {
   ConvGemmArgs g = g_in;
 #ifdef ACEZ_DIAG
@@ -1508,23 +1111,11 @@ void launch_convgemm(const ConvGemmArgs& g_in, bool relu, hipStream_t s, int til
   static const int patch_min_tiles = [] { const char* e = ACEZ_DIAG_ENV("ACEZ_PATCH_MIN_TILES"); return e ? atoi(e) : 256; }();
   if (patch_ok && (tile_mode == 3 || (tile_mode == 0 && (int64_t)((g.M + 255) / 256) * (g.Co / 256) >= patch_min_tiles))) {
     const int ntiles = g.Co / 256, mtiles = (g.M + 255) / 256;
-    const dim3 grid(8 * ntiles * ((mtiles + 7) / 8)), blk(768);
-    static const int wring = [] { const char* e = ACEZ_DIAG_ENV("ACEZ_P3_WRING"); return (e && atoi(e) == 6) ? 6 : 4; }();
-    static const int lean = [] { const char* e = ACEZ_DIAG_ENV("ACEZ_P3Q"); return e ? atoi(e) : 2; }();   // 2 (default): conv3x3r, 0: conv3x3p
+    const dim3 grid(8 * ntiles * ((mtiles + 7) / 8));
     if (!relu) abort();
-    if (lean) {
-      const dim3 blkq(512);
-      if (g.add) hipLaunchKernelGGL((conv3x3r_kernel<true, true>), grid, blkq, 0, s, g);
-      else hipLaunchKernelGGL((conv3x3r_kernel<true, false>), grid, blkq, 0, s, g);
-      return;
-    }
-    if (g.add) {
-      if (wring == 4) hipLaunchKernelGGL((conv3x3p_kernel<true, true, 4>), grid, blk, 0, s, g);
-      else hipLaunchKernelGGL((conv3x3p_kernel<true, true, 6>), grid, blk, 0, s, g);
-    } else {
-      if (wring == 4) hipLaunchKernelGGL((conv3x3p_kernel<true, false, 4>), grid, blk, 0, s, g);
-      else hipLaunchKernelGGL((conv3x3p_kernel<true, false, 6>), grid, blk, 0, s, g);
-    }
+    const dim3 blkq(512);
+    if (g.add) ACEZ_CONV_LAUNCH(conv3x3r_kernel, grid, blkq, true, true);
+    else ACEZ_CONV_LAUNCH(conv3x3r_kernel, grid, blkq, true, false);
     return;
   }
   const bool huge_ok = g.Co % 256 == 0 && g.Kp >= 256;
@@ -1533,11 +1124,11 @@ void launch_convgemm(const ConvGemmArgs& g_in, bool relu, hipStream_t s, int til
     const dim3 grid(8 * ntiles * ((mtiles + 7) / 8)), blk(768);
     if (g.add) {
       if (!relu) abort();
-      hipLaunchKernelGGL((convgemm512_kernel<true, true>), grid, blk, 0, s, g);
+      ACEZ_CONV_LAUNCH(convgemm512_kernel, grid, blk, true, true);
     } else if (relu) {
-      hipLaunchKernelGGL((convgemm512_kernel<true, false>), grid, blk, 0, s, g);
+      ACEZ_CONV_LAUNCH(convgemm512_kernel, grid, blk, true, false);
     } else {
-      hipLaunchKernelGGL((convgemm512_kernel<false, false>), grid, blk, 0, s, g);
+      ACEZ_CONV_LAUNCH(convgemm512_kernel, grid, blk, false, false);
     }
     return;
   }
@@ -1548,11 +1139,11 @@ void launch_convgemm(const ConvGemmArgs& g_in, bool relu, hipStream_t s, int til
     const dim3 grid(8 * ntiles * ((mtiles + 7) / 8)), blk(1024);
     if (g.add) {
       if (!relu) abort();
-      hipLaunchKernelGGL((convgemm256_kernel<true, true>), grid, blk, 0, s, g);
+      ACEZ_CONV_LAUNCH(convgemm256_kernel, grid, blk, true, true);
     } else if (relu) {
-      hipLaunchKernelGGL((convgemm256_kernel<true, false>), grid, blk, 0, s, g);
+      ACEZ_CONV_LAUNCH(convgemm256_kernel, grid, blk, true, false);
     } else {
-      hipLaunchKernelGGL((convgemm256_kernel<false, false>), grid, blk, 0, s, g);
+      ACEZ_CONV_LAUNCH(convgemm256_kernel, grid, blk, false, false);
     }
     return;
   }
@@ -1562,14 +1153,14 @@ void launch_convgemm(const ConvGemmArgs& g_in, bool relu, hipStream_t s, int til
   const dim3 grid(8 * ntiles * ((mtiles + 7) / 8)), blk(512);
   if (nt == 64) {
     if (g.add || !relu) abort();
-    hipLaunchKernelGGL((convgemm_kernel<64, true, false>), grid, blk, 0, s, g);
+    ACEZ_CONV_LAUNCH(convgemm_kernel, grid, blk, 64, true, false);
   } else if (g.add) {
     if (!relu) abort();
-    hipLaunchKernelGGL((convgemm_kernel<128, true, true>), grid, blk, 0, s, g);
+    ACEZ_CONV_LAUNCH(convgemm_kernel, grid, blk, 128, true, true);
   } else if (relu) {
-    hipLaunchKernelGGL((convgemm_kernel<128, true, false>), grid, blk, 0, s, g);
+    ACEZ_CONV_LAUNCH(convgemm_kernel, grid, blk, 128, true, false);
   } else {
-    hipLaunchKernelGGL((convgemm_kernel<128, false, false>), grid, blk, 0, s, g);
+    ACEZ_CONV_LAUNCH(convgemm_kernel, grid, blk, 128, false, false);
   }
 }
 
@@ -1672,26 +1263,26 @@ uint16_t host_f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-float host_bf2f(uint16_t h) {
-  uint32_t u = (uint32_t)h << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
+// fp32 -> IEEE half, round to nearest even (what torch .half() / v_cvt_f16_f32 do; overflow -> inf)
+uint16_t host_f2h(float f) {
+  const _Float16 h = (_Float16)f;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
 }
 
 }  // namespace
 
 struct acez_encoder {
   int device = 0, out_channels = 512, max_frames = 0, max_h = 0, max_w = 0, tile_mode = 0;
-  float* w1 = nullptr;                 // conv1 weights [32][9] (bf16-rounded values in fp32)
-  uint16_t* w1b = nullptr;             // conv1 weights bf16 [32][16] (k = tap, zero padded): A operand of conv12_kernel
-  bool fuse12 = true;                  // ACEZ_CONV12=0: separate conv1 / conv2 kernels
-  bool conv12p = true;   // conv12p_kernel (round 5); ACEZ_CONV12P=0 (diagnostics build, read at creation): conv12_kernel
+  bool f16 = false;                    // 16-bit operand format of every layer: bf16, or fp16 (what the reference's autocast runs the encoder in,
+                                       // ace_trainer.py:366-367, register_mapping.py:209-210); fp32 accumulation in both
+  uint16_t* w1b = nullptr;             // conv1 weights 16-bit [32][16] (k = tap, zero padded): A operand of conv12p_kernel
   float* bias[ACEZ_ENCODER_LAYERS] = {};
-  uint16_t* W[ACEZ_ENCODER_LAYERS] = {};   // bf16 [co][Kp] (layers 1..10)
+  uint16_t* W[ACEZ_ENCODER_LAYERS] = {};   // 16-bit [co][Kp] (layers 1..10)
   int K[ACEZ_ENCODER_LAYERS] = {}, Kp[ACEZ_ENCODER_LAYERS] = {}, co[ACEZ_ENCODER_LAYERS] = {};
   uint16_t* zeros = nullptr;
-  uint16_t *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *r4 = nullptr, *x5 = nullptr, *x6 = nullptr, *r7 = nullptr, *x8 = nullptr,
+  uint16_t *a2 = nullptr, *a3 = nullptr, *r4 = nullptr, *x5 = nullptr, *x6 = nullptr, *r7 = nullptr, *x8 = nullptr,
            *x9 = nullptr, *sk = nullptr;
   std::vector<void*> allocs;
 };
@@ -1704,10 +1295,11 @@ extern "C" void acez_encoder_destroy(acez_encoder* e) {
 }
 
 extern "C" int acez_encoder_create(acez_encoder** out, const float* const* h_weights, const float* const* h_biases, int out_channels,
-                                   int max_frames, int max_h, int max_w, int device) {
+                                   int max_frames, int max_h, int max_w, int compute_dtype, int device) {
   ACEZ_REQUIRE(out && h_weights && h_biases, "null pointer");
   ACEZ_REQUIRE(out_channels > 0 && out_channels % 128 == 0, "out_channels must be a positive multiple of 128");
   ACEZ_REQUIRE(max_frames > 0 && max_h >= 8 && max_w >= 8, "bad capacity");
+  ACEZ_REQUIRE(compute_dtype == ACEZ_DTYPE_BF16 || compute_dtype == ACEZ_DTYPE_FP16, "compute_dtype must be ACEZ_DTYPE_BF16 or ACEZ_DTYPE_FP16");
   for (int i = 0; i < ACEZ_ENCODER_LAYERS; ++i) ACEZ_REQUIRE(h_weights[i] && h_biases[i], "null layer pointer");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -1720,8 +1312,8 @@ extern "C" int acez_encoder_create(acez_encoder** out, const float* const* h_wei
   acez_encoder* e = new acez_encoder();
   e->device = device; e->out_channels = out_channels; e->max_frames = max_frames; e->max_h = max_h; e->max_w = max_w;
   if (const char* tm = ACEZ_DIAG_ENV("ACEZ_CONV_TILE")) e->tile_mode = atoi(tm);
-  if (const char* f12 = ACEZ_DIAG_ENV("ACEZ_CONV12")) e->fuse12 = atoi(f12) != 0;
-  if (const char* p12 = ACEZ_DIAG_ENV("ACEZ_CONV12P")) e->conv12p = atoi(p12) != 0;
+  e->f16 = compute_dtype == ACEZ_DTYPE_FP16;
+  auto cvt = [&](float f) { return e->f16 ? host_f2h(f) : host_f2bf(f); };
   auto A = [&](void** p, size_t bytes) -> hipError_t {
     hipError_t rc = hipMalloc(p, bytes);
     if (rc == hipSuccess) e->allocs.push_back(*p);
@@ -1745,15 +1337,18 @@ extern "C" int acez_encoder_create(acez_encoder** out, const float* const* h_wei
     const int K = L.k * L.k * L.ci;
     e->K[i] = K; e->Kp[i] = (K + 63) / 64 * 64;
     ACEZ_ENC_ALLOC(e->bias[i], (size_t)co * sizeof(float));
-    ACEZ_HIP_CHECK(hipMemcpy(e->bias[i], h_biases[i], (size_t)co * sizeof(float), hipMemcpyHostToDevice));
+    {
+      // fp16: autocast hands conv2d its bias in half precision too (the kernels add it in fp32 to the fp32 accumulator, as cuDNN's fused
+      // epilogue does); bf16 keeps the fp32 values
+      std::vector<float> b(h_biases[i], h_biases[i] + co);
+      if (e->f16)
+        for (float& v : b) v = (float)(_Float16)v;
+      ACEZ_HIP_CHECK(hipMemcpy(e->bias[i], b.data(), (size_t)co * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (i == 0) {
-      std::vector<float> w(32 * 9);
-      for (int j = 0; j < 32 * 9; ++j) w[j] = host_bf2f(host_f2bf(h_weights[0][j]));   // [co][1][3][3] is already [co][tap]
-      ACEZ_ENC_ALLOC(e->w1, w.size() * sizeof(float));
-      ACEZ_HIP_CHECK(hipMemcpy(e->w1, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
-      std::vector<uint16_t> wb(32 * 16, 0);
+      std::vector<uint16_t> wb(32 * 16, 0);   // [co][1][3][3] is already [co][tap]
       for (int o = 0; o < 32; ++o)
-        for (int tp = 0; tp < 9; ++tp) wb[o * 16 + tp] = host_f2bf(h_weights[0][o * 9 + tp]);
+        for (int tp = 0; tp < 9; ++tp) wb[o * 16 + tp] = cvt(h_weights[0][o * 9 + tp]);
       ACEZ_ENC_ALLOC(e->w1b, wb.size() * sizeof(uint16_t));
       ACEZ_HIP_CHECK(hipMemcpy(e->w1b, wb.data(), wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     } else {
@@ -1763,14 +1358,13 @@ extern "C" int acez_encoder_create(acez_encoder** out, const float* const* h_wei
       for (int o = 0; o < co; ++o)
         for (int c = 0; c < L.ci; ++c)
           for (int tp = 0; tp < kk; ++tp)
-            w[(size_t)o * e->Kp[i] + (size_t)tp * L.ci + c] = host_f2bf(h_weights[i][((size_t)o * L.ci + c) * kk + tp]);
+            w[(size_t)o * e->Kp[i] + (size_t)tp * L.ci + c] = cvt(h_weights[i][((size_t)o * L.ci + c) * kk + tp]);
       ACEZ_ENC_ALLOC(e->W[i], w.size() * sizeof(uint16_t));
       ACEZ_HIP_CHECK(hipMemcpy(e->W[i], w.data(), w.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
   }
   const size_t F = max_frames;
   const size_t h2 = (max_h + 1) / 2, w2 = (max_w + 1) / 2, h4 = (h2 + 1) / 2, w4 = (w2 + 1) / 2, h8 = (h4 + 1) / 2, w8 = (w4 + 1) / 2;
-  ACEZ_ENC_ALLOC(e->a1, F * max_h * max_w * 32 * 2);
   ACEZ_ENC_ALLOC(e->a2, F * h2 * w2 * 64 * 2);
   ACEZ_ENC_ALLOC(e->a3, F * h4 * w4 * 128 * 2);
   const size_t px = F * h8 * w8;
@@ -1804,34 +1398,28 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
     const int F = (n_frames - f0 < e->max_frames) ? n_frames - f0 : e->max_frames;
     const float* img = d_images + (size_t)f0 * h * w;
     uint16_t* feat = (uint16_t*)d_features + (size_t)f0 * h8 * w8 * e->out_channels;
-    if (e->fuse12) {
+    {
+      // conv1 + conv2 in one launch, software-pipelined over 4 x 32 output tiles (conv1 of tile i + 1 beside conv2 of tile i)
       Conv12Args c{};
       c.img = img; c.w1 = e->w1b; c.b1 = e->bias[0]; c.w2 = e->W[1]; c.b2 = e->bias[1]; c.out = e->a2;
       c.F = F; c.H = h; c.W = w; c.H2 = h2; c.W2 = w2; c.Kp2 = e->Kp[1]; c.zero = reinterpret_cast<const float*>(e->zeros);
       c.tiles_y = (h2 + 7) / 8; c.tiles_x = (w2 + 31) / 32; c.n_tiles = F * c.tiles_y * c.tiles_x;
-      // round 5: the software-pipelined kernel on 4 x 32 tiles (conv1 of tile i + 1 beside conv2 of tile i); ACEZ_CONV12P=0
-      // (diagnostics build): round 1's phase-by-phase kernel on 8 x 32 tiles. Bit-identical outputs.
-      if (e->conv12p) {
-        const int nt4 = F * ((h2 + 3) / 4) * c.tiles_x;
-        hipLaunchKernelGGL(conv12p_kernel<4>, dim3(nt4 < 256 ? nt4 : 256), dim3(512), 0, s, c);
-      } else {
-        hipLaunchKernelGGL(conv12_kernel, dim3(c.n_tiles < 256 ? c.n_tiles : 256), dim3(512), 0, s, c);
-      }
-    } else {
-      const int64_t npix = (int64_t)F * h * w;
-      hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, img, (const float*)e->w1, (const float*)e->bias[0], e->a1, h, w,
-                         npix);
+      const int nt4 = F * ((h2 + 3) / 4) * c.tiles_x;
+      if (e->f16) hipLaunchKernelGGL((conv12p_kernel<EltF16, 4>), dim3(nt4 < 256 ? nt4 : 256), dim3(512), 0, s, c);
+      else hipLaunchKernelGGL((conv12p_kernel<EltBf16, 4>), dim3(nt4 < 256 ? nt4 : 256), dim3(512), 0, s, c);
     }
     auto conv = [&](int li, const uint16_t* in, int hi, int wi, uint16_t* outp, int ho, int wo, const uint16_t* add, bool relu) {
       const LayerDesc& L = kLayers[li];
       ConvGemmArgs g{};
       g.In = in; g.W = e->W[li]; g.bias = e->bias[li]; g.add = add; g.out = outp; g.zeros = e->zeros;
       g.Hi = hi; g.Wi = wi; g.Ci = L.ci; g.ci_shift = __builtin_ctz(L.ci); g.Ho = ho; g.Wo = wo; g.Co = e->co[li];
-      g.ksize = L.k; g.stride = L.stride; g.pad = L.k / 2; g.K = e->K[li]; g.Kp = e->Kp[li]; g.M = F * ho * wo;
+      g.ksize = L.k; g.stride = L.stride; g.pad = L.k / 2; g.K = e->K[li]; g.Kp = e->Kp[li]; g.M = F * ho * wo; g.f16 = e->f16 ? 1 : 0;
+      // fp16 = the reference's arithmetic: relu(conv(x)) is a half tensor BEFORE `res + x` / `skip + x` (ace_network.py:52,58), so the
+      // activation is rounded before the residual is added and the sum is rounded again; bf16 keeps its single rounding of the fp32 sum
+      g.round_before_add = e->f16 ? 1 : 0;
       if (const char* d = ACEZ_DIAG_ENV("ACEZ_CONV_DBG")) g.dbg = atoi(d);
       launch_convgemm(g, relu, s, e->tile_mode);
     };
-    if (!e->fuse12) conv(1, e->a1, h, w, e->a2, h2, w2, nullptr, true);
     conv(2, e->a2, h2, w2, e->a3, h4, w4, nullptr, true);
     conv(3, e->a3, h4, w4, e->r4, h8, w8, nullptr, true);
     conv(4, e->r4, h8, w8, e->x5, h8, w8, nullptr, true);

@@ -3,11 +3,6 @@
 #include "head_kernels.hip"
 #include "pose_fused.hip"
 #include "acez_common.h"
-#ifdef ACEZ_DIAG   // measured-and-rejected row-persistent kernels: diagnostics build only
-#include "head_fused.hip"
-#include "head_chain.hip"
-#include "head_infer.hip"
-#endif
 #include "conv_launch.h"
 #include <stdlib.h>
 #include <string.h>
@@ -30,16 +25,10 @@ struct acez_trainer {
   int64_t n_wide = 0, n_params = 0, fc3_off = 0;
   int64_t fc3_stride = 0;
   int nslabs = 1;
-  int wgrad_tile = 128;
   int max_batch = 0;
   int last_n = 0;
   // device allocations
   uint16_t *Wb = nullptr, *WbT = nullptr, *W3b = nullptr;
-  uint16_t* Wp = nullptr;       // the wide layers' weights in headinfer_kernel's stream order (head_infer.hip), re-packed from Wb when stale
-  bool wp_valid = false;
-  int hi_group = 8;             // wide layers per headinfer_kernel launch (ACEZ_HI_GROUP)
-  bool head_infer = false;      // ACEZ_HEAD_INFER=1 (diagnostics build only): inference passes too large for the one-launch chains run on
-                                // headinfer_kernel (head_infer.hip, round 5: bit-identical to the large-tile launches, measured 15-20 % slower)
   std::vector<uint16_t*> out;   // post-relu output of each wide layer
   std::vector<uint16_t*> R;     // residual stream, R[0] = gathered features
   std::vector<uint16_t*> dZ;    // gradient wrt each wide layer's pre-activation
@@ -88,25 +77,13 @@ struct acez_trainer {
   std::vector<EvUse> ev_used;
   size_t ev_next = 0;
   int prof_launches = 0;  // launches inside the currently open scope
-  // persistent row-tile forward (head_fused.hip). Measured on MI355X: 115 us for the 8 layers vs 85 us for 8 rowgemm
-  // launches -> off by default; ACEZ_FUSED_FWD=1 selects it.
-  bool fused_fwd = false;
-  int gemm_tile = 80;  // rows per rowgemm workgroup: 80 (256 workgroups at batch 5120) or 128; ACEZ_GEMM_TILE overrides
-  // Row-persistent chain kernel (head_chain.hip): gather + forward + loss + input gradients in one launch, bit-exact with the
-  // per-layer launches (tests/test_chain_gpu.py). Measured on MI355X at batch 5120: 141-148 us for the chain against 147 us for
-  // the 17 launches it replaces, plus a separate schedule launch -> NOT faster; opt-in with ACEZ_CHAIN=1.
-  bool chain = false;
-  uint32_t* maskbits = nullptr;   // [L][max_blocks][512] ReLU mask bits of the chain kernel
-  unsigned long long* chain_trace = nullptr;   // [2][256] s_memtime stamps (ACEZ_CHAIN_TRACE=1; acez_trainer_debug_read kind 5)
-  int* chain_err = nullptr;       // sticky error word of the chain kernel (a bounded spin expired)
-  std::vector<uint16_t*> dRc;     // residual-gradient buffers of the chain kernel, one per fan-in (never re-read after a rewrite)
   // rowseq_kernel: the forward layers / the input-gradient layers as ONE launch each, kernel boundaries replaced by a same-XCD
   // hand-off (head_kernels.hip). Default when every workgroup can be resident (grid <= CUs); ACEZ_SEQ=0 = per-layer launches.
   bool seq = true;
   // 16-bit operand format of the GEMM chains (acez_train_config.compute_dtype): bf16, or fp16 with the gradient chain scaled by
   // grad_scale (fp16's smallest normal is 6e-5; the reference uses a GradScaler for the same reason, ace_schedule.py:70,107-113)
   bool f16 = false;
-  int loss_rows = 4;   // rows per wavefront of loss_kernel (4 waves per workgroup): 4 = 16-row workgroups; 8 with the chain kernel / ACEZ_LOSS_ROWS=8
+  int loss_rows = 4;   // rows per wavefront of loss_kernel (4 waves per workgroup): 4 = 16-row workgroups; ACEZ_LOSS_ROWS=8 (diagnostics build): 8
   int last_nblk = 0;   // loss workgroups of the last backward (the schedule wave scans their |ds| maxima in fp16 mode)
   int n_cus = 0;
   uint32_t* seq_flags = nullptr;  // [64 row tiles][32] hand-off counters, monotonically increasing
@@ -142,6 +119,7 @@ struct acez_trainer {
   uint32_t* wg_status = nullptr;  // [workgroups][8 loader waves] WgradOptArgs::status
   WgoFaultRec* wg_rec = nullptr;  // WgradOptArgs::rec
   int wgo_recovered = 0;          // faulted wgrad_opt steps the fall-back has finished (wgo_recover)
+  bool inference_only = false;    // acez_train_config.inference_only: no training buffers exist, the training entry points refuse
   bool sizing = false;            // acez_trainer_create's first pass: dmalloc only adds up
   size_t sized_total = 0;
   unsigned long long* pose_trace = nullptr;  // ACEZ_POSE_TRACE=1 (diagnostics build): [3][1024][16] stamps of the pose forward (S3) / S1 / S2 workgroups (debug_read kind 8)
@@ -269,7 +247,6 @@ static void wgo_recover(acez_trainer* tr, hipStream_t s) {
   if (tr->f16) hipLaunchKernelGGL(wgo_recover_kernel<EltF16>, grid, dim3(512), 0, s, ad, (const float*)tr->slabs, tr->n_wide, (const uint32_t*)tr->wg_status, (const WgoFaultRec*)tr->wg_rec, tr->L);
   else hipLaunchKernelGGL(wgo_recover_kernel<EltBf16>, grid, dim3(512), 0, s, ad, (const float*)tr->slabs, tr->n_wide, (const uint32_t*)tr->wg_status, (const WgoFaultRec*)tr->wg_rec, tr->L);
   (void)hipMemsetAsync(tr->wg_rec, 0, sizeof(WgoFaultRec), s);
-  tr->wp_valid = false;
   ++tr->wgo_recovered;
 }
 
@@ -327,17 +304,12 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_REQUIRE(tr, "out of host memory");
   ACEZ_HIP_CHECK(hipGetDevice(&tr->device));
   tr->cfg = *cfg;
-  if (const char* e = ACEZ_DIAG_ENV("ACEZ_FUSED_FWD")) tr->fused_fwd = atoi(e) != 0;
-  if (const char* e = ACEZ_DIAG_ENV("ACEZ_CHAIN")) tr->chain = atoi(e) != 0;
-  if (tr->fused_fwd) tr->chain = false;
   tr->f16 = cfg->compute_dtype == ACEZ_DTYPE_FP16;
-  if (tr->f16) { tr->fused_fwd = false; tr->chain = false; }   // the opt-in row-persistent kernels exist in bf16 only
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_LOSS_ROWS")) tr->loss_rows = (atoi(e) == 8) ? 8 : 4;
-  if (tr->chain) tr->loss_rows = 8;   // the chain kernel's loss phase owns 32-row tiles; partial counts follow it
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_POSE_FUSED")) tr->pose_fused = atoi(e) != 0;
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_POSE_TILE")) { const int v = atoi(e); tr->pose_tile = tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_POSE_TILE_FWD")) { const int v = atoi(e); tr->pose_tile_fwd = (v == 4 || v == 16) ? v : 8; }
-  if (cfg->pose_refinement != 2 || tr->chain || tr->fused_fwd) tr->pose_fused = false;   // (the opt-in row-persistent kernels keep round 2's pose launches)
+  if (cfg->pose_refinement != 2) tr->pose_fused = false;
   if (cfg->pose_refinement != 0 && !tr->pose_fused && !(ACEZ_DIAG_ENV("ACEZ_POSE_STREAM") && atoi(ACEZ_DIAG_ENV("ACEZ_POSE_STREAM")) == 0)) {
     ACEZ_HIP_CHECK(hipStreamCreateWithFlags(&tr->pose_stream, hipStreamNonBlocking));
     for (hipEvent_t* e : {&tr->ev_begin, &tr->ev_pose_fwd, &tr->ev_loss, &tr->ev_pose_bwd}) ACEZ_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -351,55 +323,49 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   tr->n_params = params->n_params;
   tr->fc3_stride = ((int64_t)tr->no * 513 + 3) & ~3LL;
   tr->max_batch = cfg->max_batch;
-  if (const char* e = ACEZ_DIAG_ENV("ACEZ_GEMM_TILE")) tr->gemm_tile = atoi(e) == 128 ? 128 : 80;
-  if (tr->f16) tr->gemm_tile = 80;
   if (const char* e = getenv("ACEZ_SEQ")) tr->seq = atoi(e) != 0;
   {
     hipDeviceProp_t prop;
     ACEZ_HIP_CHECK(hipGetDeviceProperties(&prop, tr->device));
     tr->n_cus = prop.multiProcessorCount;
   }
-  // wgrad_kernel: 16 tiles per layer; wgrad256_kernel (ACEZ_WGRAD_TILE=256, measured alternative: -2.8 us of wgrad, +2.4 us of
-  // adamw for the two extra slabs): 8; as many row slabs as fill the 256 CUs
-  if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGRAD_TILE")) tr->wgrad_tile = atoi(e) == 256 ? 256 : 128;
-  if (tr->f16) tr->wgrad_tile = 128;
-  tr->nslabs = 256 / ((tr->wgrad_tile == 128 ? 16 : 8) * tr->L);
+  // wgrad_kernel: 16 tiles per layer; as many row slabs as fill the 256 CUs
+  tr->nslabs = 256 / (16 * tr->L);
   if (tr->nslabs < 1) tr->nslabs = 1;
 
   int rc = ACEZ_OK;
   const size_t act_bytes = (size_t)tr->max_batch * 512 * sizeof(uint16_t);
   auto A = [&](void** p, size_t bytes) { if (rc == ACEZ_OK) rc = dmalloc(tr, p, bytes); };
-  // buffers only a trainer that trains needs (iterations = 1 is how the hosts create inference-only heads, session.scene_coordinates): the
-  // second input buffer / metadata table of the pre-gathered next batch and wgrad_opt_kernel's exchange tiles, counters and fault record
-  const bool trains = cfg->iterations > 1;
+  // buffers only a trainer that trains needs (acez_train_config.inference_only = 1: Regressor, session.scene_coordinates): gradients, weight-
+  // gradient slabs, partial sums, the second input buffer / metadata table of the pre-gathered next batch and wgrad_opt_kernel's exchange
+  // tiles, counters and fault record -- 7.5 of the 14.5 GB of a 128-frame inference context
+  const bool trains = cfg->inference_only == 0;
+  tr->inference_only = !trains;
   const int wgo_grid = 256 * ((tr->L + 7) / 8);
   for (int pass = 0; pass < 2; ++pass) {   // pass 0 adds the requests up (dmalloc, tr->sizing), pass 1 hands out pieces of ONE exact arena
   tr->sizing = pass == 0;
   A((void**)&tr->Wb, (size_t)tr->L * 262144 * 2);
   A((void**)&tr->WbT, (size_t)tr->L * 262144 * 2);
   A((void**)&tr->W3b, (size_t)tr->no * 512 * 2);
-  A((void**)&tr->Wp, (size_t)tr->L * 262144 * 2);
   tr->out.resize(tr->L, nullptr);
   tr->dZ.resize(tr->L, nullptr);
   tr->R.resize(tr->nb + 2, nullptr);
-  for (int l = 0; l < tr->L; ++l) { A((void**)&tr->out[l], act_bytes); A((void**)&tr->dZ[l], act_bytes); }
+  for (int l = 0; l < tr->L; ++l) { A((void**)&tr->out[l], act_bytes); if (trains) A((void**)&tr->dZ[l], act_bytes); }
   for (int b = 0; b < tr->nb + 2; ++b) A((void**)&tr->R[b], act_bytes);
-  A((void**)&tr->dR[0], act_bytes);
-  A((void**)&tr->dR[1], act_bytes);
-  A((void**)&tr->slabs, (size_t)tr->nslabs * tr->n_wide * sizeof(float));
-  const int max_blocks = (tr->max_batch + 4 * LOSS_ROWS - 1) / (4 * LOSS_ROWS);   // 32-row tiles of the chain kernel
   const int max_loss_blocks = (tr->max_batch + 4 * tr->loss_rows - 1) / (4 * tr->loss_rows);
-  A((void**)&tr->fc3_partials, (size_t)max_loss_blocks * tr->fc3_stride * sizeof(float));
-  A((void**)&tr->stat_partials, (size_t)max_loss_blocks * 4 * sizeof(float));
   tr->bias_layer_stride = (int64_t)max_loss_blocks * 512;
-  A((void**)&tr->bias_partials, (size_t)tr->L * tr->bias_layer_stride * sizeof(float));
-  A((void**)&tr->xyz, (size_t)tr->max_batch * 3 * sizeof(float));
-  A((void**)&tr->batch_meta, (size_t)tr->max_batch * sizeof(int4));
-  A((void**)&tr->maskbits, (size_t)tr->L * max_blocks * 512 * sizeof(uint32_t));
-  A((void**)&tr->chain_err, sizeof(int));
+  if (trains) {
+    A((void**)&tr->dR[0], act_bytes);
+    A((void**)&tr->dR[1], act_bytes);
+    A((void**)&tr->slabs, (size_t)tr->nslabs * tr->n_wide * sizeof(float));
+    A((void**)&tr->fc3_partials, (size_t)max_loss_blocks * tr->fc3_stride * sizeof(float));
+    A((void**)&tr->stat_partials, (size_t)max_loss_blocks * 4 * sizeof(float));
+    A((void**)&tr->bias_partials, (size_t)tr->L * tr->bias_layer_stride * sizeof(float));
+    A((void**)&tr->xyz, (size_t)tr->max_batch * 3 * sizeof(float));
+    A((void**)&tr->batch_meta, (size_t)tr->max_batch * sizeof(int4));
+  }
   A((void**)&tr->seq_flags, (64 * 32 + 32) * sizeof(uint32_t));
   if (ACEZ_DIAG_ENV("ACEZ_SEQ_XCC")) A((void**)&tr->seq_xcc, (8 + 256) * sizeof(uint32_t));
-  if (ACEZ_DIAG_ENV("ACEZ_CHAIN_TRACE")) A((void**)&tr->chain_trace, 512 * sizeof(unsigned long long));
   if (ACEZ_DIAG_ENV("ACEZ_POSE_TRACE")) A((void**)&tr->pose_trace, 3 * 1024 * 16 * sizeof(unsigned long long));
   if (ACEZ_DIAG_ENV("ACEZ_WGO_TRACE")) A((void**)&tr->wgo_trace, 256 * 12 * 8 * sizeof(unsigned long long));
   if (trains) {
@@ -410,8 +376,6 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
     A((void**)&tr->wg_status, (size_t)wgo_grid * WGRAD_LOADERS * sizeof(uint32_t));
     A((void**)&tr->wg_rec, sizeof(WgoFaultRec));
   }
-  tr->dRc.resize(tr->nb + 1, nullptr);
-  for (int b = 0; b <= tr->nb; ++b) A((void**)&tr->dRc[b], act_bytes);
   A((void**)&tr->zeros, 1024);
   tr->log_cap = cfg->iterations + 8;
   A((void**)&tr->log_loss, (size_t)tr->log_cap * sizeof(float));
@@ -428,9 +392,6 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_HIP_CHECK(hipMemcpy(tr->seq_flags + 64 * 32 + 1, &tr->seq_spin_limit, sizeof(uint32_t), hipMemcpyHostToDevice));
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_SEQ_FAULT_AT")) tr->seq_fault_at = atol(e);
   if (tr->seq_xcc) ACEZ_HIP_CHECK(hipMemset(tr->seq_xcc, 0, (8 + 256) * sizeof(uint32_t)));
-  if (tr->chain_trace) ACEZ_HIP_CHECK(hipMemset(tr->chain_trace, 0, 512 * sizeof(unsigned long long)));
-  if (const char* e = ACEZ_DIAG_ENV("ACEZ_HEAD_INFER")) tr->head_infer = atoi(e) != 0;
-  if (const char* e = ACEZ_DIAG_ENV("ACEZ_HI_GROUP")) tr->hi_group = std::max(1, atoi(e));
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGRAD_OPT")) tr->wgrad_opt = atoi(e) != 0;
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_AT")) tr->wgo_fault_at = atol(e);
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_WGO_FAULT_MOD")) tr->wgo_fault_mod = atoi(e);
@@ -459,7 +420,6 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   ACEZ_HIP_CHECK(hipGetLastError());
   ACEZ_HIP_CHECK(hipMemset(tr->zeros, 0, 1024));
   { TrainState one{}; one.active = 1; ACEZ_HIP_CHECK(hipMemcpy(tr->st_infer, &one, sizeof(TrainState), hipMemcpyHostToDevice)); }
-  ACEZ_HIP_CHECK(hipMemset(tr->chain_err, 0, sizeof(int)));
   ACEZ_HIP_CHECK(hipMemset(tr->log_loss, 0, (size_t)tr->log_cap * sizeof(float)));
   ACEZ_HIP_CHECK(hipMemset(tr->log_inl, 0, (size_t)tr->log_cap * sizeof(float)));
   ACEZ_HIP_CHECK(hipDeviceSynchronize());
@@ -473,6 +433,7 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
 
 extern "C" int acez_trainer_set_buffer(acez_trainer* tr, const acez_train_buffer* buf) {
   ACEZ_REQUIRE(tr && buf, "null pointer");
+  ACEZ_REQUIRE(!tr->inference_only, "an inference-only context (acez_train_config.inference_only) takes no training buffer");
   ACEZ_REQUIRE(buf->d_features && buf->d_target_px && buf->d_view_idx && buf->n_patches > 0, "empty patch buffer");
   ACEZ_REQUIRE(buf->d_view_aug_inv && buf->d_view_K && buf->d_view_Kinv && buf->d_view_image && buf->n_views > 0, "empty view table");
   ACEZ_REQUIRE(buf->d_image_pose_inv && buf->n_images > 0, "empty pose table");
@@ -539,40 +500,15 @@ extern "C" int acez_trainer_sync_weights(acez_trainer* tr, void* stream) {
   hipLaunchKernelGGL(recast_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
   ACEZ_HIP_CHECK(hipGetLastError());
   tr->pose_wt_valid = false;   // the caller may have rewritten the pose parameters as well
-  tr->wp_valid = false;
   tr->pre_idx = nullptr; tr->pre_n = 0;   // a restart point: the next step gathers its own batch
   return ACEZ_OK;
 }
-
-#ifdef ACEZ_DIAG
-// persistent row-tile forward: gather (idx may be null) + all wide layers in one launch; returns the fc2 output buffer
-static uint16_t* launch_forward_fused(acez_trainer* tr, const uint16_t* feat, const int64_t* idx, int n, bool keep, const TrainState* st,
-                                      hipStream_t s) {
-  HeadFwdArgs a{};
-  a.feat = feat; a.idx = idx; a.g_in = keep ? tr->R[0] : nullptr; a.n = n; a.n_layers = tr->L; a.Wb = tr->Wb; a.params = tr->pb.d_params; a.st = st;
-  for (int b = 0; b <= tr->nb; ++b) {
-    a.layer[3 * b] = FusedLayer{0, 1, 0, keep ? tr->out[3 * b] : nullptr, nullptr};
-    a.layer[3 * b + 1] = FusedLayer{1, 2, 0, keep ? tr->out[3 * b + 1] : nullptr, nullptr};
-    a.layer[3 * b + 2] = FusedLayer{2, 1, 1, keep ? tr->out[3 * b + 2] : nullptr, keep ? tr->R[b + 1] : nullptr};
-  }
-  const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
-  a.layer[f1] = FusedLayer{0, 1, 0, keep ? tr->out[f1] : nullptr, nullptr};
-  a.layer[f2] = FusedLayer{1, 2, 0, tr->out[f2], nullptr};
-  ProfScope ps(tr, s, KC_GEMM_FWD);
-  hipLaunchKernelGGL(headfwd_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a);
-  tr->prof_launches += tr->L;  // accounted as L layer-GEMMs so that the per-layer average stays comparable
-  return tr->out[f2];
-}
-
-#else
-static uint16_t* launch_forward_fused(acez_trainer*, const uint16_t*, const int64_t*, int, bool, const TrainState*, hipStream_t) { abort(); }   // (tr->fused_fwd is never set in the product build)
-#endif
 
 // forward chain on n rows whose input features are in `in0`; returns the fc2 output buffer
 // rowseq_kernel is usable when its workgroups wait for each other safely: all of them resident at once
 static bool seq_usable(const acez_trainer* tr, int n) {
   const int mtiles = (n + 79) / 80;
-  return tr->seq && tr->gemm_tile == 80 && mtiles <= 64 && 32 * ((mtiles + 7) / 8) <= tr->n_cus;
+  return tr->seq && mtiles <= 64 && 32 * ((mtiles + 7) / 8) <= tr->n_cus;
 }
 
 // wgrad_opt_kernel's workgroups wait for each other too: same conditions, its own grid (both slabs of a layer on one XCD: 32 workgroups
@@ -581,7 +517,7 @@ static bool seq_usable(const acez_trainer* tr, int n) {
 // (adamw_pose_kernel), 18 us that the weight tiles used to run beside for free -- measured with wgrad_opt on that path: 191.6 us per
 // step against 176.7 (profiles/r04_*_trace_mlp.csv history in DESIGN.md section 3).
 static bool wgrad_opt_usable(const acez_trainer* tr) {
-  return tr->wgrad_opt && tr->seq && tr->gemm_tile == 80 && !tr->chain && !tr->fused_fwd && tr->wgrad_tile == 128 && tr->nslabs == 2 &&
+  return tr->wgrad_opt && tr->seq && tr->nslabs == 2 &&
          tr->cfg.pose_refinement == 0 && 256 * ((tr->L + 7) / 8) <= tr->n_cus;
 }
 
@@ -623,7 +559,7 @@ static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, co
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144;
     g.add = nullptr; g.mask = nullptr; g.res = res; g.out_main = out_main; g.out_aux = out_aux;
     g.M = n; g.N = 512; g.K = 512; g.relu = 1; g.aux_mode = res ? AUX_RESIDUAL : AUX_NONE; g.st = st; g.dbg = 0; g.bias_partials = nullptr;
-    launch_rowgemm(g, tr->gemm_tile, s, tr->f16);
+    launch_rowgemm(g, s, tr->f16);
     ++tr->prof_launches;
   };
   const uint16_t* r = in0;
@@ -658,12 +594,15 @@ static void launch_loss(acez_trainer* tr, int nblk, hipStream_t s, const LossArg
   }
 }
 
-// training-mode arguments of the loss phases (loss_kernel / the chain kernel's loss phase)
-// where the gather launches of a batch leave the per-row metadata for the loss kernel (not with the chain kernel, which gathers itself)
+// training-mode arguments of the loss kernel
+// where the gather launches of a batch leave the per-row metadata for the loss kernel
 static GatherMeta gather_meta(acez_trainer* tr) {
   GatherMeta m{};
-  if (tr->chain || tr->fused_fwd) return m;
   m.dst = tr->batch_meta; m.view_idx = tr->buf.d_view_idx; m.view_image = tr->buf.d_view_image; m.target_px = tr->buf.d_target_px;
+  // EVERY training gather holds while the sticky fault word is up: a faulted wgrad_opt step is finished by the host from the
+  // rows still in R[0] (wgo_recover; rec.in0), and a step queued behind the fault -- announced or not -- must not overwrite them. The
+  // faulted launch's schedule wave has already activated the next state slot, so gather_kernel's `active` test alone does not hold them.
+  m.hold = tr->seq_err;
   return m;
 }
 
@@ -671,7 +610,7 @@ static void fill_loss_train(acez_trainer* tr, LossArgs& a, const uint16_t* act, 
   const int f2 = 3 * (tr->nb + 1) + 1;
   fill_loss_head(tr, a);
   a.act = act; a.n = n;
-  a.idx = d_indices; a.meta = (tr->chain || tr->fused_fwd) ? nullptr : tr->batch_meta; a.target_px = tr->buf.d_target_px; a.target_crds = tr->buf.d_target_crds; a.view_idx = tr->buf.d_view_idx;
+  a.idx = d_indices; a.meta = tr->batch_meta; a.target_px = tr->buf.d_target_px; a.target_crds = tr->buf.d_target_crds; a.view_idx = tr->buf.d_view_idx;
   a.view_aug_inv = tr->buf.d_view_aug_inv; a.view_K = tr->buf.d_view_K; a.view_Kinv = tr->buf.d_view_Kinv;
   a.view_image = tr->buf.d_view_image; a.image_pose_inv = pose_tables ? tr->pose_cur : tr->buf.d_image_pose_inv;
   a.row_dT = pose_tables ? tr->row_dT : nullptr; a.row_image = pose_tables ? tr->row_image : nullptr;
@@ -686,58 +625,6 @@ static void fill_loss_train(acez_trainer* tr, LossArgs& a, const uint16_t* act, 
   a.fault = tr->seq_err;
   if (const char* e = ACEZ_DIAG_ENV("ACEZ_LOSS_DBG")) a.dbg = atoi(e);   // ablation: 1 = stop after phase A, 2 = after phase B (timing only)
 }
-
-#ifdef ACEZ_DIAG
-// The dependent chain of a step as one launch of chain_kernel (head_chain.hip). phases: 1 = gather + forward (the fc2 output
-// is stored for a later phase-2 launch), 2 = loss + input gradients (from the stored fc2 output), 3 = everything.
-static void launch_chain(acez_trainer* tr, const int64_t* d_indices, int n, int phases, bool pose_tables, hipStream_t s) {
-  const int nb = tr->nb, f1 = 3 * (nb + 1), f2 = f1 + 1;
-  ChainArgs c{};
-  c.src = (phases & 1) ? (const uint16_t*)tr->buf.d_features : tr->out[f2];
-  c.idx = d_indices; c.g_in = tr->R[0]; c.g_dz_last = tr->dZ[f2]; c.maskbits = tr->maskbits;
-  c.bias_partials = tr->bias_partials; c.bias_layer_stride = tr->bias_layer_stride;
-  c.n = n; c.phases = phases; c.st = tr->st; c.err = tr->chain_err; c.trace = tr->chain_trace;
-  if (const char* e = ACEZ_DIAG_ENV("ACEZ_CHAIN_DBG")) c.dbg = atoi(e);
-  const float* P = tr->pb.d_params;
-  int k = 0;
-  auto fwd = [&](int l, uint16_t* g_out, const uint16_t* r_in, int mask_layer) {
-    ChainStep& S = c.step[k++];
-    S.W = tr->Wb + (size_t)l * 262144; S.bias = P + (int64_t)l * 262656 + 262144; S.g_out = g_out;
-    S.r_in = r_in; S.r_out = nullptr; S.mask_layer = mask_layer; S.bias_slot = 0;
-  };
-  for (int b = 0; b <= nb; ++b) {
-    fwd(3 * b, tr->out[3 * b], nullptr, 3 * b);
-    fwd(3 * b + 1, tr->out[3 * b + 1], nullptr, 3 * b + 1);
-    fwd(3 * b + 2, tr->R[b + 1], tr->R[b], 3 * b + 2);   // the relu output itself is only needed as a mask (bits); R[b+1] feeds wgrad
-  }
-  fwd(f1, tr->out[f1], nullptr, f1);
-  fwd(f2, phases == 1 ? tr->out[f2] : nullptr, nullptr, -1);   // fc2's mask is applied by the loss phase from the tile itself
-  c.n_fwd = k;
-  auto bwd = [&](int l, int l_out, const uint16_t* r_in, uint16_t* r_out) {
-    ChainStep& S = c.step[k++];
-    S.W = tr->WbT + (size_t)l * 262144; S.bias = nullptr; S.g_out = tr->dZ[l_out];
-    S.r_in = r_in; S.r_out = r_out; S.mask_layer = l_out; S.bias_slot = l_out;
-  };
-  bwd(f2, f1, nullptr, nullptr);
-  int cur = 0;
-  bwd(f1, 3 * nb + 2, nullptr, tr->dRc[cur]);
-  for (int b = nb; b >= 0; --b) {
-    bwd(3 * b + 2, 3 * b + 1, nullptr, nullptr);
-    bwd(3 * b + 1, 3 * b, nullptr, nullptr);
-    if (b > 0) {
-      bwd(3 * b, 3 * (b - 1) + 2, tr->dRc[cur], tr->dRc[cur + 1]);
-      ++cur;
-    }
-  }
-  c.n_bwd = k - c.n_fwd;
-  fill_loss_train(tr, c.loss, nullptr, d_indices, n, pose_tables);
-  if (c.dbg) hipLaunchKernelGGL(chain_kernel<true>, dim3((n + CHAIN_ROWS - 1) / CHAIN_ROWS), dim3(CHAIN_THREADS), 0, s, c);
-  else hipLaunchKernelGGL(chain_kernel<false>, dim3((n + CHAIN_ROWS - 1) / CHAIN_ROWS), dim3(CHAIN_THREADS), 0, s, c);
-}
-
-#else
-static void launch_chain(acez_trainer*, const int64_t*, int, int, bool, hipStream_t) { abort(); }   // (tr->chain is never set in the product build)
-#endif
 
 // ---- pose refinement (the flat parameter offsets in PoseNetwork.named_parameters() order are PN_* in pose_kernels.hip)
 static PoseNetArgs pose_net_args(acez_trainer* tr, const int* active, int trace_slot = 0) {
@@ -846,6 +733,7 @@ static void fill_wgrad_args(acez_trainer* tr, WgradArgs& a, int n, const TrainSt
 static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n, void* stream, bool fused, const int64_t* d_next = nullptr,
                                int n_next = 0) {
   ACEZ_REQUIRE(tr && d_indices, "null pointer");
+  ACEZ_REQUIRE(!tr->inference_only, "an inference-only context (acez_train_config.inference_only) cannot train");
   ACEZ_REQUIRE(tr->have_buf, "acez_trainer_set_buffer has not been called");
   ACEZ_REQUIRE(n > 0 && n <= tr->max_batch, "n must be in [1, max_batch]");
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
@@ -859,7 +747,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   // head's forward chain; the pose-gradient launches run beside the input-gradient chain and wgrad.
   hipStream_t ps = (pose_mlp && tr->pose_stream) ? tr->pose_stream : s;
   // mlp refinement folded into the step's own launches (pose_fused.hip): forward beside the gather, backward beside / behind the optimiser
-  const bool pf = tr->pose_fused && !tr->chain && !tr->fused_fwd;
+  const bool pf = tr->pose_fused;
   const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
   const int nblk = (n + 4 * tr->loss_rows - 1) / (4 * tr->loss_rows);
   auto pose_fwd_launches = [&](hipStream_t q) {
@@ -878,35 +766,8 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     }
   };
 
-  if (tr->chain) {
-    // ---- one launch for gather + forward + loss + input gradients (head_chain.hip). The schedule bookkeeping that closes the
-    // previous step must be complete before it starts (its workgroups read the state), so it is its own small launch here.
-    flush_post(tr, s);
-    st = tr->st;
-    if (ps != s) {
-      ACEZ_HIP_CHECK(hipEventRecord(tr->ev_begin, s));
-      ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_begin, 0));
-      pose_fwd_launches(ps);                                       // beside the forward half of the chain
-      ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_fwd, ps));
-      { ProfScope sc(tr, s, KC_GEMM_FWD); launch_chain(tr, d_indices, n, 1, pose_mlp, s); tr->prof_launches += tr->L; }
-      ACEZ_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_pose_fwd, 0));   // the loss phase projects with the refined poses
-      { ProfScope sc(tr, s, KC_GEMM_DGRAD); launch_chain(tr, d_indices, n, 2, pose_mlp, s); tr->prof_launches += tr->L - 1; }
-      ACEZ_HIP_CHECK(hipEventRecord(tr->ev_loss, s));
-      ACEZ_HIP_CHECK(hipStreamWaitEvent(ps, tr->ev_loss, 0));
-      pose_bwd_launches(ps);                                       // beside wgrad
-      ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_bwd, ps));
-    } else {
-      pose_fwd_launches(s);
-      { ProfScope sc(tr, s, KC_GEMM_FWD); launch_chain(tr, d_indices, n, 3, pose_mlp, s); tr->prof_launches += 2 * tr->L - 1; }
-      pose_bwd_launches(s);
-    }
-  } else {
   uint16_t* act = nullptr;
-  if (tr->fused_fwd) {
-    flush_post(tr, s);
-    st = tr->st;
-    act = launch_forward_fused(tr, (const uint16_t*)tr->buf.d_features, d_indices, n, true, st, s);
-  } else {
+  {
   // (pose refinement folded into the step's launches: the batch may have been gathered ahead too -- beside the loss kernel of the step
   // before, round 5 -- but the launch below still runs: the pose network's forward and the schedule wave ride in it, with no gather blocks)
   const bool pre_ok = tr->pre_idx == d_indices && tr->pre_n == n;
@@ -948,7 +809,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   }
   if (!pf) pose_fwd_launches(ps);
   if (ps != s) ACEZ_HIP_CHECK(hipEventRecord(tr->ev_pose_fwd, ps));
-  if (!tr->fused_fwd) act = launch_forward(tr, tr->R[0], n, st, s);
+  act = launch_forward(tr, tr->R[0], n, st, s);
   if (ps != s) ACEZ_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_pose_fwd, 0));   // the loss kernel projects with the refined poses
 
   {
@@ -964,7 +825,6 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
       const int gblocks = std::min(want, room);
       GatherMeta gm = gather_meta(tr);
       gm.dst = tr->batch_meta_alt;
-      gm.hold = tr->seq_err;   // after a fault nothing of the faulted step may be overwritten before the host has finished it (wgo_recover)
       if (tr->f16) hipLaunchKernelGGL((loss_gather_kernel<EltF16, 4>), dim3(nblk + gblocks), dim3(256), 0, s, a, nblk, (const uint16_t*)tr->buf.d_features, d_next, tr->R0_alt, n_next, gm);
       else hipLaunchKernelGGL((loss_gather_kernel<EltBf16, 4>), dim3(nblk + gblocks), dim3(256), 0, s, a, nblk, (const uint16_t*)tr->buf.d_features, d_next, tr->R0_alt, n_next, gm);
       tr->next_gathered = true; tr->next_idx = d_next; tr->next_n = n_next;
@@ -998,7 +858,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     g.out_main = out_main; g.out_aux = out_aux; g.M = n; g.N = 512; g.K = 512; g.relu = 0;
     g.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE; g.st = st; g.dbg = 0;
     g.absmax = tr->f16 ? tr->st->dz_absmax_slots : nullptr;
-    launch_rowgemm(g, tr->gemm_tile, s, tr->f16);
+    launch_rowgemm(g, s, tr->f16);
     ++tr->prof_launches;
   };
   ProfScope* dchain = new ProfScope(tr, s, KC_GEMM_DGRAD);
@@ -1016,7 +876,6 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   if (seq) launch_rowseq<true>(tr, sq, n, st, s);
 
   delete dchain;
-  }
   // the partial buffers of this step (reduced by grad_reduce_kernel in the split flow, by the optimiser launches in the fused step)
   {
     GradReduceArgs a{};
@@ -1026,8 +885,8 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     a.bias_partials = tr->bias_partials; a.bias_layer_stride = tr->bias_layer_stride; a.n_layers = tr->L;
     a.skip_wide = fused ? 1 : 0;
     a.fault = tr->seq_err;
-    // partial rows per layer: one per 32-row workgroup from the chain kernel / the loss kernel, one per row tile from rowgemm
-    for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2 || tr->chain) ? nblk : (tr->gemm_tile == 80 ? (n + 79) / 80 : 2 * ((n + 127) / 128));
+    // partial rows per layer: one per loss workgroup for fc2, one per 80-row tile from the input-gradient GEMMs
+    for (int l = 0; l < tr->L; ++l) a.bias_count[l] = (l == f2) ? nblk : (n + 79) / 80;
     tr->last_reduce = a;   // the fused update reduces the partials itself
   }
   // weight gradients of all wide layers in one launch
@@ -1062,16 +921,10 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
       if (tr->f16) hipLaunchKernelGGL(wgrad_opt_kernel<EltF16>, grid, dim3(WGRAD_THREADS), 0, s, a, o, post);
       else hipLaunchKernelGGL(wgrad_opt_kernel<EltBf16>, grid, dim3(WGRAD_THREADS), 0, s, a, o, post);
       tr->wide_done = true;
-      tr->wp_valid = false;
-      tr->post_done = o.do_post != 0;
+          tr->post_done = o.do_post != 0;
     }
     else if (tr->f16) hipLaunchKernelGGL(wgrad_kernel<EltF16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
-    else if (tr->wgrad_tile == 128) hipLaunchKernelGGL(wgrad_kernel<EltBf16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
-#ifdef ACEZ_DIAG
-    else hipLaunchKernelGGL(wgrad256_kernel, dim3(64 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
-#else
-    else abort();   // (wgrad_tile is 128 in the product build)
-#endif
+    else hipLaunchKernelGGL(wgrad_kernel<EltBf16>, dim3(128 * ((groups + 7) / 8)), dim3(WGRAD_THREADS), 0, s, a);
   }
   if (!fused) {
     const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
@@ -1101,6 +954,7 @@ extern "C" int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, i
 static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int layer_lo = 0, int layer_hi = -1, const int64_t* d_next = nullptr,
                              int n_next = 0) {
   ACEZ_REQUIRE(tr, "null trainer");
+  ACEZ_REQUIRE(!tr->inference_only, "an inference-only context (acez_train_config.inference_only) cannot train");
   if (layer_hi < 0) layer_hi = tr->L;
   ACEZ_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= tr->L, "layer range out of bounds");
   ACEZ_REQUIRE(!fused || (layer_lo == 0 && layer_hi == tr->L), "the fused step updates every layer");
@@ -1109,7 +963,6 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
   // two updates without a backward in between (a data-parallel rank whose shard holds no row of a batch zeroes its gradient and
   // only takes part in the all-reduce): the schedule bookkeeping of the previous step must not be lost
   flush_post(tr, s);
-  tr->wp_valid = false;   // (the 16-bit weights change below)
   AdamArgs a;
   fill_adam_args(tr, a);
   if (fused) { a.slabs = tr->slabs; a.nslabs = tr->nslabs; a.slab_stride = tr->n_wide; a.tail = tr->last_reduce; }
@@ -1130,7 +983,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     }
     return ACEZ_OK;
   }
-  const bool pf = tr->pose_fused && !tr->chain && !tr->fused_fwd;
+  const bool pf = tr->pose_fused;
   if (pf && fused) {
     // the head's AdamW with the pose network's reduce + backward chain (S1) as the first workgroups of the same launch, then the
     // pose weight gradients with AdamW in their epilogue (S2: needs S1 of every image tile)
@@ -1153,7 +1006,7 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     return ACEZ_OK;
   }
   a.layer_lo = layer_lo; a.layer_hi = layer_hi;
-  if (fused && d_next && n_next > 0 && tr->cfg.pose_refinement == 0 && !tr->chain && !tr->fused_fwd && tr->have_buf) {
+  if (fused && d_next && n_next > 0 && tr->cfg.pose_refinement == 0 && tr->have_buf) {
     // the next batch is known: its gather and this step's schedule bookkeeping ride in the optimiser's launch (adamw_next_kernel)
     int n_adam = tr->L * 64 + nsmall;
     // timing experiments (diagnostics build; results wrong by construction): 1 = no optimiser workgroups at all, 2 = no gather
@@ -1214,7 +1067,6 @@ extern "C" int acez_trainer_import_weights16(acez_trainer* tr, int layer_lo, int
   ACEZ_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= tr->L, "layer range out of bounds");
   if (layer_hi == layer_lo) return ACEZ_OK;
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
-  tr->wp_valid = false;
   ACEZ_HIP_CHECK(hipMemcpyAsync(tr->Wb + (size_t)layer_lo * 262144, d_src, (size_t)(layer_hi - layer_lo) * 262144 * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   hipLaunchKernelGGL(transpose16_kernel, dim3((layer_hi - layer_lo) * 64), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)tr->Wb, tr->WbT, layer_lo);
   ACEZ_HIP_CHECK(hipGetLastError());
@@ -1226,7 +1078,6 @@ extern "C" int acez_trainer_import_weights16_all(acez_trainer* tr, int own_lo, i
   ACEZ_REQUIRE(own_lo >= 0 && own_lo <= own_hi && own_hi <= tr->L, "layer range out of bounds");
   if (own_hi - own_lo == tr->L) return ACEZ_OK;
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
-  tr->wp_valid = false;
   hipLaunchKernelGGL(import16_kernel, dim3(tr->L * 64), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)d_src_all, tr->Wb, tr->WbT, own_lo, own_hi);
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
@@ -1260,14 +1111,8 @@ extern "C" int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out,
   // here on this trainer uses per-layer launches (acez_trainer_seq_status reports it)
   seq_fault_check(tr, (hipStream_t)stream);
   TrainState hs;
-  int chain_err = 0;
   ACEZ_HIP_CHECK(hipMemcpyAsync(&hs, tr->st, offsetof(TrainState, dz_absmax_slots), hipMemcpyDeviceToHost, (hipStream_t)stream));
-  ACEZ_HIP_CHECK(hipMemcpyAsync(&chain_err, tr->chain_err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   ACEZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-  if (chain_err) {
-    set_error("chain kernel: a bounded spin expired (internal protocol error); results of this trainer are invalid");
-    return ACEZ_ERR_HIP;
-  }
   h_out->iteration = hs.iteration; h_out->max_iterations = hs.max_iterations; h_out->in_cooldown = hs.in_cooldown;
   h_out->nan_flag = hs.nan_flag; h_out->lr = hs.lr; h_out->last_loss = hs.last_loss;
   h_out->last_batch_inliers = hs.last_inliers; h_out->focal_scale = 1.0 + hs.calib_g;
@@ -1288,6 +1133,7 @@ extern "C" int acez_trainer_get_log(acez_trainer* tr, int first, int count, floa
 
 extern "C" int acez_trainer_last_scene_coords(acez_trainer* tr, float* h_xyz, int n, void* stream) {
   ACEZ_REQUIRE(tr && h_xyz, "null pointer");
+  ACEZ_REQUIRE(!tr->inference_only, "an inference-only context has no training-step scene coordinates");
   ACEZ_REQUIRE(n > 0 && n <= tr->max_batch, "n out of range");
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   ACEZ_HIP_CHECK(hipMemcpyAsync(h_xyz, tr->xyz, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -1303,7 +1149,7 @@ static uint16_t* launch_forward_conv(acez_trainer* tr, const uint16_t* in0, int 
     ConvGemmArgs g{};
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144; g.add = add; g.out = out;
     g.zeros = tr->zeros; g.Hi = 1; g.Wi = 1; g.Ci = 512; g.ci_shift = 9; g.Ho = 1; g.Wo = 1; g.Co = 512; g.ksize = 1; g.stride = 1;
-    g.pad = 0; g.K = 512; g.Kp = 512; g.M = n; g.round_before_add = 1; g.dbg = 0;
+    g.pad = 0; g.K = 512; g.Kp = 512; g.M = n; g.round_before_add = 1; g.dbg = 0; g.f16 = tr->f16 ? 1 : 0;
     if (const char* e = ACEZ_DIAG_ENV("ACEZ_CONV_DBG")) g.dbg = atoi(e);   // (diagnostics build: convgemm512's ablation / stagger bits)
     static const int conv_tile = ACEZ_DIAG_ENV("ACEZ_HEAD_CONV_TILE") ? atoi(ACEZ_DIAG_ENV("ACEZ_HEAD_CONV_TILE")) : 0;   // (diagnostics build: 256 / 512 force a tile; round 5: the 256 x 128 tiles, which keep a third more input bytes in flight, are 8 % SLOWER here: 2.54 against 2.35 ms per 64 frames)
     launch_convgemm(g, true, s, conv_tile);
@@ -1321,49 +1167,6 @@ static uint16_t* launch_forward_conv(acez_trainer* tr, const uint16_t* in0, int 
   return tr->out[f2];
 }
 
-#ifdef ACEZ_DIAG
-// Inference on more rows than the one-launch chains take: headinfer_kernel (head_infer.hip), all wide layers in one launch with the
-// activations of a 64-row tile resident in LDS; only the input rows and the last layer's output cross HBM.
-static uint16_t* launch_forward_infer(acez_trainer* tr, const uint16_t* in0, int n, hipStream_t s) {
-  if (!tr->wp_valid) {
-    hipLaunchKernelGGL(headinfer_pack_kernel, dim3((unsigned)((int64_t)tr->L * 512 * 64 / 256)), dim3(256), 0, s, (const uint16_t*)tr->Wb, tr->Wp, tr->L);
-    tr->wp_valid = true;
-  }
-  // the layers' residual wiring: x = res + relu(conv(relu(conv(relu(conv(res))))))   ace_network.py:122-133
-  HeadInferLayer all[MAX_LAYERS] = {};
-  {
-    const uint16_t* r = in0;
-    for (int b = 0; b <= tr->nb; ++b) {
-      all[3 * b + 2].res_in = r;
-      all[3 * b + 2].res_out = b < tr->nb ? tr->R[b + 1] : nullptr;   // the next block adds it; after the last block nothing does
-      r = tr->R[b + 1];
-    }
-  }
-  // The layers go out in groups of tr->hi_group (head_infer.hip: the weights of ALL layers are exactly one XCD's L2 for the default head,
-  // and a cyclic stream over a working set of the cache's size never hits; a group's weights must stay well inside it). Between two
-  // groups the activations make one round trip through HBM.
-  const int f2 = 3 * (tr->nb + 1) + 1;
-  const uint16_t* in = in0;
-  for (int l0 = 0; l0 < tr->L; l0 += tr->hi_group) {
-    const int cnt = std::min(tr->hi_group, tr->L - l0), last = l0 + cnt - 1;
-    HeadInferArgs a{};
-    a.feat = in; a.Wp = tr->Wp + (size_t)l0 * 262144; a.params = tr->pb.d_params + (int64_t)l0 * 262656; a.n = n; a.n_layers = cnt;
-    for (int i = 0; i < cnt; ++i) a.layer[i] = all[l0 + i];
-    // the group's last layer writes ONE tile: its output; if a later layer also adds that output as its residual, that buffer is it
-    a.out = all[last].res_out ? all[last].res_out : tr->out[last];
-    const dim3 grid((unsigned)((n + HI_ROWS - 1) / HI_ROWS));
-    if (tr->f16) hipLaunchKernelGGL(headinfer_kernel<EltF16>, grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(headinfer_kernel<EltBf16>, grid, dim3(512), 0, s, a);
-    in = a.out;
-  }
-  (void)f2;
-  return const_cast<uint16_t*>(in);
-}
-
-#else
-static uint16_t* launch_forward_infer(acez_trainer*, const uint16_t*, int, hipStream_t) { abort(); }   // (tr->head_infer is never set in the product build)
-#endif
-
 static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, float* d_out, int planar_hw, void* stream) {
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1372,14 +1175,10 @@ static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, fl
   auto pass = [&]() {
     for (int done = 0; done < n; done += tr->max_batch) {
       const int cnt = (n - done < tr->max_batch) ? n - done : tr->max_batch;
-      const bool seqp = !tr->fused_fwd && seq_usable(tr, cnt);
-      const bool infer = !tr->fused_fwd && !seqp && tr->head_infer;
-      const bool conv = !infer && cnt >= 256 * 128 && !tr->f16;   // (round 4's path for large passes; the large-tile conv kernels are bf16)
+      const bool seqp = seq_usable(tr, cnt);
+      const bool conv = cnt >= 256 * 128;   // large passes: the encoder's large-tile kernels (both operand formats)
       used_seq = used_seq || (seqp && !conv);
-      uint16_t* act = tr->fused_fwd ? launch_forward_fused(tr, f + (size_t)done * 512, nullptr, cnt, false, nullptr, s)
-                      : infer       ? launch_forward_infer(tr, f + (size_t)done * 512, cnt, s)
-                      : conv        ? launch_forward_conv(tr, f + (size_t)done * 512, cnt, s)
-                                    : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
+      uint16_t* act = conv ? launch_forward_conv(tr, f + (size_t)done * 512, cnt, s) : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
       LossArgs a{};
       fill_loss_head(tr, a);
       a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr;
@@ -1445,11 +1244,10 @@ extern "C" int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, vo
   int64_t cap = 0;
   const int64_t act_bytes = (int64_t)tr->max_batch * 512 * 2;
   if (kind == 0 && index >= 0 && index < tr->L) { src = tr->out[index]; cap = act_bytes; }
-  else if (kind == 1 && index >= 0 && index < tr->L) { src = tr->dZ[index]; cap = act_bytes; }
+  else if (kind == 1 && index >= 0 && index < tr->L && tr->dZ[index]) { src = tr->dZ[index]; cap = act_bytes; }
   else if (kind == 2 && index >= 0 && index < tr->nb + 2) { src = tr->R[index]; cap = act_bytes; }
-  else if (kind == 3 && index >= 0 && index < tr->nslabs) { src = tr->slabs + (size_t)index * tr->n_wide; cap = tr->n_wide * 4; }
-  else if (kind == 4 && index >= 0 && index < tr->L) { src = tr->bias_partials + (size_t)index * tr->bias_layer_stride; cap = tr->bias_layer_stride * 4; }
-  else if (kind == 5 && tr->chain_trace) { src = tr->chain_trace; cap = 512 * 8; }
+  else if (kind == 3 && index >= 0 && index < tr->nslabs && tr->slabs) { src = tr->slabs + (size_t)index * tr->n_wide; cap = tr->n_wide * 4; }
+  else if (kind == 4 && index >= 0 && index < tr->L && tr->bias_partials) { src = tr->bias_partials + (size_t)index * tr->bias_layer_stride; cap = tr->bias_layer_stride * 4; }
   else if (kind == 6 && tr->seq_xcc) { src = tr->seq_xcc; cap = (8 + 256) * 4; }
   else if (kind == 7 && tr->wgo_trace) { src = tr->wgo_trace; cap = 256 * 12 * 8 * 8; }
   else if (kind == 8 && tr->pose_trace) { src = tr->pose_trace; cap = 3 * 1024 * 16 * 8; }

@@ -78,204 +78,10 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint16_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// rowgemm: Out[m][n] = epi( sum_k In[m][k] * W[n][k] ),  K = 512, 128 x 128 tile, BK = 64, 4 waves of 64 x 64.
-// LDS tiles are [row][64] bf16 with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7, which makes
-// the ds_read_b128 fragment reads of 32 consecutive rows conflict-free.
-// ---------------------------------------------------------------------------------------------------
-
-// K is fixed at 512 (ACEZ_HEAD_CHANNELS) = 8 K-steps of 64. Operand tiles go HBM/L2 -> LDS directly
-// (global_load_lds_dwordx4, no VGPR staging) into a 4-slot ring of [W 128x64 | In 128x64] stages (128 KiB, one
-// workgroup per CU); the first four stages are requested at kernel entry and each consumed slot is refilled one
-// barrier later, so up to 96 KiB per CU are in flight and the memory latency is paid once per launch instead of
-// once per K-step. Waits are counted (s_waitcnt vmcnt(N): each wave issues 8 DMA instructions per stage, in
-// order), barriers are raw s_barrier so that in-flight DMA is not drained. The LDS image of a stage is linear in
-// the DMA lane order; the bank swizzle is applied on the per-lane SOURCE chunk and, identically, on the reads.
-// Rows past M are clamped (never stored).
-
-template <bool BIAS_RELU, bool HAS_ADD, bool HAS_MASK, int AUX>
-__global__ __launch_bounds__(256, 1) void rowgemm_kernel(RowGemmArgs a) {
-  // the schedule's `active` flag is only needed before the stores: reading it up front would put a dependent HBM/L2
-  // round trip (~1 us) in front of every launch of the chain
-  const int active = a.st ? a.st->active : 1;
-  __shared__ __attribute__((aligned(16))) uint16_t smem[4][2][128 * 64];
-  const int t = threadIdx.x, l = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wn = w >> 1, wm = w & 1;
-  // XCD-aware decode of a 1-D grid (workgroup b runs on XCD b % 8): the four 128-column tiles of one 128-row tile
-  // re-read the same In rows, so they are placed on one XCD and share its L2 (placement affects speed only)
-  const int mtiles = (a.M + 127) >> 7;
-  const int per_xcd = (mtiles + 7) >> 3;
-  const int jx = blockIdx.x >> 3;
-  const int mt = (blockIdx.x & 7) * per_xcd + (jx >> 2);
-  if (mt >= mtiles) return;
-  const int n0 = (jx & 3) * 128, m0 = mt * 128;
-  const int M = a.M, N = a.N;
-  constexpr int K = 512, KT = 8;
-
-  // DMA instruction j (0..3) of this wave covers tile rows (w*4+j)*8 .. +7; this lane: row + (l>>3), slot l&7,
-  // which must receive the logical chunk (l&7) ^ ((row>>1)&7)
-  const uint16_t* gW[4];
-  const uint16_t* gI[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (w * 4 + j) * 8 + (l >> 3);
-    const int c = (l & 7) ^ ((row >> 1) & 7);
-    gW[j] = a.W + (size_t)(n0 + row) * K + c * 8;
-    gI[j] = a.In + (size_t)min(m0 + row, M - 1) * K + c * 8;
-  }
-  auto issue = [&](int kt) {
-    const int slot = kt & 3;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(gW[j] + kt * 64), (lvoid_t*)&smem[slot][0][(w * 4 + j) * 8 * 64], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(gI[j] + kt * 64), (lvoid_t*)&smem[slot][1][(w * 4 + j) * 8 * 64], 16, 0, 0);
-    }
-  };
-  if (!(ACEZ_DBG(a.dbg) & 4)) { issue(0); issue(1); issue(2); issue(3); }
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int rowa0 = wn * 64 + (l & 31), rowb0 = wm * 64 + (l & 31);
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    // stages issued so far: 0..3 at kt = 0, 0..kt+2 afterwards; everything after stage kt may stay in flight
-    if (kt == 0) ACEZ_VMCNT(24);
-    else if (kt <= 5) ACEZ_VMCNT(16);
-    else if (kt == 6) ACEZ_VMCNT(8);
-    else ACEZ_VMCNT(0);
-    __builtin_amdgcn_s_barrier();  // every wave's share of stage kt has landed; everyone is done with stage kt-1
-    if (kt >= 1 && kt + 3 < KT && !(ACEZ_DBG(a.dbg) & 4)) issue(kt + 3);  // refill the slot read in the previous iteration
-    if (ACEZ_DBG(a.dbg) & 2) continue;
-    const int slot = kt & 3;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fa[2], fb[2];
-      const int c = 2 * kk + (l >> 5);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *reinterpret_cast<const bf16x8*>(&smem[slot][0][swz(rowa0 + i * 32, c)]);
-        fb[i] = *reinterpret_cast<const bf16x8*>(&smem[slot][1][swz(rowb0 + i * 32, c)]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-  }
-
-  // ---- epilogue, staged through LDS so that every global access is a full 128-byte row segment.
-  // In the MFMA layout a lane holds row m (B index j = l & 31) and 4 consecutive channels per register group;
-  // storing that directly touches 32 rows x 16 B per instruction and was measured at 8-12 us per launch
-  // (tools/ablate_rowgemm.hip), 2x the rest of the kernel. Each wave owns two [64][72] bf16 regions of the
-  // (now idle) ring: A = `add` in / aux out, B = mask|res in / main out.
-  if (ACEZ_DBG(a.dbg) & 1) { if (acc[0][0][0] == 1.2345e30f) a.out_main[0] = 1; return; }
-  if (!active) return;  // schedule ended (ace_trainer.py:509-510): nothing is written
-  __syncthreads();  // every wave is done reading the ring
-  constexpr int EP = 72;
-  uint16_t* regA = &smem[0][0][0] + w * (2 * 64 * EP);
-  uint16_t* regB = regA + 64 * EP;
-  const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-  const uint16_t* in2 = HAS_MASK ? a.mask : a.res;
-  constexpr bool HAS_IN2 = HAS_MASK || AUX == AUX_RESIDUAL;
-  if (HAS_ADD || HAS_IN2) {
-    // all 8 (+8) row-segment loads are issued back to back (rows past M are clamped; their results are never
-    // stored), then written to LDS: a load inside an `if (m < M)` block gets its own vmcnt(0) and the eight round
-    // trips serialise (measured: +10 us per launch)
-    uint4 ra[8], rb[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 8 + (l >> 3), ch = l & 7;
-      const size_t o = (size_t)min(mw + row, M - 1) * N + nw + ch * 8;
-      if (HAS_ADD) ra[it] = *reinterpret_cast<const uint4*>(a.add + o);
-      if (HAS_IN2) rb[it] = *reinterpret_cast<const uint4*>(in2 + o);
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 8 + (l >> 3), ch = l & 7;
-      if (HAS_ADD) *reinterpret_cast<uint4*>(&regA[row * EP + ch * 8]) = ra[it];
-      if (HAS_IN2) *reinterpret_cast<uint4*>(&regB[row * EP + ch * 8]) = rb[it];
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  const int h = l >> 5;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int ml = j * 32 + (l & 31);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = i * 32 + 8 * g + 4 * h;
-        float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        uint16_t* pa = &regA[ml * EP + nl];
-        uint16_t* pb = &regB[ml * EP + nl];
-        if (BIAS_RELU) {
-          const float4 b = *reinterpret_cast<const float4*>(a.bias + nw + nl);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
-        if (HAS_ADD) {
-          float ad[4];
-          unpack4(*reinterpret_cast<const uint2*>(pa), ad);
-          v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3];
-        }
-        if (BIAS_RELU) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        }
-        uint2 y = pack4(v[0], v[1], v[2], v[3]);
-        if (AUX == AUX_RESIDUAL) {
-          // out_aux = bf16( float(bf16(y)) + float(res) )   (ace_network.py:126,133)
-          float yf[4], rf[4];
-          unpack4(y, yf);
-          unpack4(*reinterpret_cast<const uint2*>(pb), rf);
-          *reinterpret_cast<uint2*>(pa) = pack4(yf[0] + rf[0], yf[1] + rf[1], yf[2] + rf[2], yf[3] + rf[3]);
-        } else if (AUX == AUX_UNMASKED) {
-          *reinterpret_cast<uint2*>(pa) = y;
-        }
-        if (HAS_MASK) {
-          // relu backward: keep the gradient where the forward activation was > 0
-          const uint2 mk = *reinterpret_cast<const uint2*>(pb);
-          // bf16 > 0  <=>  sign bit clear and magnitude non-zero
-          const uint32_t m0b = mk.x & 0xffffu, m1b = mk.x >> 16, m2b = mk.y & 0xffffu, m3b = mk.y >> 16;
-          uint32_t lo = y.x, hi = y.y;
-          if (!(m0b != 0 && m0b < 0x8000u)) lo &= 0xffff0000u;
-          if (!(m1b != 0 && m1b < 0x8000u)) lo &= 0x0000ffffu;
-          if (!(m2b != 0 && m2b < 0x8000u)) hi &= 0xffff0000u;
-          if (!(m3b != 0 && m3b < 0x8000u)) hi &= 0x0000ffffu;
-          y.x = lo; y.y = hi;
-        }
-        *reinterpret_cast<uint2*>(pb) = y;
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (HAS_MASK && a.bias_partials) {
-    // bias gradient of the layer whose dZ this launch produces: db[n] = sum_m dZ[m][n] over this wave's 64 rows
-    // (lane = column; the bf16-rounded values, in row order); reduced over row tiles by grad_reduce_kernel
-    float sacc = 0.f;
-    const int rows = min(64, M - mw);
-    for (int row = 0; row < rows; ++row) sacc += bf2f(regB[row * EP + l]);
-    a.bias_partials[(size_t)(mt * 2 + wm) * 512 + nw + l] = sacc;
-  }
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 8 + (l >> 3), ch = l & 7, m = mw + row;
-    if (m < M) {
-      const size_t o = (size_t)m * N + nw + ch * 8;
-      *reinterpret_cast<uint4*>(a.out_main + o) = *reinterpret_cast<const uint4*>(&regB[row * EP + ch * 8]);
-      if (AUX != AUX_NONE) *reinterpret_cast<uint4*>(a.out_aux + o) = *reinterpret_cast<const uint4*>(&regA[row * EP + ch * 8]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// rowgemm80: the same GEMM + epilogues re-tiled to 80 rows x 128 columns so that a 5120-row batch gives 64 x 4 = 256
-// workgroups = one per CU (the 128 x 128 tiling fills only 160 of the 256 CUs). MFMA v_mfma_f32_16x16x32_bf16.
+// rowgemm80: Out[m][n] = epi( sum_k In[m][k] * W[n][k] ), K = 512 (ACEZ_HEAD_CHANNELS) = 8 K-steps of 64, on 80-row x 128-column
+// tiles so that a 5120-row batch gives 64 x 4 = 256 workgroups = one per CU (a 128 x 128 tiling -- round 1, in the git history --
+// fills only 160 of the 256 CUs). MFMA v_mfma_f32_16x16x32_{bf16,f16}. LDS tiles are [row][64] 16-bit with the 16-byte chunk index
+// XOR-swizzled by (row >> 1) & 7 (conflict-free ds_read_b128 fragment reads); rows past M are clamped (never stored).
 // Eight waves with fixed roles (waves w and w + 4 share a SIMD):
 //   waves 0..3  multiply: wave w owns output columns 32w .. 32w+31 (2 column fragments x 5 row fragments = 10
 //               accumulator tiles) and never touches global memory inside the K loop;
@@ -787,22 +593,14 @@ __global__ __launch_bounds__(512) void seq_probe_kernel(uint32_t* rec /*[256]*/,
 }
 
 // host-side dispatch on the epilogue shape (the flags of RowGemmArgs select the instantiation)
-static inline void launch_rowgemm(const RowGemmArgs& g, int tile, hipStream_t s, bool f16 = false) {
-  const dim3 blk(256);
-  (void)blk;   // (the 128-row tiling of the diagnostics build)
+static inline void launch_rowgemm(const RowGemmArgs& g, hipStream_t s, bool f16 = false) {
   const bool br = g.bias != nullptr;
-  const int mtiles = (g.M + tile - 1) / tile;
+  const int mtiles = (g.M + 79) / 80;
   const dim3 grid(8 * 4 * ((mtiles + 7) / 8));  // N = 512 -> 4 column tiles; XCD-aware decode inside the kernels
-#ifdef ACEZ_DIAG   // the 128 x 128 tiling (rowgemm_kernel) is the tested alternative of the diagnostics build; the product has 80-row tiles only
-#define ACEZ_RG128(...) hipLaunchKernelGGL((rowgemm_kernel<__VA_ARGS__>), grid, blk, 0, s, g)
-#else
-#define ACEZ_RG128(...) abort()
-#endif
 #define ACEZ_RG(...)                                                                                               \
   do {                                                                                                             \
-    if (f16) hipLaunchKernelGGL((rowgemm80_kernel<__VA_ARGS__, EltF16>), grid, dim3(512), 0, s, g); /* 80-row tiles only */ \
-    else if (tile == 80) hipLaunchKernelGGL((rowgemm80_kernel<__VA_ARGS__>), grid, dim3(512), 0, s, g);            \
-    else ACEZ_RG128(__VA_ARGS__);                                                                                  \
+    if (f16) hipLaunchKernelGGL((rowgemm80_kernel<__VA_ARGS__, EltF16>), grid, dim3(512), 0, s, g);                \
+    else hipLaunchKernelGGL((rowgemm80_kernel<__VA_ARGS__>), grid, dim3(512), 0, s, g);                            \
   } while (0)
   if (br && g.aux_mode == AUX_NONE) ACEZ_RG(true, false, false, AUX_NONE);
   else if (br && g.aux_mode == AUX_RESIDUAL) ACEZ_RG(true, false, false, AUX_RESIDUAL);
@@ -812,7 +610,6 @@ static inline void launch_rowgemm(const RowGemmArgs& g, int tile, hipStream_t s,
   else if (!br && g.mask && g.add && g.aux_mode == AUX_NONE) ACEZ_RG(false, true, true, AUX_NONE);
   else abort();  // no other epilogue shape exists in the head
 #undef ACEZ_RG
-#undef ACEZ_RG128
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1000,7 +797,7 @@ __device__ __forceinline__ bool wgrad_kloop(const WgradArgs& a, uint16_t (*smem)
 
 template <class E = EltBf16>
 __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
-  const int active = a.st ? a.st->active : 1;  // tested before the stores only (see rowgemm_kernel)
+  const int active = a.st ? a.st->active : 1;  // tested before the stores only (see rowgemm80_body)
   __shared__ __attribute__((aligned(16))) uint16_t smem[ACEZ_WGRAD_RING][2][64 * 128];
   const int l = threadIdx.x & 63;
   const int cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3, wn = cw >> 1, wc = cw & 1;
@@ -1034,128 +831,6 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-#ifdef ACEZ_DIAG   // measured alternative tiling (DESIGN.md section 3 "Round 2" (3)): diagnostics build only
-// ---------------------------------------------------------------------------------------------------
-// wgrad256: the same product on 256 (dZ columns) x 128 (In columns) workgroup tiles, four multiplier waves of 128 x 64 each.
-// Why: wgrad_kernel is bound by the LDS, not by MFMA issue -- per 16-row step its four 64 x 64 waves read 4 x 4 KiB of transposed
-// fragments while the DMA writes 8 KiB of new stage data, 1.5 LDS-cycles per MFMA-cycle (measured: 53 % of the MFMA rate) -- and
-// behind that by the L2 -> LDS fill (1.31 MB per workgroup at ~70 GB/s per CU = 19 us). A 128 x 64 wave tile needs 6 fragments
-// per 8 MFMAs instead of 4 per 4, and a 256 x 128 workgroup tile 0.98 MB per workgroup: 1.1 LDS-cycles per MFMA-cycle and 25 % less
-// fill. 8 tiles x 8 layers x 4 row slabs = 256 workgroups; the slabs are summed in slab order by adamw / grad_reduce as before.
-// Stage = [Z0 | Z1 | X], three [64 m][128] sub-tiles in the layout of wgrad_kernel (Z0 / Z1: the two column halves of the dZ tile),
-// 3-slot ring (144 KiB).
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WGRAD_THREADS) void wgrad256_kernel(WgradArgs a) {
-  const int active = a.st ? a.st->active : 1;
-  __shared__ __attribute__((aligned(16))) uint16_t smem[3][3][64 * 128];
-  const int t = threadIdx.x, l = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool loader = w >= 4;
-  const int cw = w & 3, wn = cw >> 1, wc = cw & 1;
-  const int lw = w - 4;
-  constexpr int GPL = 16 / WGRAD_LOADERS;       // 4-row DMA groups per loader, stage and sub-tile
-  // the 8 tiles of a (layer, slab) group on one XCD (workgroup b runs on XCD b % 8): their 4x / 2x re-reads of dZ / In hit its L2
-  const int b = blockIdx.x;
-  const int xcd = b & 7, jx = b >> 3;
-  const int group = xcd + 8 * (jx >> 3), tile = jx & 7;
-  if (group >= a.n_layers * a.nslabs) return;
-  const int layer = group / a.nslabs, slab = group - layer * a.nslabs;
-  const int n0 = (tile >> 2) * 256, c0 = (tile & 3) * 128;
-  const uint16_t* __restrict__ Z = a.dZ[layer];
-  const uint16_t* __restrict__ X = a.In[layer];
-  const int M = a.M;
-  const int rows_per_slab = ((M + a.nslabs * 64 - 1) / (a.nslabs * 64)) * 64;
-  const int mb = slab * rows_per_slab;
-  const int me = min(M, mb + rows_per_slab);
-  const int KT = (me > mb) ? (me - mb + 63) >> 6 : 0;
-
-  const int prow = l >> 4, pq = l & 15;
-  auto issue = [&](int kt, int slot) {
-#pragma unroll
-    for (int j = 0; j < GPL; ++j) {
-      const int srow = (lw * GPL + j) * 4 + prow;
-      const int lchunk = ((((pq >> 1) ^ ((srow & 3) << 1)) << 1) | (pq & 1)) * 8;  // element offset of the source chunk
-      const int m = mb + kt * 64 + srow;
-      const bool ok = m < me;
-      const uint16_t* gz = ok ? Z + (size_t)m * 512 + n0 + lchunk : a.zeros + pq * 8;
-      const uint16_t* gx = ok ? X + (size_t)m * 512 + c0 + lchunk : a.zeros + pq * 8;
-      __builtin_amdgcn_global_load_lds((gvoid_t*)gz, (lvoid_t*)&smem[slot][0][(lw * GPL + j) * 4 * 128], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(ok ? gz + 128 : gz), (lvoid_t*)&smem[slot][1][(lw * GPL + j) * 4 * 128], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gvoid_t*)gx, (lvoid_t*)&smem[slot][2][(lw * GPL + j) * 4 * 128], 16, 0, 0);
-    }
-  };
-
-  if (loader) {
-    if (ACEZ_DBG(a.dbg) & 4) {
-      for (int kt = 0; kt < KT; ++kt) __builtin_amdgcn_s_barrier();
-      return;
-    }
-    if (KT > 0) issue(0, 0);
-    if (KT > 1) issue(1, 1);
-    int slot = 2;                                  // slot of stage kt + 2
-    for (int kt = 0; kt < KT; ++kt) {
-      // stages issued so far: 0 .. min(kt + 1, KT - 1); a loader has 3 * GPL DMA instructions per stage in flight
-      if (kt + 1 < KT) ACEZ_VMCNT_C(3 * GPL);
-      else ACEZ_VMCNT(0);
-      __builtin_amdgcn_s_barrier();  // stage kt has landed; the multipliers are done with stage kt - 1, whose slot is refilled
-      if (kt + 2 < KT) issue(kt + 2, slot);
-      slot = (slot == 2) ? 0 : slot + 1;
-    }
-    return;
-  }
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  int offA[4], offB[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) offA[i] = tr_base(32 * i, l);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) offB[j] = tr_base(wc * 64 + 32 * j, l);
-  int slot = 0;
-  for (int kt = 0; kt < KT; ++kt) {
-    __builtin_amdgcn_s_barrier();
-    if (!(ACEZ_DBG(a.dbg) & 2)) {
-      const uint16_t* sz = &smem[slot][wn][0];
-      const uint16_t* sx = &smem[slot][2][0];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bf16x8 fa[4], fb[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sz + offA[i] + kk * 16 * 128);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = tr_frag(sx + offB[j] + kk * 16 * 128);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    slot = (slot == 2) ? 0 : slot + 1;
-  }
-
-  if (ACEZ_DBG(a.dbg) & 1) { if (acc[0][0][0] == 1.2345e30f) a.slabs[0] = 1; return; }
-  if (!active) return;
-  float* __restrict__ G = a.slabs + (size_t)slab * a.slab_stride;
-  const int h = l >> 5;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = c0 + wc * 64 + j * 32 + (l & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        G[a.w_off[layer] + (size_t)n * 512 + c] = acc[i][j][r];
-      }
-    }
-}
-
-#endif  // ACEZ_DIAG
 
 // ---------------------------------------------------------------------------------------------------
 // loss kernel (32 rows per workgroup, four wavefronts):

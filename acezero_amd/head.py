@@ -11,11 +11,29 @@ import math
 import numpy as np
 import torch
 
+from . import DEFAULT_DTYPE  # when neither an argument nor $ACEZ_DTYPE names a format
 from . import _native as N
 
 LOSS_TYPES = {"tanh": 0, "dyntanh": 1, "l1": 2, "l1+sqrt": 3, "l1+logl1": 4, "l1+log": 4}
 SCHEDULES = {"constant": 0, "1cyclepoly": 1, "circle": 2}
-DTYPES = {"bf16": 0, "fp16": 1}   # acez_train_config.compute_dtype
+DTYPES = {"bf16": 0, "fp16": 1}   # acez_train_config.compute_dtype / acez_encoder_create's compute_dtype
+
+
+def resolve_dtype(dtype=None):
+    """The 16-bit operand format of a context: an explicit "bf16" / "fp16", else $ACEZ_DTYPE, else DEFAULT_DTYPE. "fp32" (train_ace.py
+    --use_half False) is rejected: it is not implemented and must not silently run in another precision."""
+    import os
+    dtype = (dtype or os.environ.get("ACEZ_DTYPE") or DEFAULT_DTYPE).lower()
+    if dtype in ("fp32", "float32"):
+        raise NotImplementedError("fp32 arithmetic (--use_half False) is not implemented; choose dtype='fp16' (the reference's "
+                                  "autocast format) or 'bf16'")
+    if dtype not in DTYPES:
+        raise ValueError("dtype must be 'bf16' or 'fp16'")
+    return dtype
+
+
+def torch_dtype(dtype):
+    return torch.float16 if dtype == "fp16" else torch.bfloat16
 
 
 def layer_names(num_head_blocks):
@@ -72,22 +90,17 @@ class HeadTrainer:
                  cooldown_iterations=5000, cooldown_trigger_percent=0.7, refine_calibration=False, focal_init=0.0,
                  calib_lr=0.001, pose_refinement="none", pose_refinement_wait=0, pose_refinement_lr=0.001,
                  pose_refinement_weight=0.1, refinement_ortho="gram-schmidt", pose_seed=0, initial_poses=None, homogeneous_min_scale=0.01, homogeneous_max_scale=4.0,
-                 device=None, dtype=None):
+                 device=None, dtype=None, inference_only=False):
         """dtype: 16-bit operand format of the head's GEMMs, "bf16" (default) or "fp16" (the reference's autocast format,
         ace_trainer.py:517-518); None reads ACEZ_DTYPE. "fp32" (train_ace.py --use_half False) is rejected: it is not implemented
-        and must not silently run in another precision."""
+        and must not silently run in another precision.
+        inference_only: a context for get_scene_coordinates / Regressor only -- no gradient or partial-sum buffers on the device, the
+        training calls raise (acez_train_config.inference_only)."""
         if not torch.cuda.is_available():
             raise RuntimeError("HeadTrainer needs a GPU: the head kernels are HIP only (no CPU fallback)")
         self.lib = N.lib()
-        import os
-        dtype = (dtype or os.environ.get("ACEZ_DTYPE") or "bf16").lower()
-        if dtype in ("fp32", "float32"):
-            raise NotImplementedError("fp32 head arithmetic (--use_half False) is not implemented; choose dtype='fp16' (the reference's "
-                                      "autocast format) or 'bf16'")
-        if dtype not in DTYPES:
-            raise ValueError("dtype must be 'bf16' or 'fp16'")
-        self.dtype = dtype
-        self.feature_dtype = torch.float16 if dtype == "fp16" else torch.bfloat16
+        self.dtype = dtype = resolve_dtype(dtype)
+        self.feature_dtype = torch_dtype(dtype)
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.nb, self.homog = int(num_head_blocks), bool(use_homogeneous)
         self.L = 3 + 3 * self.nb + 2
@@ -145,6 +158,7 @@ class HeadTrainer:
             raise ValueError("refinement_ortho must be 'gram-schmidt' or 'procrustes'")
         cfg.pose_refinement_ortho = 1 if refinement_ortho == "procrustes" else 0
         cfg.compute_dtype = DTYPES[self.dtype]
+        cfg.inference_only = 1 if inference_only else 0
         pb = N.ParamBuffers(_ptr(self.params), _ptr(self.adam_m), _ptr(self.adam_v), _ptr(self.grad), self.n_params,
                             _ptr(self.pose_params), _ptr(self.pose_m), _ptr(self.pose_v), self.n_pose)
         h = C.c_void_p()

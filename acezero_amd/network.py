@@ -22,7 +22,9 @@ from .head import HeadTrainer, _ptr, _stream, layer_names
 class Regressor:
     OUTPUT_SUBSAMPLE = 8  # ace_network.py:159
 
-    def __init__(self, encoder_state_dict, head_state_dict, max_frames=16, max_h=480, max_w=640, device=None):
+    def __init__(self, encoder_state_dict, head_state_dict, max_frames=16, max_h=480, max_w=640, device=None, dtype=None):
+        """dtype: "bf16" / "fp16" for encoder AND head (one format: the feature rows pass between them by raw pointer); None reads
+        $ACEZ_DTYPE. fp16 is the reference's autocast arithmetic (register_mapping.py:209-210)."""
         hs = head_state_dict
         pattern = re.compile(r"^\d+c0\.weight$")                      # ace_network.py:207-208
         num_head_blocks = sum(1 for k in hs if pattern.match(k))
@@ -32,18 +34,17 @@ class Regressor:
         if use_homogeneous and "max_scale" in hs:
             kw = {"homogeneous_max_scale": float(hs["max_scale"]), "homogeneous_min_scale": float(hs["min_scale"])}
         oh, ow = output_size(max_h, max_w)
-        self.encoder = Encoder.from_state_dict(encoder_state_dict, max_frames=max_frames, max_h=max_h, max_w=max_w, device=device)
+        self.encoder = Encoder.from_state_dict(encoder_state_dict, max_frames=max_frames, max_h=max_h, max_w=max_w, device=device, dtype=dtype)
+        self.dtype = self.encoder.dtype
         self._enc_args = (max_frames, max_h, max_w)
         self.feature_dim = self.encoder.out_channels
         if self.feature_dim != 512:
             raise ValueError("the head kernels are built for 512 encoder features (ace_network.py:22 default)")
         # an inference-only context: max_batch rows per internal pass of the head (whole chunks of frames: with >= 32768 rows the
         # layers run on the encoder's large-tile kernels)
-        # dtype is pinned: the encoder emits bf16 rows and they reach the head by raw pointer (acez_head_forward_maps), so the head's
-        # operand format must not follow $ACEZ_DTYPE here
-        # iterations = 1: an inference-only head (no second input buffer, no exchange tiles: acez_trainer_create)
+        # the head takes the encoder's operand format: the rows reach it by raw pointer (acez_head_forward_maps)
         self.heads = HeadTrainer(mean, num_head_blocks=num_head_blocks, use_homogeneous=use_homogeneous, max_batch=max(4, max_frames) * oh * ow,
-                                 device=device, dtype="bf16", iterations=1, **kw)
+                                 device=device, dtype=self.dtype, iterations=1, inference_only=True, **kw)
         self.heads.load_state_dict(hs)
         self.device = self.heads.device
 
@@ -75,7 +76,7 @@ class Regressor:
         sd = torch.load(encoder_dict_file, map_location="cpu")
         old = self.encoder
         self.encoder = Encoder.from_state_dict(sd, max_frames=self._enc_args[0], max_h=self._enc_args[1], max_w=self._enc_args[2],
-                                               device=self.device.index)
+                                               device=self.device.index, dtype=self.dtype)
         old.close()
 
     @classmethod
@@ -90,7 +91,7 @@ class Regressor:
     def get_scene_coordinates(self, features_bchw):
         """Head.forward on a [B,512,h,w] feature tensor -> [B,3,h,w] (ace_network.py:262-263)."""
         b, c, h, w = features_bchw.shape
-        rows = features_bchw.permute(0, 2, 3, 1).reshape(-1, c).to(self.device, torch.bfloat16).contiguous()
+        rows = features_bchw.permute(0, 2, 3, 1).reshape(-1, c).to(self.device, self.encoder.feature_dtype).contiguous()
         return self._maps(rows, b, h, w)
 
     def _maps(self, rows, b, h, w):

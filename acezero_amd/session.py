@@ -4,7 +4,7 @@ ace_zero.py drives the reconstruction by spawning `train_ace.py` / `register_map
 (ace_zero_util.py:11-52, ace_zero.py:195-196,235,274,307): every call pays interpreter + torch import, context creation,
 data-loader start-up, and re-encodes every image.  Here the same loop (seed trials -> best seed -> map / register rounds with
 warm start, pose-MLP and focal refinement -> stopping criteria -> final refit) runs in-process on frames that are already in
-memory: HIP context, encoder weights and the ENCODER FEATURES of all frames (4.9 MB per 480x640 frame in bf16: 1000 frames
+memory: HIP context, encoder weights and the ENCODER FEATURES of all frames (4.9 MB per 480x640 frame in 16 bits: 1000 frames
 = 4.9 GB of the 288 GB) stay resident, so a mapping round is buffer sampling + the training kernels and a registration
 round is head + RANSAC on cached features.
 
@@ -69,7 +69,9 @@ def default_options(**over):
              use_homogeneous=True, repro_loss_soft_clamp_min=1, repro_loss_schedule="circle", refine_calibration_lr=0.001,
              pose_refinement_weight=0.1, learning_rate_cooldown_trigger_px_threshold=10, depth_min=0.1, depth_target=10, depth_max=1000,
              # register_mapping.py flags (:63-72)
-             inlieralpha=100.0, maxpixelerror=100.0)
+             inlieralpha=100.0, maxpixelerror=100.0,
+             # [additive] 16-bit operand format of encoder and head: "bf16" / "fp16" (the reference's autocast arithmetic); None: $ACEZ_DTYPE, else head.DEFAULT_DTYPE
+             compute_dtype=None)
     unknown = set(over) - set(o)
     if unknown:
         raise TypeError(f"unknown options: {sorted(unknown)}")
@@ -142,7 +144,8 @@ class ReconstructionSession:
         check_frame_size(int(H), int(W))                                 # before any frame is encoded
         amax = float(self.opt.aug_scale) if self.opt.use_aug else 1.0
         self.enc = Encoder.from_state_dict(encoder_state_dict, max_frames=chunk, max_h=int(math.ceil(H * amax)) + 8,
-                                           max_w=int(math.ceil(W * amax)) + 8, device=device)
+                                           max_w=int(math.ceil(W * amax)) + 8, device=device, dtype=getattr(self.opt, "compute_dtype", None))
+        self.dtype = self.enc.dtype                                      # one operand format for the encoder, the cached features and every head
         self.dev = self.enc.device
         self.images = images.to(self.dev, torch.float32).contiguous()    # 1.2 MB per 480x640 frame: resident for the augmented passes
         self._aug_rng = np.random.default_rng(self.opt.base_seed + 77)
@@ -153,7 +156,7 @@ class ReconstructionSession:
         if self.rank:   # data-parallel fills draw their augmentations / sample positions from per-rank streams (rank 0: the single-process one),
             self._aug_rng = np.random.default_rng([self.opt.base_seed + 77, self.rank])   # so the shards' views are not copies of one sequence
         self.owned = np.arange(self.rank, self.n, self.world)            # parallel.frames_of_rank; local slot of frame g: g // world
-        self.features = torch.empty((len(self.owned), self.hw, self.enc.out_channels), dtype=torch.bfloat16, device=self.dev)
+        self.features = torch.empty((len(self.owned), self.hw, self.enc.out_channels), dtype=self.enc.feature_dtype, device=self.dev)
         t0 = time.time()
         own = torch.from_numpy(self.owned).to(self.dev)
         for c0 in range(0, len(self.owned), chunk):
@@ -187,7 +190,7 @@ class ReconstructionSession:
         m = len(ids)
         total = total if total is not None else min(o.max_training_buffer_size, o.max_dataset_passes * m * o.samples_per_image)
         C = self.enc.out_channels
-        feats = torch.empty((total, C), dtype=torch.bfloat16, device=self.dev)
+        feats = torch.empty((total, C), dtype=self.enc.feature_dtype, device=self.dev)
         px = torch.empty((total, 2), dtype=torch.float32, device=self.dev)
         vidx = torch.empty((total,), dtype=torch.int32, device=self.dev)
         pix = torch.empty((total,), dtype=torch.int32, device=self.dev)
@@ -201,7 +204,7 @@ class ReconstructionSession:
             v = min(m, (total - filled + o.samples_per_image - 1) // o.samples_per_image)
             take = min(v * o.samples_per_image, total - filled)
             if take < v * o.samples_per_image:                           # last, partial view: sample whole views into scratch
-                of = torch.empty((v * o.samples_per_image, C), dtype=torch.bfloat16, device=self.dev)
+                of = torch.empty((v * o.samples_per_image, C), dtype=self.enc.feature_dtype, device=self.dev)
                 op = torch.empty((v * o.samples_per_image, 2), dtype=torch.float32, device=self.dev)
                 ov = torch.empty((v * o.samples_per_image,), dtype=torch.int32, device=self.dev)
                 ox = torch.empty((v * o.samples_per_image,), dtype=torch.int32, device=self.dev)
@@ -398,7 +401,7 @@ class ReconstructionSession:
                          refine_calibration=refine_calibration, focal_init=focal, calib_lr=o.refine_calibration_lr, pose_refinement=refinement,
                          pose_refinement_wait=pose_wait, pose_refinement_lr=o.pose_refinement_lr, pose_refinement_weight=o.pose_refinement_weight,
                          refinement_ortho=o.refinement_ortho, pose_seed=o.base_seed + 511,
-                         initial_poses=buf["image_pose_inv"][:, :3] if refinement == "naive" else None, device=self.dev.index)
+                         initial_poses=buf["image_pose_inv"][:, :3] if refinement == "naive" else None, device=self.dev.index, dtype=self.dtype)
         if load_weights is not None:
             tr.load_state_dict(load_weights)
         else:
@@ -455,8 +458,8 @@ class ReconstructionSession:
         slots = self._slots(ids)
         nb = sum(1 for k in head_sd if k.endswith("c0.weight"))
         head = HeadTrainer(head_sd["mean"].float().view(3), num_head_blocks=nb, use_homogeneous=head_sd["fc3.weight"].shape[0] == 4,
-                           max_batch=min(count, 64) * self.hw, iterations=1, device=self.dev.index,
-                           dtype="bf16")   # self.features holds the encoder's bf16 rows, handed over by raw pointer below
+                           max_batch=min(count, 64) * self.hw, iterations=1, inference_only=True, device=self.dev.index,
+                           dtype=self.dtype)   # self.features holds the encoder's 16-bit rows, handed over by raw pointer below
         head.load_state_dict(head_sd)
         contiguous = bool(np.all(np.diff(slots.cpu().numpy()) == 1)) if count > 1 else True
         for c0 in range(0, count, 64):

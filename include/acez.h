@@ -170,6 +170,10 @@ typedef struct acez_train_config {
    * schedule adapts every step, the role torch.cuda.amp.GradScaler plays in ace_schedule.py:70,107-113); ACEZ_DTYPE_BF16 is BASELINE.json's north_star and the default. --use_half False (fp32) is
    * rejected, never silently replaced. d_features of acez_train_buffer / acez_head_forward are in this format. */
   int32_t compute_dtype;
+  /* 1: a context for acez_head_forward / acez_head_forward_maps only (Regressor at registration time, register_mapping.py:201-242): no
+   * gradient, weight-gradient, partial-sum or second input buffers are allocated (they are 60 % of a whole-frame context's memory) and
+   * the training entry points return ACEZ_ERR_INVALID. 0: a trainer (which can also run inference). */
+  int32_t inference_only;
 } acez_train_config;
 #define ACEZ_DTYPE_BF16 0
 #define ACEZ_DTYPE_FP16 1
@@ -324,7 +328,8 @@ int acez_head_forward(acez_trainer* tr, const void* d_features, int n, float* d_
 /* Head.forward for whole frames, written as Regressor.forward's [B,3,H,W] maps (ace_network.py:265-270): the input of
  * acez_register_rgb_device, so that scene coordinates go encoder -> head -> RANSAC without leaving HBM
  * (register_mapping.py:209-213 copies them to the CPU instead).
- *   d_features  bfloat16 [n_frames * h * w][512], rows in (frame, y, x) order (acez_encoder_forward's output)
+ *   d_features  16-bit [n_frames * h * w][512] in the trainer's compute_dtype (bfloat16 or float16), rows in (frame, y, x) order
+ *               (acez_encoder_forward's output for an encoder of the same compute_dtype)
  *   d_out_maps  float32  [n_frames][3][h][w] */
 int acez_head_forward_maps(acez_trainer* tr, const void* d_features, int n_frames, int h, int w, float* d_out_maps,
                            void* stream);
@@ -337,14 +342,18 @@ int acez_head_forward_maps(acez_trainer* tr, const void* d_features, int n_frame
 /* Layer order of the weight/bias pointer arrays == Encoder.__init__ (ace_network.py:26-40):
  *   conv1 conv2 conv3 conv4 res1_conv1 res1_conv2 res1_conv3 res2_conv1 res2_conv2 res2_conv3 res2_skip */
 
-typedef struct acez_encoder acez_encoder; /* opaque: bf16 weight matrices + activation workspaces for max_frames frames */
+typedef struct acez_encoder acez_encoder; /* opaque: 16-bit weight matrices + activation workspaces for max_frames frames */
 
 /* h_weights[i]  float32 host pointer, torch Conv2d layout [c_out][c_in][k][k] (state_dict "<name>.weight")
  * h_biases[i]   float32 host pointer [c_out]                                   (state_dict "<name>.bias")
  * out_channels  Encoder(out_channels): c_out of res2_conv3 and res2_skip (512 in every shipped encoder)
- * max_frames / max_h / max_w   capacity of one internal pass; acez_encoder_forward chunks larger batches. */
+ * max_frames / max_h / max_w   capacity of one internal pass; acez_encoder_forward chunks larger batches.
+ * compute_dtype ACEZ_DTYPE_BF16 or ACEZ_DTYPE_FP16: the 16-bit format of the weights, of every activation and of the feature rows.
+ *               The reference runs this network under fp16 autocast (ace_trainer.py:366-367 buffer creation, register_mapping.py:209-210
+ *               registration; ace_network.py:41-59): ACEZ_DTYPE_FP16 is that arithmetic (fp16 operands, fp32 accumulation, one rounding
+ *               per layer output). Must equal the compute_dtype of the head that consumes the rows. */
 int acez_encoder_create(acez_encoder** out, const float* const* h_weights, const float* const* h_biases,
-                        int out_channels, int max_frames, int max_h, int max_w, int device);
+                        int out_channels, int max_frames, int max_h, int max_w, int compute_dtype, int device);
 void acez_encoder_destroy(acez_encoder* enc);
 
 /* Spatial size of the feature map for an h x w input: three stride-2, pad-1, 3x3 convolutions. */
@@ -352,9 +361,9 @@ int acez_encoder_output_size(int h, int w, int* out_h, int* out_w);
 
 /* Encoder.forward (ace_network.py:42-59) for n_frames grayscale frames.
  *   d_images    float32 [n_frames][1][h][w], normalised as dataset.py:150-153 does
- *   d_features  bfloat16 [n_frames * out_h * out_w][out_channels]: one row per feature-map pixel in (frame, y, x)
- *               order -- the row layout of acez_train_buffer.d_features and of acez_head_forward's input
- * bf16 operands, fp32 accumulation (the reference runs this network under fp16 autocast, register_mapping.py:209).
+ *   d_features  16-bit (the context's compute_dtype) [n_frames * out_h * out_w][out_channels]: one row per feature-map pixel in
+ *               (frame, y, x) order -- the row layout of acez_train_buffer.d_features and of acez_head_forward's input
+ * 16-bit operands, fp32 accumulation (the reference runs this network under fp16 autocast, register_mapping.py:209).
  * Asynchronous on `stream`. */
 int acez_encoder_forward(acez_encoder* enc, const float* d_images, int n_frames, int h, int w, void* d_features,
                          void* stream);
@@ -363,13 +372,13 @@ int acez_encoder_forward(acez_encoder* enc, const float* d_images, int n_frames,
  * `samples_per_view` rows are drawn uniformly with replacement among the pixels whose mask byte is non-zero
  * (torch.multinomial(mask, n, replacement=True), ace_trainer.py:419-422) and written, view after view, to the output
  * arrays -- which are slices of acez_train_buffer's d_features / d_target_px / d_view_idx at the current fill offset.
- *   d_view_features  bfloat16 [n_views * map_h * map_w][channels]   (acez_encoder_forward's output)
+ *   d_view_features  16-bit [n_views * map_h * map_w][channels]   (acez_encoder_forward's output; rows are copied, not interpreted)
  *   d_masks          uint8 [n_views][map_h][map_w] validity at feature resolution (the nearest-neighbour resize of
  *                    ace_trainer.py:373-374), or NULL = every pixel valid. Every view must have a valid pixel
  *                    (the reference skips empty views, ace_trainer.py:377-378; so must the caller).
  *   seed, first_view_id   the draw of sample s of view v is a counter-based stream keyed by (seed, first_view_id + v, s)
  *   view_index_base  value written to d_out_view_idx for view 0 (index into the caller's per-view tables)
- *   d_out_features   bfloat16 [n_views * samples_per_view][channels]
+ *   d_out_features   16-bit [n_views * samples_per_view][channels]
  *   d_out_target_px  float32  [n_views * samples_per_view][2] = 8 * (x + 0.5, y + 0.5)   (ace_util.py:7-13)
  *   d_out_view_idx   int32    [n_views * samples_per_view]
  *   d_out_pixel      int32    [n_views * samples_per_view] chosen feature-map pixel y * map_w + x, or NULL (diagnostics)

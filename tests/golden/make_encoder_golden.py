@@ -1,4 +1,6 @@
-"""Generate tests/golden/encoder_small.npz by running the REFERENCE's own ace_network.Encoder on CPU (fp32).
+"""Generate tests/golden/encoder_small.npz by running the REFERENCE's own ace_network.Encoder on CPU: in fp32, and under
+torch.autocast("cpu", dtype=torch.float16) -- the precision mode the reference itself runs this network in on its GPU
+(ace_trainer.py:366-367, register_mapping.py:209-210), here on oneDNN's half-precision convolutions (fp32 accumulation).
 
 Run in the build container only (needs /root/reference):   python tests/golden/make_encoder_golden.py
 
@@ -29,10 +31,13 @@ def main():
     img = torch.from_numpy(synth.make_gray_images(seed=77, n=2, h=64, w=96))
     with torch.no_grad():
         out = enc(img)
+        with torch.autocast("cpu", dtype=torch.float16):
+            out16 = enc(img)
+    assert out16.dtype == torch.float16
     path = os.path.join(ROOT, "tests", "golden", "encoder_small.npz")
-    np.savez_compressed(path, features=out.numpy().astype(np.float32), image_sum=np.float64(img.double().sum().item()),
+    np.savez_compressed(path, features=out.numpy().astype(np.float32), features_fp16_autocast=out16.numpy(), image_sum=np.float64(img.double().sum().item()),
                         weight_sum=np.float64(sum(v.double().sum().item() for v in sd.values())))
-    print("wrote", path, out.shape, float(out.abs().mean()))
+    print("wrote", path, out.shape, float(out.abs().mean()), "autocast fp16 vs fp32:", float((out16.float() - out).norm() / out.norm()))
 
 
 if __name__ == "__main__":

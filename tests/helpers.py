@@ -255,3 +255,10 @@ def _parity_tolerances():
 
 # the tolerance table of the T path: one file read by the tests that assert it and by bench.py, which quotes it on its JSON line
 PARITY = _parity_tolerances()
+
+
+def big_problem(n_images=24, patches_per_view=512):
+    """24 images x 2 views x 512 patches with bf16-representable features: the problem of the bitwise flow-equivalence tests."""
+    prob = synth.make_training_problem(seed=SEED + 7, n_images=n_images, views_per_image=2, patches_per_view=patches_per_view)
+    prob["features"] = torch.from_numpy(prob["features"]).to(torch.bfloat16).to(torch.float32).numpy()
+    return prob

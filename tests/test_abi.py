@@ -50,7 +50,7 @@ def test_no_silent_cpu_fallback():
     wp = (C.c_void_p * 11)(*[sd[n + ".weight"].ctypes.data for n in names])
     bp = (C.c_void_p * 11)(*[sd[n + ".bias"].ctypes.data for n in names])
     e = C.c_void_p()
-    assert lib.acez_encoder_create(C.byref(e), wp, bp, 512, 1, 64, 64, -1) == -3
+    assert lib.acez_encoder_create(C.byref(e), wp, bp, 512, 1, 64, 64, 0, -1) == -3
     assert b"no HIP device" in lib.acez_last_error()
     dummy = np.zeros(16, np.float32)
     assert lib.acez_buffer_sample_views(dummy.ctypes.data, None, 1, 2, 2, 8, 4, 1, 0, 0, dummy.ctypes.data, dummy.ctypes.data,
@@ -68,7 +68,7 @@ def test_argument_validation_without_device():
     oh, ow = C.c_int(0), C.c_int(0)
     assert lib.acez_encoder_output_size(480, 640, C.byref(oh), C.byref(ow)) == 0 and (oh.value, ow.value) == (60, 80)
     assert lib.acez_encoder_output_size(41, 77, C.byref(oh), C.byref(ow)) == 0 and (oh.value, ow.value) == (6, 10)
-    assert lib.acez_encoder_create(None, None, None, 512, 1, 64, 64, -1) == -1
+    assert lib.acez_encoder_create(None, None, None, 512, 1, 64, 64, 0, -1) == -1
     assert lib.acez_buffer_sample_views(None, None, 1, 2, 2, 8, 4, 1, 0, 0, None, None, None, None, None) == -1
     hd0 = N.HeadDesc(0, 0, (C.c_float * 3)(0, 0, 0), 0.25, 100.0, 0.9)
     assert lib.acez_head_num_params(C.byref(hd0)) == 5 * 262656 + 3 * 513
@@ -96,11 +96,12 @@ def test_product_library_has_no_ablation_surface():
     names = set(m.decode() for m in re.findall(rb"ACEZ_[A-Z][A-Z0-9_]{2,}", prod))
     env_like = {n for n in names if not n.startswith(("ACEZ_ERR", "ACEZ_OK", "ACEZ_DTYPE", "ACEZ_POSE_MLP", "ACEZ_HIP_CHECK", "ACEZ_REQUIRE", "ACEZ_LOSS_"))}
     assert env_like == {"ACEZ_SEQ", "ACEZ_SEQ_SPIN_US"}, sorted(env_like)
-    for kern in (b"chain_kernel", b"headfwd_kernel", b"wgrad256_kernel", b"14rowgemm_kernelI", b"headinfer_kernel"):
+    # (the measured-and-rejected kernels of rounds 1-5 are in neither build any more: git history + DESIGN_HISTORY.md)
+    for kern in (b"chain_kernel", b"headfwd_kernel", b"wgrad256_kernel", b"14rowgemm_kernelI", b"headinfer_kernel", b"conv12_kernel", b"conv3x3p_kernel"):
         assert kern not in prod, kern
     diag = open(b.build(diag=True), "rb").read()
-    for kern in (b"chain_kernel", b"headfwd_kernel", b"wgrad256_kernel", b"14rowgemm_kernelI", b"headinfer_kernel", b"ACEZ_SEQ_FAULT_AT", b"ACEZ_CHAIN"):
-        assert kern in diag, kern
+    for name in (b"ACEZ_SEQ_FAULT_AT", b"ACEZ_WGO_FAULT_AT", b"ACEZ_CONV_TILE"):
+        assert name in diag, name
     # the same C ABI in both builds
     def exported(path):
         out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout

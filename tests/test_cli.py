@@ -29,9 +29,9 @@ def _surface(parser):
 
 
 @pytest.mark.parametrize("name,parser,extra", [("train_ace", cli.train_parser, {"feature_buffer", "num_gpus", "compute_dtype"}),
-                                               ("register_mapping", cli.register_parser, {"feature_file"}),
-                                               ("ace_zero", cli.ace_zero_parser, {"encoder_path"}),
-                                               ("export_point_cloud", cli.export_point_cloud_parser, set())])
+                                               ("register_mapping", cli.register_parser, {"feature_file", "compute_dtype"}),
+                                               ("ace_zero", cli.ace_zero_parser, {"encoder_path", "compute_dtype"}),
+                                               ("export_point_cloud", cli.export_point_cloud_parser, {"compute_dtype"})])
 def test_flag_surface_matches_reference(name, parser, extra, golden_dir):
     ref = json.load(open(os.path.join(golden_dir, "cli_flags.json")))[name]
     mine = _surface(parser())

@@ -39,6 +39,23 @@ def test_bf16_mode_stays_close_to_fp32():
     assert torch.equal(b, b.to(torch.bfloat16).to(torch.float32))
 
 
+def test_fp16_mode_matches_reference_encoder_under_fp16_autocast():
+    """The fp16 mode restates what autocast does to the reference Encoder; the golden is the reference itself under
+    torch.autocast("cpu", float16). oneDNN's accumulation order differs from F.conv2d's on fp32 copies of the half operands, so
+    last-place flips of half roundings remain: agreement far inside one half ulp of the feature scale on average, a few ulps at most."""
+    g = np.load(GOLD)
+    sd, img = _inputs()
+    out = encoder_oracle.EncoderOracle(sd, "fp16").forward(img)
+    assert torch.equal(out, out.to(torch.float16).to(torch.float32))        # half-representable values
+    ref = torch.from_numpy(g["features_fp16_autocast"].astype(np.float32))
+    rel = float((out - ref).norm() / ref.norm())
+    assert rel < 4e-4, rel
+    assert float((out - ref).abs().max()) < 4e-3 * float(ref.abs().max())
+    # and the reference's own two precisions differ by more than the oracle differs from its autocast mode
+    ref32 = torch.from_numpy(g["features"])
+    assert rel < float((ref - ref32).norm() / ref32.norm())
+
+
 def test_rows_layout_is_pixel_major():
     sd, img = _inputs()
     o = encoder_oracle.EncoderOracle(sd, "fp32")

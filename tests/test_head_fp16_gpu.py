@@ -87,7 +87,7 @@ def test_fp16_steps_match_the_fp16_oracle(name):
 
 def test_fp16_one_launch_chains_fused_step_and_inference_are_consistent():
     """ACEZ_SEQ=0 / 1 bit for bit, acez_train_step vs backward + update bit for bit, inference (small and multi-chunk) vs the oracle."""
-    from tests.test_chain_gpu import _big_problem
+    from tests.helpers import big_problem as _big_problem
     prob = _big_problem(n_images=8, patches_per_view=512)
     flat0 = head_oracle.init_params(helpers.SEED + 1)
     cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)

@@ -220,27 +220,6 @@ def test_large_batch_inference_runs_on_conv_kernels_and_matches():
     assert _rel(Xb[:4000] - prob["mean"], Xo - prob["mean"]) < REL
 
 
-@pytest.mark.parametrize("env", [("ACEZ_GEMM_TILE", "128"), ("ACEZ_FUSED_FWD", "1")])
-def test_alternative_kernel_paths_stay_correct(env, monkeypatch, diag_lib):
-    """The 128 x 128 GEMM tiling and the persistent row-tile forward are kept as measured alternatives:
-    same rounding points as the default path, so the same checks must hold."""
-    monkeypatch.setenv(*env)
-    prob, flat0 = helpers.golden_problem()
-    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
-    tr = _trainer(prob, flat0, cfg)
-    monkeypatch.delenv(env[0])
-    ref = _trainer(prob, flat0, cfg)
-    f = torch.from_numpy(prob["features"][:700]).cuda()
-    Xa, Xr = tr.get_scene_coordinates(f).cpu().numpy(), ref.get_scene_coordinates(f).cpu().numpy()
-    assert _rel(Xa - prob["mean"], Xr - prob["mean"]) < REL
-    idx = torch.from_numpy(helpers.golden_batches(prob, 1)[0].astype(np.int64)).cuda()
-    tr.backward(idx); ref.backward(idx)
-    torch.cuda.synchronize()
-    n = flat0.numel()
-    assert _rel(tr.grad[:n].cpu().numpy(), ref.grad[:n].cpu().numpy()) < 8e-3
-    assert abs(float(tr.grad[n]) - float(ref.grad[n])) < 2e-3 * abs(float(ref.grad[n]))
-
-
 def _big_trained(patches_per_view=2048):
     prob, flat0 = helpers.trained_problem(patches_per_view=patches_per_view)   # 6 images x 2 views x 2048 = 24576 patches
     cfg = helpers.full_cfg(helpers.TRAINED_CONFIGS["head_trained_1cyclepoly"], prob)
@@ -325,7 +304,7 @@ def test_step_with_the_next_batch_announced_equals_plain_steps_bitwise(dtype):
     last), inside the optimiser's launch. Parameters, optimiser state, schedule state and the per-iteration log must equal plain
     acez_train_step calls bit for bit -- also when the announcement is wrong (another batch follows), when a state read or a split
     step comes in between, with ragged batch sizes, and across the cool-down trigger of 1cyclepoly."""
-    from tests.test_chain_gpu import _big_problem
+    from tests.helpers import big_problem as _big_problem
     prob = _big_problem(n_images=8, patches_per_view=512)
     flat0 = head_oracle.init_params(helpers.SEED + 1)
     cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)

@@ -144,7 +144,7 @@ def test_refinement_step_with_the_next_batch_announced_equals_plain_steps_bitwis
     trainer's second input buffer; the step's own launch then carries the pose network's forward and the schedule wave only). Head and
     pose-network parameters, all moments, the schedule state and the log must equal plain acez_train_step calls bit for bit -- also
     when the announcement is wrong, when a state read or a split step comes in between, and with ragged batch sizes."""
-    from tests.test_chain_gpu import _big_problem
+    from tests.helpers import big_problem as _big_problem
     from tests.test_head_gpu import _trainer
     from oracle import head_oracle
     prob = _big_problem(n_images=8, patches_per_view=512)

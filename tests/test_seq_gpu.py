@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from tests import helpers
-from tests.test_chain_gpu import _big_problem
+from tests.helpers import big_problem as _big_problem
 from tests.test_head_gpu import _trainer
 
 pytestmark = pytest.mark.gpu

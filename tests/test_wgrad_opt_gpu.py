@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from tests import helpers
-from tests.test_chain_gpu import _big_problem
+from tests.helpers import big_problem as _big_problem
 from tests.test_head_gpu import _trainer
 from tests.test_seq_gpu import _small_trainer
 
@@ -98,15 +98,17 @@ def test_product_library_fused_step_equals_backward_plus_update(name, n, dtype):
     assert torch.equal(fused.get_scene_coordinates(f), split.get_scene_coordinates(f))
 
 
-@pytest.mark.parametrize("fault_mod,dtype", [(0, "bf16"), (3, "bf16"), (3, "fp16")])
-def test_expired_exchange_poll_finishes_the_step_in_the_fall_back(fault_mod, dtype, diag_lib):
+@pytest.mark.parametrize("fault_mod,dtype,announce", [(0, "bf16", True), (3, "bf16", True), (3, "fp16", True), (3, "bf16", False), (0, "fp16", False)])
+def test_expired_exchange_poll_finishes_the_step_in_the_fall_back(fault_mod, dtype, announce, diag_lib):
     """Fault injection (ACEZ_WGO_FAULT_AT, ACEZ_WGO_FAULT_MOD): in one launch every workgroup -- or every third -- waits for a partner
     count that never comes: what a tile whose two slabs sit on different XCDs looks like. No hang; no weight tile is stored from an
     incomplete sum. The small parameters and the schedule wave of that launch read the fault word long before it is raised, so the step
     IS applied in part: the fall-back therefore FINISHES it -- every launch that writes a step's buffers
     is a no-op while the fault word is up, wgrad_kernel recomputes the slabs from the untouched operands and wgo_recover_kernel applies
     the step's own AdamW scalars to exactly the rows whose wave gave up. After the state read the trainer is, bit for bit, the two-launch
-    flow's trainer after the same steps: a step is atomic again (ace_trainer.py:620-640)."""
+    flow's trainer after the same steps: a step is atomic again (ace_trainer.py:620-640).
+    announce = False: the faulting step and the steps queued behind it do NOT announce their successors, so their gathers are
+    the plain gather launches into R[0] -- the faulted step's layer-0 operand -- which must hold while the fault word is up as well."""
     prob = _big_problem(n_images=8, patches_per_view=256)
     if dtype == "fp16":
         prob = dict(prob)
@@ -141,7 +143,10 @@ def test_expired_exchange_poll_finishes_the_step_in_the_fall_back(fault_mod, dty
     L = new.L
     wide = lambda t: torch.cat([t[l * 262656:l * 262656 + 262144] for l in range(L)])
     w0, m0 = wide(new.params).clone(), wide(new.adam_m).clone()
-    new.step(batches[1], batches[2])          # the faulting step (its successor's gather rides beside its loss kernel, before the fault)
+    if announce:
+        new.step(batches[1], batches[2])      # the faulting step (its successor's gather rides beside its loss kernel, before the fault)
+    else:
+        new.step(batches[1])                  # the faulting step, no successor announced
     torch.cuda.synchronize()
     changed = int((wide(new.params) != w0).sum())
     if fault_mod == 0:
@@ -149,8 +154,12 @@ def test_expired_exchange_poll_finishes_the_step_in_the_fall_back(fault_mod, dty
     else:
         assert 0 < changed < w0.numel()                                # the tiles whose exchange completed were stored, the others not
     p1, m1, v1 = new.params.clone(), new.adam_m.clone(), new.adam_v.clone()
-    new.step(batches[2], batches[3])          # issued before the host knows: the sticky fault word makes it a no-op ...
-    new.step(batches[3])                      # ... and the one after it
+    if announce:
+        new.step(batches[2], batches[3])      # issued before the host knows: the sticky fault word makes it a no-op ...
+        new.step(batches[3])                  # ... and the one after it
+    else:
+        new.step(batches[2])                  # an unannounced batch: its gather launch targets R[0], the faulted step's input rows
+        new.step(batches[3], batches[2])      # ... and a mismatched announcement behind it
     torch.cuda.synchronize()
     assert torch.equal(new.params, p1) and torch.equal(new.adam_m, m1) and torch.equal(new.adam_v, v1)
     st = new.state()              # the state read performs the fall-back: it finishes the faulted step

@@ -31,10 +31,10 @@ int main() {
       g.In = In; g.W = W; g.bias = v.m ? nullptr : bias; g.add = v.a ? add : nullptr; g.mask = v.m ? mask : nullptr; g.res = nullptr;
       g.out_main = out; g.out_aux = v.x ? aux : nullptr; g.M = M; g.N = 512; g.K = 512; g.relu = v.m ? 0 : 1;
       g.aux_mode = v.x ? AUX_UNMASKED : AUX_NONE; g.st = nullptr; g.dbg = v.dbg; g.bias_partials = v.m ? bpart : nullptr;
-      for (int i = 0; i < 20; ++i) launch_rowgemm(g, tile, 0);
+      for (int i = 0; i < 20; ++i) launch_rowgemm(g, 0);
       CK(hipEventRecord(e0, 0));
       const int n = 200;
-      for (int i = 0; i < n; ++i) launch_rowgemm(g, tile, 0);
+      for (int i = 0; i < n; ++i) launch_rowgemm(g, 0);
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       if (rep) printf("tile %3d %-28s %7.2f us/launch  (%.0f TFLOP/s equiv)\n", tile, v.name, ms * 1e3 / n, 2.0 * M * 512 * 512 / (ms * 1e-3 / n) / 1e12);

@@ -13,7 +13,7 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 with N.diag_library() as lib:
     from acezero_amd.head import HeadTrainer
     n = F * 4800
-    tr = HeadTrainer(np.zeros(3, np.float32), max_batch=n, iterations=1)
+    tr = HeadTrainer(np.zeros(3, np.float32), max_batch=n, iterations=1, inference_only=True)
     tr.load_flat(torch.from_numpy(synth.init_head_params(7)))
     f = (torch.randn(n, 512, device="cuda") * 0.5).to(torch.bfloat16)
     out = torch.empty((F, 3, 60, 80), dtype=torch.float32, device="cuda")

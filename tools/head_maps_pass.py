@@ -12,7 +12,7 @@ from acezero_amd import synth, _native as N
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 n = F * 4800
-tr = HeadTrainer(np.zeros(3, np.float32), max_batch=n, iterations=1)
+tr = HeadTrainer(np.zeros(3, np.float32), max_batch=n, iterations=1, inference_only=True)
 tr.load_flat(torch.from_numpy(synth.init_head_params(7)))
 f = (torch.randn(n, 512, device="cuda") * 0.5).to(torch.bfloat16)
 out = torch.empty((F, 3, 60, 80), dtype=torch.float32, device="cuda")

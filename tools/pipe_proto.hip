@@ -640,7 +640,7 @@ int main(int argc, char** argv) {
       RowGemmArgs g{};
       g.In = i ? outA[i - 1] : In; g.W = W + (size_t)i * 512 * 512; g.bias = bias + i * 512; g.out_main = outA[i]; g.M = M; g.N = 512; g.K = 512;
       g.relu = 1; g.aux_mode = AUX_NONE;
-      launch_rowgemm(g, 80, 0);
+      launch_rowgemm(g, 0);
     }
   };
   if (M % 256) { printf("this experiment wants M %% 256 == 0 (uniform micro-batch count per XCD)\n"); return 1; }

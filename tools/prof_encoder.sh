@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof_enc
 KEEP=$R/gpurun_out/prof_keep
 mkdir -p $OUT $KEEP
 CMD="timeout 200 python $R/tools/bench_encoder.py 64"
-rocprofv3 -L > $KEEP/${TAG}_counters_available.txt 2>&1
+rocprofv3 -L > gpurun_out/${TAG}_counters_available.txt 2>&1   # scratch, not a committed profile
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE -d $OUT/pmc_a -o pmc -- $CMD > $OUT/pmc_a.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d $OUT/pmc_b -o pmc -- $CMD > $OUT/pmc_b.log 2>&1

@@ -647,7 +647,7 @@ int main() {
       RowGemmArgs g{};
       g.In = i ? outA[i - 1] : In; g.W = W + (size_t)i * 512 * 512; g.bias = bias + i * 512; g.out_main = outA[i]; g.M = M; g.N = 512; g.K = 512;
       g.relu = 1; g.aux_mode = AUX_NONE;
-      launch_rowgemm(g, 80, 0);
+      launch_rowgemm(g, 0);
     }
   };
   // bit equality of the last layer's output

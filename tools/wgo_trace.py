@@ -15,7 +15,7 @@ os.environ["ACEZ_WGO_TRACE"] = "1"
 from acezero_amd import _native as N
 
 with N.diag_library():
-    from tests.test_chain_gpu import _big_problem
+    from tests.helpers import big_problem as _big_problem
     from tests.test_head_gpu import _trainer
     from tests import helpers
     from oracle import head_oracle
