@@ -101,14 +101,21 @@ class ShardedDataParallel:
     ranks -- one reduce / broadcast per owner. The trainer object needs: L, LAYER_STRIDE, grad, backward(rows), update_layers(lo, hi),
     new_weights16_buffer(), export_weights16 / import_weights16(lo, hi, tensor), master_tensors()."""
 
-    def __init__(self, trainer, group=None, one_shot=None):
+    def __init__(self, trainer, group=None, one_shot=None, proxy_world=None):
+        """proxy_world = G (measurement only, bench.py's dp_rank_compute legs): this process plays rank 0 of a G-rank job WITHOUT a process
+        group -- the same launches, staging copies and layer ownership as a real rank, every collective skipped -- so that the compute
+        half of DESIGN.md section 7's budget is a measurement on one GPU. The parameters it produces are meaningless (partial sums)."""
         self.trainer = trainer
         self.group = group
         self.rank, self.world = rank_world(group)
+        self.proxy = proxy_world is not None
+        if self.proxy:
+            assert self.world == 1, "proxy_world is a single-process measurement"
+            self.rank, self.world = 0, int(proxy_world)
         self.L, self.stride = int(trainer.L), int(trainer.LAYER_STRIDE)
         self.ranges = [shard_range(self.L, r, self.world) for r in range(self.world)]
         self.lo, self.hi = self.ranges[self.rank]
-        backend = dist.get_backend(group) if self.world > 1 else ""
+        backend = "nccl" if self.proxy else (dist.get_backend(group) if self.world > 1 else "")
         # (one_shot=True under gloo: the CPU test of this branch, with reduce_scatter_tensor emulated -- gloo has none)
         self.one_shot = (backend == "nccl" and self.L % self.world == 0) if one_shot is None else bool(one_shot)
         assert not self.one_shot or self.L % self.world == 0
@@ -117,6 +124,10 @@ class ShardedDataParallel:
         # input and output)
         self.rs_out = trainer.grad.new_empty((self.hi - self.lo) * self.stride) if self.one_shot else None
         self.w_own = self.wbuf.new_empty((self.hi - self.lo, self.wbuf.shape[1])) if self.one_shot else None
+        if self.proxy:   # what the skipped collectives would have delivered: finite stand-ins (a NaN would switch the schedule off and
+            if self.rs_out is not None:   # turn the timed steps into no-ops): zero weight gradients, the peers' layers unchanged
+                self.rs_out.zero_()
+            trainer.export_weights16(0, self.L, self.wbuf)
 
     def _global(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
@@ -137,8 +148,10 @@ class ShardedDataParallel:
         bias, tail = self._small(t.grad)
         small = torch.cat([bias.reshape(-1), tail])
         wide = t.grad[:self.L * self.stride]
-        work = [dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
-        if self.one_shot:
+        work = [] if self.proxy else [dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        if self.proxy:
+            pass
+        elif self.one_shot:
             work.append(dist.reduce_scatter_tensor(self.rs_out, wide, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             for r, (lo, hi) in enumerate(self.ranges):
@@ -156,7 +169,10 @@ class ShardedDataParallel:
         t.update_layers(self.lo, self.hi)
         if self.one_shot:
             t.export_weights16(self.lo, self.hi, self.w_own)
-            dist.all_gather_into_tensor(self.wbuf.view(-1), self.w_own.view(-1), group=self.group)
+            if not self.proxy:
+                dist.all_gather_into_tensor(self.wbuf.view(-1), self.w_own.view(-1), group=self.group)
+        elif self.proxy:
+            t.export_weights16(self.lo, self.hi, self.wbuf[self.lo:self.hi])
         else:
             t.export_weights16(self.lo, self.hi, self.wbuf[self.lo:self.hi])
             for r, (lo, hi) in enumerate(self.ranges):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the ACE Zero hot path on MI355X (contract: see the round prompt / DESIGN.md).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher's environment: re-executes itself under
+                                                                torch.distributed.run with N ranks, one per GPU)
 
 A "step" is one training iteration of the scene-coordinate head (ace_trainer.py:499-679) on 5120 patches per
 GPU drawn from an 8M-patch synthetic feature buffer resident in HBM (BASELINE config[1]: full ace_zero.py
@@ -103,18 +104,18 @@ def parse():
     return ap.parse_args()
 
 
-def make_buffer(n_patches, device, seed, n_images=1000, grid=(80, 60)):
+def make_buffer(n_patches, device, seed, n_images=1000, grid=(80, 60), feature_dtype=torch.bfloat16):
     """Synthetic training buffer directly in HBM (geometry from acezero_amd.synth, features generated on device).
     grid = feature-map size (w, h): 80 x 60 for 480x640 frames, 93 x 60 for the 480x741 frames of the garden-like leg."""
     from acezero_amd import synth
     views = 2 * n_images
     prob = synth.make_training_problem(seed=seed, n_images=n_images, views_per_image=2, patches_per_view=8, width=8 * grid[0], height=8 * grid[1])
     g = torch.Generator(device=device).manual_seed(seed)
-    feats = torch.empty(n_patches, 512, dtype=torch.bfloat16, device=device)
+    feats = torch.empty(n_patches, 512, dtype=feature_dtype, device=device)
     chunk = 1 << 20
     for lo in range(0, n_patches, chunk):
         hi = min(n_patches, lo + chunk)
-        feats[lo:hi] = torch.randn(hi - lo, 512, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+        feats[lo:hi] = torch.randn(hi - lo, 512, generator=g, device=device, dtype=torch.float32).to(feature_dtype)
     view_idx = torch.randint(0, views, (n_patches,), generator=g, device=device, dtype=torch.int32)
     gx = torch.randint(0, grid[0], (n_patches,), generator=g, device=device)
     gy = torch.randint(0, grid[1], (n_patches,), generator=g, device=device)
@@ -135,7 +136,8 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
     from acezero_amd import synth
     from acezero_amd.head import HeadTrainer
     per_rank = buffer_patches // world
-    prob, feats, target_px, view_idx = make_buffer(per_rank, device, 2089 + rank, n_images=n_images, grid=grid)
+    prob, feats, target_px, view_idx = make_buffer(per_rank, device, 2089 + rank, n_images=n_images, grid=grid,
+                                                   feature_dtype=torch.float16 if dtype == "fp16" else torch.bfloat16)
     total_iters = windows * steps + args.warmup + 64
     tr = HeadTrainer(prob["mean"], max_batch=BATCH, global_batch=BATCH if strong else BATCH * world, loss_type="tanh", schedule="1cyclepoly",
                      iterations=max(total_iters, 25000), lr_min=0.0005, lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005,
@@ -206,6 +208,35 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
     if dist is not None:
         dist.barrier()
     return dt, st, prof
+
+
+def bench_dp_rank_proxy(args, device, rows, proxy_world=8, steps=100):
+    """SURVEY 8(e), one-GPU proxy of a data-parallel rank's COMPUTE: parallel.ShardedDataParallel's launch flow (backward on `rows` rows of a
+    5120-row global batch, staging copies, AdamW on the rank's own layers, export / import of the 16-bit copies) with every collective
+    skipped (proxy_world). rows = 5120: a weak-scaling rank; rows = 640: a rank of the reference's step split eight ways. ms per step."""
+    from acezero_amd import synth
+    from acezero_amd.head import HeadTrainer
+    from acezero_amd.parallel import ShardedDataParallel
+    n = min(args.buffer_patches, 1_000_000)
+    prob, feats, target_px, view_idx = make_buffer(n, device, 2089)
+    tr = HeadTrainer(prob["mean"], max_batch=BATCH, global_batch=BATCH, loss_type="tanh", schedule="1cyclepoly", iterations=25000, lr_min=0.0005,
+                     lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005, cooldown_iterations=5000, dtype="bf16")
+    tr.load_flat(torch.from_numpy(synth.init_head_params(1)))
+    tr.set_buffer(feats, target_px, view_idx, prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"], prob["view_image"], prob["image_pose_inv"])
+    dp = ShardedDataParallel(tr, proxy_world=proxy_world)
+    perm = torch.randperm(n, generator=torch.Generator(device=device).manual_seed(8191), device=device)
+    batches = [perm[i * rows:(i + 1) * rows].contiguous() for i in range(min(n // rows, steps + 20))]
+    for i in range(20):
+        dp.step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        dp.step(batches[(20 + i) % len(batches)])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    st = tr.state()
+    assert st["iteration"] == steps + 20 and not st["nan"], st   # (the stand-in gradients are finite: every step ran)
+    return dt * 1e3
 
 
 def bench_registration(args, rank, world, device, h=60, w=80, frames=None):
@@ -282,7 +313,7 @@ ENC_FLOP_PER_FRAME = 58.37e9    # 480x640: sum over the 11 convolutions of 2*Ho*
 HEAD_FLOP_PER_FRAME = 4800 * (8 * 2 * 512 * 512 + 2 * 512 * 4)
 
 
-def bench_pipeline(args, rank, world, device):
+def bench_pipeline(args, rank, world, device, dtype="bf16", legs="all"):
     """(a) images -> encoder -> head -> RANSAC with nothing leaving HBM, (b) training-buffer creation
     (encoder + mask-weighted sampling). 480x640 synthetic grey frames, random-init encoder/head weights (no checkpoints here)."""
     import numpy as np
@@ -295,7 +326,7 @@ def bench_pipeline(args, rank, world, device):
     chunk, total = int(os.environ.get("ACEZ_E2E_CHUNK", "128")), args.e2e_frames // world
     esd = {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights(seed=4099).items()}
     hsd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(synth.init_head_params(3)).items()}
-    net = Regressor.create_from_split_state_dict(esd, hsd, max_frames=chunk, max_h=480, max_w=640)
+    net = Regressor.create_from_split_state_dict(esd, hsd, max_frames=chunk, max_h=480, max_w=640, dtype=dtype)
     img = torch.from_numpy(synth.make_gray_images(seed=1 + rank, n=4, h=480, w=640)).to(device).repeat(chunk // 4, 1, 1, 1).contiguous()
     prm = dict(hyps=32, thr=10.0, alpha=100.0, max_reproj=100.0, sub=8, max_tries=16)
     intr = [(525.0, 320.0, 240.0)] * chunk
@@ -322,6 +353,8 @@ def bench_pipeline(args, rank, world, device):
     dt = time.perf_counter() - t0
     enc_ms = enc_ms_per_frame * nfr
     del big
+    if legs == "e2e":   # (the fp16 leg: images -> poses and the encoder alone)
+        return {"frames": nfr, "e2e_s": dt, "encoder_ms": enc_ms}
     # buffer creation: 1024 samples per view (train_ace.py:128)
     bld = BufferBuilder(net.encoder, capacity=nfr * 1024, samples_per_image=1024, seed=2089)
     eye = torch.eye(4).repeat(chunk, 1, 1)
@@ -496,24 +529,50 @@ def cpu_baseline():
             "encoder_sample": f"2 frames of 480x640, oracle/encoder_oracle.py (torch conv2d fp32), {tcores} threads"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: re-execute under torch.distributed.run with N ranks on this node, one per GPU
+    (the command the driver uses; 127.0.0.1 rendezvous on a free port). Never returns. A box with fewer than N GPUs fails loudly instead
+    of printing an n_gpus = 1 line (--smoke-same-device: all ranks on cuda:0 over gloo, a control-flow check on a one-GPU box)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if not args.smoke_same_device and have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node; refusing to run fewer ranks than asked for")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if env_world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={env_world}: the launcher's rank count and --gpus must agree")
     if args.smoke_same_device:
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    rank, world, rccl_ranks = 0, 1, 0
+    if env_world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.smoke_same_device:
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=device)
-    assert world == args.gpus or world == 1, (world, args.gpus)
+        # the line's n_gpus is what the initialised process group says, not what a flag or an environment variable claims
+        rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        rccl_ranks = world if torch.distributed.get_backend() == "nccl" else 0
+    assert world == args.gpus, (world, args.gpus)
 
     dt, st, prof = bench_training(args, rank, world, device, dtype=args.dtype if args.headline_only else "bf16")
     dev_state = device_state(device) if rank == 0 else None
@@ -526,7 +585,7 @@ def main():
             torch.distributed.destroy_process_group()
         if rank == 0:
             print(json.dumps({"metric": "ACE patches/sec", "value": BATCH * world * args.steps / dt, "unit": "patches/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(np.median(st["window_ms_per_step"])),
+                              "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(np.median(st["window_ms_per_step"])),
                               "ms_per_step_mean": dt / args.steps * 1e3, "window_ms_per_step": st["window_ms_per_step"], "headline_only": True,
                               "pose_refinement": args.pose_refinement, "dtype": args.dtype,
                               "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()}, "final_loss": st["loss"], "device_state": dev_state}))
@@ -534,6 +593,9 @@ def main():
     # the headline step with fp16 operands (the reference's autocast precision; HeadTrainer(dtype="fp16")): same kernels, same rate
     dt_f16, st_f16, _ = bench_training(args, rank, world, device, steps=100, buffer_patches=min(args.buffer_patches, 2_000_000), dtype="fp16")
     dt_ref, st_ref, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000))
+    # the step every non-seed round of ace_zero.py runs, at the reference's operand precision
+    dt_ref16, st_ref16, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000),
+                                           dtype="fp16")
     # BASELINE configs[2] (Mip-NeRF 360 garden-like): 185 frames of 480x741 -> 60x93 maps, focal refinement in the loop
     dt_gar, st_gar, _ = bench_training(args, rank, world, device, pose_refinement="mlp", steps=100, buffer_patches=min(args.buffer_patches, 2_000_000),
                                        n_images=185, grid=(93, 60))
@@ -543,6 +605,9 @@ def main():
         dt_strong, st_strong, _ = bench_training(args, rank, world, device, steps=args.steps, buffer_patches=min(args.buffer_patches, 2_000_000), strong=True)
     nreg, dt_reg, reg_ok = bench_registration(args, rank, world, device)
     pipe = bench_pipeline(args, rank, world, device)
+    pipe16 = bench_pipeline(args, rank, world, device, dtype="fp16", legs="e2e")
+    # one-GPU proxies of a data-parallel rank's compute (N = 1 only: what a rank does between its collectives)
+    dp_proxy = {rows: bench_dp_rank_proxy(args, device, rows) for rows in (5120, 640)} if world == 1 else None
     sess = bench_session(args, device) if world == 1 and args.session_frames > 0 else None
     if world > 1:
         t = torch.tensor([dt, dt_reg, dt_ref, dt_strong, dt_gar, dt_gar_reg, dt_f16] + st["window_ms_per_step"], device=device, dtype=torch.float64)
@@ -613,13 +678,16 @@ def main():
         summary = {"dominant_kernel_frac": dominant["frac"], "dominant_kernel_us": dg_us, "forward_chain_frac": dominant["forward_chain"]["frac"],
                    "wgrad_opt_frac": wg_tflops / MFMA_PEAK_TFLOPS, "whole_step_frac": patches_per_s / world * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS * 1e12),
                    "refinement_ms_per_step": float(np.median(st_ref["window_ms_per_step"])), "fp16_ms_per_step": float(np.median(st_f16["window_ms_per_step"])),
+                   "refinement_fp16_ms_per_step": float(np.median(st_ref16["window_ms_per_step"])),
+                   "e2e_fp16_images_per_s": pipe16["frames"] * world / pipe16["e2e_s"], "encoder_fp16_ms_per_frame": pipe16["encoder_ms"] / pipe16["frames"],
+                   "dp_rank_compute_ms_5120": None if dp_proxy is None else dp_proxy[5120], "dp_rank_compute_ms_640": None if dp_proxy is None else dp_proxy[640],
                    "garden_ms_per_step": float(np.median(st_gar["window_ms_per_step"])),
                    "registration_images_per_s": nreg * world / dt_reg, "registration_e2e_images_per_s": pipe["frames"] * world / pipe["e2e_s"],
                    "encoder_frac_of_mfma_peak": enc_frac, "encoder_ms_per_frame": pipe["encoder_ms"] / pipe["frames"],
                    "buffer_rows_per_s": pipe["buffer_rows"] * world / pipe["buffer_s"],
                    "ransac_algorithmic_frac": rr["algorithmic_frac"], "ransac_issue_occupancy": rr["frac"]}
         out = {
-            "metric": "ACE patches/sec", "value": patches_per_s, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+            "metric": "ACE patches/sec", "value": patches_per_s, "unit": "patches/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": float(np.median(st["window_ms_per_step"])), "ms_per_step_mean": dt / args.steps * 1e3,
             "window_ms_per_step": st["window_ms_per_step"], "windows": WINDOWS, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -638,9 +706,17 @@ def main():
                                 "value": BATCH * world * 100 / dt_ref, "unit": "patches/s", "ms_per_step": dt_ref / 100 * 1e3, "steps": 100,
                                 "ms_per_step_median": float(np.median(st_ref["window_ms_per_step"])), "window_ms_per_step": st_ref["window_ms_per_step"],
                                 "n_images": 1000, "final_loss": st_ref["loss"]},
+            "dp_rank_proxy": None if dp_proxy is None else {
+                "what": "ms per step of ONE data-parallel rank's compute on one GPU: parallel.ShardedDataParallel's launch flow as rank 0 of 8 with every "
+                        "collective skipped (proxy_world) -- backward on `rows` rows, staging copies, AdamW on 1 of 8 layers + small parameters, 16-bit "
+                        "export / import. Multi-GPU itself is unmeasured on hardware; DESIGN.md section 7 adds the exchange estimate to these",
+                "rows_5120_ms": dp_proxy[5120], "rows_640_ms": dp_proxy[640]},
             "dtype_fp16": {"metric": "ACE patches/sec, the headline step with fp16 operands (the reference's autocast precision, compute_dtype fp16)",
                            "value": BATCH * world * 100 / dt_f16, "unit": "patches/s", "ms_per_step": dt_f16 / 100 * 1e3,
-                           "ms_per_step_median": float(np.median(st_f16["window_ms_per_step"])), "final_loss": st_f16["loss"]},
+                           "ms_per_step_median": float(np.median(st_f16["window_ms_per_step"])), "final_loss": st_f16["loss"],
+                           "refinement_ms_per_step_median": float(np.median(st_ref16["window_ms_per_step"])),
+                           "registration_e2e_images_per_s": pipe16["frames"] * world / pipe16["e2e_s"],
+                           "encoder_ms_per_frame": pipe16["encoder_ms"] / pipe16["frames"]},
             "garden_like": {"metric": "BASELINE configs[2] shape: 185 frames of 480x741 (60x93 feature maps), --pose_refinement mlp --refine_calibration True",
                             "training": {"value": BATCH * world * 100 / dt_gar, "unit": "patches/s", "ms_per_step": dt_gar / 100 * 1e3,
                                          "ms_per_step_median": float(np.median(st_gar["window_ms_per_step"])), "n_images": 185,

@@ -21,7 +21,8 @@ def test_bench_json_line_contract(monkeypatch, seq):
     monkeypatch.setattr(bench, "bench_training", lambda *a, **k: (300 * sum(wins) / 5 * 1e-3 if not k.get("steps") else k["steps"] * 240e-6,
                                                                   {"loss": 22.3, "focal_scale": 1.01, "window_ms_per_step": list(wins)}, prof))
     monkeypatch.setattr(bench, "bench_registration", lambda *a, **k: (2048, 2048 / 340e3, 1.0))
-    monkeypatch.setattr(bench, "bench_pipeline", lambda *a: {"frames": 256, "e2e_s": 0.025, "encoder_ms": 16.0, "buffer_rows": 262144, "buffer_s": 0.017,
+    monkeypatch.setattr(bench, "bench_dp_rank_proxy", lambda args, device, rows, **k: 0.150 if rows == 5120 else 0.110)
+    monkeypatch.setattr(bench, "bench_pipeline", lambda *a, **k: {"frames": 256, "e2e_s": 0.025, "encoder_ms": 16.0, "buffer_rows": 262144, "buffer_s": 0.017,
                                                             "cloud_frames": 256, "cloud_s": 1.4e-4, "cloud_points": 256000})
     monkeypatch.setattr(bench, "bench_session", lambda *a: {"frames": 120, "seconds": 5.4})
     monkeypatch.setattr(bench, "cpu_baseline", lambda: {"value": 5.9e4, "unit": "patches/s", "cores": 32, "kind": "port", "sample": "mock"})
@@ -64,6 +65,45 @@ def test_bench_json_line_contract(monkeypatch, seq):
     assert abs(sm["dominant_kernel_frac"] - dom["frac"]) < 1e-12 and sm["registration_images_per_s"] == d["registration"]["value"]
     assert list(d).index("summary") < list(d).index("roofline")
     assert abs(rr["algorithmic_frac"] - rr["algorithmic"]["scoring_frac_of_fp64_valu_peak"]) < 1e-15 and (rr["frac"] is None or "occupancy" in rr["frac_is"])
+    # round 6: the reference's precision end to end, the one-GPU proxy of a data-parallel rank, the rank count of the process group
+    for k in ("refinement_fp16_ms_per_step", "e2e_fp16_images_per_s", "dp_rank_compute_ms_5120", "dp_rank_compute_ms_640"):
+        assert k in sm and r["summary_" + k] == sm[k] and sm[k] > 0
+    assert d["rccl_ranks"] == 0 and d["dp_rank_proxy"]["rows_640_ms"] == 0.110 and d["dtype_fp16"]["registration_e2e_images_per_s"] > 0
+
+
+def test_gpus_flag_without_a_launcher_re_executes_under_torchrun(monkeypatch):
+    """`python bench.py --gpus 8` (the shape of the driver's N = 1 command) used to run ONE rank and print n_gpus 1. Now it
+    re-executes itself under torch.distributed.run with 8 ranks -- or refuses when the node has fewer GPUs; a launcher whose WORLD_SIZE
+    disagrees with --gpus is refused as well."""
+    import subprocess
+    import bench
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # fewer GPUs than ranks asked for: loud refusal, nothing launched
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    seen.clear()
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "only 1 GPU" in str(e.value.code) and not seen
+    # a launcher's environment that disagrees with --gpus
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "must agree" in str(e.value.code)
 
 
 def test_cpu_baseline_quotes_the_stored_reference_figure():
