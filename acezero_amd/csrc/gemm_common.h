@@ -77,6 +77,20 @@ __device__ __forceinline__ float wave_sum63(float v) {
   return v;
 }
 
+// Maximum of NON-NEGATIVE values over the wavefront, valid in lane 63 (the same DPP sequence as wave_sum63; lanes a DPP step does not
+// reach read 0, the identity of max on non-negative values). No LDS traffic: as six __shfl_xor (= ds_bpermute) rounds the fp16 mode's
+// gradient-magnitude bookkeeping cost the input-gradient chain six serial LDS round trips per layer in every multiplier wave (+6 us per step).
+#define ACEZ_DPP_MAX(v, ctrl, rowmask) fmaxf((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rowmask), 0xF, false)))
+__device__ __forceinline__ float wave_max63_nonneg(float v) {
+  v = ACEZ_DPP_MAX(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+  v = ACEZ_DPP_MAX(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+  v = ACEZ_DPP_MAX(v, 0x141, 0xF);   // row_half_mirror
+  v = ACEZ_DPP_MAX(v, 0x140, 0xF);   // row_mirror
+  v = ACEZ_DPP_MAX(v, 0x142, 0xA);   // row_bcast:15 -> rows 1 and 3 fold the row before
+  v = ACEZ_DPP_MAX(v, 0x143, 0xC);   // row_bcast:31 -> rows 2 and 3 fold rows 0..1
+  return v;
+}
+
 // ---- the two 16-bit operand formats of the head (acez_train_config.compute_dtype): bf16 (default; BASELINE.json north_star) and fp16
 // (what the reference's autocast uses, ace_trainer.py:517-518; three more mantissa bits, a narrower exponent: gradients are
 // propagated scaled, head_api.hip grad_scale). Same MFMA rate on gfx950 (v_mfma_f32_16x16x32_{bf16,f16}), fp32 accumulation in both.

@@ -33,6 +33,8 @@ struct acez_trainer {
   std::vector<uint16_t*> R;     // residual stream, R[0] = gathered features
   std::vector<uint16_t*> dZ;    // gradient wrt each wide layer's pre-activation
   uint16_t* dR[2] = {nullptr, nullptr};
+  uint2* maskbits = nullptr;    // [L][row tiles * 4 column tiles * 4 waves * 64 lanes] lane-private ReLU mask bits (RowGemmArgs::mask_out / mask_in)
+  size_t mask_stride = 0;       // uint2 elements per layer
   float* slabs = nullptr;
   int4* batch_meta = nullptr;   // [max_batch] GatherMeta of the batch in R[0]
   float* fc3_partials = nullptr;
@@ -357,6 +359,8 @@ extern "C" int acez_trainer_create(acez_trainer** out, const acez_train_config* 
   if (trains) {
     A((void**)&tr->dR[0], act_bytes);
     A((void**)&tr->dR[1], act_bytes);
+    tr->mask_stride = (size_t)((tr->max_batch + 79) / 80) * 4 * 4 * 64;
+    A((void**)&tr->maskbits, (size_t)tr->L * tr->mask_stride * sizeof(uint2));
     A((void**)&tr->slabs, (size_t)tr->nslabs * tr->n_wide * sizeof(float));
     A((void**)&tr->fc3_partials, (size_t)max_loss_blocks * tr->fc3_stride * sizeof(float));
     A((void**)&tr->stat_partials, (size_t)max_loss_blocks * 4 * sizeof(float));
@@ -547,17 +551,20 @@ static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, co
   const float* P = tr->pb.d_params;
   const bool seq = seq_usable(tr, n);
   std::vector<SeqLayer> sq;
+  // a training forward (st != null) leaves every layer's ReLU mask as bits for the input-gradient chain; fc2's mask is applied by the loss kernel
+  auto mask_out = [&](int l) -> uint2* { return (st && tr->maskbits && l != 3 * (tr->nb + 1) + 1) ? tr->maskbits + (size_t)l * tr->mask_stride : nullptr; };
   auto gemm = [&](int l, const uint16_t* in, uint16_t* out_main, const uint16_t* res, uint16_t* out_aux) {
     if (seq) {
       SeqLayer y{};
       y.In = in; y.W = tr->Wb + (size_t)l * 262144; y.bias = P + (int64_t)l * 262656 + 262144; y.res = res; y.out_main = out_main;
       y.out_aux = out_aux; y.aux_mode = res ? AUX_RESIDUAL : AUX_NONE;
+      y.mask_out = mask_out(l);
       sq.push_back(y);
       return;
     }
     RowGemmArgs g{};
     g.In = in; g.W = tr->Wb + (size_t)l * 262144; g.bias = P + (int64_t)l * 262656 + 262144;
-    g.add = nullptr; g.mask = nullptr; g.res = res; g.out_main = out_main; g.out_aux = out_aux;
+    g.add = nullptr; g.mask_out = mask_out(l); g.mask_in = nullptr; g.res = res; g.out_main = out_main; g.out_aux = out_aux;
     g.M = n; g.N = 512; g.K = 512; g.relu = 1; g.aux_mode = res ? AUX_RESIDUAL : AUX_NONE; g.st = st; g.dbg = 0; g.bias_partials = nullptr;
     launch_rowgemm(g, s, tr->f16);
     ++tr->prof_launches;
@@ -566,7 +573,9 @@ static uint16_t* launch_forward(acez_trainer* tr, const uint16_t* in0, int n, co
   for (int b = 0; b <= tr->nb; ++b) {
     gemm(3 * b, r, tr->out[3 * b], nullptr, nullptr);
     gemm(3 * b + 1, tr->out[3 * b], tr->out[3 * b + 1], nullptr, nullptr);
-    gemm(3 * b + 2, tr->out[3 * b + 1], tr->out[3 * b + 2], r, tr->R[b + 1]);
+    // the block's last activation is only ever read again as a ReLU mask (its sum with the residual stream is the next input, its
+    // weight-gradient operand is the layer before): a training forward leaves the mask bits and does not store the tile (5 MB per block)
+    gemm(3 * b + 2, tr->out[3 * b + 1], mask_out(3 * b + 2) ? nullptr : tr->out[3 * b + 2], r, tr->R[b + 1]);
     r = tr->R[b + 1];
   }
   const int f1 = 3 * (tr->nb + 1), f2 = f1 + 1;
@@ -843,18 +852,19 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   // input-gradient chain
   const bool seq = seq_usable(tr, n);
   std::vector<SeqLayer> sq;
-  auto dgrad = [&](int l, int l_out, const uint16_t* add, const uint16_t* mask, uint16_t* out_main, uint16_t* out_aux) {
+  auto dgrad = [&](int l, int l_out, const uint16_t* add, uint16_t* out_main, uint16_t* out_aux) {
+    const uint2* mask = tr->maskbits + (size_t)l_out * tr->mask_stride;   // the bits forward layer l_out left (RowGemmArgs::mask_in)
     if (seq) {
       if (add && !out_aux) abort();   // rowseq_kernel<true> has the three epilogue shapes of this chain only (an `add` comes with a residual-gradient output)
       SeqLayer y{};
-      y.In = tr->dZ[l]; y.W = tr->WbT + (size_t)l * 262144; y.add = add; y.mask = mask; y.out_main = out_main; y.out_aux = out_aux;
+      y.In = tr->dZ[l]; y.W = tr->WbT + (size_t)l * 262144; y.add = add; y.mask_in = mask; y.out_main = out_main; y.out_aux = out_aux;
       y.bias_partials = tr->bias_partials + (size_t)l_out * tr->bias_layer_stride; y.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE;
       sq.push_back(y);
       return;
     }
     RowGemmArgs g{};
     g.bias_partials = tr->bias_partials + (size_t)l_out * tr->bias_layer_stride;
-    g.In = tr->dZ[l]; g.W = tr->WbT + (size_t)l * 262144; g.bias = nullptr; g.add = add; g.mask = mask; g.res = nullptr;
+    g.In = tr->dZ[l]; g.W = tr->WbT + (size_t)l * 262144; g.bias = nullptr; g.add = add; g.mask_in = mask; g.mask_out = nullptr; g.res = nullptr;
     g.out_main = out_main; g.out_aux = out_aux; g.M = n; g.N = 512; g.K = 512; g.relu = 0;
     g.aux_mode = out_aux ? AUX_UNMASKED : AUX_NONE; g.st = st; g.dbg = 0;
     g.absmax = tr->f16 ? tr->st->dz_absmax_slots : nullptr;
@@ -862,14 +872,14 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     ++tr->prof_launches;
   };
   ProfScope* dchain = new ProfScope(tr, s, KC_GEMM_DGRAD);
-  dgrad(f2, f1, nullptr, tr->out[f1], tr->dZ[f1], nullptr);
+  dgrad(f2, f1, nullptr, tr->dZ[f1], nullptr);
   int cur = 0;
-  dgrad(f1, 3 * tr->nb + 2, nullptr, tr->out[3 * tr->nb + 2], tr->dZ[3 * tr->nb + 2], tr->dR[cur]);
+  dgrad(f1, 3 * tr->nb + 2, nullptr, tr->dZ[3 * tr->nb + 2], tr->dR[cur]);
   for (int b = tr->nb; b >= 0; --b) {
-    dgrad(3 * b + 2, 3 * b + 1, nullptr, tr->out[3 * b + 1], tr->dZ[3 * b + 1], nullptr);
-    dgrad(3 * b + 1, 3 * b, nullptr, tr->out[3 * b], tr->dZ[3 * b], nullptr);
+    dgrad(3 * b + 2, 3 * b + 1, nullptr, tr->dZ[3 * b + 1], nullptr);
+    dgrad(3 * b + 1, 3 * b, nullptr, tr->dZ[3 * b], nullptr);
     if (b > 0) {
-      dgrad(3 * b, 3 * (b - 1) + 2, tr->dR[cur], tr->out[3 * (b - 1) + 2], tr->dZ[3 * (b - 1) + 2], tr->dR[cur ^ 1]);
+      dgrad(3 * b, 3 * (b - 1) + 2, tr->dR[cur], tr->dZ[3 * (b - 1) + 2], tr->dR[cur ^ 1]);
       cur ^= 1;
     }
   }
@@ -1235,8 +1245,9 @@ extern "C" int acez_trainer_get_profile(acez_trainer* tr, float* h_ms8, int32_t*
 }
 
 // Diagnostics for the tests: copy one of the trainer's intermediate device buffers to the host. kind 0: post-ReLU output of wide
-// layer `index` [n][512] bf16; 1: dZ of layer `index` [n][512] bf16; 2: residual stream `index` [n][512] bf16 (0 = the gathered
-// batch); 3: weight-gradient slab `index` [n_wide] fp32; 4: bias-gradient partial rows of layer `index` [max_blocks][512] fp32.
+// layer `index` [n][512] bf16 (training: not kept for the last layer of a block, whose mask bits are); 1: dZ of layer `index` [n][512] bf16;
+// 2: residual stream `index` [n][512] bf16 (0 = the gathered batch); 3: weight-gradient slab `index` [n_wide] fp32; 4: bias-gradient partial
+// rows of layer `index` [max_blocks][512] fp32; 9: ReLU mask bits of layer `index` (RowGemmArgs::mask_out), 8 KiB per 80-row tile.
 extern "C" int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, void* h_out, int64_t bytes, void* stream) {
   ACEZ_REQUIRE(tr && h_out && bytes > 0, "null pointer");
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
@@ -1249,6 +1260,7 @@ extern "C" int acez_trainer_debug_read(acez_trainer* tr, int kind, int index, vo
   else if (kind == 3 && index >= 0 && index < tr->nslabs && tr->slabs) { src = tr->slabs + (size_t)index * tr->n_wide; cap = tr->n_wide * 4; }
   else if (kind == 4 && index >= 0 && index < tr->L && tr->bias_partials) { src = tr->bias_partials + (size_t)index * tr->bias_layer_stride; cap = tr->bias_layer_stride * 4; }
   else if (kind == 6 && tr->seq_xcc) { src = tr->seq_xcc; cap = (8 + 256) * 4; }
+  else if (kind == 9 && index >= 0 && index < tr->L && tr->maskbits) { src = tr->maskbits + (size_t)index * tr->mask_stride; cap = (int64_t)tr->mask_stride * 8; }
   else if (kind == 7 && tr->wgo_trace) { src = tr->wgo_trace; cap = 256 * 12 * 8 * 8; }
   else if (kind == 8 && tr->pose_trace) { src = tr->pose_trace; cap = 3 * 1024 * 16 * 8; }
   ACEZ_REQUIRE(src && bytes <= cap, "unknown buffer or size out of range");

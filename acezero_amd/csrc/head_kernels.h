@@ -79,7 +79,14 @@ struct RowGemmArgs {
   const uint16_t* W;     // [N][K] bf16
   const float* bias;     // [N] or null
   const uint16_t* add;   // [M][N] or null: added before the activation
-  const uint16_t* mask;  // [M][N] or null: out_main is zeroed where mask <= 0
+  // ReLU masks as bits (round 6; the input-gradient layers used to re-read the forward layer's whole 16-bit output tile through LDS only to
+  // test `> 0`: 36.7 MB per step, 20 KiB of LDS-DMA per tile and layer). The forward layer and the input-gradient layer that needs its mask
+  // run on the same 80 x 128 tiles with the same accumulator layout, so the mask is LANE-PRIVATE: every multiplier lane packs the 40 bits
+  // of its own outputs -- fragment f = 2 j + i: bits 9 - f / 25 - f of word x (word y) = the two (next two) of its four outputs are > 0
+  // after the 16-bit rounding -- and the backward lane loads the same 8 bytes: [(row tile * 4 + column tile) * 4 + wave][lane] uint2,
+  // 2 KiB per tile instead of 20.
+  uint2* mask_out;        // forward (bias + ReLU) launches: where the bits go, or null (inference)
+  const uint2* mask_in;   // input-gradient launches: out_main is zeroed where the bit is clear; null = not a masked launch
   const uint16_t* res;   // [M][N] residual input for AUX_RESIDUAL
   uint16_t* out_main;
   uint16_t* out_aux;

@@ -99,9 +99,15 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint16_t* __restrict_
 // max on the bit pattern (non-negative floats order like unsigned integers; +inf = 0x7f800000 is the overflow signal) of the word of
 // this workgroup's stripe. Read (absmax_all) and reset by sched_post_wave.
 __device__ __forceinline__ void absmax_publish(uint32_t* slots, float amax) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-  if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(slots + (blockIdx.x & 63) * 32, __float_as_uint(amax));
+  amax = wave_max63_nonneg(amax);   // (DPP: no LDS round trips; the maximum is in lane 63)
+  if ((threadIdx.x & 63) == 63 && amax > 0.f) atomicMax(slots + (blockIdx.x & 63) * 32, __float_as_uint(amax));
+}
+// The maximum over 64 stripe words already in registers (one per lane, all 64 lanes call it, every lane returns the result). The bit
+// patterns are non-negative floats (or +inf), which order like the unsigned integers they are: a DPP float maximum + one v_readlane, no LDS
+// round trips (absmax_all's six ds_bpermute rounds sat between the K loop and the epilogue of every wave of wgrad_opt_kernel in fp16 mode).
+__device__ __forceinline__ uint32_t absmax_reduce(uint32_t m) {
+  const float f = wave_max63_nonneg(__uint_as_float(m));
+  return (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(f), 63);
 }
 // the maximum over the 64 stripes; all 64 lanes of the wavefront must call it, every lane returns the result
 __device__ __forceinline__ uint32_t absmax_all(const TrainState* st, int lane) {
@@ -141,7 +147,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
   const int m0 = mt * 80;
   const int M = a.M, N = a.N;
   constexpr int K = 512, KT = 8;
-  constexpr bool HAS_IN2 = HAS_MASK || AUX == AUX_RESIDUAL;
+  constexpr bool HAS_IN2 = AUX == AUX_RESIDUAL;   // (the ReLU mask of an input-gradient layer is a lane-private bit word since round 6, not a tile)
   constexpr int EPI = 5 * ((HAS_ADD ? 1 : 0) + (HAS_IN2 ? 1 : 0));  // epilogue-input DMA instructions per loader
 
   if (w >= 4) {
@@ -247,7 +253,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         if (kt >= 1 && kt + 3 < KT) issue(kt + 3);
         if (kt == 4) {
           if (HAS_ADD) issue_tile(a.add, stA);
-          if (HAS_IN2) issue_tile(HAS_MASK ? a.mask : a.res, stB);
+          if (HAS_IN2) issue_tile(a.res, stB);
         }
       }
       ACEZ_VMCNT(0);
@@ -270,6 +276,14 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
     const int fr = l & 15, fq = l >> 4;
+    // this lane's 40 ReLU mask bits (RowGemmArgs::mask_in): requested now, used after the K loop. Inline asm: a plain load would be sunk
+    // to its first use by the scheduler, i.e. into the epilogue, where its round trip would be exposed
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 mb = {0u, 0u};
+    if (HAS_MASK) {
+      const uint2* mp = a.mask_in + ((size_t)(mt * 4 + (n0 >> 7)) * 4 + w) * 64 + l;
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(mb) : "v"(mp) : "memory");
+    }
     float4 bias[2];
     if (BIAS_RELU) {
 #pragma unroll
@@ -360,6 +374,7 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if (HAS_MASK) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mb)::"memory");   // the mask bits requested before the K loop (long since landed)
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int ml = j * 16 + fr;
@@ -390,15 +405,12 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         } else if (AUX == AUX_UNMASKED) {
           *reinterpret_cast<uint2*>(pa) = y;
         }
+        const int f = 2 * j + i;   // (compile-time: both loops are unrolled)
         if (HAS_MASK) {
-          const uint2 mk = rb[i][j];
-          const uint32_t m0b = mk.x & 0xffffu, m1b = mk.x >> 16, m2b = mk.y & 0xffffu, m3b = mk.y >> 16;
-          uint32_t lo = y.x, hi = y.y;
-          if (!(m0b != 0 && m0b < 0x8000u)) lo &= 0xffff0000u;
-          if (!(m1b != 0 && m1b < 0x8000u)) lo &= 0x0000ffffu;
-          if (!(m2b != 0 && m2b < 0x8000u)) hi &= 0xffff0000u;
-          if (!(m3b != 0 && m3b < 0x8000u)) hi &= 0x0000ffffu;
-          y.x = lo; y.y = hi;
+          // keep a half word iff its bit is set: sign-extended one-bit fields -> 0 / ~0, merged per half
+          const uint32_t kx = ((uint32_t)__builtin_amdgcn_sbfe((int)mb.x, 9 - f, 1) & 0x0000ffffu) | ((uint32_t)__builtin_amdgcn_sbfe((int)mb.x, 25 - f, 1) & 0xffff0000u);
+          const uint32_t ky = ((uint32_t)__builtin_amdgcn_sbfe((int)mb.y, 9 - f, 1) & 0x0000ffffu) | ((uint32_t)__builtin_amdgcn_sbfe((int)mb.y, 25 - f, 1) & 0xffff0000u);
+          y.x &= kx; y.y &= ky;
         }
         *reinterpret_cast<uint2*>(pb) = y;
       }
@@ -446,11 +458,40 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         asm volatile("global_atomic_add %0, %1, off" ::"v"(q.flag), "v"(one) : "memory");
       }
     }
-    if (AUX != AUX_NONE) {
+    if (AUX != AUX_NONE && second) {   // (null: a training forward does not keep the pre-residual activation -- only its mask bits are read again)
       if (r0 < M) *reinterpret_cast<uint4*>(second + o0) = s0;
       if (r1 < M) *reinterpret_cast<uint4*>(second + o1) = s1;
       if (q2 < 1280 && r2 < M) *reinterpret_cast<uint4*>(second + o2) = s2;
     }
+  }
+  if (BIAS_RELU && a.mask_out && w < 4) {
+    // ReLU mask bits of this launch's output tile, for the input-gradient layer that will need them (RowGemmArgs::mask_out): computed BEHIND
+    // the hand-off, from the main-output staging tile, in the time the multiplier waves would otherwise spend waiting for the next layer's
+    // first K stage (in the epilogue proper -- 60 instructions per lane in front of the signal -- they cost the forward chain 2 us per
+    // step; a store in front of the signal another 1.6 us per LAYER: its acknowledgement was waited for by the signalling vmcnt(0)).
+    // The staging tile is intact until the next layer's loaders refill it behind that layer's K stage 4.
+    // A 16-bit output is > 0 iff it is non-zero (the ReLU leaves no sign bit: v_max_f32(-0, +0) = +0): the per-half unsigned minimum with
+    // 1 is the flag (v_pk_min_u16; inline asm: written as a vector minimum the compiler scalarised it into a dozen 16-bit compares and
+    // selects per word); fragment f = 2 j + i ends at bits 9 - f and 25 - f of its word.
+    const int fr = l & 15, fq = l >> 4;
+    uint2 yv[5][2];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) yv[j][i] = *reinterpret_cast<const uint2*>(&stB[st_off(j * 16 + fr, w * 32 + i * 16 + 4 * fq)]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint2 mbits = make_uint2(0u, 0u);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        uint32_t fx, fy;
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(fx) : "v"(yv[j][i].x), "s"(0x00010001u));
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(fy) : "v"(yv[j][i].y), "s"(0x00010001u));
+        mbits.x = (mbits.x << 1) | fx;
+        mbits.y = (mbits.y << 1) | fy;
+      }
+    a.mask_out[((size_t)(mt * 4 + (n0 >> 7)) * 4 + w) * 64 + l] = mbits;   // 512 contiguous bytes per wave
   }
   if (HAS_MASK && a.bias_partials) {
     // bias gradient partial of this 80-row tile = column sums of the bf16 output tile: four 20-row groups in parallel,
@@ -509,7 +550,9 @@ __global__ __launch_bounds__(512) void rowgemm80_kernel(RowGemmArgs a) {
 struct SeqLayer {
   const uint16_t *In, *W;
   const float* bias;
-  const uint16_t *add, *mask, *res;
+  const uint16_t *add, *res;
+  uint2* mask_out;          // RowGemmArgs::mask_out / mask_in
+  const uint2* mask_in;
   uint16_t *out_main, *out_aux;
   float* bias_partials;
   int aux_mode, pad;
@@ -556,7 +599,7 @@ __global__ __launch_bounds__(512) void rowseq_kernel(RowSeqArgs a) {
   for (int layer = 0; layer < a.n_layers; ++layer) {
     const SeqLayer& y = a.layer[layer];
     RowGemmArgs g;
-    g.In = y.In; g.W = y.W; g.bias = y.bias; g.add = y.add; g.mask = y.mask; g.res = y.res; g.out_main = y.out_main; g.out_aux = y.out_aux;
+    g.In = y.In; g.W = y.W; g.bias = y.bias; g.add = y.add; g.mask_out = y.mask_out; g.mask_in = y.mask_in; g.res = y.res; g.out_main = y.out_main; g.out_aux = y.out_aux;
     g.bias_partials = y.bias_partials; g.M = a.M; g.N = 512; g.K = 512; g.relu = BWD ? 0 : 1; g.aux_mode = y.aux_mode; g.st = a.st; g.dbg = 0;
     g.absmax = (BWD && a.st) ? const_cast<uint32_t*>(a.st->dz_absmax_slots) : nullptr;
     SeqLink q;
@@ -604,10 +647,10 @@ static inline void launch_rowgemm(const RowGemmArgs& g, hipStream_t s, bool f16 
   } while (0)
   if (br && g.aux_mode == AUX_NONE) ACEZ_RG(true, false, false, AUX_NONE);
   else if (br && g.aux_mode == AUX_RESIDUAL) ACEZ_RG(true, false, false, AUX_RESIDUAL);
-  else if (!br && g.mask && !g.add && g.aux_mode == AUX_NONE) ACEZ_RG(false, false, true, AUX_NONE);
-  else if (!br && g.mask && !g.add && g.aux_mode == AUX_UNMASKED) ACEZ_RG(false, false, true, AUX_UNMASKED);
-  else if (!br && g.mask && g.add && g.aux_mode == AUX_UNMASKED) ACEZ_RG(false, true, true, AUX_UNMASKED);
-  else if (!br && g.mask && g.add && g.aux_mode == AUX_NONE) ACEZ_RG(false, true, true, AUX_NONE);
+  else if (!br && g.mask_in && !g.add && g.aux_mode == AUX_NONE) ACEZ_RG(false, false, true, AUX_NONE);
+  else if (!br && g.mask_in && !g.add && g.aux_mode == AUX_UNMASKED) ACEZ_RG(false, false, true, AUX_UNMASKED);
+  else if (!br && g.mask_in && g.add && g.aux_mode == AUX_UNMASKED) ACEZ_RG(false, true, true, AUX_UNMASKED);
+  else if (!br && g.mask_in && g.add && g.aux_mode == AUX_NONE) ACEZ_RG(false, true, true, AUX_NONE);
   else abort();  // no other epilogue shape exists in the head
 #undef ACEZ_RG
 }
@@ -2157,6 +2200,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
   const int nrow0 = n0 + 64 * slab;   // first row of the half tile this workgroup finalises
   float4 p4[4], m4[4], v4[4];
   float lp[5];   // the loss partials tail_output reads first (NaN guard)
+  uint32_t amx = 0u, amxm = 0u;   // fp16: this lane's stripe of the step's largest propagated gradient (final before this launch), prefetched with p / m / v
   const int nlb = ad.tail.n_loss_blocks;
   auto prefetch = [&]() {
 #pragma unroll
@@ -2168,6 +2212,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
     }
 #pragma unroll
     for (int u = 0; u < 5; ++u) lp[u] = ad.tail.stat_partials[(size_t)min(l + 64 * u, max(nlb - 1, 0)) * 4];
+    if (E::is_f16) amx = __builtin_nontemporal_load(&ad.st->dz_absmax_slots[l * 32]);
   };
   // the multiplier waves' small-parameter share (workgroups b < nsmall): requested once the accumulators are on their way. (In front of
   // the send it delayed every exchange by the 2.5 us the requests take to issue -- tools/wgo_trace.py; from inside the K loop, two or
@@ -2180,22 +2225,24 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
       sm.issue(ad.tail, small_opt(ad), b);
 #pragma unroll
       for (int u = 0; u < 5; ++u) lpm[u] = ad.tail.stat_partials[(size_t)min(l + 64 * u, max(nlb - 1, 0)) * 4];
+      if (E::is_f16) amxm = __builtin_nontemporal_load(&ad.st->dz_absmax_slots[l * 32]);
     }
   };
-  // tail_output's sum of the loss partials (the same additions in the same order) from five prefetched rows per lane
+  // the sum of the loss partials from five prefetched rows per lane: ONLY its NaN-ness is used (the guard tail_output applies to the step;
+  // the logged loss is tail_output's own fixed-order sum), so the cross-lane part is a DPP sum + one v_readlane instead of six ds_bpermute
+  // rounds on every wave's path from the K loop to its epilogue (a NaN stays a NaN in any order; the partials are >= 0)
   auto loss_sum = [&](const float (&v5)[5]) {
     float sum = 0.f;
 #pragma unroll
     for (int u = 0; u < 5; ++u)
       if (l + 64 * u < nlb) sum += v5[u];
     for (int r = l + 320; r < nlb; r += 64) sum += ad.tail.stat_partials[(size_t)r * 4];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
-    return sum;
+    sum = wave_sum63(sum);
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sum), 63));
   };
   f32x16 acc[2][2];
   int KT;
-  const bool loader = wgrad_kloop<E, WGO_PF>(a, smem, layer, slab, tile, acc, KT, prefetch);
+  const bool loader = wgrad_kloop<E, WGO_PF + (E::is_f16 ? 1 : 0)>(a, smem, layer, slab, tile, acc, KT, prefetch);   // (fp16: + the absmax stripe)
   if (KT == 0) __builtin_amdgcn_s_barrier();   // (wsync)
   WGO_STAMP(1);   // K loop done
   // Slot KT % RING was last written for stage KT - RING and slot (KT + 1) % RING for stage KT - RING + 1: every wave is past the barrier
@@ -2242,7 +2289,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
       sm.finish(ad.tail, small_opt(ad), b, sc, [&] {
         const float lossv = loss_sum(lpm);
         bool skip = !active || fault_now || lossv != lossv;
-        if (E::is_f16) skip = skip || absmax_all(st, l) >= 0x7f800000u;
+        if (E::is_f16) skip = skip || absmax_reduce(amxm) >= 0x7f800000u;
         return skip;
       });
     }
@@ -2260,7 +2307,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
   const int fault_now = *ad.fault;
   const float lossv = loss_sum(lp);
   bool skip = !active || fault_now || lossv != lossv || (ACEZ_DBG(a.dbg) & 8);   // adamw_body's guards
-  if (E::is_f16) skip = skip || absmax_all(st, l) >= 0x7f800000u;
+  if (E::is_f16) skip = skip || absmax_reduce(amx) >= 0x7f800000u;
   const bool skip_by_guard = skip;   // (uniform over the launch: every wave evaluates the same words)
   if (!(ACEZ_DBG(a.dbg) & 48)) {   // (ablation bits of the diagnostics build, timing only: 8 = no final stores, 16 = no poll, 32 = no send, 64 = no small parameters, 128 = no schedule wave)
     uint32_t vseen, sseen, spins, timed;

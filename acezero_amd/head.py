@@ -346,13 +346,16 @@ class HeadTrainer:
         N.check(self.lib.acez_trainer_get_profile(self._h, ms.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
 
-    DEBUG_KINDS = {"out": 0, "dZ": 1, "R": 2, "slab": 3, "bias_partials": 4}
+    DEBUG_KINDS = {"out": 0, "dZ": 1, "R": 2, "slab": 3, "bias_partials": 4, "mask": 9}
 
     def debug_read(self, kind, index, rows):
         """Intermediate buffer of the last backward call (tests): 'out' / 'dZ' / 'R' -> uint16 [rows,512] (bf16 bit patterns),
-        'slab' -> float32 [n_wide], 'bias_partials' -> float32 [rows,512]."""
+        'slab' -> float32 [n_wide], 'bias_partials' -> float32 [rows,512], 'mask' -> uint32 [80-row tiles, 2048] (the lane-private ReLU
+        mask bits a training forward leaves per layer; the pre-residual activation of a block's last layer is not kept in training)."""
         if kind in ("out", "dZ", "R"):
             out = np.zeros((rows, 512), np.uint16)
+        elif kind == "mask":
+            out = np.zeros(((rows + 79) // 80, 2048), np.uint32)
         elif kind == "slab":
             out = np.zeros(self.L * 262656, np.float32)
         else:

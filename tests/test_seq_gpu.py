@@ -44,7 +44,10 @@ def test_one_launch_chains_equal_per_layer_launches(name, n):
         new.backward(idx)
         torch.cuda.synchronize()
         for l in range(L):
-            assert np.array_equal(ref.debug_read("out", l, n), new.debug_read("out", l, n)), ("out", l, it)
+            if not (l < L - 2 and l % 3 == 2):   # (a block's last activation is not kept in training: only its ReLU mask bits are)
+                assert np.array_equal(ref.debug_read("out", l, n), new.debug_read("out", l, n)), ("out", l, it)
+            if l != L - 1:                       # (fc2's mask is applied by the loss kernel from the activation itself)
+                assert np.array_equal(ref.debug_read("mask", l, n), new.debug_read("mask", l, n)), ("mask", l, it)
             assert np.array_equal(ref.debug_read("dZ", l, n), new.debug_read("dZ", l, n)), ("dZ", l, it)
         for b in range(ref.nb + 2):
             assert np.array_equal(ref.debug_read("R", b, n), new.debug_read("R", b, n)), ("R", b, it)
@@ -53,6 +56,53 @@ def test_one_launch_chains_equal_per_layer_launches(name, n):
         new.update()
         torch.cuda.synchronize()
         assert torch.equal(ref.params, new.params) and ref.state() == new.state()
+
+
+def _decode_mask_bits(words, n):
+    """[row tiles, 2048] uint32 words of a layer (RowGemmArgs::mask_out) -> bool [n, 512]: lane-private layout of rowgemm80's accumulators."""
+    mt_n = words.shape[0]
+    w4 = words.reshape(mt_n, 4, 4, 64, 2)                     # [row tile][column tile][wave][lane][x | y]
+    out = np.zeros((mt_n * 80, 512), bool)
+    lane = np.arange(64)
+    fr, fq = lane & 15, lane >> 4
+    for j in range(5):
+        for i in range(2):
+            f = 2 * j + i
+            for nt in range(4):
+                for w in range(4):
+                    rows = (np.arange(mt_n)[:, None] * 80 + j * 16 + fr[None, :])              # [mt, lane]
+                    col0 = nt * 128 + w * 32 + i * 16 + 4 * fq                                 # [lane]
+                    for word, cbase in ((0, 0), (1, 2)):
+                        v = w4[:, nt, w, :, word]
+                        out[rows, (col0 + cbase)[None, :]] = (v >> (9 - f)) & 1
+                        out[rows, (col0 + cbase + 1)[None, :]] = (v >> (25 - f)) & 1
+    return out[:n]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("n", [5120, 637])
+def test_relu_mask_bits_are_the_sign_of_the_stored_activations(n, dtype):
+    """Round 6: the input-gradient layers take their ReLU masks as 40 lane-private bits per multiplier lane instead of re-reading the
+    forward layer's 16-bit tile. The bits a training forward leaves, decoded through the accumulator layout, must be exactly `activation
+    > 0` of the tile the same forward stored (every layer whose activation is kept), in both operand formats and with a ragged last tile."""
+    prob = _big_problem()
+    from oracle import head_oracle
+    flat0 = head_oracle.init_params(helpers.SEED + 1)
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
+    cfg["global_batch"] = n
+    tr = _trainer(prob, flat0, cfg, max_batch=5120, dtype=dtype)
+    idx = torch.from_numpy(np.random.default_rng(3).permutation(prob["features"].shape[0])[:n].astype(np.int64)).cuda()
+    tr.backward(idx)
+    torch.cuda.synchronize()
+    L = tr.L
+    for l in range(L - 1):
+        if l < L - 2 and l % 3 == 2:
+            continue                                   # pre-residual activation: not kept in training
+        act = tr.debug_read("out", l, n)               # 16-bit patterns
+        positive = (act != 0) & (act < 0x8000)
+        bits = _decode_mask_bits(tr.debug_read("mask", l, n), n)
+        assert np.array_equal(bits, positive), (l, int((bits != positive).sum()))
+        assert 0.05 < positive.mean() < 0.95           # (a real mask, not all-ones / all-zeros)
 
 
 def test_free_running_steps_stay_bitwise_equal():

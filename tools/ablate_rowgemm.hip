@@ -28,7 +28,7 @@ int main() {
   for (int rep = 0; rep < 2; ++rep)
     for (auto& v : vars) {
       RowGemmArgs g{};
-      g.In = In; g.W = W; g.bias = v.m ? nullptr : bias; g.add = v.a ? add : nullptr; g.mask = v.m ? mask : nullptr; g.res = nullptr;
+      g.In = In; g.W = W; g.bias = v.m ? nullptr : bias; g.add = v.a ? add : nullptr; g.mask_in = v.m ? reinterpret_cast<const uint2*>(mask) : nullptr; g.mask_out = v.m ? nullptr : reinterpret_cast<uint2*>(aux);   // (mask bits: any 512 KiB of device memory) g.res = nullptr;
       g.out_main = out; g.out_aux = v.x ? aux : nullptr; g.M = M; g.N = 512; g.K = 512; g.relu = v.m ? 0 : 1;
       g.aux_mode = v.x ? AUX_UNMASKED : AUX_NONE; g.st = nullptr; g.dbg = v.dbg; g.bias_partials = v.m ? bpart : nullptr;
       for (int i = 0; i < 20; ++i) launch_rowgemm(g, 0);
