@@ -131,7 +131,8 @@ class HeadOracle:
             return s[:, :3] + self.mean, None
         s3 = s[:, 3]
         bx = self.h_beta * s3
-        sp = torch.where(bx > 20.0, s3, torch.log1p(torch.exp(bx)) / self.h_beta)
+        big = bx > 20.0   # F.softplus's threshold (ace_network.py:142). The unselected branch is evaluated on a harmless argument: under autograd
+        sp = torch.where(big, s3, torch.log1p(torch.exp(torch.where(big, torch.zeros_like(bx), bx))) / self.h_beta)   # (pose path) inf * 0 would be NaN
         hraw = sp + self.max_inv_scale
         clamped = hraw > self.min_inv_scale
         h = torch.where(clamped, torch.full_like(hraw, self.min_inv_scale), hraw)
@@ -359,9 +360,10 @@ class PoseNaiveOracle:
         return torch.cat([torch.cat([R, cur[:, :3, 3:4]], dim=2), poses44[:, 3:4, :]], dim=1)
 
 
-def loss_autograd(head, s, batch, cfg, iteration, poses44_rows, focal_scale=1.0):
+def loss_autograd(head, s, batch, cfg, iteration, poses44_rows, focal_g=None):
     """ace_trainer.py:521-613 with torch ops and autograd (used where gradients wrt the poses are needed).
-    s [B,no] requires grad; poses44_rows [B,4,4] may require grad. Returns (loss_sum tensor, inliers)."""
+    s [B,no] requires grad; poses44_rows [B,4,4] may require grad; focal_g: the CalibrationRefiner's scalar (a tensor that requires grad,
+    refine_calibration.py:20-53) when cfg["refine_calibration"]. Returns (loss_sum tensor, inliers)."""
     B = s.shape[0]
     X, _ = head.dehomogenise(s)
     tu_tv = batch["target_px"]
@@ -370,7 +372,11 @@ def loss_autograd(head, s, batch, cfg, iteration, poses44_rows, focal_scale=1.0)
     Xc = torch.bmm(P, Xh[:, :, None])[:, :, 0]
     K = batch["K"].clone()
     if cfg.get("refine_calibration", False):
-        raise NotImplementedError
+        # refine_calibration.py:34-53: f = (1 + g) f0, times the per-patch augmentation scale K00 / f0 (detached), written over K[:2,:2]
+        f0 = float(cfg["focal_init"])
+        f = ((1.0 + focal_g) * np.float32(f0)) * (batch["K"][:, 0, 0] / f0)
+        zero = torch.zeros_like(f)
+        K = torch.stack([torch.stack([f, zero, K[:, 0, 2]], dim=1), torch.stack([zero, f, K[:, 1, 2]], dim=1), K[:, 2]], dim=1)
     pp = torch.bmm(K, Xc[:, :, None])[:, :, 0]
     pz = pp[:, 2].clamp(min=float(cfg["depth_min"]))
     uv = pp[:, :2] / pz[:, None]
@@ -530,12 +536,14 @@ class TrainerOracle:
             poses_all = self.pose.forward(self.image_pose_inv)
             rows = poses_all[batch["pose_idx"].long().view(-1)]
             sl = s.detach().clone().requires_grad_(True)
-            loss_sum, inl = loss_autograd(self.head, sl, batch, cfg, self.iteration, rows)
+            fg = torch.tensor(float(sch.calib_g), dtype=torch.float32, requires_grad=True) if cfg.get("refine_calibration", False) else None
+            loss_sum, inl = loss_autograd(self.head, sl, batch, cfg, self.iteration, rows, focal_g=fg)
             (loss_sum / cfg["global_batch"]).backward()
             pose_grad = self.pose.flat.grad.detach().clone()
             with torch.no_grad():
                 X = self.head.dehomogenise(sl)[0]
-            out = {"loss_sum": float(loss_sum.detach()), "inliers": inl, "ds": sl.grad.detach(), "focal_grad": 0.0, "X": X.detach()}
+            out = {"loss_sum": float(loss_sum.detach()), "inliers": inl, "ds": sl.grad.detach(), "focal_grad": float(fg.grad) if fg is not None else 0.0,
+                   "X": X.detach()}
         grad = self.head.backward(tape, out["ds"])
         self.head.next_grad_scale()   # (fp16 mode: the device adapts its gradient scale after every step; no-op otherwise)
         loss = out["loss_sum"] / cfg["global_batch"]

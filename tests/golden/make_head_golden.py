@@ -240,13 +240,14 @@ def main():
     only = sys.argv[1:]   # optional: names of the configurations to (re)generate
     from tests import helpers   # the "trained regime" configurations and their problem live next to the tests that consume them
     global B
-    for name, c in list(CONFIGS.items()) + list(helpers.TRAINED_CONFIGS.items()) + [("head_focal_drift", helpers.FOCAL_DRIFT)] + list(helpers.BIG_CONFIGS.items()):
+    for name, c in (list(CONFIGS.items()) + list(helpers.TRAINED_CONFIGS.items()) + [("head_focal_drift", helpers.FOCAL_DRIFT), ("head_trajectory", helpers.TRAJECTORY)] +
+                    list(helpers.BIG_CONFIGS.items())):
         if only and name not in only:
             continue
         B = helpers.BIG_B if name in helpers.BIG_CONFIGS else 512
         if name in helpers.BIG_CONFIGS:
             prob, flat0, cfg = helpers.problem_for(name)
-        elif name in helpers.TRAINED_CONFIGS or name == "head_focal_drift":
+        elif name in helpers.TRAINED_CONFIGS or name in ("head_focal_drift", "head_trajectory"):
             prob, flat0, cfg = helpers.problem_for(name)
         else:
             cfg = full_cfg(c)
@@ -267,7 +268,9 @@ def main():
             max_iterations=np.array(rec["max_iterations"], np.int64), focal_scale=np.array(rec["focal_scale"], np.float64),
             coords0=coords0[:64].astype(np.float32), param_sel=sel, params_after_first=first[sel], params_after_last=snaps[last_it][sel],
             last_it=np.int64(last_it), steps_run=np.int64(len(rec["loss"])),
-            poses=np.array(rec["poses"], np.float32), pose_params_sel=np.array([p[::(97 if p.size > 1000 else 1)] for p in rec["pose_params"]], np.float32))
+            poses=np.array(rec["poses"], np.float32),
+            # (long trajectories: the sampled pose parameters of every 20th step only)
+            pose_params_sel=np.array([p[::(97 if p.size > 1000 else 1)] for i, p in enumerate(rec["pose_params"]) if cfg["steps"] <= 50 or i % 20 == 19], np.float32))
         print(name, "steps run", len(rec["loss"]), "loss", rec["loss"][:3], "inl", rec["inliers"][:3], "lr", rec["lr"][:3],
               "max_it", rec["max_iterations"][-1], "focal", rec["focal_scale"][-1])
 

@@ -91,6 +91,31 @@ FOCAL_DRIFT = dict(loss_type="tanh", schedule="constant", lr_min=0.00002, lr_max
                    focal_error=1.05)
 
 
+# ---- a free-running refinement trajectory: 320 steps of the step ace_zero.py runs in its non-seed rounds -- pose MLP
+# (no wait) + focal refinement, tanh loss -- on the solved problem with a 3 % focal error AND perturbed poses (0.4 degrees / 1.5 cm per
+# image): the loss falls as the focal and the poses are corrected; loss curve, inlier fraction, refined poses and focal of the REFERENCE's
+# fp32 run are the fixture (tests/golden/head_trajectory.npz), the oracle (CPU) and the HIP trainer in both operand formats follow it.
+TRAJECTORY = dict(loss_type="tanh", schedule="constant", lr_min=0.00002, lr_max=0.0002, warmup_iterations=1000, warmup_lr=0.0005,
+                  cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=1000, refine_calibration=True, steps=320,
+                  focal_error=1.03, pose_refinement="mlp", pose_refinement_wait=0, pose_noise=(0.4, 0.015))
+
+
+def perturb_poses(image_pose_inv, deg, metres, seed):
+    """world -> camera matrices [I,4,4] left-multiplied by a small seeded rigid motion each (float64 arithmetic, float32 result)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    out = image_pose_inv.astype(np.float64).copy()
+    for i in range(out.shape[0]):
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        D = np.eye(4)
+        D[:3, :3] = Rotation.from_rotvec(ax * np.deg2rad(deg)).as_matrix()
+        t = rng.normal(size=3)
+        D[:3, 3] = t / np.linalg.norm(t) * metres
+        out[i] = D @ out[i]
+    return out.astype(np.float32)
+
+
 def trained_problem(num_head_blocks=1, use_homogeneous=True, patches_per_view=128):
     """A training problem and head weights that ALREADY solve it, built without any training so that the reference, the oracle and
     the kernels can start from bit-identical numbers on any machine: the synthetic features are (almost) linear in the scene
@@ -150,6 +175,11 @@ BIG_CONFIGS = {
     "head_b5120_trained": dict(loss_type="dyntanh", schedule="constant", lr_min=0.00005, lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005,
                                cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=20, refine_calibration=True, steps=3,
                                trained=True),
+    # THE step every non-seed round of ace_zero.py runs (ace_zero.py:86,97: --pose_refinement mlp --refine_calibration True; tanh, 1cyclepoly
+    # with ace_zero's learning rates), at BASELINE's batch on 200 images: 6 steps, the pose network moving from the third on (wait = 1)
+    "head_b5120_posemlp_calib": dict(loss_type="tanh", schedule="1cyclepoly", lr_min=0.0005, lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005,
+                                     cooldown_iterations=5000, cooldown_trigger_percent=0.7, iterations=25000, refine_calibration=True, steps=6,
+                                     pose_refinement="mlp", pose_refinement_wait=1, n_images=200),
 }
 
 
@@ -157,11 +187,15 @@ def big_problem_for(name):
     c = BIG_CONFIGS[name]
     if c.get("trained"):
         prob, flat0 = trained_problem(patches_per_view=512)
+    elif "n_images" in c:   # many images, few patches each (200 x 2 views x 16 = 6400 rows): every image's pose takes part in every batch
+        prob = synth.make_training_problem(seed=SEED + 31, n_images=c["n_images"], views_per_image=2, patches_per_view=16)
+        prob["features"] = torch.from_numpy(prob["features"]).to(torch.bfloat16).to(torch.float32).numpy()
+        flat0 = head_oracle.init_params(SEED + 1)
     else:
         prob = synth.make_training_problem(seed=SEED + 21, n_images=6, views_per_image=2, patches_per_view=512)
         prob["features"] = torch.from_numpy(prob["features"]).to(torch.bfloat16).to(torch.float32).numpy()
         flat0 = head_oracle.init_params(SEED + 1)
-    cfg = full_cfg({k: v for k, v in c.items() if k != "trained"}, prob)
+    cfg = full_cfg({k: v for k, v in c.items() if k not in ("trained", "n_images")}, prob)
     cfg["global_batch"] = BIG_B
     return prob, flat0, cfg
 
@@ -176,8 +210,8 @@ def problem_for(name):
     """(prob, flat0, cfg) of a golden configuration."""
     if name in BIG_CONFIGS:
         return big_problem_for(name)
-    if name in TRAINED_CONFIGS or name == "head_focal_drift":
-        c = TRAINED_CONFIGS[name] if name in TRAINED_CONFIGS else FOCAL_DRIFT
+    if name in TRAINED_CONFIGS or name in ("head_focal_drift", "head_trajectory"):
+        c = TRAINED_CONFIGS[name] if name in TRAINED_CONFIGS else (FOCAL_DRIFT if name == "head_focal_drift" else TRAJECTORY)
         prob, flat0 = trained_problem(c.get("num_head_blocks", 1), c.get("use_homogeneous", True))
         if "focal_error" in c:
             prob["view_K"] = prob["view_K"].copy()
@@ -185,7 +219,10 @@ def problem_for(name):
             prob["view_K"][:, 1, 1] *= np.float32(c["focal_error"])
             prob["view_Kinv"] = np.linalg.inv(prob["view_K"].astype(np.float64)).astype(np.float32)
             prob["focal"] = np.float32(float(prob["focal"]) * c["focal_error"])
-        cfg = full_cfg(c, prob)
+        if "pose_noise" in c:
+            prob["image_pose_inv_true"] = prob["image_pose_inv"].copy()
+            prob["image_pose_inv"] = perturb_poses(prob["image_pose_inv"], c["pose_noise"][0], c["pose_noise"][1], SEED + 41)
+        cfg = full_cfg({k: v for k, v in c.items() if k != "pose_noise"}, prob)
         cfg["num_head_blocks"] = c.get("num_head_blocks", 1)
         cfg["use_homogeneous"] = c.get("use_homogeneous", True)
         return prob, flat0, cfg

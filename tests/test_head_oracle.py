@@ -77,10 +77,15 @@ def test_bf16_mode_close_to_fp32():
 
 @pytest.mark.parametrize("name", list(helpers.BIG_CONFIGS))
 def test_oracle_fp32_matches_reference_golden_at_the_baseline_batch(name, golden_dir):
-    """BASELINE's batch of 5120 rows: three steps of the reference's own training_step (tests/golden/make_head_golden.py)."""
+    """BASELINE's batch of 5120 rows: three steps of the reference's own training_step (tests/golden/make_head_golden.py); six for the
+    step ace_zero.py runs in every non-seed round (pose MLP + focal refinement on 200 images), with the refined poses of every image."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     prob, flat0, cfg = helpers.problem_for(name)
-    tr = head_oracle.TrainerOracle(flat0.clone(), prob["mean"], cfg, mode="fp32", image_pose_inv=prob["image_pose_inv"])
+    pose_flat = None
+    if cfg["pose_refinement"] == "mlp":
+        from acezero_amd.head import init_pose_network
+        pose_flat = init_pose_network(helpers.SEED + 3)
+    tr = head_oracle.TrainerOracle(flat0.clone(), prob["mean"], cfg, mode="fp32", pose_flat=pose_flat, image_pose_inv=prob["image_pose_inv"])
     losses, inl, lrs, focal = [], [], [], []
     for it, idx in enumerate(helpers.big_batches(prob, cfg["steps"])):
         assert len(idx) == helpers.BIG_B
@@ -90,9 +95,39 @@ def test_oracle_fp32_matches_reference_golden_at_the_baseline_batch(name, golden
         rec = tr.step(b["features"], b)
         losses.append(rec["loss"]); inl.append(rec["inliers"]); lrs.append(rec["lr"]); focal.append(1.0 + tr.sched.calib_g)
         if it == 0:
-            np.testing.assert_allclose(tr.head.p.flat.numpy()[g["param_sel"]], g["params_after_first"], rtol=0, atol=2e-6)
+            d = np.abs(tr.head.p.flat.numpy()[g["param_sel"]] - g["params_after_first"])
+            # the first AdamW step moves a weight by lr * g / (|g| + 1e-8): a weight whose gradient is at the 1e-8 level follows the last bits of
+            # the summation order (here: autograd's) -- one such weight among the 2110 sampled in the refinement configuration
+            assert d.max() < (2.5e-5 if pose_flat is not None else 2e-6) and (d > 2e-6).mean() < 2e-3, (d.max(), (d > 2e-6).mean())
+        if pose_flat is not None:
+            # the refined poses of all 200 images and the pose network's parameters after this step, vs the reference's PoseRefiner
+            assert g["poses"].shape[1] == prob["image_pose_inv"].shape[0] >= 200
+            # (refined poses: exact until the first pose update; from then on a few sign-flipped +-lr weights move every pose by a few 1e-3
+            # per update -- the reference's own trajectory is that sensitive to the last bits of its first pose gradients)
+            upd = it - cfg["pose_refinement_wait"]
+            np.testing.assert_allclose(tr.current_poses().numpy(), g["poses"][it], atol=5e-5 if upd <= 0 else 5e-3 * upd)
+            # (the pose network's first AdamW steps move every weight by +-lr = 1e-3 with the sign of its gradient: a weight whose gradient is
+            # at the rounding level may take the other sign -- a few of the 732 sampled weights, each off by 2 lr per such step)
+            dp = np.abs(tr.pose.flat.detach().numpy()[::97] - g["pose_params_sel"][it])
+            updates = it - cfg["pose_refinement_wait"]     # pose-network updates applied so far
+            if updates <= 0:
+                assert dp.max() < 2e-6, (it, dp.max())
+            elif updates == 1:
+                assert dp.max() < 3e-3 and (dp > 2e-6).mean() < 0.02, (it, dp.max(), (dp > 2e-6).mean())
+            else:   # (the flipped weights have moved the poses, hence every later gradient: bounded drift)
+                assert dp.max() < 5e-3 and np.median(dp) < 3e-4, (it, dp.max(), np.median(dp))
     np.testing.assert_allclose(lrs, g["lr"], rtol=1e-12)
-    np.testing.assert_allclose(inl, g["inliers"], atol=1.5 / helpers.BIG_B)
     np.testing.assert_allclose(losses[:1], g["loss"][:1], rtol=2e-5)
-    np.testing.assert_allclose(losses, g["loss"], rtol=3e-4)
-    np.testing.assert_allclose(focal, g["focal_scale"], atol=2e-6)
+    if pose_flat is None:
+        np.testing.assert_allclose(inl, g["inliers"], atol=1.5 / helpers.BIG_B)
+        np.testing.assert_allclose(losses, g["loss"], rtol=3e-4)
+        np.testing.assert_allclose(focal, g["focal_scale"], atol=2e-6)
+    else:
+        # identical (1e-6) through the first pose update's forward; behind it the sign-flipped pose weights separate the two fp32 trajectories:
+        # measured 0.45 % on the loss, 2 rows of 5120 on the inlier count, 2.6e-4 on the focal scale after four pose updates
+        k = cfg["pose_refinement_wait"] + 2
+        np.testing.assert_allclose(losses[:k], g["loss"][:k], rtol=2e-5)
+        np.testing.assert_allclose(focal[:k], g["focal_scale"][:k], atol=2e-6)
+        np.testing.assert_allclose(losses, g["loss"], rtol=1e-2)
+        np.testing.assert_allclose(inl, g["inliers"], atol=3.5 / helpers.BIG_B)
+        np.testing.assert_allclose(focal, g["focal_scale"], atol=5e-4)
