@@ -54,14 +54,20 @@ def test_inference_scene_coordinates_match_oracle():
 
 
 def _ill_conditioned_rows(tr, orc_dz, n):
-    """Rows of the batch whose propagated gradient (dZ of the last wide layer, GPU debug read vs the oracle's) differs by more than 5 % of
+    """Rows of the batch whose propagated gradient (dZ of the last wide layer, GPU debug read vs the oracle's) differs by more than 2 % of
     max(its own norm, the median row norm): the criterion of tools/row_gradient_check.py. In the pose-refinement configurations ONE such
     row turns up every dozen steps -- a patch whose loss gradient moves by several percent with the last bits of its refined pose and
     carries up to a fifth of the whole gradient's norm; every other row agrees to bf16 rounding."""
     dzg = torch.from_numpy(tr.debug_read("dZ", tr.L - 1, n).astype(np.int32) << 16).view(torch.float32).numpy()
     diff = np.linalg.norm(dzg - orc_dz, axis=1)
     ref = np.linalg.norm(orc_dz, axis=1)
-    return np.where(diff > 0.05 * np.maximum(ref, np.median(ref) + 1e-30))[0]
+    off = np.where(diff > 0.02 * np.maximum(ref, np.median(ref) + 1e-30))[0]   # (bf16 rounding alone moves a 512-entry row by ~0.3 % of its norm)
+    # ... of which only the HEAVY ones matter for the step's gradient: rows that carry more than 1 % of the propagated gradient's norm (a
+    # light row that is off by 5 % moves the whole by < 5e-4; measured on head_tanh_posemlp: rows 410 / 124 with 0.3 % / 0.2 % of the norm in
+    # steps 0 / 2, row 491 with 22 % in step 4)
+    share = ref[off] / (np.linalg.norm(orc_dz) + 1e-30)
+    assert float(np.sqrt((share[share <= 0.01] ** 2).sum())) < 0.01
+    return off[share > 0.01]
 
 
 def _oracle_step_capturing_dz(orc, feats, batch):
@@ -86,7 +92,7 @@ def test_training_steps_match_oracle_and_golden(name):
     """Every step compared in isolation (the oracle's weights / optimiser state are re-synchronised with the GPU's before each), all golden
     configurations + the step ace_zero.py runs in its non-seed rounds at BASELINE's batch (pose MLP + focal refinement, 200 images, 5120 rows).
     Per-row criterion (replacing a blanket 2e-2 bound on every step of the pose configurations): rows whose
-    propagated gradient is ill-conditioned (_ill_conditioned_rows; at most 2 per 512) are taken OUT of the step's batch on both sides and
+    propagated gradient is ill-conditioned AND heavy (_ill_conditioned_rows; at most 1 per 512) are taken OUT of the step's batch on both sides and
     the step is compared on the remaining rows at the bounds every other configuration meets: 8e-3 head gradient, 5e-3 pose gradient,
     5e-2 pose update."""
     import copy
@@ -122,7 +128,7 @@ def test_training_steps_match_oracle_and_golden(name):
             break
         if mlp:
             bad = _ill_conditioned_rows(tr, dz, len(idx))
-            assert len(bad) <= 2 * ((len(idx) + 511) // 512), (it, bad)
+            assert len(bad) <= (len(idx) + 511) // 512, (it, bad)       # at most one heavy ill-conditioned row per 512
             if len(bad):
                 # the step on the batch WITHOUT those rows, on both sides (the loss stays normalised by the global batch)
                 removed_total += len(bad)
@@ -176,7 +182,7 @@ def test_training_steps_match_oracle_and_golden(name):
                 # vs the reference PoseRefiner: identical until the first pose update; afterwards each AdamW step moves every
                 # weight by ~lr with the sign of a bf16-vs-fp32 gradient, so only the scale of the drift is bounded
                 np.testing.assert_allclose(tr.current_poses(), g["poses"][it], atol=1e-5 if it <= cfg["pose_refinement_wait"] else 5e-2)
-    assert removed_total <= max(2, len(batches) // 3), removed_total      # (a rare event: one row per dozen steps on the golden problems)
+    assert removed_total <= max(1, len(batches) // 5), removed_total      # (a rare event: one row per dozen steps on the golden problems)
     loss, _ = tr.log(0, min(5, int(g["steps_run"])))
     # vs the reference's own fp32 run: bf16-level agreement. 3 % in the untrained regime; in the trained regime the loss is made of
     # few-pixel reprojection errors and the 8-bit mantissa of the bf16 weights / activations moves it by up to 9 % (the bf16-mode
