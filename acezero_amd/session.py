@@ -169,6 +169,9 @@ class ReconstructionSession:
         self.ppx, self.ppy = W / 2.0, H / 2.0                                            # dataset.py:411-412
         self.history = []
         self._views_sampled = 0
+        # where a reconstruction's wall-clock goes (reconstruct() returns it): encoding the frames once, buffer creation / training loop of
+        # the mapping rounds, registration passes
+        self.timings = {"encode_s": time.time() - t0, "buffer_s": 0.0, "loop_s": 0.0, "register_s": 0.0}
         _logger.info(f"Encoded {len(self.owned)} of {self.n} frames in {time.time() - t0:.2f}s (rank {self.rank} of {self.world}); "
                      f"features resident: {self.features.numel() * 2 / 2 ** 30:.2f} GiB")
 
@@ -436,6 +439,8 @@ class ReconstructionSession:
             dpt.gather_masters()                                         # the fp32 masters of the other ranks' layers, for the checkpoint
         dt = time.time() - t0
         t_loop = time.time() - t_loop0
+        self.timings["buffer_s"] += t_fill
+        self.timings["loop_s"] += t_loop
         out = {"head": {k: v.detach().cpu().half() for k, v in tr.state_dict().items()},      # save_model (ace_trainer.py:681-694)
                "poses_w2c": tr.current_poses(), "focal": float(st["focal_scale"] * focal) if refine_calibration else float(focal),
                "iterations": int(st["iteration"]), "seconds": dt, "fill_seconds": t_fill, "loop_seconds": t_loop,
@@ -503,6 +508,7 @@ class ReconstructionSession:
             poses, inl = full_p[ids], full_i[ids]
         poses, inl = poses.numpy(), inl.numpy()
         rate = float((inl > o.registration_confidence).mean())
+        self.timings["register_s"] += time.time() - t0
         _logger.info(f"[{tag}] {len(ids)} frames in {time.time() - t0:.2f}s, {rate * 100:.1f}% above confidence {o.registration_confidence}")
         return poses, inl
 
@@ -588,7 +594,7 @@ class ReconstructionSession:
                 scheduled_to_stop_early = True
             max_rate = max(rate, max_rate)
         out = {"poses": poses, "confidence": conf, "focal": focal, "head": current["head"], "history": self.history,
-               "iterations": iteration, "seconds": time.time() - t_start}
+               "iterations": iteration, "seconds": time.time() - t_start, "timings": dict(self.timings)}
         if o.export_point_cloud:                                         # ace_zero.py:379-400
             out["point_cloud"] = self.point_cloud(current["head"], poses, conf, focal, dense=o.dense_point_cloud)
         return out

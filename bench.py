@@ -54,7 +54,7 @@ def src_digest(files):
     return h.hexdigest()
 
 
-PROFILE_TAG = "r05"              # profiles/<tag>_* written by tools/prof_r05.sh: the stored counter / trace pass bench.py may quote
+PROFILE_TAG = "r06"              # profiles/<tag>_* written by tools/prof_r06.sh: the stored counter / trace pass bench.py may quote
 # algorithmic HBM bytes of one 5120-patch step = what must move at least once. Batch rows in (features bf16 1024 B +
 # target 8 B + view index 4 B = 1036 B per patch in this layout; the reference's per-patch replicated layout is 1230 B) + the optimiser's
 # state traffic: fp32 masters, m, v read and written (24 B / parameter), + two 16-bit compute copies of the wide layers written (4 B).

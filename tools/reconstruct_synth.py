@@ -51,6 +51,6 @@ for h in res["history"]:
               f"alignment scale {a['scale']:.3f}, centre error {a['centre_rel_median'] * 100:.2f}% of the extent (p90 {a['centre_rel_p90'] * 100:.2f}%), "
               f"rotation {a['rot_abs_deg_median']:.2f} deg (rotation-only alignment), consecutive frames {a['rot_rel_deg_median']:.3f} deg")
 out = {"frames": n, "arc_deg": arc, "render_s": t_render, "reconstruction_s": dt, "registered": float(ok.mean()), "focal": res["focal"],
-       "refine_calibration": not fixed, "rounds": rounds,
+       "refine_calibration": not fixed, "rounds": rounds, "timings": res.get("timings"), "compute_dtype": ses.dtype,
        "gpu_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}
 print(json.dumps(out))
