@@ -61,7 +61,8 @@ class TrainBuffer(C.Structure):
 
 class TrainState(C.Structure):
     _fields_ = [("iteration", C.c_int32), ("max_iterations", C.c_int32), ("in_cooldown", C.c_int32), ("nan_flag", C.c_int32),
-                ("lr", C.c_double), ("last_loss", C.c_float), ("last_batch_inliers", C.c_float), ("focal_scale", C.c_double)]
+                ("lr", C.c_double), ("last_loss", C.c_float), ("last_batch_inliers", C.c_float), ("focal_scale", C.c_double),
+                ("grad_scale", C.c_float), ("opt_steps", C.c_int32)]
 
 
 # every symbol include/acez.h declares: name -> (restype, argtypes)

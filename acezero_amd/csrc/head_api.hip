@@ -1126,6 +1126,7 @@ extern "C" int acez_trainer_get_state(acez_trainer* tr, acez_train_state* h_out,
   h_out->iteration = hs.iteration; h_out->max_iterations = hs.max_iterations; h_out->in_cooldown = hs.in_cooldown;
   h_out->nan_flag = hs.nan_flag; h_out->lr = hs.lr; h_out->last_loss = hs.last_loss;
   h_out->last_batch_inliers = hs.last_inliers; h_out->focal_scale = 1.0 + hs.calib_g;
+  h_out->grad_scale = hs.grad_scale; h_out->opt_steps = hs.opt_steps;
   return hs.nan_flag ? ACEZ_ERR_NAN : ACEZ_OK;
 }
 

@@ -96,8 +96,12 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint16_t* __restrict_
 
 // fp16 gradient-scale control: every kernel that stores propagated gradients folds the largest magnitude it produced (before the
 // conversion, in scaled units) into the trainer's 64 striped words (TrainState::dz_absmax_slots) -- a wavefront maximum, then an atomic
-// max on the bit pattern (non-negative floats order like unsigned integers; +inf = 0x7f800000 is the overflow signal) of the word of
+// max on the bit pattern (non-negative floats order like unsigned integers; anything above 65504.f is the overflow signal, f16_overflow) of the word of
 // this workgroup's stripe. Read (absmax_all) and reset by sched_post_wave.
+// The magnitudes are taken BEFORE the conversion, so the overflow test is "larger than fp16's largest finite value", not "is inf": a
+// propagated value of 7e4 is a finite float that the conversion stores as inf (round 6: a 25 000-iteration fp16 refit went through
+// exactly that window once the scale had climbed to 2^16 -- the update was not skipped and NaN reached the fp32 masters).
+__device__ __forceinline__ bool f16_overflow(uint32_t amax_bits) { return amax_bits > 0x477fe000u; }   // 65504.f; inf and NaN patterns are above it
 __device__ __forceinline__ void absmax_publish(uint32_t* slots, float amax) {
   amax = wave_max63_nonneg(amax);   // (DPP: no LDS round trips; the maximum is in lane 63)
   if ((threadIdx.x & 63) == 63 && amax > 0.f) atomicMax(slots + (blockIdx.x & 63) * 32, __float_as_uint(amax));
@@ -1362,7 +1366,7 @@ __device__ __forceinline__ float tail_output(const GradReduceArgs& a, int64_t k,
     // the optimiser step (adamw_kernel) and the replicas stay identical
     else if (a.fault) {
       const uint32_t amax_bits = absmax_all(a.st, lane);
-      if (lane == 0) acc = (*a.fault ? 1.f : 0.f) + (amax_bits >= 0x7f800000u ? 1024.f : 0.f);   // (+ fp16 overflow)
+      if (lane == 0) acc = (*a.fault ? 1.f : 0.f) + (f16_overflow(amax_bits) ? 1024.f : 0.f);   // (+ fp16 overflow)
     }
     dst = a.n_params + kk;
   }
@@ -1512,7 +1516,7 @@ struct SmallCols {
     g = ACEZ_DPP_ADD(g, 0xB1, 0xF);           // quad_perm [1,0,3,2]: butterfly level 1
     if (b == (int)((n_out - 1) / PER_BLOCK) && r.fault) {   // statistics slot 3: the fault word + the fp16 overflow flag (see tail_output)
       const uint32_t amax_bits = absmax_all(r.st, lane);
-      if (c.k == n_out - 1) g = (*r.fault ? 1.f : 0.f) + (amax_bits >= 0x7f800000u ? 1024.f : 0.f);
+      if (c.k == n_out - 1) g = (*r.fault ? 1.f : 0.f) + (f16_overflow(amax_bits) ? 1024.f : 0.f);
     }
     if (c.k < n_bias + n_fc3) g *= r.st->inv_grad_scale;   // (fp16: gradients arrive scaled; 1 for bf16, an exact product)
     if (q != 0 || c.dst < 0 || skip) return;
@@ -1624,7 +1628,7 @@ __device__ __forceinline__ void adamw_body(const AdamArgs& a, const int b, uint1
   if (lossv != lossv) return;  // NaN loss: the reference aborts before the optimiser step (ace_trainer.py:615-617)
   // fp16: an infinity was stored somewhere in the gradient chain of this step -> no update (GradScaler.step, ace_schedule.py:112); the
   // schedule wave lowers the scale. In the split flow the flag arrives all-reduced in statistics slot 3 (+1024 per overflowing rank).
-  if (a.f16 && (a.slabs ? absmax_all(st, threadIdx.x & 63) >= 0x7f800000u : a.grad[a.n_params + 3] >= 1024.f)) return;
+  if (a.f16 && (a.slabs ? f16_overflow(absmax_all(st, threadIdx.x & 63)) : a.grad[a.n_params + 3] >= 1024.f)) return;
   if (tile) {
     if (a.slabs) {   // same additions, in the same order, as grad_reduce_kernel's wide part
       for (int sl = 1; sl < a.nslabs; ++sl) {
@@ -2001,9 +2005,15 @@ __device__ void sched_post_wave(const TrainState* src, TrainState* st, const Sch
   if (loss != loss) h.nan_flag = 1;   // ace_trainer.py:615-617
   const int it = h.iteration;
   if (it < log_cap) { log_loss[it] = loss; log_inl[it] = inl; }
-  h.opt_steps += 1;
-  h.beta1_pow *= c.beta1;
-  h.beta2_pow *= c.beta2;
+  // fp16: an overflowing step's head update was skipped by adamw_body / wgrad_opt_kernel (the same test on the same words; split flow: the
+  // all-reduced flag in statistics slot 3), as GradScaler.step skips optimizer.step(): AdamW's step count does not advance either
+  // (ace_schedule.py:112-113). The pose / calibration optimisers are stepped outside the scaler (ace_trainer.py:634-640): they advance.
+  const bool head_skipped = c.f16 && (f16_overflow(amax_bits) || (!tail && grad_stats[3] >= 1024.f));
+  if (!head_skipped) {
+    h.opt_steps += 1;
+    h.beta1_pow *= c.beta1;
+    h.beta2_pow *= c.beta2;
+  }
   if (c.pose_refinement && h.pose_enable) {
     h.pose_opt_steps += 1;
     h.pose_b1pow *= c.beta1;
@@ -2055,7 +2065,7 @@ __device__ void sched_post_wave(const TrainState* src, TrainState* st, const Sch
     // one step to the next. After an overflow (an inf was stored: this step's update was skipped by adamw_body, as GradScaler.step
     // skips it) the scale drops by 2^8. Powers of two only: scaling then commutes with fp16 rounding for every value in range.
     int e = ilogbf(h.grad_scale);
-    if (amax_bits >= 0x7f800000u) e -= 8;
+    if (f16_overflow(amax_bits)) e -= 8;
     else if (amax_bits != 0u) e = ilogbf(4096.f / (__uint_as_float(amax_bits) * h.inv_grad_scale));
     e = min(16, max(-8, e));
     h.grad_scale = ldexpf(1.f, e);
@@ -2289,7 +2299,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
       sm.finish(ad.tail, small_opt(ad), b, sc, [&] {
         const float lossv = loss_sum(lpm);
         bool skip = !active || fault_now || lossv != lossv;
-        if (E::is_f16) skip = skip || absmax_reduce(amxm) >= 0x7f800000u;
+        if (E::is_f16) skip = skip || f16_overflow(absmax_reduce(amxm));
         return skip;
       });
     }
@@ -2307,7 +2317,7 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
   const int fault_now = *ad.fault;
   const float lossv = loss_sum(lp);
   bool skip = !active || fault_now || lossv != lossv || (ACEZ_DBG(a.dbg) & 8);   // adamw_body's guards
-  if (E::is_f16) skip = skip || absmax_reduce(amx) >= 0x7f800000u;
+  if (E::is_f16) skip = skip || f16_overflow(absmax_reduce(amx));
   const bool skip_by_guard = skip;   // (uniform over the launch: every wave evaluates the same words)
   if (!(ACEZ_DBG(a.dbg) & 48)) {   // (ablation bits of the diagnostics build, timing only: 8 = no final stores, 16 = no poll, 32 = no send, 64 = no small parameters, 128 = no schedule wave)
     uint32_t vseen, sseen, spins, timed;

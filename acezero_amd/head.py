@@ -313,7 +313,7 @@ class HeadTrainer:
             N.check(rc)
         return {"iteration": st.iteration, "max_iterations": st.max_iterations, "in_cooldown": bool(st.in_cooldown),
                 "nan": bool(st.nan_flag), "lr": st.lr, "loss": st.last_loss, "batch_inliers": st.last_batch_inliers,
-                "focal_scale": st.focal_scale}
+                "focal_scale": st.focal_scale, "grad_scale": st.grad_scale, "opt_steps": st.opt_steps}
 
     def seq_status(self):
         """One-launch GEMM chains (rowseq_kernel): {'enabled', 'probe' (placement probe at creation: 1 passed, 0 failed, -1 not run),

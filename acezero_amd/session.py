@@ -594,7 +594,7 @@ class ReconstructionSession:
                 scheduled_to_stop_early = True
             max_rate = max(rate, max_rate)
         out = {"poses": poses, "confidence": conf, "focal": focal, "head": current["head"], "history": self.history,
-               "iterations": iteration, "seconds": time.time() - t_start, "timings": dict(self.timings)}
+               "iterations": iteration, "seconds": time.time() - t_start, "timings": dict(getattr(self, "timings", {}))}
         if o.export_point_cloud:                                         # ace_zero.py:379-400
             out["point_cloud"] = self.point_cloud(current["head"], poses, conf, focal, dense=o.dense_point_cloud)
         return out

@@ -229,6 +229,8 @@ typedef struct acez_train_state {
   float last_loss;          /* loss of the last completed step (already / global_batch)                */
   float last_batch_inliers; /* fraction, ace_trainer.py:586                                            */
   double focal_scale;       /* 1 + global_f (refine_calibration.py:28-32)                              */
+  float grad_scale;         /* fp16: the power of two on the propagated gradients of the NEXT step (GradScaler's scale); bf16: 1 */
+  int32_t opt_steps;        /* AdamW steps applied so far (< iteration when fp16 overflows skipped updates, as GradScaler.step does) */
 } acez_train_state;
 
 typedef struct acez_trainer acez_trainer;

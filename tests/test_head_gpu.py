@@ -442,3 +442,47 @@ def test_baseline_batch_against_the_reference_golden(name, dtype):
         dpose = np.abs(tr2.current_poses() - g["poses"][-1])
         assert dpose.max() < 6e-2 and np.median(dpose) < 8e-3, (dpose.max(), np.median(dpose))
         assert abs(tr2.state()["focal_scale"] - float(g["focal_scale"][-1])) < 2e-3
+
+
+@pytest.mark.parametrize("flow", ["fused", "split", "announced"])
+def test_fp16_overflowing_step_is_skipped_and_lowers_the_scale(flow):
+    """GradScaler.step (ace_schedule.py:112-113): a step whose propagated gradients left fp16's range applies no head update, does not
+    advance AdamW's step count, and the scale drops. The magnitudes are measured before the conversion, so the test drives a FINITE fp32
+    value past 65504 (global_batch 1 multiplies every gradient by the batch size; fc3's weights are scaled up until the stored gradient
+    of the last wide layer holds an inf): the conversion stores inf while the measured maximum is an ordinary float.
+    Round 6 found this window open -- only a literal inf counted as overflow, a 25 000-iteration fp16 refit stepped through it and put
+    NaN into the fp32 masters."""
+    prob, flat0 = helpers.golden_problem()
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
+    L = 3 + 3 * cfg.get("num_head_blocks", 1) + 2
+    o3 = L * (262144 + 512)
+    idx = [torch.from_numpy(np.asarray(b, np.int64)).cuda() for b in helpers.golden_batches(prob, 2)]
+    for factor in (1.0, 30.0, 1000.0, 30000.0):
+        flat = flat0.clone()
+        flat[o3:o3 + 4 * 512] *= factor
+        tr = _trainer(prob, flat, cfg, global_batch=1, dtype="fp16")
+        s0 = tr.state()
+        assert s0["grad_scale"] == 64.0 and s0["opt_steps"] == 0
+        before = tr.params.clone()
+        if flow == "fused":
+            tr.step(idx[0])
+        elif flow == "announced":
+            tr.step(idx[0], idx[1])
+        else:
+            tr.backward(idx[0]); tr.update()
+        s1 = tr.state()
+        dz = tr.debug_read("dZ", L - 1, len(idx[0])).view(np.float16)
+        if np.isinf(dz).any():
+            break
+        assert s1["opt_steps"] == 1 and not torch.equal(tr.params, before)     # in range: an ordinary step
+        tr.close()
+    else:
+        raise AssertionError("no factor drove the gradient out of fp16's range")
+    assert not s1["nan"] and s1["iteration"] == 1 and s1["opt_steps"] == 0 and s1["grad_scale"] == 0.25, s1
+    assert torch.equal(tr.params, before) and not tr.adam_m.any() and not tr.adam_v.any()
+    # the lowered scale brings the same batch back into range (more than one drop when the overflow is by more than 2^8)
+    for _ in range(4):
+        tr.step(idx[0])
+    s2 = tr.state()
+    assert s2["iteration"] == 5 and 1 <= s2["opt_steps"] <= 4 and s2["grad_scale"] < 64.0, s2
+    assert torch.isfinite(tr.params).all() and torch.isfinite(tr.adam_v).all() and not torch.equal(tr.params, before)
