@@ -14,6 +14,13 @@ struct ConvGemmArgs {
   uint16_t* out;          // [M][Co]
   const uint16_t* zeros;  // >= 128 bytes of zeros: DMA source of every padded chunk
   int Hi, Wi, Ci, ci_shift, Ho, Wo, Co, ksize, stride, pad, K, Kp, M;
+  // fused pointwise skip (conv3x3r_kernel only; null = none): out = act(conv3x3(In) + bias) + (In2 . W2 + bias2), the second product as
+  // extra K stages on the SAME accumulators after the activation was applied to them in registers (ace_network.py:57-58: res2_skip)
+  const uint16_t* In2;    // [M][Ci2] (the skip layer's input at the output's own pixels)
+  const uint16_t* W2;     // 16-bit [Co][Kp2]
+  const float* bias2;     // [Co]
+  int Ci2, Kp2;
+  uint16_t* skip_scratch; // [M][Co]: where the launcher puts the skip product when the layer does not run on conv3x3r (small inputs: two launches)
   int f16;                // 16-bit operand format of In / W / add / out: 0 = bf16, 1 = fp16 (fp32 accumulation in both)
   int round_before_add;   // 1: the activation is rounded to 16 bits BEFORE the residual is added (the head stores it: ace_network.py:126,133)
   unsigned long long* trace;   // diagnostics build (tools/conv_trace.py): [tiles][8] s_memtime stamps of convgemm512's waves 0 and 8; else null

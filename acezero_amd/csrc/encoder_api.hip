@@ -854,8 +854,16 @@ constexpr int P3_ROWS = 448;
 // zero); the epilogue tile reuses all 128 KiB.
 // ---------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
-template <class E, bool RELU, bool HAS_ADD>
+// SKIP (res2_conv3 + res2_skip, ace_network.py:57-58: x = res2_skip(res) + relu(res2_conv3(x))): after the last 3 x 3 stage the bias and
+// the ReLU are applied to the accumulators IN REGISTERS, then Ci2 / 32 more stages multiply the skip layer's weights with its input at
+// the tile's own 256 pixels onto the same accumulators -- the separate pointwise launch (159 us per 64 frames at 0.20 of the MFMA peak),
+// its 16-bit output map and the epilogue's read of it (315 MB each way) are gone for +5.5 % of K. Skip stages live in a ring of four
+// 32 KiB slots (16 KiB weights + 16 KiB input rows, the layouts of a weight slot / of patch rows): the patch slot the last chunk does
+// not use takes stage 0 while the last chunk still multiplies; stages 1-3 go out behind the K loop's last barrier, under the
+// bias / ReLU pass and stage 0's products. The skip product is not rounded on its own (the reference's half tensor is; one rounding less).
+template <class E, bool RELU, bool HAS_ADD, bool SKIP = false>
 __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
+  static_assert(!(SKIP && HAS_ADD), "the fused skip replaces the residual add");
   typedef typename E::frag frag;
   typedef __attribute__((address_space(3))) const frag lds_frag;
   constexpr unsigned WSLOT = 16384, PATCH0 = 65536, PSLOT = 32768, ZROW = 511 * 64;
@@ -913,6 +921,28 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
     }
     pdst ^= PSLOT;
   };
+
+  // fused skip: ring of four 32 KiB slots {free patch slot, 0, 32 K, other patch slot}; stage s -> ring[s & 3]
+  const unsigned sk_free = PATCH0 + (NC & 1) * PSLOT;   // the patch slot chunk NC - 1 does NOT use
+  auto skip_base = [&](int s2) -> unsigned {
+    const int k = s2 & 3;
+    return k == 0 ? sk_free : (k == 1 ? 0u : (k == 2 ? 32768u : (sk_free ^ PSLOT)));
+  };
+  auto issue_skip = [&](int s2) {                       // 2 weight + 2 input DMA instructions per wave
+    const unsigned base = skip_base(s2);
+    // an opaque zero in every address: the compiler cannot hoist this lane arithmetic in front of the K loop (where it was spilled)
+    int opq;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (w * 2 + j) * 16 + lrow + opq;
+      const int sw8 = (lch ^ ((row >> 2) & 3)) * 8 + s2 * 32;
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(a.W2 + (size_t)(n0 + row) * a.Kp2 + sw8), (lvoid_t*)(lds + base + (w * 2 + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(a.In2 + (size_t)min(m0 + row, M - 1) * a.Ci2 + sw8), (lvoid_t*)(lds + base + 16384 + (w * 2 + j) * 1024),
+                                       16, 0, 0);
+    }
+  };
+  bool skip0_now = false;                     // set for chunk NC - 2: skip stage 0 goes out where a next patch would
 
   // ---- per-lane constants of the multiplier side
   const int wm = w >> 2, wn = w & 3;
@@ -974,7 +1004,8 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
     // W(t+1), W(t+2) (2 instructions each; fewer at the end of the last chunk) and, during the first three stages of a chunk that
     // is not the last one, the patch of the next chunk (4), issued right behind W(t+2) at the chunk's start.
     if (LAST) {
-      if (TAP <= 5) ACEZ_VMCNT(4);
+      if (SKIP && TAP <= 2) ACEZ_VMCNT(8);      // (+ skip stage 0, issued where a next patch would have been)
+      else if (TAP <= 5) ACEZ_VMCNT(4);
       else if (TAP == 6) ACEZ_VMCNT(2);
       else ACEZ_VMCNT(0);
     } else {
@@ -987,6 +1018,7 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
     wsrc = (wsrc + WSLOT) & (4 * WSLOT - 1);
     if (TAP == 8) {                           // t is the first stage of the next chunk: the patch slot of this chunk is free
       if (pdst_pending) issue_patch();
+      else if (SKIP && skip0_now) issue_skip(0);
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
@@ -1017,6 +1049,7 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
   using std::integral_constant;
   for (int cc = 0; cc + 1 < NC; ++cc) {
     pdst_pending = cc + 2 < NC;               // at the boundary to chunk cc + 1: patch cc + 2 goes into this chunk's slot
+    skip0_now = cc + 2 == NC;
     stage(integral_constant<int, 0>{}, integral_constant<bool, false>{});
     stage(integral_constant<int, 1>{}, integral_constant<bool, false>{});
     stage(integral_constant<int, 2>{}, integral_constant<bool, false>{});
@@ -1039,6 +1072,96 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
 
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();               // everybody has left the K loop: all of LDS is free
+  if (SKIP) {
+    const int NS = a.Ci2 >> 5;                // skip stages (>= 4: launcher)
+    // Everything this section needs per lane is computed HERE: an opaque zero (the compiler cannot see its value) rides in every address,
+    // or the lane constants below are hoisted in front of the K loop and spilled (55 dwords of scratch in the first build).
+    int opq;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
+    issue_skip(1); issue_skip(2); issue_skip(3);
+    const int fro = fr + opq;
+    unsigned inaddr[4];                       // B fragments of the skip input, K step 0, relative to a slot's input half
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned r = wm * 128 + j * 32 + fro;
+      inaddr[j] = 16384u + r * 64 + ((unsigned)(fh ^ ((r >> 2) & 3)) << 4);
+    }
+    // stage 0 landed long ago (it is older than the K loop's last weight stages): its first fragments are requested before the bias pass
+    frag fa0[2], fb0[4], fa1[2], fb1[4];
+    {
+      const unsigned base = skip_base(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa0[i] = *(lds_frag*)(lds + base + wfrag[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb0[j] = *(lds_frag*)(lds + base + inaddr[j]);
+    }
+    {   // bias + activation of the 3 x 3 layer on the accumulators (what the epilogue does for the unfused layer)
+      const float* bp = a.bias + n0 + wn * 64 + 4 * fh + opq;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b = *reinterpret_cast<const float4*>(bp + i * 32 + 8 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v[4] = {acc[i][j][4 * q + 0] + b.x, acc[i][j][4 * q + 1] + b.y, acc[i][j][4 * q + 2] + b.z, acc[i][j][4 * q + 3] + b.w};
+            if (RELU) {
+              v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            }
+            if (a.round_before_add) E::un4(E::pk4(v[0], v[1], v[2], v[3]), v);   // fp16: relu(conv) is a half tensor before the add
+            acc[i][j][4 * q + 0] = v[0]; acc[i][j][4 * q + 1] = v[1]; acc[i][j][4 * q + 2] = v[2]; acc[i][j][4 * q + 3] = v[3];
+          }
+        }
+    }
+    // stages in groups of four (NS % 4 == 0: launcher): ring position, wait count and "is there a stage to issue" are compile-time
+    // constants of a stage body, and no body has a second exit (early returns inside the loop made the compiler keep copies of the
+    // accumulators per exit: 500 dwords of spills)
+    auto skip_stage = [&](auto kc, auto vmc, auto morec, int c) {
+      constexpr int KR = decltype(kc)::value;   // c & 3
+      constexpr int VM = decltype(vmc)::value;  // DMA instructions younger than stage c + 1
+      const unsigned base = KR == 0 ? sk_free : (KR == 1 ? 0u : (KR == 2 ? 32768u : (sk_free ^ PSLOT)));
+      const unsigned nb = KR == 3 ? sk_free : (KR == 0 ? 0u : (KR == 1 ? 32768u : (sk_free ^ PSLOT)));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa1[i] = *(lds_frag*)(lds + base + (wfrag[i] ^ 32u));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb1[j] = *(lds_frag*)(lds + base + (inaddr[j] ^ 32u));
+      multiply(fa0, fb0);
+      ACEZ_VMCNT_C(VM);
+      __builtin_amdgcn_s_waitcnt(0xC07F);     // this wave's reads of stage c are complete
+      __builtin_amdgcn_s_barrier();           // stage c + 1 landed everywhere; nobody reads stage c any more
+      if (decltype(morec)::value) issue_skip(c + 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa0[i] = *(lds_frag*)(lds + nb + wfrag[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb0[j] = *(lds_frag*)(lds + nb + inaddr[j]);
+      multiply(fa1, fb1);
+    };
+    using IC0 = integral_constant<int, 0>; using IC1 = integral_constant<int, 1>; using IC2 = integral_constant<int, 2>;
+    using IC3 = integral_constant<int, 3>; using IC4 = integral_constant<int, 4>; using IC8 = integral_constant<int, 8>;
+    using T = integral_constant<bool, true>; using Fl = integral_constant<bool, false>;
+    int c = 0;
+#pragma clang loop unroll(disable)
+    for (; c + 4 < NS; c += 4) {
+      skip_stage(IC0{}, IC8{}, T{}, c);
+      skip_stage(IC1{}, IC8{}, T{}, c + 1);
+      skip_stage(IC2{}, IC8{}, T{}, c + 2);
+      skip_stage(IC3{}, IC8{}, T{}, c + 3);
+    }
+    skip_stage(IC0{}, IC8{}, Fl{}, c);        // the last four stages: nothing left to issue, the waits count down
+    skip_stage(IC1{}, IC4{}, Fl{}, c + 1);
+    skip_stage(IC2{}, IC0{}, Fl{}, c + 2);
+    {                                         // stage NS - 1: ring position 3
+      const unsigned base = sk_free ^ PSLOT;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa1[i] = *(lds_frag*)(lds + base + (wfrag[i] ^ 32u));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb1[j] = *(lds_frag*)(lds + base + (inaddr[j] ^ 32u));
+      multiply(fa0, fb0);
+      multiply(fa1, fb1);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();             // the skip stages are done: all of LDS is free
+  }
   if (HAS_ADD) {
     // residual tile [256][256] -> LDS, 128 DMA instructions of 2 rows x 512 bytes (16 per wave)
     for (int j = 0; j < 16; ++j) {
@@ -1055,7 +1178,7 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * fh);
+    for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const float4*>((SKIP ? a.bias2 : a.bias) + n0 + wn * 64 + i * 32 + 8 * q + 4 * fh);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int ml = wm * 128 + j * 32 + fr;
@@ -1066,7 +1189,7 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
         const int nl = wn * 64 + i * 32 + 8 * q + 4 * fh;
         const float4 b = bv[i][q];
         float v[4] = {acc[i][j][4 * q + 0] + b.x, acc[i][j][4 * q + 1] + b.y, acc[i][j][4 * q + 2] + b.z, acc[i][j][4 * q + 3] + b.w};
-        if (RELU) {
+        if (RELU && !SKIP) {                    // (SKIP: the activation went onto the accumulators before the skip stages)
           v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
         }
         uint16_t* po = &smem[st_off256(ml, nl)];
@@ -1109,12 +1232,23 @@ void launch_convgemm(const ConvGemmArgs& g_in, bool relu, hipStream_t s, int til
   // the patch kernel pays from one tile per CU on (16 frames of 480x640 at Co = 256: 0.0925 -> 0.0775 ms per frame against the
   // 80-row / 256 x 128 kernels; 32 frames: 0.0715 -> 0.067); round 1's conv3x3p needed four waves of tiles to win
   static const int patch_min_tiles = [] { const char* e = ACEZ_DIAG_ENV("ACEZ_PATCH_MIN_TILES"); return e ? atoi(e) : 256; }();
-  if (patch_ok && (tile_mode == 3 || (tile_mode == 0 && (int64_t)((g.M + 255) / 256) * (g.Co / 256) >= patch_min_tiles))) {
+  const bool use_patch = patch_ok && (tile_mode == 3 || (tile_mode == 0 && (int64_t)((g.M + 255) / 256) * (g.Co / 256) >= patch_min_tiles));
+  if (g.In2 && !(use_patch && g.Ci >= 64 && g.Ci2 % 128 == 0 && g.Kp2 >= g.Ci2 && relu)) {
+    // the unfused form: the pointwise skip as its own launch into the scratch map, added by the main layer's epilogue
+    if (!g.skip_scratch || g.add) abort();
+    ConvGemmArgs k = g;
+    k.In = g.In2; k.W = g.W2; k.bias = g.bias2; k.add = nullptr; k.out = g.skip_scratch; k.In2 = nullptr;
+    k.Hi = g.Ho; k.Wi = g.Wo; k.Ci = g.Ci2; k.ci_shift = __builtin_ctz(g.Ci2); k.ksize = 1; k.stride = 1; k.pad = 0; k.K = g.Ci2; k.Kp = g.Kp2;
+    launch_convgemm(k, false, s, tile_mode);
+    g.add = g.skip_scratch; g.In2 = nullptr;
+  }
+  if (use_patch) {
     const int ntiles = g.Co / 256, mtiles = (g.M + 255) / 256;
     const dim3 grid(8 * ntiles * ((mtiles + 7) / 8));
     if (!relu) abort();
     const dim3 blkq(512);
-    if (g.add) ACEZ_CONV_LAUNCH(conv3x3r_kernel, grid, blkq, true, true);
+    if (g.In2) ACEZ_CONV_LAUNCH(conv3x3r_kernel, grid, blkq, true, false, true);
+    else if (g.add) ACEZ_CONV_LAUNCH(conv3x3r_kernel, grid, blkq, true, true);
     else ACEZ_CONV_LAUNCH(conv3x3r_kernel, grid, blkq, true, false);
     return;
   }
@@ -1408,9 +1542,13 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
       if (e->f16) hipLaunchKernelGGL((conv12p_kernel<EltF16, 4>), dim3(nt4 < 256 ? nt4 : 256), dim3(512), 0, s, c);
       else hipLaunchKernelGGL((conv12p_kernel<EltBf16, 4>), dim3(nt4 < 256 ? nt4 : 256), dim3(512), 0, s, c);
     }
-    auto conv = [&](int li, const uint16_t* in, int hi, int wi, uint16_t* outp, int ho, int wo, const uint16_t* add, bool relu) {
+    auto conv = [&](int li, const uint16_t* in, int hi, int wi, uint16_t* outp, int ho, int wo, const uint16_t* add, bool relu, int skip_li = -1,
+                    const uint16_t* skip_in = nullptr) {
       const LayerDesc& L = kLayers[li];
       ConvGemmArgs g{};
+      if (skip_li >= 0) {
+        g.In2 = skip_in; g.W2 = e->W[skip_li]; g.bias2 = e->bias[skip_li]; g.Ci2 = kLayers[skip_li].ci; g.Kp2 = e->Kp[skip_li]; g.skip_scratch = e->sk;
+      }
       g.In = in; g.W = e->W[li]; g.bias = e->bias[li]; g.add = add; g.out = outp; g.zeros = e->zeros;
       g.Hi = hi; g.Wi = wi; g.Ci = L.ci; g.ci_shift = __builtin_ctz(L.ci); g.Ho = ho; g.Wo = wo; g.Co = e->co[li];
       g.ksize = L.k; g.stride = L.stride; g.pad = L.k / 2; g.K = e->K[li]; g.Kp = e->Kp[li]; g.M = F * ho * wo; g.f16 = e->f16 ? 1 : 0;
@@ -1427,8 +1565,9 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
     conv(6, e->x6, h8, w8, e->r7, h8, w8, e->r4, true);     // res = res + relu(res1_conv3(x))      ace_network.py:50-52
     conv(7, e->r7, h8, w8, e->x8, h8, w8, nullptr, true);
     conv(8, e->x8, h8, w8, e->x9, h8, w8, nullptr, true);
-    conv(10, e->r7, h8, w8, e->sk, h8, w8, nullptr, false); // res2_skip(res)                       ace_network.py:58
-    conv(9, e->x9, h8, w8, feat, h8, w8, e->sk, true);      // skip + relu(res2_conv3(x))
+    // res2_skip(res) + relu(res2_conv3(x))  (ace_network.py:57-58): the skip rides as extra K stages of res2_conv3 where that layer runs on
+    // conv3x3r (launch_convgemm falls back to two launches through e->sk on small inputs)
+    conv(9, e->x9, h8, w8, feat, h8, w8, nullptr, true, 10, e->r7);
   }
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
