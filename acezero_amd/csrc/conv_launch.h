@@ -16,6 +16,8 @@ struct ConvGemmArgs {
   int Hi, Wi, Ci, ci_shift, Ho, Wo, Co, ksize, stride, pad, K, Kp, M;
   // fused pointwise skip (conv3x3r_kernel only; null = none): out = act(conv3x3(In) + bias) + (In2 . W2 + bias2), the second product as
   // extra K stages on the SAME accumulators after the activation was applied to them in registers (ace_network.py:57-58: res2_skip)
+  // W2 / bias2 / Kp2 WITHOUT In2: a pointwise Co -> Co layer with ReLU that FOLLOWS this one, run back to back on conv3x3r's finished tile
+  // (Co = 256: res1_conv1 + res1_conv2); skip_scratch = the intermediate map of the two-launch fall-back
   const uint16_t* In2;    // [M][Ci2] (the skip layer's input at the output's own pixels)
   const uint16_t* W2;     // 16-bit [Co][Kp2]
   const float* bias2;     // [Co]

@@ -861,9 +861,15 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 // 32 KiB slots (16 KiB weights + 16 KiB input rows, the layouts of a weight slot / of patch rows): the patch slot the last chunk does
 // not use takes stage 0 while the last chunk still multiplies; stages 1-3 go out behind the K loop's last barrier, under the
 // bias / ReLU pass and stage 0's products. The skip product is not rounded on its own (the reference's half tensor is; one rounding less).
-template <class E, bool RELU, bool HAS_ADD, bool SKIP = false>
+// B2B (res1_conv1 + res1_conv2, ace_network.py:48-49): a 256-channel layer's whole output row fits the 256 x 256 tile, so the pointwise
+// layer that follows runs back to back on the finished tile -- out = relu(W2 . relu(conv3x3(In) + bias) + bias2): the 16-bit tile in LDS
+// (rounded exactly as the unfused layer stores it) is the B operand, W2's fragments come straight from L2 in the MFMA operand layout (a lane's
+// eight K elements are 16 contiguous bytes of a weight row; 256 KiB per tile, no ring, no barrier inside the product), the second
+// accumulators replace the first. The 157 MB intermediate map is neither written nor read and the 83 us launch is gone.
+template <class E, bool RELU, bool HAS_ADD, bool SKIP = false, bool B2B = false>
 __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
   static_assert(!(SKIP && HAS_ADD), "the fused skip replaces the residual add");
+  static_assert(!(B2B && (SKIP || HAS_ADD)), "back-to-back pointwise layer: plain 3 x 3 layer in front");
   typedef typename E::frag frag;
   typedef __attribute__((address_space(3))) const frag lds_frag;
   constexpr unsigned WSLOT = 16384, PATCH0 = 65536, PSLOT = 32768, ZROW = 511 * 64;
@@ -1204,6 +1210,72 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (B2B) {
+    // ---- second product: acc[i][j] = W2[wn*64 + i*32 .. +31][:] . tile[wm*128 + j*32 .. +31][:]  (K = 256 = 16 steps of 16)
+    int opq;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opq));   // (keeps this lane arithmetic behind the K loop: see the skip stages)
+    const uint16_t* wp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wp[i] = a.W2 + (size_t)(wn * 64 + i * 32 + fr + opq) * a.Kp2 + 8 * fh;
+    unsigned brow[4], bx[4];                  // B fragment of K step kk: lds + brow[j] + (((2 kk + fh) ^ bx[j]) << 4)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned r = wm * 128 + j * 32 + fr + opq;
+      brow[j] = r * 512;
+      bx[j] = (r & 31) ^ (unsigned)fh;        // (2 kk) ^ fh ^ (r & 31): fh and r & 31 folded
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int PF = 4;                     // weight fragments requested PF steps ahead
+    frag wa[PF][2];
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wa[k][i] = *reinterpret_cast<const frag*>(wp[i] + 16 * k);
+    frag fbx[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fbx[0][j] = *(lds_frag*)(lds + brow[j] + (bx[j] << 4));
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      if (kk + 1 < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fbx[(kk + 1) & 1][j] = *(lds_frag*)(lds + brow[j] + ((((unsigned)(2 * (kk + 1))) ^ bx[j]) << 4));
+      }
+      frag cur[2] = {wa[kk % PF][0], wa[kk % PF][1]};
+      if (kk + PF < 16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wa[kk % PF][i] = *reinterpret_cast<const frag*>(wp[i] + 16 * (kk + PF));
+      }
+      multiply(cur, fbx[kk & 1]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();             // every wave has read what it needs of the first tile
+    float4 b2v[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b2v[i][q] = *reinterpret_cast<const float4*>(a.bias2 + wn * 64 + i * 32 + 8 * q + 4 * fh + opq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ml = wm * 128 + j * 32 + fr;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nl = wn * 64 + i * 32 + 8 * q + 4 * fh;
+          const float4 b = b2v[i][q];
+          *reinterpret_cast<uint2*>(&smem[st_off256(ml, nl)]) =
+              E::pk4(fmaxf(acc[i][j][4 * q + 0] + b.x, 0.f), fmaxf(acc[i][j][4 * q + 1] + b.y, 0.f), fmaxf(acc[i][j][4 * q + 2] + b.z, 0.f),
+                     fmaxf(acc[i][j][4 * q + 3] + b.w, 0.f));
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   for (int q = t; q < 256 * 32; q += 512) {
     const int row = q >> 5, ch = q & 31, m = m0 + row;
     if (m < M)
@@ -1233,14 +1305,31 @@ void launch_convgemm(const ConvGemmArgs& g_in, bool relu, hipStream_t s, int til
   // 80-row / 256 x 128 kernels; 32 frames: 0.0715 -> 0.067); round 1's conv3x3p needed four waves of tiles to win
   static const int patch_min_tiles = [] { const char* e = ACEZ_DIAG_ENV("ACEZ_PATCH_MIN_TILES"); return e ? atoi(e) : 256; }();
   const bool use_patch = patch_ok && (tile_mode == 3 || (tile_mode == 0 && (int64_t)((g.M + 255) / 256) * (g.Co / 256) >= patch_min_tiles));
+  if (g.W2 && !g.In2) {
+    // a pointwise Co -> Co layer behind this one (res1_conv1 + res1_conv2): back to back on conv3x3r's finished tile where the layer runs
+    // there and one tile holds a whole output row; else two launches through the scratch map
+    if (use_patch && g.Co == 256 && g.Kp2 >= 256 && relu && !g.add) {
+      // (launched below with the other conv3x3r forms)
+    } else {
+      if (!g.skip_scratch || g.add) abort();
+      ConvGemmArgs k = g;
+      k.W2 = nullptr; k.bias2 = nullptr; k.out = g.skip_scratch;
+      launch_convgemm(k, relu, s, tile_mode);
+      ConvGemmArgs p = g;
+      p.In = g.skip_scratch; p.W = g.W2; p.bias = g.bias2; p.W2 = nullptr; p.bias2 = nullptr;
+      p.Hi = g.Ho; p.Wi = g.Wo; p.Ci = g.Co; p.ci_shift = __builtin_ctz(g.Co); p.ksize = 1; p.stride = 1; p.pad = 0; p.K = g.Co; p.Kp = g.Kp2;
+      launch_convgemm(p, true, s, tile_mode);
+      return;
+    }
+  }
   if (g.In2 && !(use_patch && g.Ci >= 64 && g.Ci2 % 128 == 0 && g.Kp2 >= g.Ci2 && relu)) {
     // the unfused form: the pointwise skip as its own launch into the scratch map, added by the main layer's epilogue
     if (!g.skip_scratch || g.add) abort();
     ConvGemmArgs k = g;
-    k.In = g.In2; k.W = g.W2; k.bias = g.bias2; k.add = nullptr; k.out = g.skip_scratch; k.In2 = nullptr;
+    k.In = g.In2; k.W = g.W2; k.bias = g.bias2; k.add = nullptr; k.out = g.skip_scratch; k.In2 = nullptr; k.W2 = nullptr; k.bias2 = nullptr;
     k.Hi = g.Ho; k.Wi = g.Wo; k.Ci = g.Ci2; k.ci_shift = __builtin_ctz(g.Ci2); k.ksize = 1; k.stride = 1; k.pad = 0; k.K = g.Ci2; k.Kp = g.Kp2;
     launch_convgemm(k, false, s, tile_mode);
-    g.add = g.skip_scratch; g.In2 = nullptr;
+    g.add = g.skip_scratch; g.In2 = nullptr; g.W2 = nullptr; g.bias2 = nullptr;
   }
   if (use_patch) {
     const int ntiles = g.Co / 256, mtiles = (g.M + 255) / 256;
@@ -1248,6 +1337,7 @@ void launch_convgemm(const ConvGemmArgs& g_in, bool relu, hipStream_t s, int til
     if (!relu) abort();
     const dim3 blkq(512);
     if (g.In2) ACEZ_CONV_LAUNCH(conv3x3r_kernel, grid, blkq, true, false, true);
+    else if (g.W2) ACEZ_CONV_LAUNCH(conv3x3r_kernel, grid, blkq, true, false, false, true);
     else if (g.add) ACEZ_CONV_LAUNCH(conv3x3r_kernel, grid, blkq, true, true);
     else ACEZ_CONV_LAUNCH(conv3x3r_kernel, grid, blkq, true, false);
     return;
@@ -1543,9 +1633,12 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
       else hipLaunchKernelGGL((conv12p_kernel<EltBf16, 4>), dim3(nt4 < 256 ? nt4 : 256), dim3(512), 0, s, c);
     }
     auto conv = [&](int li, const uint16_t* in, int hi, int wi, uint16_t* outp, int ho, int wo, const uint16_t* add, bool relu, int skip_li = -1,
-                    const uint16_t* skip_in = nullptr) {
+                    const uint16_t* skip_in = nullptr, int next_li = -1) {
       const LayerDesc& L = kLayers[li];
       ConvGemmArgs g{};
+      if (next_li >= 0) {
+        g.W2 = e->W[next_li]; g.bias2 = e->bias[next_li]; g.Kp2 = e->Kp[next_li]; g.skip_scratch = e->x5;
+      }
       if (skip_li >= 0) {
         g.In2 = skip_in; g.W2 = e->W[skip_li]; g.bias2 = e->bias[skip_li]; g.Ci2 = kLayers[skip_li].ci; g.Kp2 = e->Kp[skip_li]; g.skip_scratch = e->sk;
       }
@@ -1560,8 +1653,9 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
     };
     conv(2, e->a2, h2, w2, e->a3, h4, w4, nullptr, true);
     conv(3, e->a3, h4, w4, e->r4, h8, w8, nullptr, true);
-    conv(4, e->r4, h8, w8, e->x5, h8, w8, nullptr, true);
-    conv(5, e->x5, h8, w8, e->x6, h8, w8, nullptr, true);
+    // relu(res1_conv2(relu(res1_conv1(res))))  (ace_network.py:48-49): the pointwise layer back to back on res1_conv1's tiles where that
+    // layer runs on conv3x3r (two launches through e->x5 on small inputs)
+    conv(4, e->r4, h8, w8, e->x6, h8, w8, nullptr, true, -1, nullptr, 5);
     conv(6, e->x6, h8, w8, e->r7, h8, w8, e->r4, true);     // res = res + relu(res1_conv3(x))      ace_network.py:50-52
     conv(7, e->r7, h8, w8, e->x8, h8, w8, nullptr, true);
     conv(8, e->x8, h8, w8, e->x9, h8, w8, nullptr, true);
