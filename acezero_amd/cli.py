@@ -315,13 +315,11 @@ def train_with_options(opt):
     epoch, launched, done = 0, 0, False
     orig_poses = np.linalg.inv(buf["image_pose_inv"].astype(np.float64))[:, :3, 3]
     with open(log_path, "w", 1) as log:
-        from .head import epoch_permutations
-        perms = epoch_permutations(n, opt.base_seed + 8191, tr.device)   # ace_trainer.py:79-80,466 (drawn on the device)
+        from .head import epoch_batches
+        pairs = epoch_batches(n, opt.batch_size, opt.base_seed + 8191, tr.device)   # ace_trainer.py:79-80,466 (drawn on the device)
         while not done:
-            perm = next(perms)
-            for b0 in range(0, n - opt.batch_size + 1, opt.batch_size):
-                b1 = b0 + opt.batch_size
-                tr.step(perm[b0:b1], perm[b1:b1 + opt.batch_size] if b1 + opt.batch_size <= n else None)   # next slice: gathered ahead
+            for _ in range(n // opt.batch_size):
+                tr.step(*next(pairs))                                # (rows, next rows): the next batch is gathered ahead
                 launched += 1
                 if launched % opt.iterations_output == 0 or launched % 64 == 0:
                     st = tr.state()                                  # the only host synchronisation of the loop

@@ -1230,7 +1230,10 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    constexpr int PF = 4;                     // weight fragments requested PF steps ahead
+#ifndef ACEZ_B2B_PF
+#define ACEZ_B2B_PF 4
+#endif
+    constexpr int PF = ACEZ_B2B_PF;           // weight fragments requested PF steps ahead
     frag wa[PF][2];
 #pragma unroll
     for (int k = 0; k < PF; ++k)

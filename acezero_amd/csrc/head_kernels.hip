@@ -331,6 +331,9 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
       // for it -- lgkmcnt(0) -- and multiplied, two to three times per stage (60 such read-wait pairs in rowseq_kernel<true>'s K loops
       // against 3 in the forward chain's; ISA scan, round 5: -2.0 ... -2.6 us on the input-gradient chain). Same MFMAs, same order.
       typename E::frag fa[2][2], fb[2][5];
+      // The counted waits below assume ONE ds_read_b128 per fragment (fourteen reads in flight): a fragment is 16 bytes at a 16-byte aligned
+      // LDS address (swz() returns multiples of eight elements). A wider / split fragment would turn the counts into wrong hints.
+      static_assert(sizeof(typename E::frag) == 16 && alignof(typename E::frag) == 16, "one ds_read_b128 per fragment: ACEZ_KSTEP's lgkmcnt ladder");
       // request order = use order: fa[kk][0], fb[kk][0..4], fa[kk][1] for kk = 0, 1 (LDS returns in order)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -2407,7 +2410,10 @@ __global__ __launch_bounds__(WGRAD_THREADS) void wgrad_opt_kernel(WgradArgs a, W
     uint32_t q[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) q[k] = (uint32_t)tileT[cl][part * 16 + 2 * k] | ((uint32_t)tileT[cl][part * 16 + 2 * k + 1] << 16);
-    if (!skip) {
+    // skip_by_guard, not skip: a wave whose own poll timed out still stores its W^T COLUMNS -- they hold the rows of the waves of this
+    // workgroup that did complete (their W / parameter rows were stored above); its own rows of every column are rewritten by
+    // wgo_recover_kernel. (With `skip` here a partial time-out inside one workgroup left W^T old where W was new.)
+    if (!skip_by_guard) {
       uint16_t* dst = ad.WbT + (size_t)layer * 262144 + (size_t)(c0 + cl) * 512 + nrow0 + part * 16;
       *reinterpret_cast<uint4*>(dst) = make_uint4(q[0], q[1], q[2], q[3]);
       *reinterpret_cast<uint4*>(dst + 8) = make_uint4(q[4], q[5], q[6], q[7]);

@@ -76,8 +76,35 @@ def epoch_permutations(n, seed, device):
     same law (a uniform permutation per epoch), different stream."""
     gen = torch.Generator(device=device)
     gen.manual_seed(int(seed))
+    # Small buffers (a seed round of ace_zero.py maps ONE image: 10 240 rows = two steps per epoch): one randperm call per epoch is several
+    # small launches per two training steps, so the permutations of `group` epochs come out of one draw -- the ranks of independent uniform
+    # doubles (53 random bits: no ties to break), row by row. Same law, one batched sort instead of `group` small ones.
+    group = max(1, 262144 // max(n, 1))
     while True:
-        yield torch.randperm(n, generator=gen, device=device)
+        if group == 1:
+            yield torch.randperm(n, generator=gen, device=device)
+        else:
+            block = torch.rand((group, n), generator=gen, device=device, dtype=torch.float64).argsort(dim=1)
+            for k in range(group):
+                yield block[k]
+
+
+def epoch_batches(n, batch, seed, device):
+    """The walk of TrainerACE.run_epoch (ace_trainer.py:454-497) as an endless stream of (rows of this step, rows of the NEXT step): per
+    epoch one permutation of the buffer rows in slices of `batch` (a tail that does not fill a batch is dropped). The announcement crosses
+    the epoch boundary -- the next epoch's permutation is drawn an epoch ahead -- so every step of the loop is an
+    acez_train_step_next whose successor's gather rides in its optimiser launch (a seed round has two steps per epoch: every other step
+    used to be unannounced). The second tensor of a pair has the data pointer of the first tensor of the following pair."""
+    perms = epoch_permutations(n, seed, device)
+    nb = n // batch
+    if nb < 1:
+        raise ValueError(f"training buffer of {n} rows is smaller than one batch ({batch})")
+    cur = next(perms)
+    while True:
+        nxt = next(perms)
+        for b in range(nb):
+            yield cur[b * batch:(b + 1) * batch], (cur[(b + 1) * batch:(b + 2) * batch] if b + 1 < nb else nxt[:batch])
+        cur = nxt
 
 
 class HeadTrainer:

@@ -33,7 +33,7 @@ from . import dsacstar
 from .encoder import Encoder, output_size
 import torch.distributed as dist
 
-from .head import HeadTrainer, _ptr, _stream, epoch_permutations
+from .head import HeadTrainer, _ptr, _stream, epoch_batches, epoch_permutations
 from .parallel import epoch_local_batches, gather_registrations, make_data_parallel, rank_world
 
 _logger = logging.getLogger("acezero_amd.session")
@@ -107,7 +107,11 @@ def warp_views(images_b1hw, scale, angles, jitter=None):
         g = ((g - m) * ct + m).clamp(0, 1)
         src = (g - 0.4) / 0.25
     views = torch.nn.functional.grid_sample(src, grid, mode="bilinear", padding_mode="reflection", align_corners=False)
-    masks = torch.nn.functional.grid_sample(torch.ones_like(images_b1hw), grid, mode="bilinear", padding_mode="zeros", align_corners=False) > 0
+    # mask = "a zero-padded bilinear lookup into an all-ones image is positive": at least one of the four taps lies inside the frame with a
+    # non-zero weight, i.e. the source coordinate is in the open intervals (-1, W) x (-1, H) -- two comparisons on the grid instead of a
+    # second grid_sample over a ones image (same mask, bit for bit, on every view of tests/test_session_cpu.py)
+    ix, iy = ((grid[..., 0] + 1) * W - 1) / 2, ((grid[..., 1] + 1) * H - 1) / 2
+    masks = ((ix > -1) & (ix < W) & (iy > -1) & (iy < H))[:, None]
     return views, masks, grid
 
 
@@ -127,7 +131,7 @@ def view_depth(depth_11hw, grid, oh, ow):
 
 
 class ReconstructionSession:
-    def __init__(self, encoder_state_dict, images, opt=None, depth=None, device=None, chunk=32, group=None):
+    def __init__(self, encoder_state_dict, images, opt=None, depth=None, device=None, chunk=64, group=None):
         """images [n,1,H,W] float32 normalised (dataset.py:150-153), any device; depth [n,H/8,W/8] camera z at the feature-map
         pixel centres (metres, 0 = invalid) or None -- only the seed images' maps are read.
 
@@ -271,9 +275,10 @@ class ReconstructionSession:
         bld = BufferBuilder(self.enc, capacity=total, samples_per_image=o.samples_per_image, seed=o.base_seed + 4095 + 7919 * self.rank + self._views_sampled)
         poses_c2w = torch.as_tensor(poses_c2w, dtype=torch.float64).reshape(m, 4, 4)
         pose_inv = torch.linalg.inv(poses_c2w).to(torch.float32)
-        # views per warp / encoder / sampling batch (<= the encoder's max_frames). 32 instead of 16: the 3x3 patch kernel gets a full
-        # wave of tiles per layer (1000-frame session: 8 M rows in 0.95 s instead of 1.10 s)
-        chunk = int(os.environ.get("ACEZ_AUG_CHUNK", "32"))
+        # views per warp / encoder / sampling batch (<= the encoder's max_frames). 64 (round 6; 32 before, 16 in round 3): the 3 x 3 patch
+        # kernel gets two to five waves of tiles per layer instead of one or two (1000-frame session, 16 scale levels: buffer creation
+        # 6.71 -> 5.26 s of 26.6 s; 128 views per batch or 8 scale levels add nothing: profiles/r06_session_chunk_sweep.log)
+        chunk = int(os.environ.get("ACEZ_AUG_CHUNK", "64"))
         chunk = max(1, min(chunk, self.enc.max_frames))
         crds = []
         while not bld.full:
@@ -414,18 +419,18 @@ class ReconstructionSession:
         torch.cuda.synchronize(self.dev)
         t_loop0 = time.time()
         launched, done = 0, False
-        perms = epoch_permutations(n, o.base_seed + 8191, self.dev)       # ace_trainer.py:79-80 seed of the training generator
+        perms = epoch_permutations(n, o.base_seed + 8191, self.dev) if dp else None       # ace_trainer.py:79-80 seed of the training generator
+        pairs = None if dp else epoch_batches(n, o.batch_size, o.base_seed + 8191, self.dev)  # (rows, next rows): the next batch is gathered ahead
         dpt = make_data_parallel(tr, self.group) if dp else None          # reduce-scatter / sharded AdamW / all-gather (parallel.py)
         while not done:                                                  # TrainerACE.train / run_epoch (ace_trainer.py:454-497)
-            perm = next(perms)
             if dp:
+                perm = next(perms)
                 local, offs = epoch_local_batches(perm, o.batch_size, shard_lo, shard_lo + n_local)
             for b in range(n // o.batch_size):
                 if dp:
                     dpt.step(local[offs[b]:offs[b + 1]])   # RCCL: head + pose gradients, loss / inlier / focal statistics
                 else:
-                    nxt = perm[(b + 1) * o.batch_size:(b + 2) * o.batch_size] if b + 1 < n // o.batch_size else None
-                    tr.step(perm[b * o.batch_size:(b + 1) * o.batch_size], nxt)   # (the next slice of the permutation is gathered ahead)
+                    tr.step(*next(pairs))
                 launched += 1
                 if launched % 64 == 0:                                   # the only host synchronisation of the loop
                     st = tr.state()

@@ -54,6 +54,33 @@ def src_digest(files):
     return h.hexdigest()
 
 
+def product_digest():
+    """sha256 over every product source (acezero_amd/csrc/* and acezero_amd/*.py): the gate of stored WHOLE-PIPELINE figures (the 1000-frame
+    session), which depend on all of it."""
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.dirname(CSRC)
+    for d in (CSRC, pkg):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".h", ".py")):
+                with open(os.path.join(d, name), "rb") as f:
+                    h.update(name.encode())
+                    h.update(f.read())
+    return h.hexdigest()
+
+
+def stored_session():
+    """profiles/<tag>_session_1000_frames.json (tools/reconstruct_synth.py 1000 144 --store: BASELINE configs[1] as a reconstruction -- 1000
+    frames, 8 M-row buffer, the reference's iteration caps) if it was measured on the running product sources, else (None, reason)."""
+    tf = os.path.join(ROOT, "profiles", PROFILE_TAG + "_session_1000_frames.json")
+    if not os.path.exists(tf):
+        return None, f"profiles/{PROFILE_TAG}_session_1000_frames.json not found"
+    tj = json.load(open(tf))
+    if tj.get("source_digest") != product_digest():
+        return None, f"profiles/{PROFILE_TAG}_session_1000_frames.json was measured on different product sources than this build: not quoted"
+    return tj, None
+
+
 PROFILE_TAG = "r06"              # profiles/<tag>_* written by tools/prof_r06.sh: the stored counter / trace pass bench.py may quote
 # SURVEY.md section 8(d): algorithmic HBM bytes of one 5120-patch step = what must move at least once. Batch rows in (features bf16 1024 B +
 # target 8 B + view index 4 B = 1036 B per patch in this layout; the reference's per-patch replicated layout is 1230 B) + the optimiser's
@@ -93,7 +120,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--buffer-patches", type=int, default=8_000_000)   # train_ace.py:122
     ap.add_argument("--reg-frames", type=int, default=2048)
-    ap.add_argument("--e2e-frames", type=int, default=1024)
+    ap.add_argument("--e2e-frames", type=int, default=1088)   # 8 passes of 136 frames
     ap.add_argument("--pose-refinement", default="none", choices=["none", "mlp"])   # ace_zero.py:86 maps every non-seed iteration with mlp
     ap.add_argument("--session-frames", type=int, default=120, help="frames of the in-process ACE0 reconstruction leg (N = 1 only; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -323,7 +350,10 @@ def bench_pipeline(args, rank, world, device, dtype="bf16", legs="all"):
     # frames per encoder pass: 128 (round 5; 64 before: a 3x3 layer of 64 frames is 2400 tiles of 118 us = 9.4 waves over 256 CUs, and the
     # last, 37 % full wave costs a whole tile time -- 6.5 % of the launch; at 128 frames it is 1.3 %. tools/e2e_chunk_sweep.py: 64 / 128 /
     # 256 frames -> 0.0646 / 0.0621 / 0.0618 ms per frame; ACEZ_E2E_CHUNK for the comparison)
-    chunk, total = int(os.environ.get("ACEZ_E2E_CHUNK", "128")), args.e2e_frames // world
+    # Round 6: 136. A 480 x 640 frame is 18.75 tiles of 256 feature-map pixels, so 136 frames are 2550 tiles = 9.96 waves over 256 CUs for the
+    # 256-channel layers (128 frames: 2400 = 9.375 -> ten waves, the last 37 % full) and 19.92 for the 512-channel ones; 137 would be 10.03.
+    # tools/bench_encoder.py 128 / 136 on one box: 1091 / 1110 TFLOP/s.
+    chunk, total = int(os.environ.get("ACEZ_E2E_CHUNK", "136")), args.e2e_frames // world
     esd = {k: torch.from_numpy(v) for k, v in synth.init_encoder_weights(seed=4099).items()}
     hsd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(synth.init_head_params(3)).items()}
     net = Regressor.create_from_split_state_dict(esd, hsd, max_frames=chunk, max_h=480, max_w=640, dtype=dtype)
@@ -686,6 +716,15 @@ def main():
                    "encoder_frac_of_mfma_peak": enc_frac, "encoder_ms_per_frame": pipe["encoder_ms"] / pipe["frames"],
                    "buffer_rows_per_s": pipe["buffer_rows"] * world / pipe["buffer_s"],
                    "ransac_algorithmic_frac": rr["algorithmic_frac"], "ransac_issue_occupancy": rr["frac"]}
+        # BASELINE configs[1] as a RECONSTRUCTION (1000 frames, 8 M-row buffer, the reference's iteration caps): a stored figure (its run is
+        # 25-30 s of GPU on top of a 20 s render), quoted only while the product sources are the ones it was measured on
+        ss, ss_why = stored_session()
+        tm = (ss or {}).get("timings") or {}
+        tot = (ss or {}).get("reconstruction_s")
+        summary.update({"session_1000_s": tot, "session_loop_frac": (tm.get("loop_s") / tot) if tot and tm else None,
+                        "session_buffer_frac": (tm.get("buffer_s") / tot) if tot and tm else None,
+                        "session_register_frac": (tm.get("register_s") / tot) if tot and tm else None,
+                        "session_1000_registered": (ss or {}).get("registered"), "session_1000_source": ss_why or "profiles/%s_session_1000_frames.json" % PROFILE_TAG})
         out = {
             "metric": "ACE patches/sec", "value": patches_per_s, "unit": "patches/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": float(np.median(st["window_ms_per_step"])), "ms_per_step_mean": dt / args.steps * 1e3,

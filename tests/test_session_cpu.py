@@ -188,3 +188,18 @@ def test_reconstruction_loop_makes_the_reference_decisions(golden_dir, name):
     first = 0 if name == "seed_network" else 2          # rates consumed before the first mapping round: none / the two seed checks
     assert [c["images"] for c in trains] == [round(r * 200) for r in g["rates"][first:first + len(trains)]]
     assert res["iterations"] == len(trains)
+
+
+def test_view_mask_equals_the_zero_padded_lookup_into_a_ones_image():
+    """warp_views takes the validity mask from the sampling grid (source coordinate inside (-1, W) x (-1, H)); the definition is
+    dataset.py:327-328's: the mask image goes through the same warp with zero padding."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(3)
+    img = torch.from_numpy(rng.standard_normal((3, 1, 96, 128)).astype(np.float32))
+    for scale in (0.9, 1.0, 1.1):
+        ang = np.radians(rng.uniform(-15, 15, size=3))
+        _, mask, grid = session.warp_views(img, scale, ang)
+        ref = torch.nn.functional.grid_sample(torch.ones_like(img), grid, mode="bilinear", padding_mode="zeros", align_corners=False) > 0
+        assert mask.shape == ref.shape and torch.equal(mask, ref)
+        assert 0.5 < float(mask.float().mean()) < 1.0

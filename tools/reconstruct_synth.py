@@ -23,8 +23,9 @@ logging.basicConfig(level=logging.INFO)
 from tools.pose_geometry import geometry
 
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-arc = float(sys.argv[2]) if len(sys.argv) > 2 else 0.36 * n
+pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(pos[0]) if len(pos) > 0 else 1000
+arc = float(pos[1]) if len(pos) > 1 else 0.36 * n
 t0 = time.time()
 seq = synth.render_room_sequence(seed=2089, n_frames=n, arc_deg=arc, device="cuda")
 torch.cuda.synchronize()
@@ -34,7 +35,9 @@ import os
 fixed = os.environ.get("ACEZ_STUDY_FIXED_FOCAL", "0") == "1"
 opt = default_options(use_external_focal_length=seq["focal"], aug_rotation=2, aug_scale=1.06, aug_black_white=0.02, refine_calibration=not fixed)
 t0 = time.time()
-ses = ReconstructionSession(esd, seq["images"], opt=opt, depth=seq["depth"])
+if os.environ.get("ACEZ_STUDY_LEVELS"):      # (study knobs: frames per encoder pass, augmentation scale levels)
+    ReconstructionSession.AUG_SCALE_LEVELS = int(os.environ["ACEZ_STUDY_LEVELS"])
+ses = ReconstructionSession(esd, seq["images"], opt=opt, depth=seq["depth"], chunk=int(os.environ.get("ACEZ_STUDY_CHUNK", "32")))
 res = ses.reconstruct()
 torch.cuda.synchronize()
 dt = time.time() - t0
@@ -54,3 +57,11 @@ out = {"frames": n, "arc_deg": arc, "render_s": t_render, "reconstruction_s": dt
        "refine_calibration": not fixed, "rounds": rounds, "timings": res.get("timings"), "compute_dtype": ses.dtype,
        "gpu_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}
 print(json.dumps(out))
+if "--store" in sys.argv:   # the stored figure bench.py quotes while the product sources are unchanged (bench.stored_session)
+    import bench
+    out["source_digest"] = bench.product_digest()
+    out["command"] = "python tools/reconstruct_synth.py %d %g --store" % (n, arc)
+    keep = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "prof_keep")
+    os.makedirs(keep, exist_ok=True)
+    tag = bench.PROFILE_TAG + "_session_1000_frames" + ("_" + ses.dtype if ses.dtype != "bf16" else "")
+    json.dump(out, open(os.path.join(keep, tag + ".json"), "w"), indent=1)
