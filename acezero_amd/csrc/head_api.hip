@@ -2,6 +2,7 @@
 // Host-side orchestration only: every entry point enqueues kernels of head_kernels.hip on the caller's stream.
 #include "head_kernels.hip"
 #include "pose_fused.hip"
+#include "head_maps.hip"
 #include "acez_common.h"
 #include "conv_launch.h"
 #include <stdlib.h>
@@ -29,6 +30,7 @@ struct acez_trainer {
   int last_n = 0;
   // device allocations
   uint16_t *Wb = nullptr, *WbT = nullptr, *W3b = nullptr;
+  uint16_t* Wf = nullptr;       // fragment-ordered copy of Wb for head_maps_kernel (allocated at the first whole-frame pass)
   std::vector<uint16_t*> out;   // post-relu output of each wide layer
   std::vector<uint16_t*> R;     // residual stream, R[0] = gathered features
   std::vector<uint16_t*> dZ;    // gradient wrt each wide layer's pre-activation
@@ -1178,6 +1180,28 @@ static uint16_t* launch_forward_conv(acez_trainer* tr, const uint16_t* in0, int 
   return tr->out[f2];
 }
 
+// Whole-frame passes since round 6: the wide layers as ONE launch on LDS-resident 128-row tiles (head_maps.hip). The fragment-ordered weight
+// copy is rebuilt from Wb at the start of every pass (4 MiB: whoever changed the weights since -- an optimiser step, a checkpoint load, an
+// imported all-gather -- is covered without a dirty flag). Returns null when the context cannot run it (allocation failure, more residual
+// blocks than the argument block holds): the caller falls back to the per-layer launches.
+static uint16_t* launch_forward_maps(acez_trainer* tr, const uint16_t* in0, int n, hipStream_t s) {
+  static const bool off = ACEZ_DIAG_ENV("ACEZ_HEAD_CHAIN") && atoi(ACEZ_DIAG_ENV("ACEZ_HEAD_CHAIN")) == 0;   // (diagnostics build: the eight launches)
+  if (off || tr->nb + 1 > 7) return nullptr;
+  if (!tr->Wf && dmalloc(tr, (void**)&tr->Wf, (size_t)tr->L * 262144 * sizeof(uint16_t)) != ACEZ_OK) { tr->Wf = nullptr; return nullptr; }
+  const int n_frags = tr->L * 16 * 32;
+  hipLaunchKernelGGL(wfrag_pack_kernel, dim3((n_frags + 3) / 4), dim3(256), 0, s, tr->Wb, tr->Wf, n_frags);
+  HeadMapsArgs a{};
+  a.In = in0; a.Wf = tr->Wf; a.params = tr->pb.d_params; a.n = n; a.nb = tr->nb;
+  for (int b = 1; b <= tr->nb; ++b) a.R[b] = tr->R[b];
+  const int f2 = 3 * (tr->nb + 1) + 1;
+  a.Out = tr->out[f2];
+  const int ntiles = (n + 127) / 128, cus = tr->n_cus > 0 ? tr->n_cus : 256;
+  const dim3 grid(ntiles < cus ? ntiles : cus), blk(512);
+  if (tr->f16) hipLaunchKernelGGL((head_maps_kernel<EltF16>), grid, blk, 0, s, a);
+  else hipLaunchKernelGGL((head_maps_kernel<EltBf16>), grid, blk, 0, s, a);
+  return tr->out[f2];
+}
+
 static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, float* d_out, int planar_hw, void* stream) {
   ACEZ_HIP_CHECK(hipSetDevice(tr->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1189,7 +1213,8 @@ static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, fl
       const bool seqp = seq_usable(tr, cnt);
       const bool conv = cnt >= 256 * 128;   // large passes: the encoder's large-tile kernels (both operand formats)
       used_seq = used_seq || (seqp && !conv);
-      uint16_t* act = conv ? launch_forward_conv(tr, f + (size_t)done * 512, cnt, s) : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
+      uint16_t* act = conv ? launch_forward_maps(tr, f + (size_t)done * 512, cnt, s) : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
+      if (conv && !act) act = launch_forward_conv(tr, f + (size_t)done * 512, cnt, s);
       LossArgs a{};
       fill_loss_head(tr, a);
       a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr;
