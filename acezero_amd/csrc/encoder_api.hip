@@ -886,6 +886,9 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(ConvGemmArgs a) {
   if (mt >= mtiles) return;
   const int n0 = (jx % ntiles) << 8, m0 = mt << 8;
   const int NC = a.Ci >> 5;                   // 32-channel chunks; stage s = 9 * chunk + tap
+  // (Round 6: walking the chunks from a workgroup-dependent start -- the rotation that takes the head's whole-frame kernel off its L2-channel
+  // queue, head_maps.hip -- was measured here and is 5-6 % SLOWER: 350 -> 370 us (res1_conv1), 1168 -> 1243 us (res2_conv3). These weight
+  // panels are 1.2-4.7 MB; in lockstep every workgroup asks for the same lines at the same time and one fill serves all of them.)
   if (t < 32) {                               // the zero rows of both patch slots (visible after the first barrier)
     *(__attribute__((address_space(3))) unsigned*)(lds + PATCH0 + (t >> 4) * PSLOT + ZROW + (t & 15) * 4) = 0u;
     __builtin_amdgcn_s_waitcnt(0xC07F);

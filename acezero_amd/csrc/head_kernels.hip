@@ -173,6 +173,9 @@ __device__ __forceinline__ void rowgemm80_body(const RowGemmArgs& a, uint16_t* s
         const int row = (lw * 3 + j) * 8 + (l >> 3);
         gI[j] = a.In + (size_t)min(m0 + row, M - 1) * K + ((l & 7) ^ ((row >> 1) & 7)) * 8;
       }
+      // (Round 6: K stages started at stage (row tile & 7), so that the eight row tiles an XCD holds of one column tile pull eight different
+      // weight stages at any moment -- the rotation head_maps.hip gains 15 % from -- measured +3.5 us on the forward chain and +1.5 us on the
+      // input-gradient chain (profiles/r06_krot_experiments.log): in lockstep one L2 fill serves every workgroup that shares the stage.)
       auto issueW = [&](int kt) {
         uint16_t* slot = smem + (kt & 3) * STAGE;
 #pragma unroll
