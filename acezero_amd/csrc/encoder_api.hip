@@ -300,6 +300,87 @@ __global__ __launch_bounds__(512) void conv12p_kernel(Conv12Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Augmented views (acez_buffer_warp_views, include/acez.h): the batched affine warp in front of the encoder when the buffer is filled with
+// augmentation (dataset.py:283-343). HBM-bound by construction: 4 B read (gathered, cache-friendly: a rotation of a few degrees) + 4 B
+// written per output pixel; the framework version moved an 8 B sampling-grid entry three times per pixel on top.
+// Arithmetic follows ATen's grid sampler (GridSampler.h): unnormalise ((g + 1) * size - 1) / 2, reflect about -0.5 / size - 0.5, clip,
+// four taps with bounds checks; the mask is "the zero-padded lookup into an all-ones image is positive" = source coordinate in (-1, size).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float warp_reflect(float x, int size) {   // reflect_coordinates(x, -1, 2 size - 1) then clip_coordinates
+  const float mn = -0.5f, span = (float)size;
+  x = fabsf(x - mn);
+  const float extra = fmodf(x, span);
+  const int flips = (int)floorf(x / span);
+  x = (flips & 1) ? span - extra + mn : extra + mn;
+  return fminf((float)(size - 1), fmaxf(x, 0.f));
+}
+__device__ __forceinline__ float warp_jitter(float v, float br, float ct, float m) {   // ColorJitter on the de-normalised grey value
+  float g = fminf(fmaxf((v * 0.25f + 0.4f) * br, 0.f), 1.f);
+  g = fminf(fmaxf((g - m) * ct + m, 0.f), 1.f);
+  return (g - 0.4f) / 0.25f;
+}
+// mean over the frame of clamp((v * 0.25 + 0.4) * brightness, 0, 1): torchvision's adjust_contrast blends with the mean of the image it is
+// given (the brightness-adjusted one). One workgroup per view, fixed summation order.
+__global__ __launch_bounds__(1024) void warp_mean_kernel(const float* __restrict__ images, const int32_t* __restrict__ index, const float* __restrict__ jitter,
+                                                         int hw, float* __restrict__ out_mean) {
+  __shared__ float part[16];
+  const int v = blockIdx.x, t = threadIdx.x;
+  const float* img = images + (size_t)index[v] * hw;
+  const float br = jitter[2 * v];
+  float acc = 0.f;
+  for (int i = t; i < hw; i += 1024) acc += fminf(fmaxf((img[i] * 0.25f + 0.4f) * br, 0.f), 1.f);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((t & 63) == 0) part[t >> 6] = acc;
+  __syncthreads();
+  if (t == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += part[i];
+    out_mean[v] = s / (float)hw;
+  }
+}
+__global__ __launch_bounds__(256) void warp_views_kernel(const float* __restrict__ images, const int32_t* __restrict__ index, const float* __restrict__ theta,
+                                                         const float* __restrict__ jitter, const float* __restrict__ mean, int H, int W, int hs, int ws,
+                                                         float* __restrict__ out) {
+  const int v = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hs * ws) return;
+  const int y = p / ws, x = p - y * ws;
+  const float* th = theta + 6 * v;
+  const float xn = (2.f * x + 1.f) / ws - 1.f, yn = (2.f * y + 1.f) / hs - 1.f;     // affine_grid's base grid, align_corners = False
+  const float gx = xn * th[0] + yn * th[1] + th[2], gy = xn * th[3] + yn * th[4] + th[5];
+  const float ix = warp_reflect(((gx + 1.f) * W - 1.f) * 0.5f, W), iy = warp_reflect(((gy + 1.f) * H - 1.f) * 0.5f, H);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - fx, wy1 = iy - fy, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy;
+  const float* img = images + (size_t)index[v] * H * W;
+  float br = 1.f, ct = 1.f, m = 0.f;
+  const bool jit = jitter != nullptr;
+  if (jit) { br = jitter[2 * v]; ct = jitter[2 * v + 1]; m = mean[v]; }
+  auto tap = [&](int yy, int xx) -> float {
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) return 0.f;
+    const float val = img[(size_t)yy * W + xx];
+    return jit ? warp_jitter(val, br, ct, m) : val;
+  };
+  out[((size_t)v * hs + y) * ws + x] = tap(y0, x0) * (wx0 * wy0) + tap(y0, x1) * (wx1 * wy0) + tap(y1, x0) * (wx0 * wy1) + tap(y1, x1) * (wx1 * wy1);
+}
+// the validity mask at feature resolution: cell (my, mx) reads view pixel (floor(my * hs / map_h), floor(mx * ws / map_w)) (the nearest-
+// neighbour resize, ace_trainer.py:373-374), whose source coordinate must lie inside (-1, W) x (-1, H)
+__global__ __launch_bounds__(256) void warp_mask_kernel(const float* __restrict__ theta, int H, int W, int hs, int ws, int mh, int mw, uint8_t* __restrict__ mask) {
+  const int v = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= mh * mw) return;
+  const int my = c / mw, mx = c - my * mw;
+  const float sy = (float)hs / (float)mh, sx = (float)ws / (float)mw;
+  const int y = min((int)floorf(my * sy), hs - 1), x = min((int)floorf(mx * sx), ws - 1);
+  const float* th = theta + 6 * v;
+  const float xn = (2.f * x + 1.f) / ws - 1.f, yn = (2.f * y + 1.f) / hs - 1.f;
+  const float gx = xn * th[0] + yn * th[1] + th[2], gy = xn * th[3] + yn * th[4] + th[5];
+  const float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f;
+  mask[(size_t)v * mh * mw + c] = (ix > -1.f && ix < (float)W && iy > -1.f && iy < (float)H) ? 1 : 0;
+}
+
 // [80][64] staging tile of the 64-column variant: chunk index XOR row & 7
 __device__ __forceinline__ int st_off64(int row, int col) { return row * 64 + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7)); }
 
@@ -1669,6 +1750,31 @@ extern "C" int acez_encoder_forward(acez_encoder* e, const float* d_images, int 
     // conv3x3r (launch_convgemm falls back to two launches through e->sk on small inputs)
     conv(9, e->x9, h8, w8, feat, h8, w8, nullptr, true, 10, e->r7);
   }
+  ACEZ_HIP_CHECK(hipGetLastError());
+  return ACEZ_OK;
+}
+
+extern "C" int acez_buffer_warp_views(const float* d_images, int n_images, int H, int W, const int32_t* d_image_index, const float* d_theta,
+                                      const float* d_jitter, int n_views, int hs, int ws, float* d_out_views, uint8_t* d_out_mask, int map_h,
+                                      int map_w, float* d_scratch, void* stream) {
+  ACEZ_REQUIRE(d_images && d_image_index && d_theta && d_out_views, "null pointer");
+  ACEZ_REQUIRE(n_images > 0 && H > 0 && W > 0 && n_views > 0 && hs > 0 && ws > 0, "bad shape");
+  ACEZ_REQUIRE(!d_jitter || d_scratch, "jitter needs the per-view scratch");
+  ACEZ_REQUIRE(!d_out_mask || (map_h > 0 && map_w > 0), "bad mask shape");
+  {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+      (void)hipGetLastError();
+      acez::set_error("no HIP device visible: the view warp runs on a gfx950 GPU (there is no CPU fallback)");
+      return ACEZ_ERR_NODEVICE;
+    }
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (d_jitter) hipLaunchKernelGGL(warp_mean_kernel, dim3(n_views), dim3(1024), 0, s, d_images, d_image_index, d_jitter, H * W, d_scratch);
+  hipLaunchKernelGGL(warp_views_kernel, dim3((hs * ws + 255) / 256, n_views), dim3(256), 0, s, d_images, d_image_index, d_theta, d_jitter, d_scratch, H, W,
+                     hs, ws, d_out_views);
+  if (d_out_mask)
+    hipLaunchKernelGGL(warp_mask_kernel, dim3((map_h * map_w + 255) / 256, n_views), dim3(256), 0, s, d_theta, H, W, hs, ws, map_h, map_w, d_out_mask);
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
 }

@@ -10,10 +10,12 @@
 //     loads 1 KiB contiguous; wfrag_pack_kernel, re-run at the start of every pass: 4 MiB, a few microseconds);
 //   * wave w owns output columns 64 w .. 64 w + 63 of all 128 rows (2 x 4 accumulator blocks of 32 x 32), reads its A fragments (weights)
 //     from L2 four K steps ahead and its B fragments (activations) from the tile, 16-byte chunk index XOR row & 31: conflict free;
-//   * the K steps of a layer start at a WORKGROUP-DEPENDENT step (rot = (blockIdx >> 3) & 31: the 32 workgroups of an XCD read 32 different
-//     weight lines at any moment instead of queueing on one L2 channel: prototype 1765 -> 1506 us for eight layers; with the same
-//     weights for every layer, i.e. all CUs on the same 512 KiB, it was 2182). fp32 accumulation order therefore depends on the tile's
-//     workgroup: deterministic for a given launch, equal to the per-layer kernels up to accumulation order (same rounding points);
+//   * every row's dot products run over K in the same order whatever tile, wave or pass the row falls into: a frame's scene coordinates do
+//     not depend on what else is in the batch (tests/test_session_gpu.py registers the same frames in two folder compositions and compares
+//     pose files). The price is 7 %: started at a WORKGROUP-DEPENDENT K step (-DACEZ_HM_ROT=1: rot = (blockIdx >> 3) & 31), the 32
+//     workgroups of an XCD read 32 different weight lines at any moment instead of queueing on one L2 channel -- 3.35 -> 3.13 ms per 136
+//     frames (prototype, fully unrolled loop: 1765 -> 1506 us; with ONE weight panel for all layers, i.e. all CUs on the same 512 KiB: 2182)
+//     -- but fp32 accumulation order would then depend on the tile's workgroup. Not taken;
 //   * residual adds (ace_network.py:126,133: res = res + relu(conv(x)), the activation a 16-bit tensor before the add) as a second,
 //     coalesced pass over the tile: the block input is re-read from global memory (block 0: the features themselves; later blocks: the
 //     tile is copied out to R[b] when it is produced) -- a residual kept in registers would be 64 VGPRs next to 128 accumulators.
@@ -53,7 +55,10 @@ __global__ __launch_bounds__(512) void head_maps_kernel(HeadMapsArgs a) {
   const int fr = l & 31, fh = l >> 5;
   const int n = a.n, ntiles = (n + 127) >> 7;
   const int L = 3 * (a.nb + 1) + 2;
-  const int rot = (int)((blockIdx.x >> 3) & 31);
+#ifndef ACEZ_HM_ROT
+#define ACEZ_HM_ROT 0   // 1: timing variant (tools/lib_variant.sh), see the header comment
+#endif
+  const int rot = ACEZ_HM_ROT ? (int)((blockIdx.x >> 3) & 31) : 0;
   constexpr int PF = 4;
   unsigned baddr[4], bx[4];
 #pragma unroll

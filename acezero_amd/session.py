@@ -89,14 +89,9 @@ def warp_views(images_b1hw, scale, angles, jitter=None):
     Returns (views [B,1,hs,ws], masks [B,1,hs,ws] bool, grid [B,hs,ws,2] of normalised source coordinates)."""
     B, _, H, W = images_b1hw.shape
     dev = images_b1hw.device
-    hs, ws = int(H * scale), int(W * scale)
-    sx, sy = ws / W, hs / H
-    ang = torch.as_tensor(angles, dtype=torch.float32).reshape(B)
-    c, s_ = torch.cos(ang), torch.sin(ang)
-    z = torch.zeros_like(c)
     # output offset p' (pixels, scaled canvas) -> source offset p = R'^T p' / scale; in normalised coordinates x_n = x / (W/2)
-    theta = torch.stack([torch.stack([c * ((ws / 2) / sx / (W / 2)), -s_ * ((hs / 2) / sx / (W / 2)), z], dim=1),
-                         torch.stack([s_ * ((ws / 2) / sy / (H / 2)), c * ((hs / 2) / sy / (H / 2)), z], dim=1)], dim=1).to(dev)
+    theta, hs, ws = warp_theta(H, W, scale, angles)
+    theta = theta.to(dev)
     grid = torch.nn.functional.affine_grid(theta, (B, 1, hs, ws), align_corners=False)
     src = images_b1hw
     if jitter is not None:
@@ -113,6 +108,45 @@ def warp_views(images_b1hw, scale, angles, jitter=None):
     ix, iy = ((grid[..., 0] + 1) * W - 1) / 2, ((grid[..., 1] + 1) * H - 1) / 2
     masks = ((ix > -1) & (ix < W) & (iy > -1) & (iy < H))[:, None]
     return views, masks, grid
+
+
+def warp_theta(H, W, scale, angles):
+    """The affine maps of warp_views ([B,2,3], normalised output -> normalised source coordinates, align_corners=False) and the canvas size."""
+    hs, ws = int(H * scale), int(W * scale)
+    sx, sy = ws / W, hs / H
+    ang = torch.as_tensor(angles, dtype=torch.float32).reshape(-1)
+    c, s_ = torch.cos(ang), torch.sin(ang)
+    z = torch.zeros_like(c)
+    theta = torch.stack([torch.stack([c * ((ws / 2) / sx / (W / 2)), -s_ * ((hs / 2) / sx / (W / 2)), z], dim=1),
+                         torch.stack([s_ * ((ws / 2) / sy / (H / 2)), c * ((hs / 2) / sy / (H / 2)), z], dim=1)], dim=1)
+    return theta, hs, ws
+
+
+def warp_views_device(images_n1hw, image_index, scale, angles, jitter=None, mask_hw=None):
+    """warp_views on the GPU through acez_buffer_warp_views (one launch per batch; no sampling grid, no gathered copy of the source frames):
+    views of frames `image_index` of the resident table `images_n1hw`. Returns (views [B,1,hs,ws] float32, mask): mask is uint8
+    [B,1,oh,ow] at the feature resolution `mask_hw` = (oh, ow) -- the cells the nearest-neighbour resize of ace_trainer.py:373-374 reads -- or
+    None. Same arithmetic as warp_views (tests/test_buffer_gpu.py: values to 1e-5, masks identical)."""
+    import ctypes as C
+    from . import _native as N
+    assert images_n1hw.is_cuda and images_n1hw.dtype == torch.float32 and images_n1hw.is_contiguous()
+    n, _, H, W = images_n1hw.shape
+    dev = images_n1hw.device
+    theta, hs, ws = warp_theta(H, W, scale, angles)
+    B = theta.shape[0]
+    idx = torch.as_tensor(image_index, dtype=torch.int32).reshape(B).to(dev)
+    th = theta.reshape(B, 6).contiguous().to(dev)
+    jt = None
+    if jitter is not None:
+        jt = torch.stack([torch.as_tensor(jitter[0], dtype=torch.float32).reshape(B), torch.as_tensor(jitter[1], dtype=torch.float32).reshape(B)], dim=1).contiguous().to(dev)
+    views = torch.empty((B, 1, hs, ws), dtype=torch.float32, device=dev)
+    mask = torch.empty((B, 1) + tuple(mask_hw), dtype=torch.uint8, device=dev) if mask_hw is not None else None
+    scratch = torch.empty((B,), dtype=torch.float32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    N.check(N.lib().acez_buffer_warp_views(p(images_n1hw), n, H, W, p(idx), p(th), p(jt), B, hs, ws, p(views), p(mask),
+                                           mask_hw[0] if mask_hw else 0, mask_hw[1] if mask_hw else 0, p(scratch),
+                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return views, mask
 
 
 def warp_view(image_11hw, scale, angle, jitter=None):
@@ -296,13 +330,16 @@ class ReconstructionSession:
                         break
                     js = sel[c0:c0 + chunk]
                     b = len(js)
-                    views, masks, grid = warp_views(self.images[ids[js].to(self.dev)], scale, angles[js], None if jit is None else (jit[0][js], jit[1][js]))
                     rot_inv = self._rot_inv(angles[js])
                     if not with_depth:
-                        # a rotation of at most aug_rotation degrees never empties the mask: no per-batch host synchronisation
-                        bld.add_views(views, masks.float(), rot_inv, pose_inv[js], K.repeat(b, 1, 1), Kinv.repeat(b, 1, 1), [int(j) for j in js],
-                                      check_empty=False)
+                        # one launch: warp + colour jitter + the mask at feature resolution (acez_buffer_warp_views); a rotation of at most
+                        # aug_rotation degrees never empties the mask: no per-batch host synchronisation
+                        views, mask8 = warp_views_device(self.images, ids[js], scale, angles[js], None if jit is None else (jit[0][js], jit[1][js]),
+                                                         mask_hw=output_size(hs, ws))
+                        bld.add_views(views, mask8, rot_inv, pose_inv[js], K.repeat(b, 1, 1), Kinv.repeat(b, 1, 1), [int(j) for j in js],
+                                      check_empty=False, mask_at_feature_resolution=True)
                         continue
+                    views, masks, grid = warp_views(self.images[ids[js].to(self.dev)], scale, angles[js], None if jit is None else (jit[0][js], jit[1][js]))
                     # depth-supervised (seed) views: depth at the feature-map pixel centres through the same warp (dataset.py:331-334, order=0)
                     oh, ow = output_size(hs, ws)
                     for k, j in enumerate(js):

@@ -390,6 +390,25 @@ int acez_buffer_sample_views(const void* d_view_features, const uint8_t* d_masks
                              int32_t view_index_base, void* d_out_features, float* d_out_target_px,
                              int32_t* d_out_view_idx, int32_t* d_out_pixel, void* stream);
 
+/* Augmented training views of resident frames (dataset.py:283-343: resize by a common factor, rotate about the centre, ColorJitter
+ * brightness / contrast on the grey values, a validity mask that goes through the same warp with zero padding), the step in front of the
+ * encoder when ace_trainer.py:293-452 fills the buffer with --use_aug True. One launch per batch of views of one canvas size (+ a
+ * per-view reduction when jitter is on) instead of a dozen framework kernels and a 157 MB sampling grid per 64 views.
+ *   d_images      float32 [n_images][H][W] normalised grey frames, resident on the device
+ *   d_image_index int32 [n_views]: the frame each view is taken from
+ *   d_theta       float32 [n_views][6]: the affine map of torch.nn.functional.affine_grid(align_corners=False) -- normalised output
+ *                 coordinates (x_n, y_n, 1) -> normalised source coordinates -- row-major 2 x 3
+ *   d_jitter      float32 [n_views][2] = (brightness, contrast) factors applied as torchvision's ColorJitter does on (v * 0.25 + 0.4)
+ *                 clamped to [0, 1] (dataset.py:148), or NULL
+ *   d_out_views   float32 [n_views][hs][ws]: bilinear, reflection padding (F.grid_sample(..., padding_mode="reflection", align_corners=False))
+ *   d_out_mask    uint8 [n_views][map_h][map_w] or NULL: the zero-padded bilinear warp of an all-ones image, > 0, taken at the pixels the
+ *                 nearest-neighbour resize to feature resolution reads (ace_trainer.py:373-374): what acez_buffer_sample_views expects
+ *   d_scratch     float32 [n_views] (the per-view mean of the brightness-adjusted frame; used only with d_jitter)
+ * Asynchronous on `stream`. */
+int acez_buffer_warp_views(const float* d_images, int n_images, int H, int W, const int32_t* d_image_index, const float* d_theta,
+                           const float* d_jitter, int n_views, int hs, int ws, float* d_out_views, uint8_t* d_out_mask, int map_h,
+                           int map_w, float* d_scratch, void* stream);
+
 /* =====================================================================================================
  * F. Point-cloud extraction
  * =====================================================================================================
