@@ -75,6 +75,8 @@ __global__ __launch_bounds__(512) void head_maps_kernel(HeadMapsArgs a) {
       if (m < n) *reinterpret_cast<uint4*>(dst + (size_t)m * 512 + ch * 8) = *reinterpret_cast<const uint4*>(&tile[row * 512 + ((ch ^ (row & 31)) << 3)]);
     }
   };
+  // (Starting the workgroups of an XCD one K step apart in TIME -- same arithmetic order everywhere -- does not buy what the rotation buys:
+  // 3.38 against 3.36 ms; the queue on the hot line re-synchronises them.)
   for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
     const int m0 = tl << 7;
     // ---- input rows -> LDS by LDS-DMA: wave w rows 16 w .. 16 w + 15, one row (1 KiB) per instruction, lane = 16-byte chunk (swizzled source)
