@@ -1184,7 +1184,10 @@ static uint16_t* launch_forward_conv(acez_trainer* tr, const uint16_t* in0, int 
 // copy is rebuilt from Wb at the start of every pass (4 MiB: whoever changed the weights since -- an optimiser step, a checkpoint load, an
 // imported all-gather -- is covered without a dirty flag). Returns null when the context cannot run it (allocation failure, more residual
 // blocks than the argument block holds): the caller falls back to the per-layer launches.
-static uint16_t* launch_forward_maps(acez_trainer* tr, const uint16_t* in0, int n, hipStream_t s) {
+// xyz != null: fc3 + de-homogenisation run inside the launch and the scene coordinates go to `xyz` (rows offset by row_offset, planar maps
+// with planar_hw > 0); the returned pointer is then only a success token.
+static uint16_t* launch_forward_maps(acez_trainer* tr, const uint16_t* in0, int n, hipStream_t s, float* xyz = nullptr, int planar_hw = 0,
+                                     int row_offset = 0) {
   static const bool off = ACEZ_DIAG_ENV("ACEZ_HEAD_CHAIN") && atoi(ACEZ_DIAG_ENV("ACEZ_HEAD_CHAIN")) == 0;   // (diagnostics build: the eight launches)
   if (off || tr->nb + 1 > 7) return nullptr;
   if (!tr->Wf && dmalloc(tr, (void**)&tr->Wf, (size_t)tr->L * 262144 * sizeof(uint16_t)) != ACEZ_OK) { tr->Wf = nullptr; return nullptr; }
@@ -1195,6 +1198,14 @@ static uint16_t* launch_forward_maps(acez_trainer* tr, const uint16_t* in0, int 
   for (int b = 1; b <= tr->nb; ++b) a.R[b] = tr->R[b];
   const int f2 = 3 * (tr->nb + 1) + 1;
   a.Out = tr->out[f2];
+  if (xyz) {
+    LossArgs h{};
+    fill_loss_head(tr, h);
+    a.fc3 = 1; a.W3 = h.W3; a.b3 = h.b3; a.no = h.no; a.use_homogeneous = h.use_homogeneous;
+    for (int i = 0; i < 3; ++i) a.mean[i] = h.mean[i];
+    a.max_inv_scale = h.max_inv_scale; a.min_inv_scale = h.min_inv_scale; a.h_beta = h.h_beta;
+    a.out_xyz = xyz; a.planar_hw = planar_hw; a.row_offset = row_offset;
+  }
   const int ntiles = (n + 127) / 128, cus = tr->n_cus > 0 ? tr->n_cus : 256;
   const dim3 grid(ntiles < cus ? ntiles : cus), blk(512);
   if (tr->f16) hipLaunchKernelGGL((head_maps_kernel<EltF16>), grid, blk, 0, s, a);
@@ -1213,8 +1224,9 @@ static int head_forward_impl(acez_trainer* tr, const void* d_features, int n, fl
       const bool seqp = seq_usable(tr, cnt);
       const bool conv = cnt >= 256 * 128;   // large passes: the encoder's large-tile kernels (both operand formats)
       used_seq = used_seq || (seqp && !conv);
-      uint16_t* act = conv ? launch_forward_maps(tr, f + (size_t)done * 512, cnt, s) : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
-      if (conv && !act) act = launch_forward_conv(tr, f + (size_t)done * 512, cnt, s);
+      if (conv && launch_forward_maps(tr, f + (size_t)done * 512, cnt, s, planar_hw > 0 ? d_out : d_out + (size_t)done * 3, planar_hw, planar_hw > 0 ? done : 0))
+        continue;   // wide layers + fc3 + de-homogenisation in one launch
+      uint16_t* act = conv ? launch_forward_conv(tr, f + (size_t)done * 512, cnt, s) : launch_forward(tr, f + (size_t)done * 512, cnt, nullptr, s);
       LossArgs a{};
       fill_loss_head(tr, a);
       a.act = act; a.n = cnt; a.idx = nullptr; a.st = nullptr;

@@ -30,8 +30,18 @@ struct HeadMapsArgs {
   const uint16_t* Wf;       // fragment-ordered weights of the L wide layers
   const float* params;      // the flat fp32 parameter vector (bias of layer l at l * 262656 + 262144)
   uint16_t* R[8];           // R[b], b = 1 .. nb: [n][512] scratch of the residual stream after block b - 1 (unused entries null)
-  uint16_t* Out;            // [n][512]: the output of the last wide layer (fc2), what loss_kernel's fc3 reads
+  uint16_t* Out;            // [n][512]: the output of the last wide layer (fc2), what loss_kernel's fc3 reads -- or null with `fc3` below
   int n, nb;
+  // fc3 + de-homogenisation on the finished tile (ace_network.py:135-149): the arithmetic of loss_body's phases A / B (same per-lane FMA
+  // chains, the same DPP wave sum, the same expressions: the same function of the activations as loss_kernel's); the
+  // [n][512] activation map is then neither written nor read (315 MB each way per 64 frames) and the separate launch (117 us) is gone.
+  int fc3;                  // 1: write scene coordinates to out_xyz instead of activations to Out
+  const uint16_t* W3;       // [no][512] 16-bit
+  const float* b3;          // [no]
+  int no, use_homogeneous;
+  float mean[3], max_inv_scale, min_inv_scale, h_beta;
+  float* out_xyz;           // [n][3], or with planar_hw > 0 [frames][3][planar_hw] (row m = frame * planar_hw + pixel), rows offset by row_offset
+  int planar_hw, row_offset;
 };
 
 // Wf[((l * 16 + cb) * 32 + kk) * 512 + lane * 8 + e] = Wb[l][cb * 32 + (lane & 31)][kk * 16 + (lane >> 5) * 8 + e]
@@ -49,6 +59,7 @@ __global__ __launch_bounds__(512) void head_maps_kernel(HeadMapsArgs a) {
   typedef __attribute__((address_space(3))) const frag lds_frag;
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   __shared__ __attribute__((aligned(16))) uint16_t tile[128 * 512];
+  __shared__ float s_s[128][4];               // fc3 outputs of the tile's rows
   lds_byte* const lds = (lds_byte*)tile;
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -182,7 +193,79 @@ __global__ __launch_bounds__(512) void head_maps_kernel(HeadMapsArgs a) {
         if (blk < a.nb) copy_out(a.R[blk + 1], m0);   // the next block's residual input (each thread re-reads the chunks it wrote: no barrier)
       }
     }
-    copy_out(a.Out, m0);
+    if (!a.fc3) {
+      copy_out(a.Out, m0);
+      continue;
+    }
+    // ---- fc3: wave w takes rows 16 w .. 16 w + 15, a row at a time: lane l holds channels 8 l .. 8 l + 7 (loss_body phase A)
+    {
+      const int no = a.no;
+      float w3[4][8], b3v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint4 wr = *reinterpret_cast<const uint4*>(a.W3 + (size_t)(j < no ? j : 0) * 512 + l * 8);
+        E::un4(make_uint2(wr.x, wr.y), &w3[j][0]);
+        E::un4(make_uint2(wr.z, wr.w), &w3[j][4]);
+        if (j >= no) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w3[j][e] = 0.f;
+        }
+        b3v[j] = (j < no) ? a.b3[j] : 0.f;
+      }
+#pragma unroll 4
+      for (int rr = 0; rr < 16; ++rr) {
+        const int r = w * 16 + rr;
+        const uint4 xr = *reinterpret_cast<const uint4*>(&tile[r * 512 + ((l ^ (r & 31)) << 3)]);
+        float x[8];
+        E::un4(make_uint2(xr.x, xr.y), &x[0]);
+        E::un4(make_uint2(xr.z, xr.w), &x[4]);
+        float p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sacc = fmaf(x[e], w3[j][e], sacc);
+          p[j] = wave_sum63(sacc);
+        }
+        if (l == 63) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s_s[r][j] = (j < no) ? p[j] + b3v[j] : 0.f;
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    // ---- de-homogenisation + mean (loss_body phase B's expressions), one thread per row, coalesced planar stores
+    if (t < 128 && m0 + t < n) {
+      const float s0 = s_s[t][0], s1 = s_s[t][1], s2 = s_s[t][2], s3 = s_s[t][3];
+      float X[3];
+      if (a.use_homogeneous) {
+        const float bx = a.h_beta * s3;
+        const float sp = (bx > 20.f) ? s3 : log1pf(expf(bx)) / a.h_beta;  // F.softplus(beta), ace_network.py:142
+        const float hraw = sp + a.max_inv_scale;
+        const float hval = (hraw > a.min_inv_scale) ? a.min_inv_scale : hraw;   // clamp_(max=min_inv_scale) :143
+        X[0] = s0 / hval + a.mean[0];
+        X[1] = s1 / hval + a.mean[1];
+        X[2] = s2 / hval + a.mean[2];
+      } else {
+        X[0] = s0 + a.mean[0];
+        X[1] = s1 + a.mean[1];
+        X[2] = s2 + a.mean[2];
+      }
+      const int m = m0 + t;
+      if (a.planar_hw > 0) {   // Regressor.forward's [B,3,H,W] layout (ace_network.py:265-270), what RANSAC reads
+        const int64_t mg = (int64_t)a.row_offset + m;
+        const int64_t fr2 = mg / a.planar_hw, px = mg - fr2 * a.planar_hw;
+        float* o = a.out_xyz + fr2 * 3 * a.planar_hw + px;
+        o[0] = X[0];
+        o[(size_t)a.planar_hw] = X[1];
+        o[(size_t)2 * a.planar_hw] = X[2];
+      } else {
+        a.out_xyz[(size_t)m * 3 + 0] = X[0];
+        a.out_xyz[(size_t)m * 3 + 1] = X[1];
+        a.out_xyz[(size_t)m * 3 + 2] = X[2];
+      }
+    }
   }
 }
 

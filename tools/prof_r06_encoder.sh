@@ -2,7 +2,7 @@
 # Round-6 per-LAYER profile of the encoder and of the head's whole-frame inference (gpurun): bash tools/prof_r06_encoder.sh
 #   pass 1  rocprofv3 --kernel-trace (per-dispatch start / end), pass 2 --pmc FETCH_SIZE, pass 3 --pmc WRITE_SIZE (separate runs),
 # of (a) tools/bench_encoder.py 64 and (b) tools/head_maps_pass.py 64. Several layers share a kernel name, so the dispatches are told apart
-# by their position in the pass (8 launches per encoder pass since round 6 -- res1_conv2 and res2_skip ride inside conv3x3r launches --, 2 per head pass: the wide layers are one launch since round 6) -> profiles/r06_encoder_layers.json: per layer us, HBM-side
+# by their position in the pass (8 launches per encoder pass since round 6 -- res1_conv2 and res2_skip ride inside conv3x3r launches --, 1 per head pass: the wide layers, fc3 and the de-homogenisation are one launch since round 6) -> profiles/r06_encoder_layers.json: per layer us, HBM-side
 # bytes (FETCH_SIZE x 2 x 1024 / 2... see the factors below: FETCH_SIZE is in KiB and counts half of the bytes on gfx950, WRITE_SIZE all of
 # them: profiles/r04_step_hbm_traffic.json "calibration"), TFLOP/s and TB/s.
 cd /tmp && export TMPDIR=/tmp
@@ -26,8 +26,8 @@ ENC = ["conv12 (conv1 1->32 + conv2 32->64 s2)", "conv3 64->128 s2", "conv4 128-
        "res1_conv3 3x3 256->256 +res", "res2_conv1 3x3 256->512", "res2_conv2 1x1 512->512", "res2_conv3 3x3 512->512 + res2_skip 1x1 256->512 (extra K stages)"]
 ENC_FLOP = [2 * 480 * 640 * 32 * 9 + 2 * 240 * 320 * 64 * 288, 2 * 120 * 160 * 128 * 576, 2 * 60 * 80 * 256 * 1152, 2 * 4800 * 256 * 2304 + 2 * 4800 * 256 * 256,
             2 * 4800 * 256 * 2304, 2 * 4800 * 512 * 2304, 2 * 4800 * 512 * 512, 2 * 4800 * 512 * 4608 + 2 * 4800 * 512 * 256]
-HEAD = ["head: eight wide layers 512->512 as one launch (head_maps_kernel)", "fc3 + de-homogenisation (loss_kernel)"]
-HEAD_FLOP = [8 * 2 * 4800 * 512 * 512, 2 * 4800 * 512 * 4]
+HEAD = ["head: eight wide layers 512->512 + fc3 + de-homogenisation as one launch (head_maps_kernel)"]
+HEAD_FLOP = [8 * 2 * 4800 * 512 * 512 + 2 * 4800 * 512 * 4]
 res = {}
 for what, names, flops in (("enc", ENC, ENC_FLOP), ("head", HEAD, HEAD_FLOP)):
     per = len(names)
