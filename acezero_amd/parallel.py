@@ -61,19 +61,23 @@ def rank_world(group=None):
 
 
 class DataParallelTrainer:
-    """Wraps a trainer exposing backward(indices), grad (flat tensor incl. statistics) and update()."""
+    """The default exchange (make_data_parallel): backward on the rank's rows, ONE synchronous all-reduce of the flat gradient bucket
+    (head gradients + statistics [+ pose-network gradient]), the identical AdamW / schedule update on every rank. Wraps a trainer exposing
+    backward(indices), grad and update(). force_exchange: a one-rank group still calls the collective (the RCCL call on a one-GPU box:
+    tests/test_dp_gpu.py, bench.py's world-1 leg)."""
 
-    def __init__(self, trainer, group=None, one_shot=None):
+    def __init__(self, trainer, group=None, one_shot=None, force_exchange=False):
         self.trainer = trainer
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.exchange = self.world > 1 or bool(force_exchange)
 
     def step(self, local_indices):
         if local_indices.numel() > 0:
             self.trainer.backward(local_indices)
         else:
             self.trainer.grad.zero_()     # this shard holds no row of the batch: it contributes nothing to the sum
-        if self.world > 1:
+        if self.exchange:
             dist.all_reduce(self.trainer.grad, op=dist.ReduceOp.SUM, group=self.group)
         self.trainer.update()
 
@@ -101,25 +105,34 @@ class ShardedDataParallel:
     ranks -- one reduce / broadcast per owner. The trainer object needs: L, LAYER_STRIDE, grad, backward(rows), update_layers(lo, hi),
     new_weights16_buffer(), export_weights16 / import_weights16(lo, hi, tensor), master_tensors()."""
 
-    def __init__(self, trainer, group=None, one_shot=None, proxy_world=None):
-        """proxy_world = G (measurement only, bench.py's dp_rank_compute legs): this process plays rank 0 of a G-rank job WITHOUT a process
+    def __init__(self, trainer, group=None, one_shot=None, proxy_world=None, force_exchange=False, async_collectives=False):
+        """async_collectives: issue the first phase's collectives with async_op=True (round 5's form). Measured with a one-rank RCCL group
+        (tools/dp_host_probe.py): 246 us per step against 215 us with synchronous calls -- an async collective is a round trip through
+        torch's RCCL stream, two cross-stream events each; the synchronous ones run in the launch stream's order. Default off.
+        force_exchange (tests/test_dp_gpu.py, bench.py's rccl_world1 leg): a ONE-rank group still goes through the whole exchange -- the
+        staging copies and every collective call, which with RCCL and one rank are real RCCL launches on this stack -- instead of the
+        world == 1 short cut. The only way to run the RCCL branch on a one-GPU box; results are bit-identical to the short cut.
+        proxy_world = G (measurement only, bench.py's dp_rank_compute legs): this process plays rank 0 of a G-rank job WITHOUT a process
         group -- the same launches, staging copies and layer ownership as a real rank, every collective skipped -- so that the compute
         half of DESIGN.md section 7's budget is a measurement on one GPU. The parameters it produces are meaningless (partial sums)."""
         self.trainer = trainer
         self.group = group
         self.rank, self.world = rank_world(group)
         self.proxy = proxy_world is not None
+        self.async_collectives = bool(async_collectives)
+        self.exchange = self.world > 1 or bool(force_exchange)
         if self.proxy:
             assert self.world == 1, "proxy_world is a single-process measurement"
             self.rank, self.world = 0, int(proxy_world)
+            self.exchange = True
         self.L, self.stride = int(trainer.L), int(trainer.LAYER_STRIDE)
         self.ranges = [shard_range(self.L, r, self.world) for r in range(self.world)]
         self.lo, self.hi = self.ranges[self.rank]
-        backend = "nccl" if self.proxy else (dist.get_backend(group) if self.world > 1 else "")
+        backend = "nccl" if self.proxy else (dist.get_backend(group) if self.exchange else "")
         # (one_shot=True under gloo: the CPU test of this branch, with reduce_scatter_tensor emulated -- gloo has none)
         self.one_shot = (backend == "nccl" and self.L % self.world == 0) if one_shot is None else bool(one_shot)
         assert not self.one_shot or self.L % self.world == 0
-        self.wbuf = trainer.new_weights16_buffer() if self.world > 1 else None
+        self.wbuf = trainer.new_weights16_buffer() if self.exchange else None
         # separate send / receive staging for the one-shot collectives (1 MB + 0.5 MB per owned layer; no aliasing of a collective's
         # input and output)
         self.rs_out = trainer.grad.new_empty((self.hi - self.lo) * self.stride) if self.one_shot else None
@@ -142,24 +155,26 @@ class ShardedDataParallel:
             t.backward(local_indices)
         else:
             t.grad.zero_()     # this shard holds no row of the batch: it contributes nothing to the sums
-        if self.world == 1:
+        if not self.exchange:
             t.update_layers(0, self.L)
             return
         bias, tail = self._small(t.grad)
         small = torch.cat([bias.reshape(-1), tail])
         wide = t.grad[:self.L * self.stride]
-        work = [] if self.proxy else [dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        ao = self.async_collectives
+        work = [] if self.proxy else [dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group, async_op=ao)]
         if self.proxy:
             pass
         elif self.one_shot:
-            work.append(dist.reduce_scatter_tensor(self.rs_out, wide, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            work.append(dist.reduce_scatter_tensor(self.rs_out, wide, op=dist.ReduceOp.SUM, group=self.group, async_op=ao))
         else:
             for r, (lo, hi) in enumerate(self.ranges):
                 if hi > lo:
                     work.append(dist.reduce(wide[lo * self.stride:hi * self.stride], dst=self._global(r),
-                                            op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                                            op=dist.ReduceOp.SUM, group=self.group, async_op=ao))
         for w in work:
-            w.wait()
+            if w is not None:
+                w.wait()
         if self.one_shot:
             wide[self.lo * self.stride:self.hi * self.stride].copy_(self.rs_out)
         # biases / fc3 / statistics / pose gradient: everyone uses the all-reduced values (also the owner, whose reduce-scatter result
@@ -197,10 +212,27 @@ class ShardedDataParallel:
             self.trainer.masters_synced()
 
 
-def make_data_parallel(trainer, group=None, mode=None):
-    """ACEZ_DP_MODE = "sharded" (default) | "allreduce" (round 2's single all-reduce + replicated update)."""
+DEFAULT_DP_MODE = "allreduce"
+
+
+def dp_mode(mode=None):
     import os
-    mode = (mode or os.environ.get("ACEZ_DP_MODE", "sharded")).lower()
+    return (mode or os.environ.get("ACEZ_DP_MODE", DEFAULT_DP_MODE)).lower()
+
+
+def make_data_parallel(trainer, group=None, mode=None):
+    """ACEZ_DP_MODE = "allreduce" (default) | "sharded" | "sharded_oneshot".
+
+    allreduce  ONE synchronous all-reduce of the flat gradient bucket (8.7 MB fp32), AdamW replicated -- BASELINE.json north_star's
+               "RCCL all-reduce over xGMI on the head gradients only".
+    sharded    reduce-scatter by layer + AdamW on the owned layers + all-gather of the 16-bit weights (ShardedDataParallel): a third
+               fewer bytes on the wire and 1 / G of the optimiser traffic, but three collectives and five staging launches per step.
+    Why all-reduce is the default (round 6, tools/dp_host_probe.py on one MI355X with a ONE-rank RCCL group, i.e. every cost but the wire
+    time; profiles/r06_dp_host_probe.log): split flow 168 us, + one synchronous all_reduce 175 us; sharded flow with its collectives
+    skipped 186 us, called synchronously 215 us, called with async_op=True (round 5's form: every async collective is a round trip
+    through torch's RCCL stream) 246 us. The sharded exchange saves ~4 MB of ring traffic per step (20-40 us at 100-200 GB/s) and pays
+    ~33 us of launches and two more collective latencies for it: a wash at best at G <= 8, and the all-reduce is the simpler path."""
+    mode = dp_mode(mode)
     if mode == "allreduce":
         return DataParallelTrainer(trainer, group)
     return ShardedDataParallel(trainer, group, one_shot=True if mode == "sharded_oneshot" else None)

@@ -458,7 +458,7 @@ class ReconstructionSession:
         launched, done = 0, False
         perms = epoch_permutations(n, o.base_seed + 8191, self.dev) if dp else None       # ace_trainer.py:79-80 seed of the training generator
         pairs = None if dp else epoch_batches(n, o.batch_size, o.base_seed + 8191, self.dev)  # (rows, next rows): the next batch is gathered ahead
-        dpt = make_data_parallel(tr, self.group) if dp else None          # reduce-scatter / sharded AdamW / all-gather (parallel.py)
+        dpt = make_data_parallel(tr, self.group) if dp else None          # one all-reduce of the gradient bucket per step (parallel.py)
         while not done:                                                  # TrainerACE.train / run_epoch (ace_trainer.py:454-497)
             if dp:
                 perm = next(perms)

@@ -189,9 +189,9 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
 
     dp = None
     if dist is not None:
-        # the step's exchange over RCCL (acezero_amd/parallel.py): reduce-scatter of the weight gradients by layer, AdamW on the rank's
-        # own layers, all-gather of the 16-bit compute copies, one small all-reduce for biases / fc3 / statistics / pose gradient
-        # (ACEZ_DP_MODE=allreduce: round 2's single all-reduce of the whole bucket + replicated update)
+        # the step's exchange over RCCL (acezero_amd/parallel.py): ONE synchronous all-reduce of the flat gradient bucket, AdamW replicated
+        # (ACEZ_DP_MODE=sharded: reduce-scatter of the weight gradients by layer, AdamW on the rank's own layers, all-gather of the 16-bit
+        # compute copies, one small all-reduce -- parallel.make_data_parallel says why that is not the default)
         from acezero_amd.parallel import make_data_parallel
         dp = make_data_parallel(tr)
 
@@ -237,20 +237,38 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
     return dt, st, prof
 
 
-def bench_dp_rank_proxy(args, device, rows, proxy_world=8, steps=100):
-    """SURVEY 8(e), one-GPU proxy of a data-parallel rank's COMPUTE: parallel.ShardedDataParallel's launch flow (backward on `rows` rows of a
-    5120-row global batch, staging copies, AdamW on the rank's own layers, export / import of the 16-bit copies) with every collective
-    skipped (proxy_world). rows = 5120: a weak-scaling rank; rows = 640: a rank of the reference's step split eight ways. ms per step."""
+def bench_dp_rank_proxy(args, device, rows, mode=None, proxy_world=8, steps=100, rccl_world1=False):
+    """SURVEY 8(e), one-GPU proxy of a data-parallel rank's COMPUTE: the launch flow of parallel.make_data_parallel(mode) -- backward on `rows`
+    rows of a 5120-row global batch, [the exchange], the update -- with every collective skipped. rows = 5120: a weak-scaling rank;
+    rows = 640: a rank of the reference's step split eight ways. ms per step.
+      mode "allreduce" (the default): backward + update; the skipped all-reduce leaves the rank's own gradient in the bucket.
+      mode "sharded": ShardedDataParallel(proxy_world): staging copies, AdamW on 1 of proxy_world layers, 16-bit export / import.
+    rccl_world1: the same flow in a ONE-rank RCCL group with the collectives CALLED: every collective is the identity, so what it adds is
+    what the RCCL launches and their stream hand-overs cost per step on this stack, no wire time."""
     from acezero_amd import synth
     from acezero_amd.head import HeadTrainer
-    from acezero_amd.parallel import ShardedDataParallel
+    from acezero_amd.parallel import DataParallelTrainer, ShardedDataParallel, dp_mode
+    mode = dp_mode(mode)
     n = min(args.buffer_patches, 1_000_000)
     prob, feats, target_px, view_idx = make_buffer(n, device, 2089)
     tr = HeadTrainer(prob["mean"], max_batch=BATCH, global_batch=BATCH, loss_type="tanh", schedule="1cyclepoly", iterations=25000, lr_min=0.0005,
                      lr_max=0.003, warmup_iterations=1000, warmup_lr=0.0005, cooldown_iterations=5000, dtype="bf16")
     tr.load_flat(torch.from_numpy(synth.init_head_params(1)))
     tr.set_buffer(feats, target_px, view_idx, prob["view_aug_inv"], prob["view_K"], prob["view_Kinv"], prob["view_image"], prob["image_pose_inv"])
-    dp = ShardedDataParallel(tr, proxy_world=proxy_world)
+    if rccl_world1:
+        if not torch.distributed.is_initialized():
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        assert torch.distributed.get_backend() == "nccl"
+        dp = DataParallelTrainer(tr, force_exchange=True) if mode == "allreduce" else ShardedDataParallel(tr, force_exchange=True)
+    else:
+        dp = DataParallelTrainer(tr) if mode == "allreduce" else ShardedDataParallel(tr, proxy_world=proxy_world)
+        assert not (mode == "allreduce" and dp.exchange)
     perm = torch.randperm(n, generator=torch.Generator(device=device).manual_seed(8191), device=device)
     batches = [perm[i * rows:(i + 1) * rows].contiguous() for i in range(min(n // rows, steps + 20))]
     for i in range(20):
@@ -263,6 +281,7 @@ def bench_dp_rank_proxy(args, device, rows, proxy_world=8, steps=100):
     dt = (time.perf_counter() - t0) / steps
     st = tr.state()
     assert st["iteration"] == steps + 20 and not st["nan"], st   # (the stand-in gradients are finite: every step ran)
+    tr.close()
     return dt * 1e3
 
 
@@ -578,12 +597,34 @@ def self_launch(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def dp_mode_name():
+    from acezero_amd.parallel import dp_mode
+    return dp_mode()
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout, and libraries write to file descriptor 1 behind Python's back (RCCL prints a five-line
+    version banner there at the first communicator of a process -- found when the one-rank RCCL leg joined the default run). The real
+    stdout is kept for the line; descriptor 1 -- Python's sys.stdout and every C library's -- goes to stderr from here on. A caller that
+    has replaced sys.stdout by an object of its own (tests) keeps it."""
+    try:
+        if sys.stdout.fileno() != 1:
+            return sys.stdout
+    except (AttributeError, OSError, ValueError):
+        return sys.stdout
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(line_fd, "w")
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    line_out = claim_stdout()
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if env_world != args.gpus:
@@ -618,7 +659,8 @@ def main():
                               "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(np.median(st["window_ms_per_step"])),
                               "ms_per_step_mean": dt / args.steps * 1e3, "window_ms_per_step": st["window_ms_per_step"], "headline_only": True,
                               "pose_refinement": args.pose_refinement, "dtype": args.dtype,
-                              "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()}, "final_loss": st["loss"], "device_state": dev_state}))
+                              "per_class_us_per_step": {k: v[0] / 20 * 1e3 for k, v in prof.items()}, "final_loss": st["loss"], "device_state": dev_state}),
+                  file=line_out, flush=True)
         return
     # the headline step with fp16 operands (the reference's autocast precision; HeadTrainer(dtype="fp16")): same kernels, same rate
     dt_f16, st_f16, _ = bench_training(args, rank, world, device, steps=100, buffer_patches=min(args.buffer_patches, 2_000_000), dtype="fp16")
@@ -638,6 +680,16 @@ def main():
     pipe16 = bench_pipeline(args, rank, world, device, dtype="fp16", legs="e2e")
     # one-GPU proxies of a data-parallel rank's compute (N = 1 only: what a rank does between its collectives)
     dp_proxy = {rows: bench_dp_rank_proxy(args, device, rows) for rows in (5120, 640)} if world == 1 else None
+    dp_w1 = None
+    if world == 1:   # what the RCCL calls themselves cost per step (one rank: no wire time), against the same flow with the calls skipped
+        try:
+            dp_w1 = {"allreduce_rccl": bench_dp_rank_proxy(args, device, 5120, rccl_world1=True),
+                     "sharded_skipped": bench_dp_rank_proxy(args, device, 5120, mode="sharded", proxy_world=1),
+                     "sharded_rccl": bench_dp_rank_proxy(args, device, 5120, mode="sharded", rccl_world1=True),
+                     "sharded_rank_of_8": bench_dp_rank_proxy(args, device, 5120, mode="sharded")}
+        finally:
+            if torch.distributed.is_initialized():
+                torch.distributed.destroy_process_group()
     sess = bench_session(args, device) if world == 1 and args.session_frames > 0 else None
     if world > 1:
         t = torch.tensor([dt, dt_reg, dt_ref, dt_strong, dt_gar, dt_gar_reg, dt_f16] + st["window_ms_per_step"], device=device, dtype=torch.float64)
@@ -711,6 +763,7 @@ def main():
                    "refinement_fp16_ms_per_step": float(np.median(st_ref16["window_ms_per_step"])),
                    "e2e_fp16_images_per_s": pipe16["frames"] * world / pipe16["e2e_s"], "encoder_fp16_ms_per_frame": pipe16["encoder_ms"] / pipe16["frames"],
                    "dp_rank_compute_ms_5120": None if dp_proxy is None else dp_proxy[5120], "dp_rank_compute_ms_640": None if dp_proxy is None else dp_proxy[640],
+                   "dp_world1_exchange_rccl_ms": None if dp_w1 is None else dp_w1["allreduce_rccl"],
                    "garden_ms_per_step": float(np.median(st_gar["window_ms_per_step"])),
                    "registration_images_per_s": nreg * world / dt_reg, "registration_e2e_images_per_s": pipe["frames"] * world / pipe["e2e_s"],
                    "encoder_frac_of_mfma_peak": enc_frac, "encoder_ms_per_frame": pipe["encoder_ms"] / pipe["frames"],
@@ -733,23 +786,30 @@ def main():
             "config": {"workload": "7-Scenes-chess-like ace_zero mapping step: 8M-patch bf16 feature buffer in HBM, batch 5120 per GPU, "
                                    "default head (1 block, 2 103 300 params), tanh loss, 1cyclepoly AdamW, pose_refinement " + args.pose_refinement,
                        "buffer_patches": args.buffer_patches, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
-                       "parallelism": f"dp{world}" + ("" if world == 1 else " (" + ("one all-reduce of the gradient bucket, replicated AdamW" if os.environ.get("ACEZ_DP_MODE", "sharded").lower() == "allreduce" else "reduce-scatter of the weight gradients by layer, AdamW on the owned layers, all-gather of the 16-bit weights") + ")")},
+                       "parallelism": f"dp{world}" + ("" if world == 1 else " (" + ("one all-reduce of the gradient bucket, replicated AdamW" if dp_mode_name() == "allreduce" else "reduce-scatter of the weight gradients by layer, AdamW on the owned layers, all-gather of the 16-bit weights") + ")")},
             "summary": summary,
             "whole_step_flop_frac_of_mfma_peak": patches_per_s / world * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS * 1e12),
             "strong_scaling": None if dt_strong is None else {
                 "metric": "ACE patches/sec, the reference's step: global batch 5120 split over the ranks by buffer shard, one gradient exchange per step (see `collective`)",
                 "value": BATCH * args.steps / dt_strong, "unit": "patches/s", "ms_per_step": dt_strong / args.steps * 1e3, "scaling": "strong",
-                "collective": os.environ.get("ACEZ_DP_MODE", "sharded"),
+                "collective": dp_mode_name(),
                 "global_batch": BATCH, "rows_per_gpu": BATCH / world},
             "refinement_step": {"metric": "ACE patches/sec with --pose_refinement mlp --refine_calibration True (every non-seed mapping iteration of ace_zero.py)",
                                 "value": BATCH * world * 100 / dt_ref, "unit": "patches/s", "ms_per_step": dt_ref / 100 * 1e3, "steps": 100,
                                 "ms_per_step_median": float(np.median(st_ref["window_ms_per_step"])), "window_ms_per_step": st_ref["window_ms_per_step"],
                                 "n_images": 1000, "final_loss": st_ref["loss"]},
             "dp_rank_proxy": None if dp_proxy is None else {
-                "what": "ms per step of ONE data-parallel rank's compute on one GPU: parallel.ShardedDataParallel's launch flow as rank 0 of 8 with every "
-                        "collective skipped (proxy_world) -- backward on `rows` rows, staging copies, AdamW on 1 of 8 layers + small parameters, 16-bit "
-                        "export / import. Multi-GPU itself is unmeasured on hardware; DESIGN.md section 7 adds the exchange estimate to these",
-                "rows_5120_ms": dp_proxy[5120], "rows_640_ms": dp_proxy[640]},
+                "what": "ms per step of ONE data-parallel rank's compute on one GPU, the default exchange (parallel.make_data_parallel: backward on "
+                        "`rows` rows of a 5120-row global batch, ONE all-reduce of the gradient bucket, replicated AdamW) with the collective skipped. "
+                        "Multi-GPU itself is unmeasured on hardware; DESIGN.md section 7 adds the wire estimate to these",
+                "mode": dp_mode_name(), "rows_5120_ms": dp_proxy[5120], "rows_640_ms": dp_proxy[640],
+                "world1_exchange": None if dp_w1 is None else {
+                    "what": "5120 rows, a ONE-rank RCCL group with the collectives CALLED (identity transfers): what the RCCL launches and their "
+                            "stream hand-overs cost per step on this stack, without any wire time. allreduce_rccl_ms against rows_5120_ms: the "
+                            "default; sharded_*: ACEZ_DP_MODE=sharded as the only rank with its collectives skipped / called, and as rank 0 of 8 "
+                            "(AdamW on one layer) with them skipped",
+                    "allreduce_rccl_ms": dp_w1["allreduce_rccl"], "sharded_skipped_ms": dp_w1["sharded_skipped"], "sharded_rccl_ms": dp_w1["sharded_rccl"],
+                    "sharded_rank_of_8_skipped_ms": dp_w1["sharded_rank_of_8"]}},
             "dtype_fp16": {"metric": "ACE patches/sec, the headline step with fp16 operands (the reference's autocast precision, compute_dtype fp16)",
                            "value": BATCH * world * 100 / dt_f16, "unit": "patches/s", "ms_per_step": dt_f16 / 100 * 1e3,
                            "ms_per_step_median": float(np.median(st_f16["window_ms_per_step"])), "final_loss": st_f16["loss"],
@@ -804,7 +864,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), file=line_out, flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -69,6 +69,10 @@ def test_bench_json_line_contract(monkeypatch, seq):
     for k in ("refinement_fp16_ms_per_step", "e2e_fp16_images_per_s", "dp_rank_compute_ms_5120", "dp_rank_compute_ms_640"):
         assert k in sm and r["summary_" + k] == sm[k] and sm[k] > 0
     assert d["rccl_ranks"] == 0 and d["dp_rank_proxy"]["rows_640_ms"] == 0.110 and d["dtype_fp16"]["registration_e2e_images_per_s"] > 0
+    # the RCCL calls themselves on a one-rank group (the only hardware run of that branch a one-GPU box allows)
+    w1 = d["dp_rank_proxy"]["world1_exchange"]
+    assert w1["allreduce_rccl_ms"] == 0.150 and w1["sharded_rccl_ms"] == 0.150 and sm["dp_world1_exchange_rccl_ms"] == r["summary_dp_world1_exchange_rccl_ms"] == 0.150
+    assert d["dp_rank_proxy"]["mode"] == "allreduce"
 
 
 def test_gpus_flag_without_a_launcher_re_executes_under_torchrun(monkeypatch):
@@ -116,3 +120,17 @@ def test_cpu_baseline_quotes_the_stored_reference_figure():
     assert rs["patches_per_s"] > 1e3 and rs["threads"] >= 1 and "training_step" in rs["what"]
     src = open(os.path.join(root, "bench.py")).read()
     assert "reference (stored)" in src and "r04_cpu_reference_training_step.json" in src
+
+
+def test_stdout_carries_only_the_json_line_whatever_libraries_write_to_descriptor_1():
+    """RCCL prints a version banner to file descriptor 1 at the first communicator of a process (seen on the GPU box: five lines behind
+    the JSON line). bench.claim_stdout() keeps the real stdout for the line and sends descriptor 1 to stderr."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; out = bench.claim_stdout(); os.write(1, b'RCCL version : banner\\n'); "
+            "print('python-level chatter'); print('{\"metric\": 1}', file=out, flush=True)" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"metric": 1}\n'
+    assert "RCCL version : banner" in r.stderr and "python-level chatter" in r.stderr

@@ -242,3 +242,65 @@ def test_sharded_update_equals_the_all_reduce_path_bitwise():
             assert got[3] == ref[3] and np.array_equal(got[4], ref[4]), (r, mode)
         assert res[r]["sharded"][5] and res[r]["sharded_oneshot"][5] and not res[r]["allreduce"][5]      # masters of the other rank's layers were stale until gathered
     assert ref[3]["iteration"] == 4
+
+
+def _rccl_world1_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from acezero_amd import parallel
+    prob, flat0 = _problem()
+    n = prob["features"].shape[0]
+    gen = torch.Generator(device="cuda").manual_seed(8191)
+    perm = torch.randperm(n, generator=gen, device="cuda")
+    local, offs = parallel.epoch_local_batches(perm, B, 0, n)
+    out = {}
+    for name, kw in (("short_cut", {}), ("rccl", {"force_exchange": True}), ("rccl_per_owner", {"force_exchange": True, "one_shot": False})):
+        tr = _make_trainer(prob, flat0, 0, n)
+        dp = parallel.ShardedDataParallel(tr, **kw)
+        if kw:
+            assert dp.exchange and dp.one_shot == kw.get("one_shot", True), (dp.exchange, dp.one_shot)
+        for b in range(4):
+            dp.step(local[offs[b]:offs[b + 1]])
+        torch.cuda.synchronize()
+        dp.gather_masters()
+        f = torch.from_numpy(prob["features"][:777]).cuda()
+        out[name] = (tr.params.cpu().numpy(), tr.adam_m.cpu().numpy(), tr.adam_v.cpu().numpy(), tr.state(), tr.get_scene_coordinates(f).cpu().numpy())
+        tr.close()
+    # the all-reduce mode's one collective, and the registration gather, on the same backend
+    tr = _make_trainer(prob, flat0, 0, n)
+    dpa = parallel.DataParallelTrainer(tr, force_exchange=True)   # the default mode's one collective: with one rank the sum is the rank's own gradient
+    assert dpa.exchange
+    for b in range(4):
+        dpa.step(local[offs[b]:offs[b + 1]])
+    torch.cuda.synchronize()
+    out["allreduce"] = (tr.params.cpu().numpy(), tr.adam_m.cpu().numpy(), tr.adam_v.cpu().numpy(), tr.state())
+    tr.close()
+    q.put((0, out, dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_branch_of_the_exchange_runs_on_this_stack_with_one_rank():
+    """The ONLY hardware run of the RCCL calls a one-GPU box allows: a one-rank "nccl" group, ShardedDataParallel(force_exchange=True):
+    async all_reduce of the small bucket, reduce_scatter_tensor / all_gather_into_tensor on the staging buffers (and the per-owner
+    reduce / broadcast form), the stream hand-over between RCCL's stream and the launch stream of libacez, import16. With one rank
+    every collective is the identity, so parameters, moments, schedule state and scene coordinates must equal the short cut bitwise."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    (_, out, backend), = _collect([p], q, 300)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and backend == "nccl"
+    ref = out["short_cut"]
+    for mode in ("rccl", "rccl_per_owner"):
+        for k in range(3):
+            assert np.array_equal(out[mode][k], ref[k]), (mode, k)
+        assert out[mode][3] == ref[3] and np.array_equal(out[mode][4], ref[4]), mode
+    assert ref[3]["iteration"] == 4
+    # all-reduce mode: replicated update through acez_train_update (another launch flow: equal to rounding of the schedule only -- same kernels'
+    # arithmetic, so bitwise here as in test_sharded_update_equals_the_all_reduce_path_bitwise)
+    for k in range(3):
+        assert np.array_equal(out["allreduce"][k], ref[k]), ("allreduce", k)
