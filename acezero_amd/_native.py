@@ -86,6 +86,7 @@ SYMBOLS = {
     "acez_trainer_sync_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
     "acez_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "acez_train_update": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "acez_train_update_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "acez_train_update_layers": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "acez_trainer_export_weights16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "acez_trainer_import_weights16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

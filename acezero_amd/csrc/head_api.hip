@@ -940,7 +940,7 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
   }
   if (!fused) {
     const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
-    const int64_t tail_blocks = ((int64_t)tr->L * 512 + tr->n_params - tr->n_wide + 4 + 63) / 64;   // 64 outputs per workgroup (SmallCols<4>)
+    const int64_t tail_blocks = grad_reduce_tail_blocks(tr->L, tr->n_params - tr->n_wide);
     ProfScope ps(tr, s, KC_REDUCE);
     hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, tr->last_reduce);
   }
@@ -1018,8 +1018,10 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     return ACEZ_OK;
   }
   a.layer_lo = layer_lo; a.layer_hi = layer_hi;
-  if (fused && d_next && n_next > 0 && tr->cfg.pose_refinement == 0 && tr->have_buf) {
-    // the next batch is known: its gather and this step's schedule bookkeeping ride in the optimiser's launch (adamw_next_kernel)
+  if (d_next && n_next > 0 && tr->cfg.pose_refinement == 0 && tr->have_buf && layer_lo == 0 && layer_hi == tr->L) {
+    // the next batch is known: its gather and this step's schedule bookkeeping ride in the optimiser's launch (adamw_next_kernel).
+    // fused: the optimiser sums the weight-gradient slabs itself; else (acez_train_update_next: a data-parallel rank) it reads the
+    // all-reduced bucket like adamw_kernel, and the schedule wave takes the statistics from the bucket too (a.tail is null)
     int n_adam = tr->L * 64 + nsmall;
     // timing experiments (diagnostics build; results wrong by construction): 1 = no optimiser workgroups at all, 2 = no gather
     const int tail_abl = ACEZ_DIAG_ENV("ACEZ_TAIL_ABL") ? atoi(ACEZ_DIAG_ENV("ACEZ_TAIL_ABL")) : 0;
@@ -1055,6 +1057,10 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
 }
 
 extern "C" int acez_train_update(acez_trainer* tr, void* stream) { return train_update_impl(tr, stream, false); }
+extern "C" int acez_train_update_next(acez_trainer* tr, const int64_t* d_indices_next, int n_next, void* stream) {
+  ACEZ_REQUIRE(n_next >= 0 && (!tr || n_next <= tr->max_batch), "n_next must be in [0, max_batch]");
+  return train_update_impl(tr, stream, false, 0, -1, d_indices_next, n_next);
+}
 
 // Sharded data-parallel update (ZeRO-1 by layer): this rank applies AdamW to the weight matrices of wide layers [layer_lo, layer_hi)
 // only -- d_grad must hold their reduced gradients -- and to ALL small parameters (biases, fc3; their gradients are all-reduced and

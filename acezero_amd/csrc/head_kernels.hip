@@ -1548,35 +1548,51 @@ __device__ __forceinline__ void adamw_small_columns(const AdamArgs& a, const int
   sm.finish(a.tail, o, b, s, [] { return false; });
 }
 
+#ifndef GR_LPO
+#define GR_LPO 8   // lanes per output of grad_reduce_kernel's tail (4: 97 workgroups with 80 loads per lane in flight; 8: 193 with 40)
+#endif
+__host__ __device__ inline int grad_reduce_tail_blocks(int n_layers, int64_t n_fc3) { return small_cols_blocks(n_layers, n_fc3, GR_LPO); }
+// Grid: the tail workgroups FIRST (GR_LPO lanes per output: biases, fc3, statistics), then the wide part (split flow only). The tail is the
+// launch's long pole -- every lane sums up to 80 partials behind two load levels -- and, dispatched behind the 2052 wide workgroups, it
+// started when those were done; every load of a workgroup is requested before the schedule's `active` word is looked at (three dependent
+// round trips per workgroup of a launch that is one wave of workgroups long). Round 6: 18.4 -> see profiles/r06_dp_host_probe.log.
 __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
-  if (a.st && !a.st->active) {
-    // switched off by a rowseq fault in THIS step (not by the end of the schedule): the bucket keeps whatever it held, but statistics
-    // slot 3 must still tell the other ranks, which then all skip the optimiser step
-    if (a.fault && *a.fault && blockIdx.x == 0 && threadIdx.x == 0) a.grad[a.n_params + 3] = 1.f;
-    return;
-  }
-  const int wide_blocks = (int)((a.n_wide / 4 + 255) / 256);
-  const int bx = (int)blockIdx.x + (a.skip_wide ? wide_blocks : 0);
-  if (bx < wide_blocks) {  // weights: 16-byte loads, slabs summed in slab order
-    const int64_t i4 = ((int64_t)bx * 256 + threadIdx.x) * 4;
-    if (i4 >= a.n_wide) return;
-    if ((i4 % 262656) >= 262144) return;  // bias slots are produced by the tail path below
+  const int tail_blocks = grad_reduce_tail_blocks(a.n_layers, a.n_params - a.n_wide);
+  const int b = (int)blockIdx.x;
+#ifdef GR_ABL   // timing-only ablation builds (tools/lib_variant.sh): 1 = no tail, 2 = no wide part
+  if ((GR_ABL & 1) && b < tail_blocks) return;
+  if ((GR_ABL & 2) && b >= tail_blocks) return;
+#endif
+  if (b >= tail_blocks) {  // weights: 16-byte loads, slabs summed in slab order
+    const int64_t i4 = ((int64_t)(b - tail_blocks) * 256 + threadIdx.x) * 4;
+    if (a.skip_wide || i4 >= a.n_wide) return;
+    if ((i4 % 262656) >= 262144) return;  // bias slots are produced by the tail path
     float4 acc = *reinterpret_cast<const float4*>(a.slabs + i4);
+    float4 v1 = acc;
+    if (a.nslabs > 1) v1 = *reinterpret_cast<const float4*>(a.slabs + (size_t)a.slab_stride + i4);
+    const int active = a.st ? a.st->active : 1;
+    const float inv = a.st->inv_grad_scale;
+    if (!active) return;   // (a rowseq fault of this step: the tail's first workgroup raises statistics slot 3)
     for (int s = 1; s < a.nslabs; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)s * a.slab_stride + i4);
+      const float4 v = s == 1 ? v1 : *reinterpret_cast<const float4*>(a.slabs + (size_t)s * a.slab_stride + i4);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    const float inv = a.st->inv_grad_scale;
     acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
     *reinterpret_cast<float4*>(a.grad + i4) = acc;
     return;
   }
   // the tail: 64 outputs per workgroup, four lanes each, coalesced partial-row reads (SmallCols: tail_output's summation order, the same bits;
   // a wavefront per output -- 1538 workgroups whose lanes stride the partial ROWS -- touched 64 cache lines with every load)
-  SmallCols<4> sm;
+  SmallCols<GR_LPO> sm;
   const SmallOpt none{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-  sm.issue(a, none, bx - wide_blocks);
-  sm.finish(a, none, bx - wide_blocks, AdamScalars{}, [] { return false; });
+  sm.issue(a, none, b);
+  if (a.st && !a.st->active) {
+    // switched off by a rowseq fault in THIS step (not by the end of the schedule): the bucket keeps whatever it held, but statistics
+    // slot 3 must still tell the other ranks, which then all skip the optimiser step
+    if (a.fault && *a.fault && b == 0 && threadIdx.x == 0) a.grad[a.n_params + 3] = 1.f;
+    return;
+  }
+  sm.finish(a, none, b, AdamScalars{}, [] { return false; });
 }
 
 // One workgroup's share of the optimiser step (b = workgroup index inside the optimiser's part of a launch; tileT: 64 x 66 bf16 LDS).
@@ -2131,8 +2147,17 @@ __global__ __launch_bounds__(256) void adamw_next_kernel(AdamArgs a, int n_adam,
     return;
   }
   if (b == (int)gridDim.x - 1) {
-    if (threadIdx.x < 64)
-      sched_post_wave(p.src, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault, p.stat_partials, p.n_loss_blocks, &a.tail);
+    if (threadIdx.x < 64) {
+      // fused flow (a.slabs): the statistics are being reduced by sibling workgroups of this launch, the wave reduces the loss kernel's
+      // partials itself; split flow (acez_train_update_next): they are in the bucket, reduced by grad_reduce_kernel and all-reduced since
+      // (two call sites: a run-time choice between &a.tail and null makes the kernel arguments addressable -- the compiler copies them to
+      // scratch, 680 bytes per lane, and the launch takes 51 us instead of 22)
+      if (a.slabs) {
+        sched_post_wave(p.src, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault, p.stat_partials, p.n_loss_blocks, &a.tail);
+      } else {
+        sched_post_wave(p.src, p.st, p.c, p.grad_stats, p.inv_global_batch, p.log_loss, p.log_inl, p.log_cap, p.fault, p.stat_partials, p.n_loss_blocks);
+      }
+    }
     return;
   }
   const int lane = threadIdx.x & 63;

@@ -285,8 +285,15 @@ class HeadTrainer:
         assert indices.dtype == torch.int64 and indices.is_cuda and indices.is_contiguous()
         N.check(self.lib.acez_train_backward(self._h, _ptr(indices), int(indices.numel()), _stream()))
 
-    def update(self):
-        N.check(self.lib.acez_train_update(self._h, _stream()))
+    def update(self, next_indices=None):
+        """AdamW + schedule. next_indices: the rows of the NEXT backward() call, if known (data-parallel ranks draw the same epoch
+        permutation): gathered inside the optimiser's launch; pass the very same tensor to that backward()."""
+        if next_indices is None or next_indices.numel() == 0:
+            N.check(self.lib.acez_train_update(self._h, _stream()))
+        else:
+            assert next_indices.dtype == torch.int64 and next_indices.is_cuda and next_indices.is_contiguous()
+            self._next_keepalive = next_indices     # the device pointer must stay valid until the next call has consumed it
+            N.check(self.lib.acez_train_update_next(self._h, _ptr(next_indices), int(next_indices.numel()), _stream()))
 
     # ---- sharded data-parallel update (parallel.ShardedDataParallel; DESIGN.md section 7)
     LAYER_STRIDE = 262144 + 512          # floats of one wide layer (weight + bias) in the flat parameter / gradient vectors

@@ -71,15 +71,22 @@ class DataParallelTrainer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.exchange = self.world > 1 or bool(force_exchange)
+        import inspect
+        self._announce = "next_indices" in inspect.signature(trainer.update).parameters   # (the CPU tests' stand-in trainer has none)
 
-    def step(self, local_indices):
+    def step(self, local_indices, next_local_indices=None):
+        """next_local_indices: this rank's rows of the NEXT batch (the very tensor the next call will pass), if known: gathered inside this
+        step's optimiser launch (HeadTrainer.update(next_indices))."""
         if local_indices.numel() > 0:
             self.trainer.backward(local_indices)
         else:
             self.trainer.grad.zero_()     # this shard holds no row of the batch: it contributes nothing to the sum
         if self.exchange:
             dist.all_reduce(self.trainer.grad, op=dist.ReduceOp.SUM, group=self.group)
-        self.trainer.update()
+        if next_local_indices is None or not self._announce:
+            self.trainer.update()
+        else:
+            self.trainer.update(next_local_indices)
 
     def gather_masters(self):
         pass   # every rank updates every parameter: nothing to gather
@@ -149,8 +156,8 @@ class ShardedDataParallel:
         wide = grad[:self.L * self.stride].view(self.L, self.stride)
         return wide[:, self.stride - 512:], grad[self.L * self.stride:]
 
-    def step(self, local_indices):
-        t = self.trainer
+    def step(self, local_indices, next_local_indices=None):
+        t = self.trainer     # (next_local_indices: accepted for DataParallelTrainer's signature; this flow gathers at the start of a step)
         if local_indices.numel() > 0:
             t.backward(local_indices)
         else:

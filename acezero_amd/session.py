@@ -463,9 +463,12 @@ class ReconstructionSession:
             if dp:
                 perm = next(perms)
                 local, offs = epoch_local_batches(perm, o.batch_size, shard_lo, shard_lo + n_local)
-            for b in range(n // o.batch_size):
+            nb = n // o.batch_size
+            for b in range(nb):
                 if dp:
-                    dpt.step(local[offs[b]:offs[b + 1]])   # RCCL: head + pose gradients, loss / inlier / focal statistics
+                    # RCCL: head + pose gradients, loss / inlier / focal statistics; the rank's rows of the next batch are announced to the
+                    # update (gathered inside the optimiser's launch; the first batch of an epoch gathers for itself)
+                    dpt.step(local[offs[b]:offs[b + 1]], local[offs[b + 1]:offs[b + 2]] if b + 1 < nb else None)
                 else:
                     tr.step(*next(pairs))
                 launched += 1

@@ -200,7 +200,7 @@ def bench_training(args, rank, world, device, pose_refinement=None, steps=None, 
         if dp is None:
             tr.step(idx, batches[(i + 1) % len(batches)])   # the next batch is known (run_epoch): gathered inside this step's optimiser launch
         else:
-            dp.step(idx)
+            dp.step(idx, batches[(i + 1) % len(batches)])   # the rank's rows of the next batch: gathered inside this step's optimiser launch
 
     for i in range(args.warmup):
         step(i)
@@ -272,11 +272,11 @@ def bench_dp_rank_proxy(args, device, rows, mode=None, proxy_world=8, steps=100,
     perm = torch.randperm(n, generator=torch.Generator(device=device).manual_seed(8191), device=device)
     batches = [perm[i * rows:(i + 1) * rows].contiguous() for i in range(min(n // rows, steps + 20))]
     for i in range(20):
-        dp.step(batches[i % len(batches)])
+        dp.step(batches[i % len(batches)], batches[(i + 1) % len(batches)])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        dp.step(batches[(20 + i) % len(batches)])
+        dp.step(batches[(20 + i) % len(batches)], batches[(21 + i) % len(batches)])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     st = tr.state()

@@ -251,6 +251,13 @@ int acez_trainer_sync_weights(acez_trainer* tr, void* stream);
  * (iteration >= max_iterations, ace_trainer.py:509-510) is a device-side no-op. */
 int acez_train_backward(acez_trainer* tr, const int64_t* d_indices, int n, void* stream);
 int acez_train_update(acez_trainer* tr, void* stream);
+/* acez_train_update with the NEXT acez_train_backward's indices announced (a data-parallel rank knows its rows of the next batch: every
+ * rank draws the same epoch permutation, ace_trainer.py:466-494): the next batch is gathered, and this step's schedule bookkeeping
+ * closed, inside the optimiser's launch, so the next acez_train_backward called with the same device pointer and count starts with the
+ * forward chain instead of a gather launch. Same contract for the announced indices as acez_train_step_next; any other next call is
+ * still correct. Bitwise the same parameters and state as acez_train_update. With pose refinement, or d_indices_next == NULL, or
+ * n_next == 0 (a rank whose shard holds no row of the next batch): exactly acez_train_update. */
+int acez_train_update_next(acez_trainer* tr, const int64_t* d_indices_next, int n_next, void* stream);
 /* Sharded data-parallel update (reduce-scatter of the weight gradients, each rank updates its own layers, all-gather
  * of the 16-bit compute copies; no reference counterpart -- the reference is single-GPU):
  *   acez_train_update_layers        AdamW on the weight matrices of wide layers [layer_lo, layer_hi) only (d_grad holds their reduced

@@ -387,6 +387,48 @@ def test_step_with_the_next_batch_announced_equals_plain_steps_bitwise(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_split_step_with_the_next_batch_announced_equals_plain_split_steps_bitwise(dtype):
+    """acez_train_update_next (the data-parallel rank's flow: backward / all-reduce / update, with the rank's rows of the next batch
+    announced to the update): the optimiser's launch gathers the next batch and closes the step's schedule from the statistics in the
+    bucket. Parameters, moments, schedule state, log and the gradient bucket of every step equal backward() + update() bit for bit --
+    with wrong announcements, empty announcements, fused steps and state reads in between, ragged sizes, across the cool-down trigger."""
+    from tests.helpers import big_problem as _big_problem
+    prob = _big_problem(n_images=8, patches_per_view=512)
+    flat0 = head_oracle.init_params(helpers.SEED + 1)
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_1cyclepoly"], prob)
+    cfg.update(global_batch=2048, iterations=60, warmup_iterations=5, cooldown_iterations=10, cooldown_trigger_percent=-1.0)
+    plain, piped = (_trainer(prob, flat0, cfg, max_batch=2048, dtype=dtype) for _ in range(2))
+    rng = np.random.default_rng(29)
+    N = prob["features"].shape[0]
+    batches = [torch.from_numpy(rng.permutation(N)[:(2048 if i % 5 else 1111)].astype(np.int64)).cuda() for i in range(40)]
+    other = torch.from_numpy(rng.permutation(N)[:2048].astype(np.int64)).cuda()
+    empty = torch.zeros(0, dtype=torch.int64, device="cuda")
+    for i, b in enumerate(batches):
+        plain.backward(b)
+        gp = plain.grad.clone()
+        plain.update()
+        nxt = batches[i + 1] if i + 1 < len(batches) else None
+        if i % 7 == 3:
+            nxt = other                       # a wrong announcement: the next backward must notice and gather its own batch
+        if i % 13 == 6:
+            nxt = empty                       # a rank whose shard holds no row of the next batch
+        if i % 11 == 5:
+            piped.step(b, nxt)                # a fused step in between
+        else:
+            piped.backward(b)
+            assert torch.equal(gp, piped.grad), i
+            piped.update(nxt)
+        if i % 9 == 4:
+            assert plain.state() == piped.state()
+    torch.cuda.synchronize()
+    assert torch.equal(plain.params, piped.params) and torch.equal(plain.adam_m, piped.adam_m) and torch.equal(plain.adam_v, piped.adam_v)
+    sp, sq = plain.state(), piped.state()
+    assert sp == sq and sp["iteration"] == sp["max_iterations"] < 60
+    lp, lq = plain.log(0, sp["iteration"]), piped.log(0, sp["iteration"])
+    assert np.array_equal(lp[0], lq[0]) and np.array_equal(lp[1], lq[1])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", list(helpers.BIG_CONFIGS))
 def test_baseline_batch_against_the_reference_golden(name, dtype):
     """BASELINE's batch (5120 rows) against three steps of the REFERENCE's fp32 training_step (tests/golden/head_b5120_*.npz), in both

@@ -36,15 +36,18 @@ def trainer():
     return tr
 
 
-def run(name, make_step):
+def run(name, make_step, announce=False):
     tr = trainer()
     step = make_step(tr)
+    if not announce:
+        step1 = step
+        step = lambda b, nxt: step1(b)
     for i in range(30):
-        step(batches[i % len(batches)])
+        step(batches[i % len(batches)], batches[(i + 1) % len(batches)])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        step(batches[(30 + i) % len(batches)])
+        step(batches[(30 + i) % len(batches)], batches[(31 + i) % len(batches)])
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
@@ -78,8 +81,18 @@ def sharded(tr, **kw):
 
 
 run("fused step (acez_train_step), no exchange", fused)
+run("fused step, next batch announced (acez_train_step_next)", lambda tr: (lambda b, nxt: tr.step(b, nxt)), announce=True)
 run("backward + update (split flow), no exchange", split)
 run("split flow + ONE RCCL all_reduce of the 8.7 MB bucket", allreduce_rccl)
+def split_announced(tr):
+    def s(b, nxt):
+        tr.backward(b)
+        tr.update(nxt)
+    return s
+
+
+run("split flow, next batch announced to the update", split_announced, announce=True)
+run("DEFAULT: DataParallelTrainer, one-rank RCCL all_reduce, next batch announced", lambda tr: parallel.DataParallelTrainer(tr, force_exchange=True).step, announce=True)
 run("sharded flow, collectives skipped (proxy_world=1)", lambda tr: sharded(tr, proxy_world=1))
 run("sharded flow, 3 RCCL collectives (force_exchange)", lambda tr: sharded(tr, force_exchange=True))
 run("sharded flow, 3 RCCL collectives, all synchronous calls", lambda tr: sharded(tr, force_exchange=True, async_collectives=False))
