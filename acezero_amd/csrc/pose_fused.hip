@@ -77,8 +77,14 @@ __global__ __launch_bounds__(pose_fwd_threads<T>()) void pose_fwd_t_kernel(PoseN
 }
 
 // AdamW of the head + S1: blocks [0, np) = reduce + backward chain of one image tile each, the rest = adamw_kernel's blocks.
+// Register budget: 3 waves per SIMD (168 VGPRs, one spilled dword in S1) = three 256-thread workgroups per CU for the launch's 859; as
+// compiled for 2 (170 VGPRs) it was 21.8 us, for 3 it is 20.2 (same box, two alternations; the step 164.5 -> 163.8 us); for 4 (128 VGPRs)
+// S1 spills 120 dwords and the launch takes 52 us.
+#ifndef ACEZ_APK_WAVES
+#define ACEZ_APK_WAVES 3
+#endif
 template <int T>
-__global__ __launch_bounds__(256, 2) void adamw_pose_kernel(AdamArgs a, PoseNetArgs pn, const float* row_dT, const int* row_image, int n, int np) {
+__global__ __launch_bounds__(256, ACEZ_APK_WAVES) void adamw_pose_kernel(AdamArgs a, PoseNetArgs pn, const float* row_dT, const int* row_image, int n, int np) {
   constexpr int SMEM = pose_s1_smem_bytes<T>() > 64 * 66 * 2 ? pose_s1_smem_bytes<T>() : 64 * 66 * 2;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
   if ((int)blockIdx.x < np) {

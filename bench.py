@@ -680,16 +680,21 @@ def main():
     pipe16 = bench_pipeline(args, rank, world, device, dtype="fp16", legs="e2e")
     # one-GPU proxies of a data-parallel rank's compute (N = 1 only: what a rank does between its collectives)
     dp_proxy = {rows: bench_dp_rank_proxy(args, device, rows) for rows in (5120, 640)} if world == 1 else None
-    dp_w1 = None
+    dp_w1, dp_w1_error = None, None
     if world == 1:   # what the RCCL calls themselves cost per step (one rank: no wire time), against the same flow with the calls skipped
         try:
             dp_w1 = {"allreduce_rccl": bench_dp_rank_proxy(args, device, 5120, rccl_world1=True),
                      "sharded_skipped": bench_dp_rank_proxy(args, device, 5120, mode="sharded", proxy_world=1),
                      "sharded_rccl": bench_dp_rank_proxy(args, device, 5120, mode="sharded", rccl_world1=True),
                      "sharded_rank_of_8": bench_dp_rank_proxy(args, device, 5120, mode="sharded")}
+        except Exception as e:   # a box on which a one-rank RCCL group cannot be formed loses this auxiliary leg, not the line
+            dp_w1, dp_w1_error = None, repr(e)[:300]
         finally:
-            if torch.distributed.is_initialized():
-                torch.distributed.destroy_process_group()
+            try:
+                if torch.distributed.is_initialized():
+                    torch.distributed.destroy_process_group()
+            except Exception as e:
+                dp_w1_error = (dp_w1_error or "") + " destroy: " + repr(e)[:200]
     sess = bench_session(args, device) if world == 1 and args.session_frames > 0 else None
     if world > 1:
         t = torch.tensor([dt, dt_reg, dt_ref, dt_strong, dt_gar, dt_gar_reg, dt_f16] + st["window_ms_per_step"], device=device, dtype=torch.float64)
@@ -803,7 +808,7 @@ def main():
                         "`rows` rows of a 5120-row global batch, ONE all-reduce of the gradient bucket, replicated AdamW) with the collective skipped. "
                         "Multi-GPU itself is unmeasured on hardware; DESIGN.md section 7 adds the wire estimate to these",
                 "mode": dp_mode_name(), "rows_5120_ms": dp_proxy[5120], "rows_640_ms": dp_proxy[640],
-                "world1_exchange": None if dp_w1 is None else {
+                "world1_exchange": {"error": dp_w1_error} if dp_w1 is None else {
                     "what": "5120 rows, a ONE-rank RCCL group with the collectives CALLED (identity transfers): what the RCCL launches and their "
                             "stream hand-overs cost per step on this stack, without any wire time. allreduce_rccl_ms against rows_5120_ms: the "
                             "default; sharded_*: ACEZ_DP_MODE=sharded as the only rank with its collectives skipped / called, and as rank 0 of 8 "
