@@ -942,19 +942,21 @@ static int train_backward_impl(acez_trainer* tr, const int64_t* d_indices, int n
     const int64_t wide_blocks = (tr->n_wide / 4 + 255) / 256;
     const int64_t tail_blocks = grad_reduce_tail_blocks(tr->L, tr->n_params - tr->n_wide);
     ProfScope ps(tr, s, KC_REDUCE);
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, tr->last_reduce);
+    if (pf) {
+      // split flow with the pose network folded in (a data-parallel host all-reduces d_grad next, so the pose gradients must be complete
+      // now): the reduce + backward chain (S1) rides at the front of the gradient-reduction launch, the weight gradients (S2) follow
+      const PoseNetArgs a = pose_net_args(tr, &tr->st->active);
+      const int T = tr->pose_tile, np = (tr->buf.n_images + T - 1) / T;
+#define ACEZ_GRP(TT) hipLaunchKernelGGL(grad_reduce_pose_kernel<TT>, dim3((unsigned)(np + wide_blocks + tail_blocks)), dim3(256), 0, s, tr->last_reduce, a, \
+                                        (const float*)tr->row_dT, (const int*)tr->row_image, n, np)
+      if (T == 16) ACEZ_GRP(16); else if (T == 4) ACEZ_GRP(4); else ACEZ_GRP(8);
+#undef ACEZ_GRP
+    } else {
+      hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(wide_blocks + tail_blocks)), dim3(256), 0, s, tr->last_reduce);
+    }
   }
   if (ps != s) ACEZ_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_pose_bwd, 0));   // d_grad's pose tail: read by the all-reduce and by the pose AdamW
-  if (pf && !fused) {
-    // split flow (a data-parallel host all-reduces d_grad next): the pose gradients must be complete now -- reduce + backward chain
-    // (S1) and the weight gradients as two launches on this stream; the single-GPU step runs S1 beside the head's AdamW instead
-    const PoseNetArgs a = pose_net_args(tr, &tr->st->active);
-    const int T = tr->pose_tile, np = (tr->buf.n_images + T - 1) / T;
-#define ACEZ_S1(TT) hipLaunchKernelGGL(pose_s1t_kernel<TT>, dim3(np), dim3(pose_threads<TT>()), 0, s, a, (const float*)tr->row_dT, (const int*)tr->row_image, n)
-    if (T == 16) ACEZ_S1(16); else if (T == 4) ACEZ_S1(4); else ACEZ_S1(8);
-#undef ACEZ_S1
-    launch_pose_wgrad(tr, &tr->st->active, false, s);
-  }
+  if (pf && !fused) launch_pose_wgrad(tr, &tr->st->active, false, s);
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;
 }
@@ -1045,12 +1047,30 @@ static int train_update_impl(acez_trainer* tr, void* stream, bool fused, int lay
     ACEZ_HIP_CHECK(hipGetLastError());
     return ACEZ_OK;
   }
-  { ProfScope ps(tr, s, KC_ADAMW); hipLaunchKernelGGL(adamw_kernel, dim3((layer_hi - layer_lo) * 64 + nsmall), dim3(256), 0, s, a); }
-  if (tr->cfg.pose_refinement != 0) tr->pose_wt_valid = false;   // adamw_small_kernel does not refresh the transposed copies
-  if (tr->cfg.pose_refinement != 0)
-    hipLaunchKernelGGL(adamw_small_kernel, dim3((unsigned)((tr->pb.n_pose_params + 255) / 256)), dim3(256), 0, s, tr->pb.d_pose_params, tr->pb.d_pose_m,
-                       tr->pb.d_pose_v, (const float*)(tr->pb.d_grad + tr->n_params + 4), (int64_t)0, 1, tr->pb.n_pose_params,
-                       (const AdamScalars*)&tr->st->pose_adam, (const int*)&tr->st->pose_enable, (const int*)&tr->st->active, (const int*)tr->seq_err);
+  if (tr->cfg.pose_refinement != 0) {
+    // the pose parameters' AdamW (and, for the network, the refresh of its four transposed copies) at the front of the head's optimiser launch
+    float* wt = (tr->cfg.pose_refinement == 2 && tr->pose_fused) ? tr->pose_wt : nullptr;
+    const int npb = (int)((tr->pb.n_pose_params + 255) / 256);
+    const int n_adam = (layer_hi - layer_lo) * 64 + nsmall;
+    // the next batch announced (acez_train_update_next) and the pose network folded into the step's launches: its rows are gathered here,
+    // the next backward's first launch keeps the pose forward and the schedule wave (step_begin_pose_kernel without gather workgroups)
+    const bool ahead = d_next && n_next > 0 && tr->pose_fused && tr->have_buf && layer_lo == 0 && layer_hi == tr->L;
+    int gblocks = 0;
+    if (ahead) {
+      const int gwant = (n_next + 3) / 4 < 1024 ? (n_next + 3) / 4 : 1024;
+      gblocks = std::max(64, std::min(gwant, 4 * tr->n_cus - n_adam - npb));
+    }
+    { ProfScope ps(tr, s, KC_ADAMW);
+      hipLaunchKernelGGL(adamw_split_pose_kernel, dim3(npb + n_adam + gblocks), dim3(256), 0, s, a, npb, tr->pb.d_pose_params, tr->pb.d_pose_m,
+                         tr->pb.d_pose_v, (const float*)(tr->pb.d_grad + tr->n_params + 4), (int64_t)tr->pb.n_pose_params,
+                         (const AdamScalars*)&tr->st->pose_adam, (const int*)&tr->st->pose_enable, (const int*)&tr->st->active, (const int*)tr->seq_err, wt,
+                         n_adam, (const uint16_t*)tr->buf.d_features, d_next, tr->R[0], ahead ? n_next : 0, gather_meta(tr)); }
+    if (ahead) { tr->pre_idx = d_next; tr->pre_n = n_next; }
+    if (!wt) tr->pose_wt_valid = false;   // no transposed copies kept here: the next folded forward rebuilds them
+  } else {
+    ProfScope ps(tr, s, KC_ADAMW);
+    hipLaunchKernelGGL(adamw_kernel, dim3((layer_hi - layer_lo) * 64 + nsmall), dim3(256), 0, s, a);
+  }
   tr->post_pending = true;   // sched_post: with the next step's gather, or at the next state read-out (flush_post)
   ACEZ_HIP_CHECK(hipGetLastError());
   return ACEZ_OK;

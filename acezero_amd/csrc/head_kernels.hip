@@ -1556,9 +1556,8 @@ __host__ __device__ inline int grad_reduce_tail_blocks(int n_layers, int64_t n_f
 // launch's long pole -- every lane sums up to 80 partials behind two load levels -- and, dispatched behind the 2052 wide workgroups, it
 // started when those were done; every load of a workgroup is requested before the schedule's `active` word is looked at (three dependent
 // round trips per workgroup of a launch that is one wave of workgroups long). Round 6: 18.4 -> see profiles/r06_dp_host_probe.log.
-__global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
+__device__ __forceinline__ void grad_reduce_body(const GradReduceArgs& a, const int b) {
   const int tail_blocks = grad_reduce_tail_blocks(a.n_layers, a.n_params - a.n_wide);
-  const int b = (int)blockIdx.x;
 #ifdef GR_ABL   // timing-only ablation builds (tools/lib_variant.sh): 1 = no tail, 2 = no wide part
   if ((GR_ABL & 1) && b < tail_blocks) return;
   if ((GR_ABL & 2) && b >= tail_blocks) return;
@@ -1594,6 +1593,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) {
   }
   sm.finish(a, none, b, AdamScalars{}, [] { return false; });
 }
+__global__ __launch_bounds__(256) void grad_reduce_kernel(GradReduceArgs a) { grad_reduce_body(a, (int)blockIdx.x); }
 
 // One workgroup's share of the optimiser step (b = workgroup index inside the optimiser's part of a launch; tileT: 64 x 66 bf16 LDS).
 // The body of adamw_kernel and of adamw_pose_kernel (pose_fused.hip), where the pose network's backward runs beside it.
@@ -2137,16 +2137,24 @@ __global__ __launch_bounds__(256) void step_begin_kernel(const uint16_t* __restr
 // loss kernel's statistic partials and the state slot of step k and writes the OTHER slot (sched_post_wave), which only later launches
 // read. Saves the step_begin launch (5 us + a kernel boundary) of every step: the gather hides under the HBM-bound optimiser.
 // (First version: one slot, bookkeeping in the workgroup that finished last, found with a ticket counter -- 1700 atomics on one word
-// cost 20 us.)   blocks [0, n_adam) = adamw_kernel's; then the gather blocks; the last block = the schedule wave
-__global__ __launch_bounds__(256) void adamw_next_kernel(AdamArgs a, int n_adam, const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx_next,
+// cost 20 us.)   Grid: the gather blocks, the schedule wave, then adamw_kernel's n_adam blocks (order: below)
+__global__ __launch_bounds__(256, 4) void adamw_next_kernel(AdamArgs a, int n_adam, const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx_next,
                                                          uint16_t* __restrict__ out, int n_next, PostArgs p, GatherMeta meta) {
   __shared__ uint16_t tileT[64][66];
+  // Grid order (round 6): the gather workgroups FIRST, then the schedule wave, then the optimiser's. The gather is a chain of three dependent
+  // load levels (~7 us) and used to sit at the END of the grid, where its workgroups started when optimiser workgroups retired: the launch
+  // was adamw_kernel's 12.2 us + 5.2. In front, the chain runs under the optimiser's HBM traffic from the first cycle. <= 128 VGPRs
+  // (launch bounds): all 1024 workgroups of the launch are resident at once.
   const int b = (int)blockIdx.x;
-  if (b < n_adam) {
-    adamw_body(a, b, tileT);
+  const int gblocks = (int)gridDim.x - 1 - n_adam;
+  if (b < gblocks) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (b * (int)blockDim.x + (int)threadIdx.x) >> 6;
+    const int nwaves = (gblocks * (int)blockDim.x) >> 6;
+    gather_rows(feat, idx_next, out, n_next, wave, nwaves, lane, meta);
     return;
   }
-  if (b == (int)gridDim.x - 1) {
+  if (b == gblocks) {
     if (threadIdx.x < 64) {
       // fused flow (a.slabs): the statistics are being reduced by sibling workgroups of this launch, the wave reduces the loss kernel's
       // partials itself; split flow (acez_train_update_next): they are in the bucket, reduced by grad_reduce_kernel and all-reduced since
@@ -2160,10 +2168,7 @@ __global__ __launch_bounds__(256) void adamw_next_kernel(AdamArgs a, int n_adam,
     }
     return;
   }
-  const int lane = threadIdx.x & 63;
-  const int wave = ((b - n_adam) * (int)blockDim.x + (int)threadIdx.x) >> 6;
-  const int nwaves = (((int)gridDim.x - 1 - n_adam) * (int)blockDim.x) >> 6;
-  gather_rows(feat, idx_next, out, n_next, wave, nwaves, lane, meta);
+  adamw_body(a, b - gblocks - 1, tileT);
 }
 
 // cos(pi x) for x in [0,1] with basic operations only (Taylor around the nearest multiple of 1/2).

@@ -95,4 +95,63 @@ __global__ __launch_bounds__(256, ACEZ_APK_WAVES) void adamw_pose_kernel(AdamArg
   adamw_body(a, (int)blockIdx.x - np, reinterpret_cast<uint16_t (*)[66]>(smem));
 }
 
+// ---- the split flow (backward / all-reduce / update: a data-parallel rank) with pose refinement. As separate launches its tail was
+// wgrad -> grad_reduce -> S1 -> S2 -> [all-reduce] -> adamw -> adamw_small -> (next step) pose_transpose: five small dependent launches
+// where the fused step has two. S1 only needs the loss kernel's per-row pose gradients and grad_reduce has no LDS of its own, so S1 rides
+// at the front of ITS launch; the pose parameters' AdamW and the refresh of the four transposed 128 x 128 copies ride at the front of the
+// head's optimiser launch (adamw_small_kernel's arithmetic element by element, pose_transpose_kernel's copies: the same bits).
+template <int T>
+__global__ __launch_bounds__(256, 3) void grad_reduce_pose_kernel(GradReduceArgs a, PoseNetArgs pn, const float* row_dT, const int* row_image, int n, int np) {
+  __shared__ __attribute__((aligned(16))) char smem[pose_s1_smem_bytes<T>()];
+  if ((int)blockIdx.x < np) {
+    if (pn.active && !*pn.active) return;
+    pose_s1_tile<T>(pn, row_dT, row_image, n, blockIdx.x, smem);
+    return;
+  }
+  grad_reduce_body(a, (int)blockIdx.x - np);
+}
+
+// blocks: the workgroups (if any) that gather the NEXT batch's rows (acez_train_update_next: the following backward's launch then carries
+// the pose forward and the schedule wave only), npb of 256 pose parameters each, n_adam = adamw_kernel's. Wt: the transposed copies
+// (null: none kept)
+__global__ __launch_bounds__(256, 4) void adamw_split_pose_kernel(AdamArgs a, int npb, float* p, float* m, float* v, const float* g, int64_t n,
+                                                               const AdamScalars* sc, const int* enable, const int* active, const int* fault, float* Wt,
+                                                               int n_adam, const uint16_t* __restrict__ feat, const int64_t* __restrict__ idx_next,
+                                                               uint16_t* __restrict__ out, int n_next, GatherMeta meta) {
+  __shared__ uint16_t tileT[64][66];
+  // grid order: gather workgroups first (their three dependent load levels start with the launch: adamw_next_kernel), pose parameters, optimiser
+  const int ngb = (int)gridDim.x - npb - n_adam;
+  int b = (int)blockIdx.x;
+  if (b < ngb) {
+    gather_rows(feat, idx_next, out, n_next, (b * (int)blockDim.x + (int)threadIdx.x) >> 6, (ngb * (int)blockDim.x) >> 6, threadIdx.x & 63, meta);
+    return;
+  }
+  b -= ngb;
+  if (b >= npb) {
+    adamw_body(a, b - npb, tileT);
+    return;
+  }
+  if (active && !*active) return;
+  if (fault && *fault) return;   // abandoned step (rowseq fault, head_kernels.hip)
+  if (enable && !*enable) return;
+  const int64_t i = (int64_t)b * 256 + threadIdx.x;
+  if (i >= n) return;
+  const AdamScalars s = *sc;
+  float gv = 0.f;
+  gv += g[i];                    // (adamw_small_kernel with one partial vector: 0 + g, the same bits)
+  float mv = m[i], vv = v[i];
+  const float pn = adamw_small_one(p[i], gv, mv, vv, s);
+  p[i] = pn;
+  m[i] = mv;
+  v[i] = vv;
+  if (Wt) {
+    const int64_t off[4] = {PN_C2_W, PN_C3_W, PN_F1_W, PN_F2_W};
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int64_t r = i - off[l];
+      if (r >= 0 && r < 16384) Wt[(size_t)l * 16384 + (r & 127) * 128 + (r >> 7)] = pn;   // Wt[l][k][n] = W_l[n][k]
+    }
+  }
+}
+
 }  // namespace acez

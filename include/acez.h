@@ -255,8 +255,9 @@ int acez_train_update(acez_trainer* tr, void* stream);
  * rank draws the same epoch permutation, ace_trainer.py:466-494): the next batch is gathered, and this step's schedule bookkeeping
  * closed, inside the optimiser's launch, so the next acez_train_backward called with the same device pointer and count starts with the
  * forward chain instead of a gather launch. Same contract for the announced indices as acez_train_step_next; any other next call is
- * still correct. Bitwise the same parameters and state as acez_train_update. With pose refinement, or d_indices_next == NULL, or
- * n_next == 0 (a rank whose shard holds no row of the next batch): exactly acez_train_update. */
+ * still correct. Bitwise the same parameters and state as acez_train_update. With the pose network (--pose_refinement mlp) the rows are
+ * gathered in the optimiser's launch as well and the next backward's first launch keeps the pose forward and the schedule wave. With
+ * d_indices_next == NULL or n_next == 0 (a rank whose shard holds no row of the next batch): exactly acez_train_update. */
 int acez_train_update_next(acez_trainer* tr, const int64_t* d_indices_next, int n_next, void* stream);
 /* Sharded data-parallel update (reduce-scatter of the weight gradients, each rank updates its own layers, all-gather
  * of the 16-bit compute copies; no reference counterpart -- the reference is single-GPU):

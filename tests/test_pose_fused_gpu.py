@@ -174,3 +174,48 @@ def test_refinement_step_with_the_next_batch_announced_equals_plain_steps_bitwis
     assert sp == sq and sp["iteration"] == 24
     lp, lq = plain.log(0, 24), piped.log(0, 24)
     assert np.array_equal(lp[0], lq[0]) and np.array_equal(lp[1], lq[1])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_split_refinement_step_folded_and_announced_equals_fused_steps_bitwise(dtype):
+    """Round 6, the data-parallel rank's refinement step (backward / all-reduce / update with --pose_refinement mlp): S1 rides at the front
+    of the gradient-reduction launch, the pose parameters' AdamW and the refresh of the transposed copies at the front of the head's
+    optimiser launch, and -- with the rank's rows of the next batch announced to the update -- the gather too. Head and pose-network
+    parameters, all moments, the refined poses, the schedule state and the log equal the fused single-GPU steps bit for bit, with wrong and
+    empty announcements, fused steps and state reads in between, ragged batch sizes."""
+    from tests.helpers import big_problem as _big_problem
+    from tests.test_head_gpu import _trainer
+    from oracle import head_oracle
+    prob = _big_problem(n_images=8, patches_per_view=512)
+    flat0 = head_oracle.init_params(helpers.SEED + 1)
+    cfg = helpers.full_cfg(helpers.HEAD_CONFIGS["head_tanh_posemlp"], prob)
+    cfg.update(global_batch=2048, iterations=60, refine_calibration=True)
+    plain, piped = (_trainer(prob, flat0, cfg, max_batch=2048, dtype=dtype) for _ in range(2))
+    rng = np.random.default_rng(31)
+    N = prob["features"].shape[0]
+    batches = [torch.from_numpy(rng.permutation(N)[:(2048 if i % 5 else 1111)].astype(np.int64)).cuda() for i in range(24)]
+    other = torch.from_numpy(rng.permutation(N)[:2048].astype(np.int64)).cuda()
+    empty = torch.zeros(0, dtype=torch.int64, device="cuda")
+    for i, b in enumerate(batches):
+        plain.step(b)
+        nxt = batches[i + 1] if i + 1 < len(batches) else None
+        if i % 7 == 3:
+            nxt = other
+        if i % 13 == 6:
+            nxt = empty
+        if i % 11 == 5:
+            piped.step(b, nxt)
+        else:
+            piped.backward(b)
+            piped.update(nxt)
+        if i % 9 == 4:
+            assert plain.state() == piped.state()
+            np.testing.assert_array_equal(plain.current_poses(), piped.current_poses())
+    torch.cuda.synchronize()
+    assert torch.equal(plain.params, piped.params) and torch.equal(plain.adam_m, piped.adam_m) and torch.equal(plain.adam_v, piped.adam_v)
+    assert torch.equal(plain.pose_params, piped.pose_params) and torch.equal(plain.pose_m, piped.pose_m) and torch.equal(plain.pose_v, piped.pose_v)
+    sp, sq = plain.state(), piped.state()
+    assert sp == sq and sp["iteration"] == 24
+    lp, lq = plain.log(0, 24), piped.log(0, 24)
+    assert np.array_equal(lp[0], lq[0]) and np.array_equal(lp[1], lq[1])
+    np.testing.assert_array_equal(plain.current_poses(), piped.current_poses())
