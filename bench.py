@@ -391,7 +391,7 @@ def bench_pipeline(args, rank, world, device, dtype="bf16", legs="all"):
     torch.cuda.synchronize()
     enc_ms_per_frame = e0.elapsed_time(e1) / (4 * chunk)
     # (2) the whole pipeline on `total` frames (the same 32 views repeated: content does not change the work)
-    nfr = (total // chunk) * chunk
+    nfr = max(1, total // chunk) * chunk          # whole passes; at least one per rank (a small --e2e-frames over many ranks)
     big = img.repeat(nfr // chunk, 1, 1, 1)
     intr_all = intr * (nfr // chunk)
     net.register(big[:2 * chunk], intr_all[:2 * chunk], prm, 1305)   # warm-up of the grouped path
@@ -411,7 +411,7 @@ def bench_pipeline(args, rank, world, device, dtype="bf16", legs="all"):
     Ki = torch.linalg.inv(K)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for c in range(total // chunk):
+    for c in range(nfr // chunk):
         bld.add_views(img, None, eye, eye, K, Ki, list(range(chunk)))
     torch.cuda.synchronize()
     dtb = time.perf_counter() - t1
