@@ -128,6 +128,8 @@ def parse():
     ap.add_argument("--headline-only", action="store_true", help="only the timed training steps (the leg rocprofv3 is pointed at: tools/prof_r02.sh)")
     # control-flow smoke of the N > 1 path on a ONE-GPU box: every rank on cuda:0, gloo instead of RCCL (not a measurement)
     ap.add_argument("--smoke-same-device", action="store_true")
+    # internal: the one-rank RCCL legs as a child process of the default run (dp_world1_legs)
+    ap.add_argument("--dp-world1-legs", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -597,6 +599,35 @@ def self_launch(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def dp_world1_legs(args):
+    """What the RCCL calls themselves cost per step (one rank: no wire time), against the same flow with the calls skipped: the legs that
+    form a one-rank RCCL group run in a CHILD process under a hard time limit -- a box on which RCCL cannot bootstrap (or hangs doing so)
+    loses these auxiliary figures, never the line. Returns (figures or None, error or None)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--dp-world1-legs", "--buffer-patches", str(args.buffer_patches)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return None, ("rc %d: " % r.returncode) + r.stderr[-300:]
+        return json.loads(lines[-1]), None
+    except Exception as e:
+        return None, repr(e)[:300]
+
+
+def dp_world1_child(args):
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    line_out = claim_stdout()
+    out = {"allreduce_rccl": bench_dp_rank_proxy(args, device, 5120, rccl_world1=True),
+           "sharded_skipped": bench_dp_rank_proxy(args, device, 5120, mode="sharded", proxy_world=1),
+           "sharded_rccl": bench_dp_rank_proxy(args, device, 5120, mode="sharded", rccl_world1=True),
+           "sharded_rank_of_8": bench_dp_rank_proxy(args, device, 5120, mode="sharded")}
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    print(json.dumps(out), file=line_out, flush=True)
+
+
 def dp_mode_name():
     from acezero_amd.parallel import dp_mode
     return dp_mode()
@@ -622,6 +653,8 @@ def main():
     args = parse()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if args.dp_world1_legs:
+        return dp_world1_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     line_out = claim_stdout()
@@ -680,21 +713,7 @@ def main():
     pipe16 = bench_pipeline(args, rank, world, device, dtype="fp16", legs="e2e")
     # one-GPU proxies of a data-parallel rank's compute (N = 1 only: what a rank does between its collectives)
     dp_proxy = {rows: bench_dp_rank_proxy(args, device, rows) for rows in (5120, 640)} if world == 1 else None
-    dp_w1, dp_w1_error = None, None
-    if world == 1:   # what the RCCL calls themselves cost per step (one rank: no wire time), against the same flow with the calls skipped
-        try:
-            dp_w1 = {"allreduce_rccl": bench_dp_rank_proxy(args, device, 5120, rccl_world1=True),
-                     "sharded_skipped": bench_dp_rank_proxy(args, device, 5120, mode="sharded", proxy_world=1),
-                     "sharded_rccl": bench_dp_rank_proxy(args, device, 5120, mode="sharded", rccl_world1=True),
-                     "sharded_rank_of_8": bench_dp_rank_proxy(args, device, 5120, mode="sharded")}
-        except Exception as e:   # a box on which a one-rank RCCL group cannot be formed loses this auxiliary leg, not the line
-            dp_w1, dp_w1_error = None, repr(e)[:300]
-        finally:
-            try:
-                if torch.distributed.is_initialized():
-                    torch.distributed.destroy_process_group()
-            except Exception as e:
-                dp_w1_error = (dp_w1_error or "") + " destroy: " + repr(e)[:200]
+    dp_w1, dp_w1_error = (None, None) if world > 1 else dp_world1_legs(args)
     sess = bench_session(args, device) if world == 1 and args.session_frames > 0 else None
     if world > 1:
         t = torch.tensor([dt, dt_reg, dt_ref, dt_strong, dt_gar, dt_gar_reg, dt_f16] + st["window_ms_per_step"], device=device, dtype=torch.float64)

@@ -22,6 +22,8 @@ def test_bench_json_line_contract(monkeypatch, seq):
                                                                   {"loss": 22.3, "focal_scale": 1.01, "window_ms_per_step": list(wins)}, prof))
     monkeypatch.setattr(bench, "bench_registration", lambda *a, **k: (2048, 2048 / 340e3, 1.0))
     monkeypatch.setattr(bench, "bench_dp_rank_proxy", lambda args, device, rows, **k: 0.150 if rows == 5120 else 0.110)
+    monkeypatch.setattr(bench, "dp_world1_legs", lambda args: ({"allreduce_rccl": 0.150, "sharded_skipped": 0.150, "sharded_rccl": 0.150,
+                                                                 "sharded_rank_of_8": 0.150}, None))   # (a child process on the GPU box)
     monkeypatch.setattr(bench, "bench_pipeline", lambda *a, **k: {"frames": 256, "e2e_s": 0.025, "encoder_ms": 16.0, "buffer_rows": 262144, "buffer_s": 0.017,
                                                             "cloud_frames": 256, "cloud_s": 1.4e-4, "cloud_points": 256000})
     monkeypatch.setattr(bench, "bench_session", lambda *a: {"frames": 120, "seconds": 5.4})
@@ -134,3 +136,22 @@ def test_stdout_carries_only_the_json_line_whatever_libraries_write_to_descripto
     assert r.returncode == 0, r.stderr
     assert r.stdout == '{"metric": 1}\n'
     assert "RCCL version : banner" in r.stderr and "python-level chatter" in r.stderr
+
+
+def test_one_rank_rccl_legs_cannot_take_the_line_down(monkeypatch):
+    """The legs that form a one-rank RCCL group run in a child process under a time limit; a failing or hanging child yields (None, error)."""
+    import subprocess
+    import types
+    import bench
+    args = types.SimpleNamespace(buffer_patches=1000)
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=1, stdout="", stderr="RCCL bootstrap failed"))
+    out, err = bench.dp_world1_legs(args)
+    assert out is None and "rc 1" in err and "bootstrap" in err
+
+    def hang(*a, **k):
+        raise subprocess.TimeoutExpired(a[0], k.get("timeout"))
+    monkeypatch.setattr(subprocess, "run", hang)
+    out, err = bench.dp_world1_legs(args)
+    assert out is None and "TimeoutExpired" in err
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=0, stdout='RCCL version : x\n{"allreduce_rccl": 0.16}\n', stderr=""))
+    assert bench.dp_world1_legs(args) == ({"allreduce_rccl": 0.16}, None)
