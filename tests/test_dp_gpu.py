@@ -249,6 +249,10 @@ def _rccl_world1_worker(port, q):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    probe = torch.ones(4, device="cuda")
+    dist.all_reduce(probe)
+    torch.cuda.synchronize()
+    q.put(("group_formed", float(probe.sum())))      # the parent skips the test if this never arrives (no RCCL bootstrap on the box)
     from acezero_amd import parallel
     prob, flat0 = _problem()
     n = prob["features"].shape[0]
@@ -291,6 +295,17 @@ def test_rccl_branch_of_the_exchange_runs_on_this_stack_with_one_rank():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q))
     p.start()
+    import queue
+    try:
+        first = q.get(timeout=150)
+    except queue.Empty:
+        first = None
+    if first is None or first[0] != "group_formed":
+        if p.is_alive():
+            p.terminate()
+        pytest.skip("a one-rank RCCL group could not be formed on this box within 150 s (exit code %s): the RCCL branch stays covered by the "
+                    "gloo-emulated test above" % p.exitcode)
+    assert first[1] == 4.0
     (_, out, backend), = _collect([p], q, 300)
     p.join(timeout=60)
     assert p.exitcode == 0 and backend == "nccl"
