@@ -1987,7 +1987,10 @@ __device__ void sched_post_wave(const TrainState* src, TrainState* st, const Sch
     const int64_t k0 = (int64_t)tail->n_layers * 512 + (tail->n_params - tail->n_wide);
     g0 = tail_output(*tail, k0, lane, d); g1 = tail_output(*tail, k0 + 1, lane, d); g2 = tail_output(*tail, k0 + 2, lane, d);
   }
-  if ((fault && *fault) || !h.active) {
+  // (split flow: a rank's fault arrives all-reduced in statistics slot 3, and adamw_body raises the local fault word from it -- in
+  // adamw_next_kernel inside the SAME launch as this wave, so the word itself would be a race here; the statistic is not)
+  const bool fault_reduced = !tail && fmodf(grad_stats[3], 1024.f) != 0.f;
+  if ((fault && *fault) || fault_reduced || !h.active) {
     // the step was abandoned (rowseq fault: no iteration is counted, nothing is logged) or the schedule has ended (state frozen,
     // ace_trainer.py:509-510): the other slot becomes a copy
     if (src != st) {

@@ -270,7 +270,8 @@ def test_expired_handoff_poll_abandons_the_step_and_falls_back_to_per_layer_laun
     assert torch.equal(new.get_scene_coordinates(f), ref.get_scene_coordinates(f))
 
 
-def test_fault_word_travels_in_the_gradient_bucket(diag_lib):
+@pytest.mark.parametrize("announce", [False, True])
+def test_fault_word_travels_in_the_gradient_bucket(announce, diag_lib):
     """Data-parallel flow (backward / all-reduce / update): statistics slot 3 of the bucket carries the rank's fault word, so that
     after the all-reduce EVERY rank skips the optimiser step and the replicas stay identical. One process plays both ranks here:
     rank A faults, rank B does not; B receives A's slot through the (emulated) sum and must skip its update and fall back too."""
@@ -291,10 +292,17 @@ def test_fault_word_travels_in_the_gradient_bucket(diag_lib):
     a.grad.copy_(total)
     b.grad.copy_(total)
     p0 = b.params.clone()
-    a.update()
-    b.update()
+    # announce: acez_train_update_next -- the schedule wave that closes the step sits in the SAME launch as the optimiser workgroup that
+    # raises the local fault word from the all-reduced slot; it must decide on the slot itself (no iteration counted on either rank)
+    nxt = torch.from_numpy(rng.permutation(prob["features"].shape[0])[:2048].astype(np.int64)).cuda() if announce else None
+    a.update(nxt)
+    b.update(nxt)
     torch.cuda.synchronize()
     assert torch.equal(b.params, p0) and torch.equal(a.params, p0)
+    if announce:     # a step issued before the host knows (with the announced rows): a no-op on both
+        a.backward(nxt); b.backward(nxt)
+        torch.cuda.synchronize()
+        assert torch.equal(b.params, p0) and torch.equal(a.params, p0)
     assert a.state()["iteration"] == 0 and b.state()["iteration"] == 0
     assert a.seq_status()["faults"] == 1 and b.seq_status()["faults"] == 1 and not b.seq_status()["enabled"]
 
